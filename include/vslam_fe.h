@@ -1,0 +1,143 @@
+/* include/vslam_fe.h -- C ABI of the MI355X-native visual front-end (libvslam_fe.so).
+ *
+ * Drop-in boundary for ONE hot path of KMS-TEAM/vi_slam: ORB extraction + 256-bit Hamming matching.
+ * Every entry point names the reference interface it replaces (paths relative to the reference root).
+ * Plain pointers and sizes only; all functions return VSLAM_OK (0) or a negative error code and never
+ * abort (the reference asserts / exit()s, see fextractor.cpp:1041, cuda_common.h:49-82).
+ *
+ * The library is HIP-only: there is no CPU fallback.  If no gfx950 device is usable, vslam_fe_create()
+ * fails with VSLAM_ERR_NO_DEVICE.
+ *
+ * Threading: a vslam_fe context is stateful (it owns the image pyramids, like FExtractor owns
+ * mvImagePyramid, fextractor.h:64) and is NOT re-entrant; use one context per concurrent stream, exactly
+ * as the reference allocates Left/Right/Ini extractors (tracking.cpp:1087-1093).  Different contexts may
+ * be driven from different host threads (frame.cpp:107-108).
+ */
+#ifndef VSLAM_FE_H
+#define VSLAM_FE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_OK 0
+#define VSLAM_ERR_INVALID (-1)     /* bad argument / empty image (FExtractor::compute returns -1, :1037) */
+#define VSLAM_ERR_NO_DEVICE (-2)   /* no usable HIP device */
+#define VSLAM_ERR_HIP (-3)         /* a HIP runtime call failed; see vslam_last_error() */
+#define VSLAM_ERR_CAPACITY (-4)    /* caller buffer or an internal candidate buffer too small */
+#define VSLAM_ERR_UNSUPPORTED (-5) /* geometry the reference itself cannot process (e.g. nIni == 0) */
+
+#define VSLAM_MAX_LEVELS 16
+#define VSLAM_MAX_BATCH 32
+
+/* flags for vslam_fe_params.flags: OpenCV build-dependent arithmetic the reference inherits */
+#define VSLAM_FLAG_ATAN_FMA 1u /* cv::fastAtan2 Horner polynomial FMA-contracted (AVX2/FMA3 dispatch, aarch64) */
+
+/* Same 28-byte layout and field order as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave,
+ * class_id) so std::vector<cv::KeyPoint> storage can be handed over directly. */
+typedef struct vslam_kp {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} vslam_kp;
+
+typedef struct vslam_fe_params {
+    int32_t width, height;   /* level-0 image size (reference: image.cols/rows at compute()) */
+    int32_t nfeatures;       /* ORBextractor.nFeatures   (tracking.cpp:1021-1085) */
+    float scale_factor;      /* ORBextractor.scaleFactor */
+    int32_t nlevels;         /* ORBextractor.nLevels     */
+    int32_t ini_th_fast;     /* ORBextractor.iniThFAST   */
+    int32_t min_th_fast;     /* ORBextractor.minThFAST   */
+    int32_t device;          /* HIP device ordinal */
+    int32_t max_batch;       /* image slots processed per batched call, 1..VSLAM_MAX_BATCH */
+    uint32_t flags;          /* VSLAM_FLAG_* */
+    int32_t gauss_taps[7];   /* all zero -> OpenCV 4.2 taps {18,34,48,56,48,34,18} */
+} vslam_fe_params;
+
+typedef struct vslam_fe vslam_fe;
+
+/* ---------------------------------------------------------------- extractor (FExtractor) */
+
+/* FExtractor::FExtractor (fextractor.cpp:401-461): allocates pyramids for max_batch image slots, builds
+ * scale tables, per-level quotas, resize coefficient tables and the FAST cell list. */
+int vslam_fe_create(const vslam_fe_params* params, vslam_fe** out);
+void vslam_fe_destroy(vslam_fe* fe);
+const char* vslam_last_error(void);
+
+/* FExtractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (fextractor.h:42-62) + mnFeaturesPerLevel.  Arrays of nlevels; any may be NULL. */
+int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* features_per_level);
+
+/* FExtractor::compute (fextractor.h:38-40, fextractor.cpp:1034-1133) for one host image, synchronous.
+ *   img/pitch : CV_8UC1 rows.   lap0/lap1 : vLappingArea (frame.cpp:107-108 passes {0,0}, :289 {0,1000}).
+ *   kps/desc  : caller storage for cap keypoints / cap*32 descriptor bytes; cap >= nfeatures + 4*nlevels.
+ *   *n        : keypoints written;  *mono_index : the reference's return value.
+ * Uses image slot 0. */
+int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, int lap1, vslam_kp* kps,
+                     uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Batched form: nimg (<= max_batch) images in one pass of the kernels; slot i <- imgs[i].
+ *   imgs_on_device != 0: imgs[i] are device pointers that stay valid until the call returns (zero-copy
+ *   level 0); otherwise host pointers (uploaded).  kps/desc/n/mono_index are host arrays of nimg entries;
+ *   kps[i] holds cap keypoints, desc[i] cap*32 bytes.  kps/desc may be NULL to keep results on the
+ *   device only (read them with vslam_fe_slot_buffers). */
+int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
+                           int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
+                           uint8_t* const* desc, int cap, int* n, int* mono_index);
+
+/* FExtractor::mvImagePyramid[level] (fextractor.h:64; read by frame.cpp:830,920,932,937).  Copies the
+ * borderless level image of a slot into dst (dst_pitch >= level width).  blurred != 0 returns the
+ * GaussianBlur'ed clone used for the descriptors (fextractor.cpp:1085-1086). */
+int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h);
+int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurred, uint8_t* dst, size_t dst_pitch);
+
+/* Stage taps for parity tests and profilers: per-level FAST candidates of the last extract of a slot in
+ * the reference's vToDistributeKeys order (fextractor.cpp:769-817): x,y relative to the 16-px border,
+ * response = FAST score.  Returns the count (or a negative error); writes at most cap entries. */
+int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int cap);
+
+/* Device-resident outputs of the last extract of a slot (valid until the next extract on this context):
+ * keypoints (vslam_kp[n]) and descriptors (n*32 bytes) in HBM, for device-side matching / RCCL. */
+int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, const uint8_t** dev_desc,
+                          int* n);
+
+/* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */
+void* vslam_fe_stream(vslam_fe* fe);
+
+/* ---------------------------------------------------------------- matcher (FMatcher / Frame) */
+
+/* FMatcher::DescriptorDistance (fmatcher.h:77, fmatcher.cpp:2859-2875) over device arrays: all-pairs
+ * 256-bit Hamming, two nearest train descriptors per query (the cv::BFMatcher::knnMatch(…,2) sites,
+ * frame.cpp:1167-1174; fmatcher.cpp:204-229).  q/t: nq*32 / nt*32 bytes in HBM.  idx2/dist2: host arrays
+ * of nq*2 (first = best; ties -> lower train index; missing -> idx -1, dist 2^31-1).
+ * Runs on fe's stream and device. */
+int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
+                       int32_t* idx2, int32_t* dist2);
+
+/* Dense distance matrix (nq x nt, uint8, 255 = distance >= 255) on the device -> host; used by the
+ * order-dependent matchers whose sequential part is replayed on the host. */
+int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
+                         uint8_t* out);
+
+/* Frame::ComputeStereoMatches (frame.h:293, frame.cpp:823-997) for the pair (feL slot sL, feR slot sR)
+ * after both have been extracted.  bf = Camera.bf, fx = Camera.fx.  u_right/depth: host arrays of the
+ * left keypoint count (mvuRight, mvDepth; -1 = no match).  feL and feR may be the same context. */
+int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, float bf, float fx, float* u_right,
+                       float* depth);
+
+/* FMatcher::SearchForInitialization (fmatcher.h:106, fmatcher.cpp:983-1098).  Frame 1 / frame 2
+ * keypoints+descriptors are device arrays (e.g. from vslam_fe_slot_buffers, or a slot of an RCCL
+ * all-gather buffer); kps1_host/kps2_host are the same keypoints on the host.  prev_matched: 2*n1 floats
+ * in/out (vbPrevMatched).  matches12: n1 ints out.  Returns the match count in *nmatches. */
+int vslam_search_for_initialization(vslam_fe* fe, const vslam_kp* kps1_host, const uint8_t* dev_desc1,
+                                    int n1, const vslam_kp* kps2_host, const uint8_t* dev_desc2, int n2,
+                                    int img_w, int img_h, float* prev_matched, int32_t* matches12,
+                                    int window, float nnratio, int check_orientation, int* nmatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_FE_H */

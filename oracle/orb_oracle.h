@@ -1,0 +1,118 @@
+/* oracle/orb_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement ("oracle-R") of the reference's visual front-end hot path.  Nothing in the
+ * product (vi_slam_amd/, include/) may include, link or call this; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference as a whole -- the reference has no test or
+ * golden vector for this path and its pixel arithmetic lives in OpenCV 4.2, which is
+ * neither vendored under /root/reference nor installed.  What IS pinned:
+ *   - the FAST stage, against the reference's own Rosten FAST sources compiled into oracle/_ref/
+ *     (thirdparty/vilib/visual_lib/src/feature_detection/fast/rosten/{fast,fast_9,nonmax}.cpp);
+ *   - DescriptorDistance, against hardware popcount;
+ *   - constructor tables (quotas, umax, scale factors) against the values in SURVEY.md 8.
+ * The OpenCV 4.2.0 primitives (resize INTER_LINEAR 8u, FAST 9/16 + NMS, GaussianBlur 8u fixed point,
+ * fastAtan2, cvRound) are restated from their published algorithm; every build/version dependent
+ * constant is a named knob in orbo::Knobs.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace orbo {
+
+/* Same field order and size as cv::KeyPoint (28 bytes). */
+struct KeyPoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+};
+static_assert(sizeof(KeyPoint) == 28, "KeyPoint must mirror cv::KeyPoint");
+
+struct Knobs {
+    /* cv::GaussianBlur(7x7, sigma=2) CV_8U fixed-point taps (8 fractional bits).  OpenCV >= 3.4.9/4.2.0
+     * diffuses the rounding error so the taps sum to 256: {18,34,48,56,48,34,18}.  Older 3.4/4.x rounded
+     * each tap independently: {18,34,49,55,49,34,18} (sum 257). */
+    int gauss_taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    /* cv::fastAtan2 polynomial: 0 = separate mul/add (baseline-ISA build), 1 = FMA-contracted Horner
+     * (what GCC emits for OpenCV's AVX2/FMA3 dispatch unit and on aarch64). */
+    int atan_fma = 0;
+};
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px; /* contiguous, stride == w */
+    const uint8_t* row(int y) const { return px.data() + (size_t)y * w; }
+    uint8_t* row(int y) { return px.data() + (size_t)y * w; }
+};
+
+/* ---- OpenCV primitive restatements (each cites the call site in the reference) ---- */
+int cv_round_f(float v);   /* cvRound(float): round-half-even  (fextractor.cpp:72,106,110,433,1140) */
+int cv_round_d(double v);  /* cvRound(double)                  (fextractor.cpp:451) */
+void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
+                      size_t dstride); /* cv::resize(..., INTER_LINEAR), fextractor.cpp:1148 */
+void fast_detect(const uint8_t* img, int w, int h, size_t stride, int threshold, bool nonmax,
+                 std::vector<KeyPoint>& out); /* cv::FAST(img,kps,th,true), fextractor.cpp:800-806 */
+void gaussian_blur7(const Image& src, Image& dst, const int taps[7]); /* fextractor.cpp:1086 */
+float fast_atan2(float y, float x, int fma);                        /* fextractor.cpp:94 */
+int descriptor_distance(const uint8_t* a, const uint8_t* b);       /* fmatcher.cpp:2859-2875 */
+
+std::vector<KeyPoint> distribute_octree(const std::vector<KeyPoint>& keys, int minX, int maxX, int minY,
+                                        int maxY, int N); /* fextractor.cpp:530-754 */
+
+class Extractor { /* FExtractor, fextractor.h:26-91 */
+public:
+    Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+              const Knobs& knobs = Knobs());
+
+    /* FExtractor::compute (fextractor.cpp:1034-1133).  Returns monoIndex, or -1 on empty image.
+     * desc is N x 32 bytes row-major. */
+    int compute(const uint8_t* img, int w, int h, size_t stride, int lap0, int lap1,
+                std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc);
+
+    int nfeatures;
+    double scaleFactor;
+    int nlevels, iniThFAST, minThFAST;
+    Knobs knobs;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+
+    /* State after compute(), exposed for stage-wise parity tests. */
+    std::vector<Image> mvImagePyramid;                   /* borderless level images (fextractor.h:64) */
+    std::vector<Image> mvBlurred;                        /* blurred clones, only levels with keypoints */
+    std::vector<std::vector<KeyPoint>> vToDistribute;    /* per level FAST candidates, coords minus border */
+    std::vector<std::vector<KeyPoint>> allKeypoints;     /* per level after octree+orientation, level coords */
+
+    void ComputePyramid(const uint8_t* img, int w, int h, size_t stride);
+    void ComputeKeyPointsOctTree();
+};
+
+/* Frame::ComputeStereoMatches (frame.cpp:823-997).  Pyramids come from the two extractors.
+ * uRight/depth are resized to kpsL.size() and filled with -1 for unmatched. */
+void compute_stereo_matches(const Extractor& exL, const Extractor& exR, const std::vector<KeyPoint>& kpsL,
+                            const std::vector<uint8_t>& descL, const std::vector<KeyPoint>& kpsR,
+                            const std::vector<uint8_t>& descR, float bf, float fx,
+                            std::vector<float>& uRight, std::vector<float>& depth,
+                            std::vector<int>* bestIdxR = nullptr, std::vector<int>* bestSad = nullptr);
+
+/* Frame grid (frame.cpp:386-414, 678-756) for an undistorted W x H image. */
+struct FrameGrid {
+    static const int COLS = 64, ROWS = 48; /* frame.h:42-43 */
+    float mnMinX, mnMaxX, mnMinY, mnMaxY, invW, invH;
+    std::vector<int> cell[COLS][ROWS];
+    const std::vector<KeyPoint>* kps;
+    FrameGrid(const std::vector<KeyPoint>& k, int imgW, int imgH);
+    std::vector<int> GetFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel) const;
+};
+
+/* FMatcher::SearchForInitialization (fmatcher.cpp:983-1098).  Returns nmatches. */
+int search_for_initialization(const std::vector<KeyPoint>& kps1, const std::vector<uint8_t>& desc1,
+                              const std::vector<KeyPoint>& kps2, const std::vector<uint8_t>& desc2,
+                              int imgW, int imgH, std::vector<float>& prevMatchedXY /* 2*N1, in/out */,
+                              std::vector<int>& matches12, int windowSize, float nnratio, bool checkOri);
+
+} // namespace orbo
+
+#endif

@@ -1,0 +1,166 @@
+/* oracle/orb_oracle_c.cpp -- TEST INFRASTRUCTURE ONLY.  Flat C bindings of orb_oracle.h for ctypes. */
+#include <cmath>
+#include <cstring>
+
+#include "orb_oracle.h"
+
+using namespace orbo;
+
+extern "C" {
+
+void* orbo_create(int nfeatures, float scale, int nlevels, int iniTh, int minTh, const int* taps7,
+                  int atan_fma) {
+    Knobs k;
+    if (taps7) memcpy(k.gauss_taps, taps7, sizeof(k.gauss_taps));
+    k.atan_fma = atan_fma;
+    return new Extractor(nfeatures, scale, nlevels, iniTh, minTh, k);
+}
+void orbo_destroy(void* h) { delete (Extractor*)h; }
+
+int orbo_tables(void* h, float* sf, float* isf, float* s2, float* is2, int* quota, int* umax16) {
+    Extractor* e = (Extractor*)h;
+    for (int i = 0; i < e->nlevels; i++) {
+        sf[i] = e->mvScaleFactor[i];
+        isf[i] = e->mvInvScaleFactor[i];
+        s2[i] = e->mvLevelSigma2[i];
+        is2[i] = e->mvInvLevelSigma2[i];
+        quota[i] = e->mnFeaturesPerLevel[i];
+    }
+    for (int i = 0; i < 16; i++) umax16[i] = e->umax[i];
+    return e->nlevels;
+}
+
+/* returns monoIndex (or -1); *n_out = number of keypoints; fails with -2 if cap is too small */
+int orbo_compute(void* h, const uint8_t* img, int w, int hh, size_t stride, int lap0, int lap1,
+                 KeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
+    Extractor* e = (Extractor*)h;
+    std::vector<KeyPoint> k;
+    std::vector<uint8_t> d;
+    int mono = e->compute(img, w, hh, stride, lap0, lap1, k, d);
+    if (mono < 0) { *n_out = 0; return mono; }
+    *n_out = (int)k.size();
+    if ((int)k.size() > cap) return -2;
+    if (!k.empty()) {
+        memcpy(kps, k.data(), k.size() * sizeof(KeyPoint));
+        memcpy(desc, d.data(), d.size());
+    }
+    return mono;
+}
+
+int orbo_pyramid_only(void* h, const uint8_t* img, int w, int hh, size_t stride) {
+    ((Extractor*)h)->ComputePyramid(img, w, hh, stride);
+    return 0;
+}
+
+int orbo_level_size(void* h, int level, int* w, int* hh) {
+    Extractor* e = (Extractor*)h;
+    if (level < 0 || level >= e->nlevels) return -1;
+    *w = e->mvImagePyramid[level].w;
+    *hh = e->mvImagePyramid[level].h;
+    return 0;
+}
+int orbo_level_copy(void* h, int level, int blurred, uint8_t* dst) {
+    Extractor* e = (Extractor*)h;
+    if (level < 0 || level >= e->nlevels) return -1;
+    const Image& im = blurred ? e->mvBlurred[level] : e->mvImagePyramid[level];
+    if (im.px.empty()) return -2;
+    memcpy(dst, im.px.data(), im.px.size());
+    return 0;
+}
+int orbo_candidates(void* h, int level, KeyPoint* out, int cap) {
+    Extractor* e = (Extractor*)h;
+    const std::vector<KeyPoint>& v = e->vToDistribute[level];
+    if (out && (int)v.size() <= cap && !v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+int orbo_level_keys(void* h, int level, KeyPoint* out, int cap) {
+    Extractor* e = (Extractor*)h;
+    const std::vector<KeyPoint>& v = e->allKeypoints[level];
+    if (out && (int)v.size() <= cap && !v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+
+/* ---- primitives ---- */
+void orbo_resize(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
+                 size_t dstride) {
+    resize_linear_u8(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+int orbo_fast_detect(const uint8_t* img, int w, int h, size_t stride, int th, int nonmax, KeyPoint* out,
+                     int cap) {
+    std::vector<KeyPoint> v;
+    fast_detect(img, w, h, stride, th, nonmax != 0, v);
+    if (out && (int)v.size() <= cap && !v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+void orbo_blur7(const uint8_t* src, int w, int h, uint8_t* dst, const int* taps7) {
+    Image s, d;
+    s.w = w;
+    s.h = h;
+    s.px.assign(src, src + (size_t)w * h);
+    Knobs k;
+    gaussian_blur7(s, d, taps7 ? taps7 : k.gauss_taps);
+    memcpy(dst, d.px.data(), d.px.size());
+}
+float orbo_fast_atan2(float y, float x, int fma) { return fast_atan2(y, x, fma); }
+int orbo_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+float orbo_cosf(float x) { return cosf(x); } /* the host libm the reference would call */
+float orbo_sinf(float x) { return sinf(x); }
+int orbo_cv_round_f(float v) { return cv_round_f(v); }
+
+int orbo_distribute_octree(const KeyPoint* keys, int n, int minX, int maxX, int minY, int maxY, int N,
+                           KeyPoint* out, int cap) {
+    std::vector<KeyPoint> v(keys, keys + n);
+    std::vector<KeyPoint> r = distribute_octree(v, minX, maxX, minY, maxY, N);
+    if (out && (int)r.size() <= cap && !r.empty()) memcpy(out, r.data(), r.size() * sizeof(KeyPoint));
+    return (int)r.size();
+}
+
+/* all-pairs distance matrix, for matcher parity tests */
+void orbo_hamming_matrix(const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out) {
+    for (int i = 0; i < na; i++)
+        for (int j = 0; j < nb; j++)
+            out[(size_t)i * nb + j] = (uint16_t)descriptor_distance(a + (size_t)i * 32, b + (size_t)j * 32);
+}
+
+void orbo_stereo(void* hL, void* hR, const KeyPoint* kpsL, int nL, const uint8_t* descL,
+                 const KeyPoint* kpsR, int nR, const uint8_t* descR, float bf, float fx, float* uRight,
+                 float* depth, int* bestIdxR, int* bestSad) {
+    std::vector<KeyPoint> kl(kpsL, kpsL + nL), kr(kpsR, kpsR + nR);
+    std::vector<uint8_t> dl(descL, descL + (size_t)nL * 32), dr(descR, descR + (size_t)nR * 32);
+    std::vector<float> u, d;
+    std::vector<int> bi, bs;
+    compute_stereo_matches(*(Extractor*)hL, *(Extractor*)hR, kl, dl, kr, dr, bf, fx, u, d, &bi, &bs);
+    if (nL) {
+        memcpy(uRight, u.data(), nL * sizeof(float));
+        memcpy(depth, d.data(), nL * sizeof(float));
+        if (bestIdxR) memcpy(bestIdxR, bi.data(), nL * sizeof(int));
+        if (bestSad) memcpy(bestSad, bs.data(), nL * sizeof(int));
+    }
+}
+
+int orbo_search_init(const KeyPoint* kps1, int n1, const uint8_t* desc1, const KeyPoint* kps2, int n2,
+                     const uint8_t* desc2, int imgW, int imgH, float* prevMatchedXY, int* matches12,
+                     int windowSize, float nnratio, int checkOri) {
+    std::vector<KeyPoint> k1(kps1, kps1 + n1), k2(kps2, kps2 + n2);
+    std::vector<uint8_t> d1(desc1, desc1 + (size_t)n1 * 32), d2(desc2, desc2 + (size_t)n2 * 32);
+    std::vector<float> pm(prevMatchedXY, prevMatchedXY + 2 * (size_t)n1);
+    std::vector<int> m;
+    int nm = search_for_initialization(k1, d1, k2, d2, imgW, imgH, pm, m, windowSize, nnratio,
+                                       checkOri != 0);
+    if (n1) {
+        memcpy(prevMatchedXY, pm.data(), pm.size() * sizeof(float));
+        memcpy(matches12, m.data(), m.size() * sizeof(int));
+    }
+    return nm;
+}
+
+int orbo_grid_query(const KeyPoint* kps, int n, int imgW, int imgH, float x, float y, float r, int minL,
+                    int maxL, int* out, int cap) {
+    std::vector<KeyPoint> k(kps, kps + n);
+    FrameGrid g(k, imgW, imgH);
+    std::vector<int> v = g.GetFeaturesInArea(x, y, r, minL, maxL);
+    if (out && (int)v.size() <= cap && !v.empty()) memcpy(out, v.data(), v.size() * sizeof(int));
+    return (int)v.size();
+}
+
+} /* extern "C" */

@@ -1,0 +1,249 @@
+"""ctypes loader for the TEST-ONLY CPU oracle (oracle/liborb_oracle.so) and oracle/_ref.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+_lib = None
+_ref = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liborb_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orbo_create.restype = C.c_void_p
+        L.orbo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_destroy.argtypes = [C.c_void_p]
+        L.orbo_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orbo_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbo_pyramid_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.orbo_level_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbo_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orbo_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_level_keys.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_size_t]
+        L.orbo_fast_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int]
+        L.orbo_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbo_fast_atan2.restype = C.c_float
+        L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.orbo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbo_cosf.restype = C.c_float
+        L.orbo_cosf.argtypes = [C.c_float]
+        L.orbo_sinf.restype = C.c_float
+        L.orbo_sinf.argtypes = [C.c_float]
+        L.orbo_cv_round_f.argtypes = [C.c_float]
+        L.orbo_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_int]
+        L.orbo_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbo_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+        L.orbo_search_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                       C.c_int]
+        L.orbo_grid_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref_rosten():
+    """The reference's own Rosten FAST (oracle/_ref/libref_rosten.so) or None if it was never built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(HERE, "_ref", "libref_rosten.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_fast9_detect_nonmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int]
+        _ref = R
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """orbo::Extractor == the reference's FExtractor (fextractor.h:26-91)."""
+
+    def __init__(self, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=7, taps=None, atan_fma=0):
+        self.L = lib()
+        t = None
+        if taps is not None:
+            self._taps = np.asarray(taps, dtype=np.int32)
+            t = _p(self._taps)
+        self.h = self.L.orbo_create(nfeatures, scale, nlevels, ini_th, min_th, t, atan_fma)
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbo_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orbo_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(quota), _p(umax))
+        return dict(scale=sf, inv_scale=isf, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def compute(self, img, lap=(0, 0)):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures * 2 + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        mono = self.L.orbo_compute(self.h, _p(img), w, h, img.strides[0], lap[0], lap[1], _p(kps), _p(desc),
+                                   cap, C.byref(n))
+        if mono == -2:
+            raise RuntimeError("oracle output capacity too small")
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono
+
+    def pyramid_only(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self.L.orbo_pyramid_only(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0])
+
+    def level(self, lvl, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self.L.orbo_level_size(self.h, lvl, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        rc = self.L.orbo_level_copy(self.h, lvl, int(blurred), _p(out))
+        return out if rc == 0 else None
+
+    def candidates(self, lvl):
+        n = self.L.orbo_candidates(self.h, lvl, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orbo_candidates(self.h, lvl, _p(out), n)
+        return out[:n]
+
+    def level_keys(self, lvl):
+        n = self.L.orbo_level_keys(self.h, lvl, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orbo_level_keys(self.h, lvl, _p(out), n)
+        return out[:n]
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_resize(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dst.strides[0])
+    return dst
+
+
+def fast_detect(img, th, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(max(cap, 1), KP_DTYPE)
+    n = lib().orbo_fast_detect(_p(img), img.shape[1], img.shape[0], img.strides[0], th, int(nonmax), _p(out),
+                               cap)
+    return out[:n]
+
+
+def ref_fast9(img, th):
+    """The REFERENCE's Rosten fast9_detect_nonmax<true> -> (n,3) int array of x,y,score."""
+    R = ref_rosten()
+    if R is None:
+        return None
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros((max(cap, 1), 3), np.int32)
+    n = R.ref_fast9_detect_nonmax(_p(img), img.shape[1], img.shape[0], img.strides[0], th, _p(out), cap)
+    return out[:n]
+
+
+def blur7(img, taps=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    t = None
+    if taps is not None:
+        taps = np.asarray(taps, np.int32)
+        t = _p(taps)
+    lib().orbo_blur7(_p(img), img.shape[1], img.shape[0], _p(out), t)
+    return out
+
+
+def fast_atan2(y, x, fma=0):
+    return lib().orbo_fast_atan2(float(y), float(x), fma)
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbo_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_matrix(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.zeros((a.shape[0], b.shape[0]), np.uint16)
+    lib().orbo_hamming_matrix(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+    return out
+
+
+def distribute_octree(keys, minX, maxX, minY, maxY, N):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    out = np.zeros(len(keys) + 8, KP_DTYPE)
+    n = lib().orbo_distribute_octree(_p(keys), len(keys), minX, maxX, minY, maxY, N, _p(out), len(out))
+    return out[:n]
+
+
+def stereo(exL, exR, kpsL, descL, kpsR, descR, bf, fx):
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8)
+    descR = np.ascontiguousarray(descR, np.uint8)
+    n = len(kpsL)
+    u = np.zeros(n, np.float32)
+    d = np.zeros(n, np.float32)
+    bi = np.zeros(n, np.int32)
+    bs = np.zeros(n, np.int32)
+    lib().orbo_stereo(exL.h, exR.h, _p(kpsL), n, _p(descL), _p(kpsR), len(kpsR), _p(descR), bf, fx, _p(u),
+                      _p(d), _p(bi), _p(bs))
+    return u, d, bi, bs
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, W, H, prev_matched=None, window=100, nnratio=0.9,
+                              check_ori=True):
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    if prev_matched is None:
+        prev_matched = np.stack([kps1["x"], kps1["y"]], 1)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m = np.full(len(kps1), -1, np.int32)
+    nm = lib().orbo_search_init(_p(kps1), len(kps1), _p(desc1), _p(kps2), len(kps2), _p(desc2), W, H, _p(pm),
+                                _p(m), window, nnratio, int(check_ori))
+    return nm, m, pm
+
+
+def grid_query(kps, W, H, x, y, r, min_level, max_level):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(len(kps) + 1, np.int32)
+    n = lib().orbo_grid_query(_p(kps), len(kps), W, H, x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n]

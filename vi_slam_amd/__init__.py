@@ -1,0 +1,277 @@
+"""vi_slam_amd -- MI355X-native ORB front-end (extract + Hamming match) behind vi_slam's FExtractor /
+FMatcher / Frame interface.
+
+This package is a thin ctypes mirror of the C ABI in include/vslam_fe.h (libvslam_fe.so, hand-written
+HIP for gfx950).  There is NO CPU fallback: constructing an extractor without the built library or
+without a GPU raises.  The reference-side names are kept (FExtractor.compute, GetScaleFactors,
+FMatcher.DescriptorDistance / SearchForInitialization, Frame.ComputeStereoMatches) so tests read like
+the reference's call sites (src/datastructures/frame.cpp:107-127,289; src/core/tracking.cpp:2323-2324).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvslam_fe.so")
+HOST_LIB_PATH = os.path.join(_HERE, "libvslam_host.so")
+
+VSLAM_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+FLAG_ATAN_FMA = 1
+MAX_BATCH = 32
+
+#: numpy view of vslam_kp == cv::KeyPoint (28 bytes)
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+# include/vslam_fe.h entry points: every one of these must be exported by libvslam_fe.so
+ABI_SYMBOLS = [
+    "vslam_fe_create", "vslam_fe_destroy", "vslam_last_error", "vslam_fe_tables", "vslam_fe_extract",
+    "vslam_fe_extract_batch", "vslam_fe_level_size", "vslam_fe_level_copy", "vslam_fe_candidates",
+    "vslam_fe_slot_buffers", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
+    "vslam_stereo_match", "vslam_search_for_initialization",
+]
+
+
+class VslamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vslam error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("nfeatures", C.c_int32),
+                ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
+                ("min_th_fast", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),
+                ("flags", C.c_uint32), ("gauss_taps", C.c_int32 * 7)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libvslam_fe.so (the HIP product library).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C vi_slam_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.vslam_fe_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
+        L.vslam_fe_destroy.argtypes = [vp]
+        L.vslam_fe_destroy.restype = None
+        L.vslam_last_error.restype = C.c_char_p
+        L.vslam_fe_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.vslam_fe_extract.argtypes = [vp, vp, C.c_size_t, i, i, vp, vp, i, vp, vp]
+        L.vslam_fe_extract_batch.argtypes = [vp, i, vp, C.c_size_t, i, i, i, vp, vp, i, vp, vp]
+        L.vslam_fe_level_size.argtypes = [vp, i, vp, vp]
+        L.vslam_fe_level_copy.argtypes = [vp, i, i, i, vp, C.c_size_t]
+        L.vslam_fe_candidates.argtypes = [vp, i, i, vp, i]
+        L.vslam_fe_slot_buffers.argtypes = [vp, i, vp, vp, vp]
+        L.vslam_fe_stream.argtypes = [vp]
+        L.vslam_fe_stream.restype = vp
+        L.vslam_hamming_top2.argtypes = [vp, vp, i, vp, i, vp, vp]
+        L.vslam_hamming_matrix.argtypes = [vp, vp, i, vp, i, vp]
+        L.vslam_stereo_match.argtypes = [vp, i, vp, i, f, f, vp, vp]
+        L.vslam_search_for_initialization.argtypes = [vp, vp, vp, i, vp, vp, i, i, i, vp, vp, i, f, i, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != VSLAM_OK:
+        raise VslamError(rc, lib().vslam_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FExtractor:
+    """vi_slam::geometry::FExtractor (include/vi_slam/geometry/fextractor.h:26-91) on one MI355X.
+
+    Unlike the reference the image size is fixed at construction (pyramids live in HBM) and a context
+    owns `max_batch` image slots so several frames go through each kernel launch.
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, device=0,
+                 max_batch=1, flags=0, gauss_taps=None):
+        L = lib()
+        p = _Params(width, height, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, max_batch,
+                    flags, (C.c_int32 * 7)(*(gauss_taps or [0] * 7)))
+        h = C.c_void_p()
+        _check(L.vslam_fe_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.nfeatures, self.nlevels, self.width, self.height = nfeatures, nlevels, width, height
+        self.scaleFactor = scaleFactor
+        self.max_batch = max_batch
+        self.cap = nfeatures + 4 * nlevels + 8
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vslam_fe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters (fextractor.h:42-62)
+    def _tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        q = np.zeros(n, np.int32)
+        lib().vslam_fe_tables(self._h, _p(sf), _p(isf), _p(s2), _p(is2), _p(q))
+        return sf, isf, s2, is2, q
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return self.scaleFactor
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        return self._tables()[4]
+
+    # ---- compute (fextractor.h:38-40)
+    def compute(self, image, vLappingArea=(0, 0)):
+        """FExtractor::compute.  Returns (keypoints[KP_DTYPE], descriptors[N,32] u8, monoIndex)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        if image.ndim != 2 or image.shape != (self.height, self.width):
+            raise VslamError(ERR_INVALID, "image must be %dx%d CV_8UC1" % (self.width, self.height))
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        _check(lib().vslam_fe_extract(self._h, _p(image), image.strides[0], vLappingArea[0], vLappingArea[1],
+                                      _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def compute_batch(self, images, vLappingArea=(0, 0), device_ptrs=None, pitch=None, to_host=True):
+        """Batched compute: `images` is a list of HxW uint8 arrays (host), or pass `device_ptrs`
+        (list of int device addresses, rows `pitch` bytes apart) for zero-copy HBM-resident input.
+        Returns a list of (keypoints, descriptors, monoIndex); with to_host=False only counts."""
+        if device_ptrs is not None:
+            nimg = len(device_ptrs)
+            ptrs = (C.c_void_p * nimg)(*device_ptrs)
+            on_dev = 1
+            keep = None
+        else:
+            keep = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+            for im in keep:
+                if im.shape != (self.height, self.width):
+                    raise VslamError(ERR_INVALID, "image must be %dx%d CV_8UC1" % (self.width, self.height))
+            nimg = len(keep)
+            ptrs = (C.c_void_p * nimg)(*[im.ctypes.data for im in keep])
+            pitch = self.width
+            on_dev = 0
+        n = (C.c_int * nimg)()
+        mono = (C.c_int * nimg)()
+        if to_host:
+            kps = np.zeros((nimg, self.cap), KP_DTYPE)
+            desc = np.zeros((nimg, self.cap, 32), np.uint8)
+            kp_ptrs = (C.c_void_p * nimg)(*[kps[i].ctypes.data for i in range(nimg)])
+            d_ptrs = (C.c_void_p * nimg)(*[desc[i].ctypes.data for i in range(nimg)])
+        else:
+            kp_ptrs = d_ptrs = None
+        _check(lib().vslam_fe_extract_batch(self._h, nimg, ptrs, pitch, on_dev, vLappingArea[0], vLappingArea[1],
+                                            kp_ptrs, d_ptrs, self.cap, n, mono))
+        if not to_host:
+            return [(n[i], mono[i]) for i in range(nimg)]
+        return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
+
+    # ---- mvImagePyramid (fextractor.h:64)
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().vslam_fe_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def mvImagePyramid(self, level, slot=0, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(lib().vslam_fe_level_copy(self._h, slot, level, int(blurred), _p(out), w))
+        return out
+
+    def candidates(self, level, slot=0):
+        """vToDistributeKeys of the last compute (fextractor.cpp:769-817) for stage-wise parity tests."""
+        n = lib().vslam_fe_candidates(self._h, slot, level, None, 0)
+        if n < 0:
+            _check(n)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        lib().vslam_fe_candidates(self._h, slot, level, _p(out), n)
+        return out[:n]
+
+    def slot_buffers(self, slot=0):
+        """(device address of vslam_kp[n], device address of descriptors, n) of the last compute."""
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        _check(lib().vslam_fe_slot_buffers(self._h, slot, C.byref(k), C.byref(d), C.byref(n)))
+        return k.value, d.value, n.value
+
+    def stream(self):
+        return lib().vslam_fe_stream(self._h)
+
+
+class FMatcher:
+    """vi_slam::geometry::FMatcher (include/vi_slam/geometry/fmatcher.h:70-147), hot-path subset."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # fmatcher.cpp:313-315
+
+    def __init__(self, extractor, nnratio=0.6, checkOri=True):
+        self.fe = extractor
+        self.mfNNratio = nnratio
+        self.mbCheckOrientation = checkOri
+
+    def hamming_top2(self, dev_q, nq, dev_t, nt):
+        """All-pairs DescriptorDistance (fmatcher.cpp:2859-2875) -> two nearest per query."""
+        idx = np.zeros((max(nq, 1), 2), np.int32)
+        dist = np.zeros((max(nq, 1), 2), np.int32)
+        _check(lib().vslam_hamming_top2(self.fe._h, dev_q, nq, dev_t, nt, _p(idx), _p(dist)))
+        return idx[:nq], dist[:nq]
+
+    def hamming_matrix(self, dev_q, nq, dev_t, nt):
+        out = np.zeros((max(nq, 1), max(nt, 1)), np.uint8)
+        _check(lib().vslam_hamming_matrix(self.fe._h, dev_q, nq, dev_t, nt, _p(out)))
+        return out[:nq, :nt]
+
+    def SearchForInitialization(self, kps1, dev_desc1, kps2, dev_desc2, vbPrevMatched, windowSize=10,
+                                img_size=None):
+        """FMatcher::SearchForInitialization (fmatcher.cpp:983-1098).
+
+        kps1/kps2: host keypoint arrays; dev_desc1/2: device addresses of their descriptors.
+        Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        pm = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m = np.full(max(len(kps1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        w, h = img_size or (self.fe.width, self.fe.height)
+        _check(lib().vslam_search_for_initialization(self.fe._h, _p(kps1), dev_desc1, len(kps1), _p(kps2),
+                                                     dev_desc2, len(kps2), w, h, _p(pm), _p(m), windowSize,
+                                                     self.mfNNratio, int(self.mbCheckOrientation),
+                                                     C.byref(nm)))
+        return nm.value, m[:len(kps1)], pm
+
+
+def ComputeStereoMatches(feL, slotL, feR, slotR, bf, fx):
+    """Frame::ComputeStereoMatches (frame.cpp:823-997) -> (mvuRight, mvDepth) for the left keypoints."""
+    _, _, n = feL.slot_buffers(slotL)
+    u = np.full(max(n, 1), -1, np.float32)
+    d = np.full(max(n, 1), -1, np.float32)
+    _check(lib().vslam_stereo_match(feL._h, slotL, feR._h, slotR, bf, fx, _p(u), _p(d)))
+    return u[:n], d[:n]

@@ -1,0 +1,56 @@
+/* vslam_device.h -- structs shared by the host context (vslam_fe.hip) and the kernels. */
+#ifndef VSLAM_DEVICE_H
+#define VSLAM_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vslam_fe.h"
+
+#define VSLAM_EDGE 19        /* EDGE_THRESHOLD, fextractor.cpp:66 */
+#define VSLAM_BORDER 16      /* EDGE_THRESHOLD-3: FAST cells start here, fextractor.cpp:764 */
+#define VSLAM_HALF_PATCH 15  /* HALF_PATCH_SIZE, fextractor.cpp:65 */
+
+/* One pyramid level of the context geometry (identical for every image slot). */
+struct LevelGeom {
+    int32_t w, h;        /* level size: cvRound(cols*inv), cvRound(rows*inv), fextractor.cpp:1139-1140 */
+    int32_t pitch;       /* bytes per row in the slot buffers (multiple of 128) */
+    uint32_t off;        /* byte offset of the level inside a slot's pyramid / blur buffer */
+    float scale;         /* mvScaleFactor[level] */
+    int32_t pad[3];
+};
+
+struct PyramidGeom {
+    int32_t nlevels;
+    int32_t pad[3];
+    LevelGeom lv[VSLAM_MAX_LEVELS];
+};
+
+/* Level-0 sources of the current batch: internal staging or caller device memory (zero copy). */
+struct BatchSrc {
+    const uint8_t* l0[VSLAM_MAX_BATCH];
+    uint32_t pitch0[VSLAM_MAX_BATCH];
+};
+
+/* One executed FAST cell (fextractor.cpp:780-819): window [x0,x1) x [y0,y1) in level coordinates. */
+struct CellDesc {
+    uint16_t level, x0, y0, x1, y1, pad;
+};
+
+/* Per-slot candidate region, contiguous so one D2H moves header + cell table + candidates:
+ *   uint32 total; uint32 overflow; CellOut cells[ncells]; uint32 cand[cap]
+ * cand = (score << 24) | ((y-16) << 12) | (x-16), level coordinates. */
+struct CellOut {
+    uint32_t base, count;
+};
+
+/* A keypoint chosen by the quadtree, as the orientation/descriptor kernel wants it. */
+struct SelKp {
+    uint16_t x, y;     /* level coordinates */
+    uint8_t level, slot;
+    uint8_t response;  /* FAST score (cv::KeyPoint::response is this integer as float) */
+    uint8_t pad;
+    uint32_t out;      /* index into the slot's output arrays (lapping-area order, fextractor.cpp:1118-1127) */
+};
+
+#endif

@@ -1,0 +1,691 @@
+/* vslam_fe.hip -- the C ABI of include/vslam_fe.h: context, memory layout in HBM, launch sequence.
+ *
+ * Per batch of image slots the extractor issues, on ONE stream:
+ *     [H2D level 0 | zero-copy]  ->  7 x k_resize_level  ->  k_fast_cells  ->  D2H candidates (event)
+ *     ->  k_blur7 (overlaps the host quadtree)  ->  H2D selected keypoints  ->  k_orient_describe
+ *     ->  D2H keypoints + descriptors
+ * The quadtree distribution (FExtractor::DistributeOctTree) is sequential by construction and runs on
+ * the host, one task per (slot, level), on a small worker pool.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vslam_orb_pattern.h"
+#include "vslam_host.h"
+#include "vslam_kernels.h"
+
+static thread_local std::string g_err;
+extern "C" const char* vslam_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return VSLAM_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+/* ------------------------------------------------------------------ tiny worker pool */
+class WorkerPool {
+public:
+    explicit WorkerPool(int n) : stop_(false), next_(0), total_(0), pending_(0), gen_(0) {
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            next_.store(0);
+            total_ = n;
+            pending_ = n;
+            gen_++;
+        }
+        cv_.notify_all();
+        run();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= total_) break;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> l(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            run();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    bool stop_;
+    std::atomic<int> next_;
+    int total_, pending_;
+    unsigned long gen_;
+    const std::function<void(int)>* fn_ = nullptr;
+};
+
+/* ------------------------------------------------------------------ context */
+struct vslam_fe {
+    vslam_fe_params p;
+    vslam::ExtractorTables tab;
+    PyramidGeom geom;
+    size_t slot_stride = 0; /* bytes per slot in d_pyr / d_blur */
+    int B = 1, cap = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_cand = nullptr;
+
+    uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;
+    /* resize tables, one set per destination level >= 1 */
+    uint16_t* d_xtab[VSLAM_MAX_LEVELS] = {};
+    int16_t* d_xa[VSLAM_MAX_LEVELS] = {};
+    uint16_t* d_ytab[VSLAM_MAX_LEVELS] = {};
+    int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
+    /* FAST cells */
+    std::vector<vslam::HostCell> cells;
+    int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};
+    CellDesc* d_cells = nullptr;
+    int tile_pitch = 0, tile_rows = 0, max_px = 0;
+    /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
+    uint8_t* d_cand = nullptr;
+    uint8_t* h_cand = nullptr; /* pinned */
+    size_t cand_stride = 0;
+    int cand_cap = 0;
+    /* blur tiles */
+    uint32_t* d_blur_tiles = nullptr;
+    int n_blur_tiles = 0;
+    int32_t taps[7];
+    /* selection + outputs */
+    SelKp* d_sel = nullptr;
+    SelKp* h_sel = nullptr; /* pinned, B*cap */
+    vslam_kp* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    vslam_kp* h_kps = nullptr; /* pinned staging, B*cap */
+    uint8_t* h_desc = nullptr;
+    int8_t* d_pattern = nullptr;
+    BatchSrc src;
+    int n_out[VSLAM_MAX_BATCH] = {};
+    int mono_out[VSLAM_MAX_BATCH] = {};
+    std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
+    std::vector<std::vector<vslam::Cand>> cand_level;
+    /* matcher scratch (grown on demand) */
+    uint32_t* d_part = nullptr;
+    size_t part_bytes = 0;
+    int32_t* d_idx2 = nullptr;
+    int32_t* d_dist2 = nullptr;
+    size_t top2_cap = 0;
+    uint8_t* d_dmat = nullptr;
+    size_t dmat_bytes = 0;
+    uint8_t* d_tmp_desc[2] = {nullptr, nullptr};
+    size_t tmp_desc_bytes[2] = {0, 0};
+    /* stereo scratch */
+    void* d_stereo = nullptr;
+    size_t stereo_bytes = 0;
+
+    WorkerPool* pool = nullptr;
+};
+
+static void free_ctx(vslam_fe* fe) {
+    if (!fe) return;
+    if (fe->stream) hipStreamSynchronize(fe->stream);
+    delete fe->pool;
+    hipFree(fe->d_pyr);
+    hipFree(fe->d_blur);
+    for (int l = 0; l < VSLAM_MAX_LEVELS; l++) {
+        hipFree(fe->d_xtab[l]);
+        hipFree(fe->d_xa[l]);
+        hipFree(fe->d_ytab[l]);
+        hipFree(fe->d_yb[l]);
+    }
+    hipFree(fe->d_cells);
+    hipFree(fe->d_cand);
+    if (fe->h_cand) hipHostFree(fe->h_cand);
+    hipFree(fe->d_blur_tiles);
+    hipFree(fe->d_sel);
+    if (fe->h_sel) hipHostFree(fe->h_sel);
+    hipFree(fe->d_kps);
+    hipFree(fe->d_desc);
+    if (fe->h_kps) hipHostFree(fe->h_kps);
+    if (fe->h_desc) hipHostFree(fe->h_desc);
+    hipFree(fe->d_pattern);
+    hipFree(fe->d_part);
+    hipFree(fe->d_idx2);
+    hipFree(fe->d_dist2);
+    hipFree(fe->d_dmat);
+    hipFree(fe->d_tmp_desc[0]);
+    hipFree(fe->d_tmp_desc[1]);
+    hipFree(fe->d_stereo);
+    if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
+    if (fe->stream) hipStreamDestroy(fe->stream);
+    delete fe;
+}
+
+extern "C" void vslam_fe_destroy(vslam_fe* fe) {
+    if (fe) hipSetDevice(fe->p.device);
+    free_ctx(fe);
+}
+
+template <typename T>
+static int upload(T** dst, const void* src, size_t bytes) {
+    HIPCHK(hipMalloc((void**)dst, bytes ? bytes : 4));
+    if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return VSLAM_OK;
+}
+
+static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
+    const vslam_fe_params& p = fe->p;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p.device >= ndev) {
+        g_err = "no usable HIP device (this library has no CPU fallback)";
+        return VSLAM_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(p.device));
+    (void)pp;
+    vslam::build_tables(p.nfeatures, p.scale_factor, p.nlevels, fe->tab);
+    fe->B = p.max_batch;
+    fe->cap = p.nfeatures + 4 * p.nlevels + 8;
+    static const int32_t def_taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    bool zero = true;
+    for (int i = 0; i < 7; i++) zero = zero && p.gauss_taps[i] == 0;
+    for (int i = 0; i < 7; i++) fe->taps[i] = zero ? def_taps[i] : p.gauss_taps[i];
+
+    /* geometry: level sizes, pitches, offsets (level 0 staging included at offset 0) */
+    memset(&fe->geom, 0, sizeof(fe->geom));
+    fe->geom.nlevels = p.nlevels;
+    size_t off = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        int lw, lh;
+        vslam::level_size(fe->tab, p.width, p.height, l, &lw, &lh);
+        LevelGeom& g = fe->geom.lv[l];
+        g.w = lw;
+        g.h = lh;
+        g.pitch = (lw + 127) & ~127;
+        g.off = (uint32_t)off;
+        g.scale = fe->tab.scale[l];
+        off += (size_t)g.pitch * lh;
+        off = (off + 255) & ~(size_t)255;
+        if (lw < 40 || lh < 40 || lw > 4095 + 32 || lh > 4095 + 32) {
+            g_err = "image too small/large for this level count";
+            return VSLAM_ERR_UNSUPPORTED;
+        }
+        /* DistributeOctTree needs nIni = round(W/H) >= 1 (fextractor.cpp:534) */
+        if ((int)std::round((float)(lw - 32) / (float)(lh - 32)) < 1) {
+            g_err = "portrait aspect ratio: the reference's DistributeOctTree has nIni == 0 (undefined)";
+            return VSLAM_ERR_UNSUPPORTED;
+        }
+    }
+    fe->slot_stride = off;
+    HIPCHK(hipMalloc((void**)&fe->d_pyr, fe->slot_stride * fe->B));
+    HIPCHK(hipMalloc((void**)&fe->d_blur, fe->slot_stride * fe->B));
+    HIPCHK(hipMemset(fe->d_pyr, 0, fe->slot_stride * fe->B));
+    HIPCHK(hipMemset(fe->d_blur, 0, fe->slot_stride * fe->B));
+
+    for (int l = 1; l < p.nlevels; l++) {
+        vslam::ResizeTables r;
+        const LevelGeom &s = fe->geom.lv[l - 1], &d = fe->geom.lv[l];
+        vslam::build_resize_tables(s.w, s.h, d.w, d.h, r);
+        int rc;
+        if ((rc = upload(&fe->d_xtab[l], r.xtab.data(), r.xtab.size() * 2))) return rc;
+        if ((rc = upload(&fe->d_xa[l], r.xa.data(), r.xa.size() * 2))) return rc;
+        if ((rc = upload(&fe->d_ytab[l], r.ytab.data(), r.ytab.size() * 2))) return rc;
+        if ((rc = upload(&fe->d_yb[l], r.yb.data(), r.yb.size() * 2))) return rc;
+    }
+
+    /* FAST cells */
+    size_t total_px = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        fe->level_cell_first[l] = (int)fe->cells.size();
+        vslam::build_cells(l, fe->geom.lv[l].w, fe->geom.lv[l].h, fe->cells);
+        total_px += (size_t)fe->geom.lv[l].w * fe->geom.lv[l].h;
+    }
+    fe->level_cell_first[p.nlevels] = (int)fe->cells.size();
+    int maxw = 8, maxh = 8;
+    std::vector<CellDesc> dc(fe->cells.size());
+    for (size_t i = 0; i < fe->cells.size(); i++) {
+        const vslam::HostCell& c = fe->cells[i];
+        dc[i].level = c.level; dc[i].x0 = c.x0; dc[i].y0 = c.y0; dc[i].x1 = c.x1; dc[i].y1 = c.y1; dc[i].pad = 0;
+        maxw = std::max(maxw, c.x1 - c.x0);
+        maxh = std::max(maxh, c.y1 - c.y0);
+    }
+    fe->tile_pitch = (maxw + 3) & ~3;
+    fe->tile_rows = maxh;
+    fe->max_px = (maxw - 6) * (maxh - 6);
+    if (fe->max_px > 8192) {
+        g_err = "FAST cell larger than 8192 px";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    {
+        int rc;
+        if ((rc = upload(&fe->d_cells, dc.data(), dc.size() * sizeof(CellDesc)))) return rc;
+    }
+    const int ncells = (int)fe->cells.size();
+    /* a strict 3x3 local maximum needs its own 2x2 block at least: <= total_px/4 candidates; real images
+     * stay far below; size for 1/10 of the pixels and report overflow as an error */
+    fe->cand_cap = (int)std::max<size_t>(total_px / 10, 4096);
+    fe->cand_stride = (8 + (size_t)ncells * sizeof(CellOut) + (size_t)fe->cand_cap * 4 + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc((void**)&fe->d_cand, fe->cand_stride * fe->B));
+    HIPCHK(hipHostMalloc((void**)&fe->h_cand, fe->cand_stride * fe->B, hipHostMallocDefault));
+
+    /* blur tiles */
+    std::vector<uint32_t> tiles;
+    for (int l = 0; l < p.nlevels; l++) {
+        const int tx = (fe->geom.lv[l].w + 63) / 64, ty = (fe->geom.lv[l].h + 15) / 16;
+        for (int y = 0; y < ty; y++)
+            for (int x = 0; x < tx; x++) tiles.push_back(((uint32_t)l << 24) | ((uint32_t)y << 12) | (uint32_t)x);
+    }
+    fe->n_blur_tiles = (int)tiles.size();
+    {
+        int rc;
+        if ((rc = upload(&fe->d_blur_tiles, tiles.data(), tiles.size() * 4))) return rc;
+        if ((rc = upload(&fe->d_pattern, VSLAM_ORB_PATTERN, 1024))) return rc;
+    }
+    vk_upload_disc(fe->tab.disc_u.data(), fe->tab.disc_v.data(), (int)fe->tab.disc_u.size());
+
+    const size_t nk = (size_t)fe->B * fe->cap;
+    HIPCHK(hipMalloc((void**)&fe->d_sel, nk * sizeof(SelKp)));
+    HIPCHK(hipHostMalloc((void**)&fe->h_sel, nk * sizeof(SelKp), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&fe->d_kps, nk * sizeof(vslam_kp)));
+    HIPCHK(hipMalloc((void**)&fe->d_desc, nk * 32));
+    HIPCHK(hipHostMalloc((void**)&fe->h_kps, nk * sizeof(vslam_kp), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&fe->h_desc, nk * 32, hipHostMallocDefault));
+    HIPCHK(hipMemset(fe->d_kps, 0, nk * sizeof(vslam_kp)));
+    HIPCHK(hipMemset(fe->d_desc, 0, nk * 32));
+
+    HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
+    fe->sel_level.resize((size_t)fe->B * p.nlevels);
+    fe->cand_level.resize((size_t)fe->B * p.nlevels);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = (int)std::min<unsigned>(hw ? hw : 4, 16) - 1;
+    nthreads = std::min(nthreads, fe->B * p.nlevels - 1);
+    fe->pool = new WorkerPool(std::max(nthreads, 0));
+    HIPCHK(hipDeviceSynchronize());
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_create(const vslam_fe_params* p, vslam_fe** out) {
+    if (!p || !out) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    if (p->width <= 0 || p->height <= 0 || p->nfeatures <= 0 || p->nlevels < 1 ||
+        p->nlevels > VSLAM_MAX_LEVELS || p->scale_factor <= 1.0f || p->max_batch < 1 ||
+        p->max_batch > VSLAM_MAX_BATCH || p->min_th_fast < 1 || p->ini_th_fast < p->min_th_fast ||
+        p->ini_th_fast > 254 || p->nfeatures > 60000) {
+        g_err = "invalid parameters";
+        return VSLAM_ERR_INVALID;
+    }
+    vslam_fe* fe = new vslam_fe();
+    fe->p = *p;
+    int rc = create_impl(p, fe);
+    if (rc != VSLAM_OK) {
+        std::string keep = g_err;
+        free_ctx(fe);
+        g_err = keep;
+        return rc;
+    }
+    *out = fe;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scale, float* sigma2,
+                               float* inv_sigma2, int32_t* quota) {
+    if (!fe) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < fe->p.nlevels; i++) {
+        if (scale) scale[i] = fe->tab.scale[i];
+        if (inv_scale) inv_scale[i] = fe->tab.inv_scale[i];
+        if (sigma2) sigma2[i] = fe->tab.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = fe->tab.inv_sigma2[i];
+        if (quota) quota[i] = fe->tab.quota[i];
+    }
+    return fe->p.nlevels;
+}
+
+extern "C" void* vslam_fe_stream(vslam_fe* fe) { return fe ? (void*)fe->stream : nullptr; }
+
+extern "C" int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h) {
+    if (!fe || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
+    if (w) *w = fe->geom.lv[level].w;
+    if (h) *h = fe->geom.lv[level].h;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurred, uint8_t* dst,
+                                   size_t dst_pitch) {
+    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels || !dst) return VSLAM_ERR_INVALID;
+    const LevelGeom& g = fe->geom.lv[level];
+    if (dst_pitch < (size_t)g.w) return VSLAM_ERR_INVALID;
+    HIPCHK(hipSetDevice(fe->p.device));
+    const uint8_t* s;
+    size_t spitch;
+    if (!blurred && level == 0) {
+        s = fe->src.l0[slot];
+        spitch = fe->src.pitch0[slot];
+        if (!s) return VSLAM_ERR_INVALID;
+    } else {
+        s = (blurred ? fe->d_blur : fe->d_pyr) + (size_t)slot * fe->slot_stride + g.off;
+        spitch = g.pitch;
+    }
+    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, s, spitch, g.w, g.h, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
+/* ------------------------------------------------------------------ extraction */
+static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                       int lap0, int lap1) {
+    const vslam_fe_params& p = fe->p;
+    const int L = p.nlevels;
+    hipStream_t st = fe->stream;
+    HIPCHK(hipSetDevice(p.device));
+
+    /* 1. level 0 */
+    for (int s = 0; s < nimg; s++) {
+        if (!imgs[s]) {
+            g_err = "null image";
+            return VSLAM_ERR_INVALID;
+        }
+        if (on_device) {
+            fe->src.l0[s] = imgs[s];
+            fe->src.pitch0[s] = (uint32_t)pitch;
+        } else {
+            uint8_t* d = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
+            HIPCHK(hipMemcpy2DAsync(d, fe->geom.lv[0].pitch, imgs[s], pitch, p.width, p.height,
+                                    hipMemcpyHostToDevice, st));
+            fe->src.l0[s] = d;
+            fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
+        }
+    }
+    /* 2. candidate headers (total, overflow) */
+    HIPCHK(hipMemset2DAsync(fe->d_cand, fe->cand_stride, 0, 8, nimg, st));
+    /* 3. pyramid */
+    for (int l = 1; l < L; l++)
+        vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
+                        fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
+    /* 4. FAST */
+    const int ncells = (int)fe->cells.size();
+    vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, ncells, fe->d_cand,
+                  fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch, fe->tile_rows,
+                  fe->max_px, nimg);
+    /* 5. candidates to the host; first chunk speculatively, the rest only if a slot needs it */
+    const size_t hdr_bytes = 8 + (size_t)ncells * sizeof(CellOut);
+    const size_t first_cands = std::min<size_t>((size_t)fe->cand_cap, 40960);
+    HIPCHK(hipMemcpy2DAsync(fe->h_cand, fe->cand_stride, fe->d_cand, fe->cand_stride,
+                            hdr_bytes + first_cands * 4, nimg, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(fe->ev_cand, st));
+    /* 6. blur runs while the host distributes */
+    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
+             fe->taps, nimg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(fe->ev_cand));
+    bool need_more = false;
+    for (int s = 0; s < nimg; s++) {
+        const uint32_t* hdr = (const uint32_t*)(fe->h_cand + (size_t)s * fe->cand_stride);
+        if (hdr[1]) {
+            g_err = "FAST candidate buffer overflow";
+            return VSLAM_ERR_CAPACITY;
+        }
+        if (hdr[0] > first_cands) need_more = true;
+    }
+    if (need_more) {
+        HIPCHK(hipMemcpy2DAsync(fe->h_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
+                                fe->d_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
+                                ((size_t)fe->cand_cap - first_cands) * 4, nimg, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+
+    /* 7. host: gather per level in cell order, distribute */
+    std::atomic<int> bad(0);
+    fe->pool->parallel_for(nimg * L, [&](int task) {
+        const int s = task / L, l = task % L;
+        const uint8_t* base = fe->h_cand + (size_t)s * fe->cand_stride;
+        const CellOut* co = (const CellOut*)(base + 8);
+        const uint32_t* cand = (const uint32_t*)(base + hdr_bytes);
+        std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)s * L + l];
+        cl.clear();
+        for (int c = fe->level_cell_first[l]; c < fe->level_cell_first[l + 1]; c++) {
+            const uint32_t* q = cand + co[c].base;
+            for (uint32_t k = 0; k < co[c].count; k++) {
+                vslam::Cand cd;
+                cd.x = (int16_t)(q[k] & 0xFFF);
+                cd.y = (int16_t)((q[k] >> 12) & 0xFFF);
+                cd.response = (uint8_t)(q[k] >> 24);
+                cl.push_back(cd);
+            }
+        }
+        const LevelGeom& g = fe->geom.lv[l];
+        if (!vslam::distribute_octree(cl.data(), (int)cl.size(), g.w - 2 * VSLAM_FAST_BORDER,
+                                      g.h - 2 * VSLAM_FAST_BORDER, fe->tab.quota[l],
+                                      fe->sel_level[(size_t)s * L + l]))
+            bad++;
+    });
+    if (bad.load()) {
+        g_err = "DistributeOctTree: nIni == 0";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    /* 8. output order (fextractor.cpp:1071-1129): level-major, lapping-area keypoints from the tail */
+    int nsel = 0;
+    for (int s = 0; s < nimg; s++) {
+        int nk = 0;
+        for (int l = 0; l < L; l++) nk += (int)fe->sel_level[(size_t)s * L + l].size();
+        if (nk > fe->cap) {
+            g_err = "internal keypoint capacity exceeded";
+            return VSLAM_ERR_CAPACITY;
+        }
+        int monoIndex = 0, stereoIndex = nk - 1;
+        for (int l = 0; l < L; l++) {
+            const float scale = fe->tab.scale[l];
+            for (const vslam::Cand& c : fe->sel_level[(size_t)s * L + l]) {
+                const int lx = c.x + VSLAM_FAST_BORDER, ly = c.y + VSLAM_FAST_BORDER;
+                float px = (float)lx;
+                if (l != 0) px = px * scale;
+                SelKp k;
+                k.x = (uint16_t)lx;
+                k.y = (uint16_t)ly;
+                k.level = (uint8_t)l;
+                k.slot = (uint8_t)s;
+                k.response = c.response;
+                k.pad = 0;
+                k.out = (px >= (float)lap0 && px <= (float)lap1) ? (uint32_t)stereoIndex-- : (uint32_t)monoIndex++;
+                fe->h_sel[nsel++] = k;
+            }
+        }
+        fe->n_out[s] = nk;
+        fe->mono_out[s] = monoIndex;
+    }
+    /* 9. orientation + descriptors */
+    if (nsel) {
+        HIPCHK(hipMemcpyAsync(fe->d_sel, fe->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
+        vk_orient_describe(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, nsel,
+                           fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap,
+                           (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0);
+    }
+    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
+                                      int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
+                                      uint8_t* const* desc, int cap, int* n, int* mono_index) {
+    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    int rc = run_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1);
+    if (rc != VSLAM_OK) {
+        hipStreamSynchronize(fe->stream);
+        return rc;
+    }
+    hipStream_t st = fe->stream;
+    const bool want_host = kps && desc;
+    if (want_host) {
+        for (int s = 0; s < nimg; s++) {
+            if (fe->n_out[s] > cap) {
+                hipStreamSynchronize(st);
+                g_err = "caller keypoint capacity too small";
+                return VSLAM_ERR_CAPACITY;
+            }
+            if (fe->n_out[s] == 0) continue;
+            HIPCHK(hipMemcpyAsync(fe->h_kps + (size_t)s * fe->cap, fe->d_kps + (size_t)s * fe->cap,
+                                  (size_t)fe->n_out[s] * sizeof(vslam_kp), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(fe->h_desc + (size_t)s * fe->cap * 32, fe->d_desc + (size_t)s * fe->cap * 32,
+                                  (size_t)fe->n_out[s] * 32, hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (int s = 0; s < nimg; s++) {
+        if (want_host && fe->n_out[s]) {
+            memcpy(kps[s], fe->h_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp));
+            memcpy(desc[s], fe->h_desc + (size_t)s * fe->cap * 32, (size_t)fe->n_out[s] * 32);
+        }
+        if (n) n[s] = fe->n_out[s];
+        if (mono_index) mono_index[s] = fe->mono_out[s];
+    }
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, int lap1,
+                                vslam_kp* kps, uint8_t* desc, int cap, int* n, int* mono_index) {
+    if (!fe || !img || !kps || !desc || !n) {
+        g_err = "invalid arguments";
+        if (mono_index) *mono_index = -1; /* FExtractor::compute returns -1 on an empty image */
+        return VSLAM_ERR_INVALID;
+    }
+    const uint8_t* imgs[1] = {img};
+    vslam_kp* k[1] = {kps};
+    uint8_t* d[1] = {desc};
+    return vslam_fe_extract_batch(fe, 1, imgs, pitch, 0, lap0, lap1, k, d, cap, n, mono_index);
+}
+
+extern "C" int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int cap) {
+    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
+    const std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)slot * fe->p.nlevels + level];
+    for (int i = 0; i < (int)cl.size() && i < cap && out; i++) {
+        out[i].x = (float)cl[i].x;
+        out[i].y = (float)cl[i].y;
+        out[i].size = 7.f;
+        out[i].angle = -1.f;
+        out[i].response = (float)cl[i].response;
+        out[i].octave = 0;
+        out[i].class_id = -1;
+    }
+    return (int)cl.size();
+}
+
+extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, const uint8_t** dev_desc,
+                                     int* n) {
+    if (!fe || slot < 0 || slot >= fe->B) return VSLAM_ERR_INVALID;
+    if (dev_kps) *dev_kps = fe->d_kps + (size_t)slot * fe->cap;
+    if (dev_desc) *dev_desc = fe->d_desc + (size_t)slot * fe->cap * 32;
+    if (n) *n = fe->n_out[slot];
+    return VSLAM_OK;
+}
+
+/* ------------------------------------------------------------------ matcher */
+static int ensure(void** p, size_t* have, size_t want) {
+    if (*have >= want) return VSLAM_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, want));
+    *have = want;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
+                                  int32_t* idx2, int32_t* dist2) {
+    if (!fe || nq < 0 || nt < 0 || nt > 65535 || (nq && (!dev_q || !idx2 || !dist2)) || (nt && !dev_t)) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    if (nq == 0) return VSLAM_OK;
+    HIPCHK(hipSetDevice(fe->p.device));
+    const int ntiles = std::max(vk_hamming_top2_tiles(nt), 1);
+    int rc;
+    if ((rc = ensure((void**)&fe->d_part, &fe->part_bytes, (size_t)nq * ntiles * 8))) return rc;
+    if (fe->top2_cap < (size_t)nq) {
+        hipFree(fe->d_idx2);
+        hipFree(fe->d_dist2);
+        fe->d_idx2 = fe->d_dist2 = nullptr;
+        fe->top2_cap = 0;
+        HIPCHK(hipMalloc((void**)&fe->d_idx2, (size_t)nq * 8));
+        HIPCHK(hipMalloc((void**)&fe->d_dist2, (size_t)nq * 8));
+        fe->top2_cap = nq;
+    }
+    if (nt == 0) HIPCHK(hipMemsetAsync(fe->d_part, 0xFF, (size_t)nq * ntiles * 8, fe->stream));
+    vk_hamming_top2(fe->stream, dev_q, nq, dev_t, nt, fe->d_part, fe->d_idx2, fe->d_dist2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(idx2, fe->d_idx2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipMemcpyAsync(dist2, fe->d_dist2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
+                                    uint8_t* out) {
+    if (!fe || nq < 0 || nt < 0 || (nq && nt && (!dev_q || !dev_t || !out))) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    if (nq == 0 || nt == 0) return VSLAM_OK;
+    HIPCHK(hipSetDevice(fe->p.device));
+    int rc;
+    if ((rc = ensure((void**)&fe->d_dmat, &fe->dmat_bytes, (size_t)nq * nt))) return rc;
+    vk_hamming_matrix(fe->stream, dev_q, nq, dev_t, nt, fe->d_dmat);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, fe->d_dmat, (size_t)nq * nt, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
+/* TEMP stubs (replaced by vslam_match.hip in the next commit) */
+extern "C" int vslam_stereo_match(vslam_fe*, int, vslam_fe*, int, float, float, float*, float*) {
+    g_err = "not implemented yet";
+    return VSLAM_ERR_UNSUPPORTED;
+}
+extern "C" int vslam_search_for_initialization(vslam_fe*, const vslam_kp*, const uint8_t*, int, const vslam_kp*,
+                                               const uint8_t*, int, int, int, float*, int32_t*, int, float, int,
+                                               int*) {
+    g_err = "not implemented yet";
+    return VSLAM_ERR_UNSUPPORTED;
+}

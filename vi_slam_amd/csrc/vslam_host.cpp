@@ -1,0 +1,556 @@
+/* vslam_host.cpp -- see vslam_host.h.  Reference lines are cited per function. */
+#include "vslam_host.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace vslam {
+
+/* cvRound / cvFloor / cvCeil as OpenCV 4.2 defines them on x86-64 (fast_math.hpp): SSE round-to-nearest-even */
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline int cv_floor(float v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+static inline int cv_ceil(float v) {
+    int i = (int)v;
+    return i + (i < v);
+}
+static inline int16_t sat_short(float v) {
+    int iv = cv_round(v);
+    return (int16_t)std::min(std::max(iv, (int)SHRT_MIN), (int)SHRT_MAX);
+}
+
+void build_tables(int nfeatures, float scaleFactorF, int nlevels, ExtractorTables& t) {
+    /* fextractor.cpp:401-461; scaleFactor is a double member initialised from the float argument */
+    const double scaleFactor = scaleFactorF;
+    t.nlevels = nlevels;
+    t.scale.assign(nlevels, 1.0f);
+    t.sigma2.assign(nlevels, 1.0f);
+    for (int i = 1; i < nlevels; i++) {
+        t.scale[i] = (float)(t.scale[i - 1] * scaleFactor);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    t.inv_scale.resize(nlevels);
+    t.inv_sigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+        t.inv_scale[i] = 1.0f / t.scale[i];
+        t.inv_sigma2[i] = 1.0f / t.sigma2[i];
+    }
+    t.quota.assign(nlevels, 0);
+    const float factor = (float)(1.0f / scaleFactor);
+    float want = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        t.quota[level] = cv_round(want);
+        sum += t.quota[level];
+        want *= factor;
+    }
+    t.quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+
+    /* umax (fextractor.cpp:445-460) */
+    const int HP = 15;
+    int v, v0;
+    const int vmax = cv_floor(HP * sqrtf(2.f) / 2 + 1);
+    const int vmin = cv_ceil(HP * sqrtf(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v <= vmax; ++v) t.umax[v] = cv_round(sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+        while (t.umax[v0] == t.umax[v0 + 1]) ++v0;
+        t.umax[v] = v0;
+        ++v0;
+    }
+    t.disc_u.clear();
+    t.disc_v.clear();
+    for (v = -HP; v <= HP; v++) {
+        const int d = t.umax[std::abs(v)];
+        for (int u = -d; u <= d; u++) {
+            t.disc_u.push_back((int8_t)u);
+            t.disc_v.push_back((int8_t)v);
+        }
+    }
+}
+
+void level_size(const ExtractorTables& t, int w, int h, int level, int* lw, int* lh) {
+    const float scale = t.inv_scale[level];
+    *lw = cv_round((float)w * scale);
+    *lh = cv_round((float)h * scale);
+}
+
+void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables& r) {
+    /* OpenCV 4.2 resize.cpp, INTER_LINEAR, depth 8U: coefficients in 11-bit fixed point */
+    const int ONE = 2048;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    r.xtab.resize(2 * dw);
+    r.xa.resize(2 * dw);
+    r.ytab.resize(2 * dh);
+    r.yb.resize(2 * dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; } /* dx >= xmax: D = S[sx] * ONE */
+        r.xtab[2 * dx] = (uint16_t)sx;
+        r.xtab[2 * dx + 1] = (uint16_t)std::min(sx + 1, sw - 1);
+        r.xa[2 * dx] = sat_short((1.f - fx) * ONE);
+        r.xa[2 * dx + 1] = sat_short(fx * ONE);
+    }
+    auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        r.ytab[2 * dy] = (uint16_t)clip(sy, 0, sh);
+        r.ytab[2 * dy + 1] = (uint16_t)clip(sy + 1, 0, sh);
+        r.yb[2 * dy] = sat_short((1.f - fy) * ONE);
+        r.yb[2 * dy + 1] = sat_short(fy * ONE);
+    }
+}
+
+void build_cells(int level, int lw, int lh, std::vector<HostCell>& out) {
+    /* fextractor.cpp:764-797 */
+    const float W = 30;
+    const int minBorderX = VSLAM_FAST_BORDER, minBorderY = VSLAM_FAST_BORDER;
+    const int maxBorderX = lw - VSLAM_FAST_BORDER, maxBorderY = lh - VSLAM_FAST_BORDER;
+    const float width = (float)(maxBorderX - minBorderX);
+    const float height = (float)(maxBorderY - minBorderY);
+    const int nCols = (int)(width / W);
+    const int nRows = (int)(height / W);
+    if (nCols < 1 || nRows < 1) return;
+    const int wCell = (int)std::ceil(width / nCols);
+    const int hCell = (int)std::ceil(height / nRows);
+    for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBorderX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBorderX - 6) continue;
+            if (maxX > maxBorderX) maxX = (float)maxBorderX;
+            HostCell c;
+            c.level = (uint16_t)level;
+            c.x0 = (uint16_t)iniX;
+            c.y0 = (uint16_t)iniY;
+            c.x1 = (uint16_t)maxX;
+            c.y1 = (uint16_t)maxY;
+            if (c.x1 - c.x0 < 7 || c.y1 - c.y0 < 7) continue; /* cv::FAST finds nothing in < 7 px */
+            out.push_back(c);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ quadtree distribution */
+namespace {
+struct QNode {
+    int x0, y0, x1, y1; /* UL.x, UL.y, UR.x(=BR.x), BR.y(=BL.y) */
+    int begin, count;   /* range in the permutation array (vKeys, order preserved) */
+    int prev, next;     /* std::list links */
+    bool noMore;
+};
+
+struct QTree {
+    std::vector<QNode> pool; /* index == creation order (the tie-break key) */
+    std::vector<int> perm, tmp;
+    const Cand* c;
+    int head = -1, tail = -1, size = 0;
+
+    int push_front(const QNode& n) {
+        int id = (int)pool.size();
+        pool.push_back(n);
+        pool[id].prev = -1;
+        pool[id].next = head;
+        if (head >= 0) pool[head].prev = id;
+        head = id;
+        if (tail < 0) tail = id;
+        size++;
+        return id;
+    }
+    int push_back(const QNode& n) {
+        int id = (int)pool.size();
+        pool.push_back(n);
+        pool[id].next = -1;
+        pool[id].prev = tail;
+        if (tail >= 0) pool[tail].next = id;
+        tail = id;
+        if (head < 0) head = id;
+        size++;
+        return id;
+    }
+    void erase(int id) {
+        const int p = pool[id].prev, nx = pool[id].next;
+        if (p >= 0) pool[p].next = nx; else head = nx;
+        if (nx >= 0) pool[nx].prev = p; else tail = p;
+        size--;
+    }
+    /* ExtractorNode::DivideNode (fextractor.cpp:472-528): children in order n1..n4, each keeps the
+     * parent's key order; returns child ids (or -1 if empty) after push_front in that order. */
+    void divide(int id, int child[4]) {
+        const QNode P = pool[id];
+        const int halfX = (P.x1 - P.x0 + 1) >> 1; /* ceil((float)d/2), d >= 0 */
+        const int halfY = (P.y1 - P.y0 + 1) >> 1;
+        const int mx = P.x0 + halfX, my = P.y0 + halfY;
+        int cnt[4] = {0, 0, 0, 0};
+        for (int i = P.begin; i < P.begin + P.count; i++) {
+            const Cand& k = c[perm[i]];
+            const int q = (k.x < mx) ? ((k.y < my) ? 0 : 2) : ((k.y < my) ? 1 : 3);
+            cnt[q]++;
+        }
+        int off[4] = {P.begin, P.begin + cnt[0], P.begin + cnt[0] + cnt[1], P.begin + cnt[0] + cnt[1] + cnt[2]};
+        int w[4] = {off[0], off[1], off[2], off[3]};
+        for (int i = P.begin; i < P.begin + P.count; i++) {
+            const Cand& k = c[perm[i]];
+            const int q = (k.x < mx) ? ((k.y < my) ? 0 : 2) : ((k.y < my) ? 1 : 3);
+            tmp[w[q]++] = perm[i];
+        }
+        memcpy(&perm[P.begin], &tmp[P.begin], sizeof(int) * P.count);
+        const int bx[4][4] = {{P.x0, P.y0, mx, my}, {mx, P.y0, P.x1, my}, {P.x0, my, mx, P.y1}, {mx, my, P.x1, P.y1}};
+        for (int q = 0; q < 4; q++) {
+            child[q] = -1;
+            if (cnt[q] == 0) continue;
+            QNode n;
+            n.x0 = bx[q][0]; n.y0 = bx[q][1]; n.x1 = bx[q][2]; n.y1 = bx[q][3];
+            n.begin = off[q];
+            n.count = cnt[q];
+            n.noMore = cnt[q] == 1;
+            n.prev = n.next = -1;
+            child[q] = push_front(n);
+        }
+    }
+};
+} // namespace
+
+bool distribute_octree(const Cand* cands, int n, int W, int H, int N, std::vector<Cand>& out) {
+    out.clear();
+    const int nIni = (int)std::round((float)W / (float)H);
+    if (nIni < 1) return false;
+    if (n == 0) return true;
+    const float hX = (float)W / nIni;
+    QTree T;
+    T.c = cands;
+    T.perm.resize(n);
+    T.tmp.resize(n);
+    T.pool.reserve(4 * (size_t)std::max(N, 16) + 64);
+
+    /* initial nodes and stable bucketing of the candidates (fextractor.cpp:543-561) */
+    std::vector<int> bucket(n), cnt(nIni + 1, 0);
+    for (int i = 0; i < n; i++) {
+        int b = (int)((float)cands[i].x / hX);
+        if (b >= nIni) b = nIni - 1;
+        bucket[i] = b;
+        cnt[b + 1]++;
+    }
+    for (int b = 0; b < nIni; b++) cnt[b + 1] += cnt[b];
+    {
+        std::vector<int> w(cnt.begin(), cnt.end() - 1);
+        for (int i = 0; i < n; i++) T.perm[w[bucket[i]]++] = i;
+    }
+    for (int i = 0; i < nIni; i++) {
+        QNode ni;
+        ni.x0 = (int)(hX * (float)i);
+        ni.x1 = (int)(hX * (float)(i + 1));
+        ni.y0 = 0;
+        ni.y1 = H;
+        ni.begin = cnt[i];
+        ni.count = cnt[i + 1] - cnt[i];
+        ni.noMore = ni.count == 1;
+        ni.prev = ni.next = -1;
+        if (ni.count == 0) continue; /* erased at fextractor.cpp:572-573 */
+        T.push_back(ni);
+    }
+
+    typedef std::pair<int, int> SP; /* (size, node id); id order == creation order */
+    std::vector<SP> vSize, vPrev;
+    bool bFinish = false;
+    while (!bFinish) {
+        int prevSize = T.size;
+        int nToExpand = 0;
+        vSize.clear();
+        for (int cur = T.head; cur >= 0;) {
+            const int next = T.pool[cur].next;
+            if (!T.pool[cur].noMore) {
+                int ch[4];
+                T.divide(cur, ch);
+                for (int q = 0; q < 4; q++)
+                    if (ch[q] >= 0 && T.pool[ch[q]].count > 1) {
+                        nToExpand++;
+                        vSize.push_back(SP(T.pool[ch[q]].count, ch[q]));
+                    }
+                T.erase(cur);
+            }
+            cur = next;
+        }
+        if (T.size >= N || T.size == prevSize) {
+            bFinish = true;
+        } else if (T.size + nToExpand * 3 > N) {
+            while (!bFinish) {
+                prevSize = T.size;
+                vPrev = vSize;
+                vSize.clear();
+                std::sort(vPrev.begin(), vPrev.end()); /* ascending (size, creation id) */
+                for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+                    int ch[4];
+                    T.divide(vPrev[j].second, ch);
+                    for (int q = 0; q < 4; q++)
+                        if (ch[q] >= 0 && T.pool[ch[q]].count > 1) vSize.push_back(SP(T.pool[ch[q]].count, ch[q]));
+                    T.erase(vPrev[j].second);
+                    if (T.size >= N) break;
+                }
+                if (T.size >= N || T.size == prevSize) bFinish = true;
+            }
+        }
+    }
+    out.reserve(T.size);
+    for (int cur = T.head; cur >= 0; cur = T.pool[cur].next) {
+        const QNode& nd = T.pool[cur];
+        int best = T.perm[nd.begin];
+        int maxResponse = cands[best].response;
+        for (int k = 1; k < nd.count; k++) {
+            const int id = T.perm[nd.begin + k];
+            if (cands[id].response > maxResponse) {
+                best = id;
+                maxResponse = cands[id].response;
+            }
+        }
+        out.push_back(cands[best]);
+    }
+    return true;
+}
+
+/* ------------------------------------------------------------------ matcher host logic */
+void compute_three_maxima(const int* hs, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0; /* fmatcher.cpp:2813-2854 */
+    for (int i = 0; i < L; i++) {
+        const int s = hs[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+void FrameGrid::build(const vslam_kp* k, int n_, int imgW, int imgH) {
+    kps = k;
+    n = n_;
+    minX = 0.0f; maxX = (float)imgW; minY = 0.0f; maxY = (float)imgH; /* frame.cpp:814-820 */
+    invW = (float)COLS / (maxX - minX);                                /* frame.cpp:322-323 */
+    invH = (float)ROWS / (maxY - minY);
+    std::vector<int> cellOf(n, -1);
+    cell_start.assign(COLS * ROWS + 1, 0);
+    for (int i = 0; i < n; i++) { /* PosInGrid, frame.cpp:746-756 */
+        const int px = (int)std::round((k[i].x - minX) * invW);
+        const int py = (int)std::round((k[i].y - minY) * invH);
+        if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+        cellOf[i] = px * ROWS + py;
+        cell_start[cellOf[i] + 1]++;
+    }
+    for (int cidx = 0; cidx < COLS * ROWS; cidx++) cell_start[cidx + 1] += cell_start[cidx];
+    cell_items.resize(cell_start[COLS * ROWS]);
+    std::vector<int> w(cell_start.begin(), cell_start.end() - 1);
+    for (int i = 0; i < n; i++)
+        if (cellOf[i] >= 0) cell_items[w[cellOf[i]]++] = i; /* ascending index inside a cell */
+}
+
+void FrameGrid::query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const {
+    out.clear(); /* frame.cpp:678-744 */
+    const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+    if (nMinCellX >= COLS) return;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - minX + r) * invW));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+    if (nMinCellY >= ROWS) return;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int cidx = ix * ROWS + iy;
+            for (int e = cell_start[cidx]; e < cell_start[cidx + 1]; e++) {
+                const int idx = cell_items[e];
+                const vslam_kp& kp = kps[idx];
+                if (bCheckLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                const float distx = kp.x - x, disty = kp.y - y;
+                if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(idx);
+            }
+        }
+}
+
+int search_for_initialization_replay(const vslam_kp* kps1, int n1, const vslam_kp* kps2, int n2,
+                                     const uint8_t* dmat, const int* row_of_i1, const int* col_of_i2,
+                                     int ncols, int imgW, int imgH, float* prevMatched, int32_t* vnMatches12,
+                                     int windowSize, float mfNNratio, bool checkOri) {
+    /* fmatcher.cpp:983-1098 */
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    FrameGrid grid2;
+    grid2.build(kps2, n2, imgW, imgH);
+    std::vector<int> vIndices2;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;
+        grid2.query(prevMatched[2 * i1], prevMatched[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t* drow = dmat + (size_t)row_of_i1[i1] * ncols;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            const int dist = drow[col_of_i2[i2]];
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        compute_three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (vnMatches12[idx1] >= 0) {
+                    vnMatches12[idx1] = -1;
+                    nmatches--;
+                }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) {
+            prevMatched[2 * i1] = kps2[vnMatches12[i1]].x;
+            prevMatched[2 * i1 + 1] = kps2[vnMatches12[i1]].y;
+        }
+    return nmatches;
+}
+
+} // namespace vslam
+
+/* ---------------------------------------------------------------------------------------------
+ * C hooks for the CPU test-suite (libvslam_host.so); not part of the product ABI.
+ * ------------------------------------------------------------------------------------------- */
+extern "C" {
+
+int vslamh_tables(int nfeatures, float scale, int nlevels, float* sf, float* isf, float* s2, float* is2,
+                  int* quota, int* umax16, int* disc_n) {
+    vslam::ExtractorTables t;
+    vslam::build_tables(nfeatures, scale, nlevels, t);
+    for (int i = 0; i < nlevels; i++) {
+        sf[i] = t.scale[i]; isf[i] = t.inv_scale[i]; s2[i] = t.sigma2[i]; is2[i] = t.inv_sigma2[i];
+        quota[i] = t.quota[i];
+    }
+    for (int i = 0; i < 16; i++) umax16[i] = t.umax[i];
+    *disc_n = (int)t.disc_u.size();
+    return 0;
+}
+
+int vslamh_level_size(int nfeatures, float scale, int nlevels, int w, int h, int level, int* lw, int* lh) {
+    vslam::ExtractorTables t;
+    vslam::build_tables(nfeatures, scale, nlevels, t);
+    vslam::level_size(t, w, h, level, lw, lh);
+    return 0;
+}
+
+/* CPU evaluation of the resize tables exactly as k_resize_level consumes them */
+int vslamh_resize_with_tables(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh,
+                              size_t dstride) {
+    vslam::ResizeTables r;
+    vslam::build_resize_tables(sw, sh, dw, dh, r);
+    for (int dy = 0; dy < dh; dy++)
+        for (int dx = 0; dx < dw; dx++) {
+            const uint8_t* r0 = src + (size_t)r.ytab[2 * dy] * sstride;
+            const uint8_t* r1 = src + (size_t)r.ytab[2 * dy + 1] * sstride;
+            const int sx0 = r.xtab[2 * dx], sx1 = r.xtab[2 * dx + 1], a0 = r.xa[2 * dx], a1 = r.xa[2 * dx + 1];
+            const int h0 = r0[sx0] * a0 + r0[sx1] * a1, h1 = r1[sx0] * a0 + r1[sx1] * a1;
+            const int b0 = r.yb[2 * dy], b1 = r.yb[2 * dy + 1];
+            dst[(size_t)dy * dstride + dx] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        }
+    return 0;
+}
+
+int vslamh_cells(int level, int lw, int lh, uint16_t* out5, int cap) {
+    std::vector<vslam::HostCell> c;
+    vslam::build_cells(level, lw, lh, c);
+    for (int i = 0; i < (int)c.size() && i < cap; i++) {
+        out5[5 * i] = c[i].level; out5[5 * i + 1] = c[i].x0; out5[5 * i + 2] = c[i].y0;
+        out5[5 * i + 3] = c[i].x1; out5[5 * i + 4] = c[i].y1;
+    }
+    return (int)c.size();
+}
+
+/* keys: n x (x, y, response) int32 triples; returns count, writes triples */
+int vslamh_octree(const int32_t* xyr, int n, int W, int H, int N, int32_t* out_xyr, int cap) {
+    std::vector<vslam::Cand> c(n), o;
+    for (int i = 0; i < n; i++) {
+        c[i].x = (int16_t)xyr[3 * i]; c[i].y = (int16_t)xyr[3 * i + 1]; c[i].response = (uint8_t)xyr[3 * i + 2];
+    }
+    if (!vslam::distribute_octree(c.data(), n, W, H, N, o)) return -1;
+    for (int i = 0; i < (int)o.size() && i < cap; i++) {
+        out_xyr[3 * i] = o[i].x; out_xyr[3 * i + 1] = o[i].y; out_xyr[3 * i + 2] = o[i].response;
+    }
+    return (int)o.size();
+}
+
+int vslamh_grid_query(const vslam_kp* kps, int n, int W, int H, float x, float y, float r, int minL, int maxL,
+                      int* out, int cap) {
+    vslam::FrameGrid g;
+    g.build(kps, n, W, H);
+    std::vector<int> v;
+    g.query(x, y, r, minL, maxL, v);
+    for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+/* dense host replay with a caller-provided full n1 x n2 u8 distance matrix */
+int vslamh_search_init(const vslam_kp* kps1, int n1, const vslam_kp* kps2, int n2, const uint8_t* dmat_full,
+                       int W, int H, float* prevMatched, int32_t* matches12, int window, float nnratio,
+                       int checkOri) {
+    std::vector<int> rows(n1), cols(n2);
+    for (int i = 0; i < n1; i++) rows[i] = i;
+    for (int i = 0; i < n2; i++) cols[i] = i;
+    return vslam::search_for_initialization_replay(kps1, n1, kps2, n2, dmat_full, rows.data(), cols.data(), n2,
+                                                   W, H, prevMatched, matches12, window, nnratio, checkOri != 0);
+}
+
+} /* extern "C" */

@@ -1,0 +1,85 @@
+/* vslam_host.h -- host-side logic of the front-end that involves no GPU call: constructor tables,
+ * resize coefficient tables, the FAST cell list, the sequential quadtree distribution and the
+ * order-dependent matcher replays.  Plain C++17; built into libvslam_fe.so (with the kernels) and into
+ * libvslam_host.so (g++, no HIP) so the CPU test-suite can exercise it without a GPU.
+ */
+#ifndef VSLAM_HOST_H
+#define VSLAM_HOST_H
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/vslam_fe.h"
+
+/* EDGE_THRESHOLD-3: the FAST cell grid starts 16 px inside the level (fextractor.cpp:764-767) */
+#define VSLAM_FAST_BORDER 16
+
+namespace vslam {
+
+/* FExtractor constructor tables (fextractor.cpp:401-461). */
+struct ExtractorTables {
+    int nlevels = 0;
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota; /* mnFeaturesPerLevel */
+    int umax[16];
+    std::vector<int8_t> disc_u, disc_v; /* flattened radius-15 disc of IC_Angle (fextractor.cpp:75-92) */
+};
+void build_tables(int nfeatures, float scaleFactor, int nlevels, ExtractorTables& t);
+
+/* level sizes (fextractor.cpp:1139-1140) */
+void level_size(const ExtractorTables& t, int w, int h, int level, int* lw, int* lh);
+
+/* cv::resize INTER_LINEAR 8u coefficient tables for one (src -> dst) level pair, in the layout
+ * k_resize_level reads: xtab = {sx, min(sx+1, sw-1)} per dx, xa = {alpha0, alpha1}; ytab = clipped
+ * {sy, sy+1}, yb = {beta0, beta1}. */
+struct ResizeTables {
+    std::vector<uint16_t> xtab, ytab;
+    std::vector<int16_t> xa, yb;
+};
+void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables& r);
+
+/* FAST cell grid of one level (fextractor.cpp:764-797).  Cells are listed in the reference's visiting
+ * order (row-major, skipped cells omitted). */
+struct HostCell {
+    uint16_t level, x0, y0, x1, y1;
+};
+void build_cells(int level, int lw, int lh, std::vector<HostCell>& out);
+
+/* A FAST candidate / selected keypoint in level coordinates relative to the 16-px border. */
+struct Cand {
+    int16_t x, y;
+    uint8_t response;
+};
+
+/* FExtractor::DistributeOctTree (fextractor.cpp:530-754) on integer candidates.
+ * W = maxBorderX - minBorderX, H = maxBorderY - minBorderY, N = mnFeaturesPerLevel[level].
+ * Result order = the reference's lNodes order (front to back).  Tie-break of equal-size nodes in the
+ * "largest first" phase: the node created later is split first (the reference sorts by heap address,
+ * which is not reproducible).  Returns false when nIni < 1 (reference UB). */
+bool distribute_octree(const Cand* cands, int n, int W, int H, int N, std::vector<Cand>& out);
+
+/* FMatcher::ComputeThreeMaxima (fmatcher.cpp:2813-2854) on bin sizes. */
+void compute_three_maxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3);
+
+/* Frame::AssignFeaturesToGrid + GetFeaturesInArea (frame.cpp:386-414, 678-756), undistorted image. */
+struct FrameGrid {
+    static const int COLS = 64, ROWS = 48; /* frame.h:42-43 */
+    float minX, maxX, minY, maxY, invW, invH;
+    std::vector<int> cell_start; /* COLS*ROWS+1, cells indexed ix*ROWS+iy */
+    std::vector<int> cell_items;
+    const vslam_kp* kps;
+    int n;
+    void build(const vslam_kp* k, int n_, int imgW, int imgH);
+    void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const;
+};
+
+/* FMatcher::SearchForInitialization (fmatcher.cpp:983-1098) sequential replay.  dist(i1,i2) is read
+ * from a dense matrix over the octave-0 keypoints of both frames: row r of `dmat` belongs to l0_1[r],
+ * column c to l0_2[c] (map2[i2] = column or -1). */
+int search_for_initialization_replay(const vslam_kp* kps1, int n1, const vslam_kp* kps2, int n2,
+                                     const uint8_t* dmat, const int* row_of_i1, const int* col_of_i2,
+                                     int ncols, int imgW, int imgH, float* prevMatched, int32_t* matches12,
+                                     int windowSize, float nnratio, bool checkOri);
+
+} // namespace vslam
+#endif

@@ -1,0 +1,31 @@
+/* vslam_kernels.h -- launch wrappers implemented in vslam_kernels.hip / vslam_match_kernels.hip. */
+#ifndef VSLAM_KERNELS_H
+#define VSLAM_KERNELS_H
+
+#include "vslam_device.h"
+
+void vk_upload_disc(const int8_t* u, const int8_t* v, int n);
+
+void vk_resize_level(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                     const LevelGeom& sg, const LevelGeom& dg, int src_level, const uint16_t* xtab,
+                     const int16_t* xa, const uint16_t* ytab, const int16_t* yb, int nslots);
+
+void vk_fast_cells(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                   const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                   size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_pitch, int tile_rows,
+                   int max_px, int nslots);
+
+void vk_blur7(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+              const PyramidGeom& g, uint8_t* blur, const uint32_t* tiles, int ntiles, const int32_t taps[7],
+              int nslots);
+
+void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
+                        const BatchSrc& src, const PyramidGeom& g, const SelKp* sel, int nsel,
+                        const int8_t* pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma);
+
+void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out);
+int vk_hamming_top2_tiles(int nt);
+void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
+                     int32_t* idx2, int32_t* dist2);
+
+#endif
