@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the ORB extract + match front-end on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W            # N=1, the driver's default call
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic frames per rank: `--batch` frames go
+through extraction (pyramid, FAST+NMS per cell, quadtree, orientation, blur, rBRIEF) and each frame is
+matched against its predecessor in video order (mono: FMatcher::SearchForInitialization, window 100;
+stereo: Frame::ComputeStereoMatches L<->R).  Frames are dealt round-robin over ranks; the only collective
+is one all-gather of packed result slots per step (mono workload, N>1).  Input frames are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: KITTI-00 mono, 8-level pyramid, 1000 features/frame
+    "kitti00_mono_1241x376_n1000": dict(w=1241, h=376, nf=1000, stereo=False),
+    # configs[2]: KITTI-00 stereo (YAML: 2000 features), L<->R Hamming match
+    "kitti00_stereo_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True),
+    # configs[4]: synthetic 1920x1080 stream, 4000 features/frame
+    "synthetic_stereo_1920x1080_n4000": dict(w=1920, h=1080, nf=4000, stereo=True),
+}
+BF, FX = 386.1448, 718.856  # config/KITTI00-Stereo.yaml Camera.bf, Camera.fx
+
+
+def level_pixels(fe):
+    return [fe.level_size(l)[0] * fe.level_size(l)[1] for l in range(fe.nlevels)]
+
+
+def algorithmic_bytes(fe, nf):
+    """SURVEY.md 8(d) per-image algorithmic bytes of each kernel stage."""
+    px = level_pixels(fe)
+    P = sum(px)
+    return dict(pyramid=(P - px[-1]) + (P - px[0]), fast=P, blur=2 * P, describe=2 * P + 60 * nf, total_px=P)
+
+
+def cpu_baseline(cfg, seconds=12.0):
+    """The oracle (a port of the reference's CPU path, oracle/) timed on this box's host cores: the same
+    workload on a bounded sample of frames, reference-faithful threading (1 thread per image; the two
+    images of a stereo frame on 2 threads, frame.cpp:107-108)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orbo
+    from vi_slam_amd import synth
+    w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    nsample = 6
+    t_end = time.time() + seconds
+    frames = 0
+    t0 = time.time()
+    if stereo:
+        pairs = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
+        eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
+        pool = ThreadPoolExecutor(2)
+        t0 = time.time()
+        while time.time() < t_end:
+            L, R = pairs[frames % nsample]
+            fl = pool.submit(eL.compute, L)
+            fr = pool.submit(eR.compute, R)
+            (kL, dL, _), (kR, dR, _) = fl.result(), fr.result()
+            orbo.stereo(eL, eR, kL, dL, kR, dR, BF, FX)
+            frames += 1
+        cores = 2
+        sample = "%d synthetic stereo frames %dx%d, %d features: 2 threads extract L/R + ComputeStereoMatches" % (
+            frames, w, h, nf)
+    else:
+        imgs = [synth.make_frame(w, h, step=s) for s in range(nsample)]
+        e = orbo.Extractor(nf)
+        prev = None
+        t0 = time.time()
+        while time.time() < t_end:
+            k, d, _ = e.compute(imgs[frames % nsample], lap=(0, 1000))
+            if prev is not None:
+                orbo.search_for_initialization(prev[0], prev[1], k, d, w, h, window=100, nnratio=0.9)
+            prev = (k, d)
+            frames += 1
+        cores = 1
+        sample = "%d synthetic mono frames %dx%d, %d features: extract + SearchForInitialization(prev)" % (
+            frames, w, h, nf)
+    dt = time.time() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=16, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vi_slam_amd as V
+    from vi_slam_amd import dist as vd
+    from vi_slam_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = WORKLOADS[args.workload]
+    w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    B = args.batch
+    if stereo and B % 2:
+        B += 1
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B)
+    matcher = V.FMatcher(fe, 0.9, True)
+    lap = (0, 0) if stereo else (0, 1000)  # frame.cpp:107-108 vs :289
+
+    # ---- synthetic frames, resident in HBM before the timed region
+    pitch = (w + 127) & ~127
+    dev_frames = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(B):
+        if stereo:
+            fr = synth.make_frame(w, h, step=(s // 2) * world + rank, right=bool(s & 1))
+        else:
+            fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world))
+        dev_frames[s, :, :w] = torch.from_numpy(fr).cuda()
+    ptrs = [dev_frames[s].data_ptr() for s in range(B)]
+    slot_bytes = fe.slot_bytes
+    packed = torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
+    carry = torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda")
+    state = {"carry_kps": None, "matches": 0}
+    torch.cuda.synchronize()
+
+    def slot_host_kps(view):
+        hdr = view[:16].cpu().numpy().view(np.int32)
+        n = int(hdr[0])
+        kp = view[16:16 + n * 28].cpu().numpy().view(V.KP_DTYPE)
+        return kp
+
+    def step():
+        res = fe.compute_batch(None, lap, device_ptrs=ptrs, pitch=pitch)
+        if stereo:
+            out = V.ComputeStereoMatchesBatch(fe, list(range(0, B, 2)), fe, list(range(1, B, 2)), BF, FX)
+            state["matches"] = sum(int((u >= 0).sum()) for u, _ in out)
+            return
+        fe.pack_slots(B, packed.data_ptr(), slot_bytes)
+        vd.exchange_slots(packed, gathered)
+        nm_total = 0
+        for s in range(B):
+            pr, ps, prev_step = vd.predecessor(rank, s, world, B)
+            if prev_step:
+                if state["carry_kps"] is None:
+                    continue
+                pview, k_prev = carry, state["carry_kps"]
+            else:
+                pview = vd.slot_view(gathered, pr, ps, B, slot_bytes)
+                k_prev = res[ps][0] if pr == rank else slot_host_kps(pview)
+            k_cur = res[s][0]
+            cview = vd.slot_view(gathered, rank, s, B, slot_bytes)
+            d_prev = pview.data_ptr() + 16 + fe.cap * 28
+            d_cur = cview.data_ptr() + 16 + fe.cap * 28
+            prevm = np.stack([k_prev["x"], k_prev["y"]], 1)
+            nm, _, _ = matcher.SearchForInitialization(k_prev, d_prev, k_cur, d_cur, prevm, 100, (w, h))
+            nm_total += nm
+        # the last frame of this step precedes the first frame of the next one
+        lastv = vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes)
+        carry.copy_(lastv)
+        state["carry_kps"] = res[B - 1][0] if rank == world - 1 else slot_host_kps(lastv)
+        state["matches"] = nm_total
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fe.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = fe.get_profile()
+    fe.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_per_step = (B // 2 if stereo else B) * world
+    value = frames_per_step * args.steps / dt
+
+    if rank == 0:
+        ab = algorithmic_bytes(fe, nf)
+        nb = max(prof["batches"], 1)
+        stage_ms = {"pyramid": prof["pyramid_ms"] / nb, "fast": prof["fast_ms"] / nb, "blur": prof["blur_ms"] / nb,
+                    "describe": prof["describe_ms"] / nb}
+        dom = max(stage_ms, key=stage_ms.get)
+        kernel = {"pyramid": "k_resize_level(x7)", "fast": "k_fast_cells", "blur": "k_blur7",
+                  "describe": "k_orient_describe"}[dom]
+        bytes_per_launch = ab[dom] * B
+        achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "frames/sec ORB extract+match",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "frames_per_step_per_gpu": B // 2 if stereo else B,
+                       "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
+                       "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100",
+                       "sharding": "frames round-robin over ranks; one all-gather of result slots per step"
+                       if not stereo else "stereo frames independent per rank, no collective",
+                       "matches_last_step_rank0": state["matches"]},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": stage_ms[dom], "stage_ms_per_batch": stage_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    fe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,19 @@ int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, cons
 /* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */
 void* vslam_fe_stream(vslam_fe* fe);
 
+/* Pack the results of slots 0..nslots-1 into caller device memory (e.g. this rank's send buffer of an
+ * RCCL all-gather): per slot `slot_bytes` >= 16 + cap*60 laid out as
+ *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = nfeatures + 4*nlevels + 8)
+ * Returns after the copies have completed. */
+int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
+
+/* Stage timing with HIP events on the context's stream (the reference's REGISTER_TIMES spans,
+ * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..3] = pyramid (7 launches), FAST cells,
+ * Gaussian blur, orientation+descriptor, accumulated over `batches` batched calls / `images` images since
+ * profiling was switched on.  Profiling adds one stream synchronisation per extract call. */
+int vslam_fe_set_profiling(vslam_fe* fe, int on);
+int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[4], long* batches, long* images);
+
 /* ---------------------------------------------------------------- matcher (FMatcher / Frame) */
 
 /* FMatcher::DescriptorDistance (fmatcher.h:77, fmatcher.cpp:2859-2875) over device arrays: all-pairs
@@ -128,6 +141,11 @@ int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8
 int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, float bf, float fx, float* u_right,
                        float* depth);
 
+/* The same for npairs (<= 16) stereo pairs in one pass of the kernels: pair j = (feL slot slotsL[j],
+ * feR slot slotsR[j]); u_right[j]/depth[j] are host arrays of that pair's left keypoint count. */
+int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL, const int* slotsR,
+                             float bf, float fx, float* const* u_right, float* const* depth);
+
 /* FMatcher::SearchForInitialization (fmatcher.h:106, fmatcher.cpp:983-1098).  Frame 1 / frame 2
  * keypoints+descriptors are device arrays (e.g. from vslam_fe_slot_buffers, or a slot of an RCCL
  * all-gather buffer); kps1_host/kps2_host are the same keypoints on the host.  prev_matched: 2*n1 floats
@@ -136,6 +154,13 @@ int vslam_search_for_initialization(vslam_fe* fe, const vslam_kp* kps1_host, con
                                     int n1, const vslam_kp* kps2_host, const uint8_t* dev_desc2, int n2,
                                     int img_w, int img_h, float* prev_matched, int32_t* matches12,
                                     int window, float nnratio, int check_orientation, int* nmatches);
+
+/* ---------------------------------------------------------------- diagnostics */
+
+/* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
+ * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
+int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);
+int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, int fma, float* deg);
 
 #ifdef __cplusplus
 }

@@ -145,6 +145,9 @@ void fast_detect(const uint8_t* img, int w, int h, size_t stride, int threshold,
     for (int k = 16; k < N; k++) pixel[k] = pixel[k - 16];
     threshold = std::min(std::max(threshold, 0), 255);
     if (w < 7 || h < 7) return;
+    uint8_t threshold_tab[512];
+    for (int i = -255; i <= 255; i++)
+        threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
 
     std::vector<uint8_t> bufs(3 * (size_t)w, 0);
     std::vector<int> cps(3 * ((size_t)w + 1), 0);
@@ -160,17 +163,31 @@ void fast_detect(const uint8_t* img, int w, int h, size_t stride, int threshold,
         if (i < h - 3) {
             for (int j = 3; j < w - 3; j++, ptr++) {
                 const int v = ptr[0];
+                const uint8_t* tab = &threshold_tab[0] - v + 255;
+                /* FAST_t<16> pre-test: a 9-arc always contains one pixel of each opposite pair */
+                int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+                d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+                d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+                d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+                d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+                d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
                 const int vd = v - threshold, vb = v + threshold;
                 bool corner = false;
-                int count = 0;
-                for (int k = 0; k < N; k++) { /* >= 9 contiguous darker */
-                    if (ptr[pixel[k]] < vd) {
-                        if (++count > K) { corner = true; break; }
-                    } else
-                        count = 0;
+                if (d & 1) {
+                    int count = 0;
+                    for (int k = 0; k < N; k++) { /* >= 9 contiguous darker */
+                        if (ptr[pixel[k]] < vd) {
+                            if (++count > K) { corner = true; break; }
+                        } else
+                            count = 0;
+                    }
                 }
-                if (!corner) {
-                    count = 0;
+                if (!corner && (d & 2)) {
+                    int count = 0;
                     for (int k = 0; k < N; k++) { /* >= 9 contiguous brighter */
                         if (ptr[pixel[k]] > vb) {
                             if (++count > K) { corner = true; break; }
@@ -228,23 +245,32 @@ void gaussian_blur7(const Image& src, Image& dst, const int taps[7]) {
     dst.h = h;
     dst.px.assign((size_t)w * h, 0);
     std::vector<uint16_t> tmp((size_t)w * h);
+    const uint32_t k0 = taps[0], k1 = taps[1], k2 = taps[2], k3 = taps[3], k4 = taps[4], k5 = taps[5], k6 = taps[6];
     for (int y = 0; y < h; y++) {
         const uint8_t* s = src.row(y);
         uint16_t* t = tmp.data() + (size_t)y * w;
-        for (int x = 0; x < w; x++) {
+        auto edge = [&](int x) {
             uint32_t acc = 0;
             for (int k = 0; k < 7; k++) acc += (uint32_t)taps[k] * s[reflect101(x + k - 3, w)];
             t[x] = (uint16_t)std::min<uint32_t>(acc, 0xFFFF); /* ufixedpoint16 adds saturate */
+        };
+        int x = 0;
+        for (; x < std::min(3, w); x++) edge(x);
+        for (; x < w - 3; x++) { /* interior: no border handling, vectorisable */
+            const uint32_t acc = k0 * s[x - 3] + k1 * s[x - 2] + k2 * s[x - 1] + k3 * s[x] + k4 * s[x + 1] +
+                                 k5 * s[x + 2] + k6 * s[x + 3];
+            t[x] = (uint16_t)std::min<uint32_t>(acc, 0xFFFF);
         }
+        for (; x < w; x++) edge(x);
     }
     for (int y = 0; y < h; y++) {
         const uint16_t* r[7];
         for (int k = 0; k < 7; k++) r[k] = tmp.data() + (size_t)reflect101(y + k - 3, h) * w;
         uint8_t* d = dst.row(y);
         for (int x = 0; x < w; x++) {
-            uint32_t acc = 0;
-            for (int k = 0; k < 7; k++) acc += (uint32_t)taps[k] * r[k][x];
-            uint32_t v = (acc + 32768u) >> 16;
+            const uint32_t acc = k0 * r[0][x] + k1 * r[1][x] + k2 * r[2][x] + k3 * r[3][x] + k4 * r[4][x] +
+                                 k5 * r[5][x] + k6 * r[6][x];
+            const uint32_t v = (acc + 32768u) >> 16;
             d[x] = (uint8_t)std::min<uint32_t>(v, 255);
         }
     }

@@ -1,0 +1,196 @@
+"""GPU (-m gpu): the HIP extractor behind the C ABI vs the CPU oracle, bit-exact, stage by stage.
+Mirrors the reference's only test idea: CPU implementation as oracle, exact compare."""
+import os
+
+import numpy as np
+import pytest
+
+import vi_slam_amd as V
+from oracle import orbo
+from vi_slam_amd import synth
+
+from conftest import kp_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(res, ref, tag=""):
+    k, d, m = res
+    ko, do, mo = ref
+    assert len(k) == len(ko), tag
+    for f in k.dtype.names:
+        assert np.array_equal(k[f], ko[f]), (tag, f)
+    assert np.array_equal(d, do), tag
+    assert m == mo, tag
+
+
+@pytest.fixture(scope="module")
+def kitti():
+    fe = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=8)
+    yield fe
+    fe.close()
+
+
+def test_tables_getters(kitti):
+    t = orbo.Extractor(2000).tables()
+    assert kitti.GetLevels() == 8
+    assert np.array_equal(kitti.GetScaleFactors(), t["scale"])
+    assert np.array_equal(kitti.GetInverseScaleFactors(), t["inv_scale"])
+    assert np.array_equal(kitti.GetScaleSigmaSquares(), t["sigma2"])
+    assert np.array_equal(kitti.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+    assert np.array_equal(kitti.features_per_level(), t["quota"])
+
+
+def test_stagewise_parity_kitti(kitti):
+    img = synth.make_frame(1241, 376)
+    res = kitti.compute(img)
+    e = orbo.Extractor(2000)
+    ref = e.compute(img)
+    for l in range(8):
+        assert np.array_equal(kitti.mvImagePyramid(l), e.level(l)), ("pyramid", l)
+        assert np.array_equal(kitti.mvImagePyramid(l, blurred=True), e.level(l, blurred=True)), ("blur", l)
+        ca, cb = kitti.candidates(l), e.candidates(l)
+        assert len(ca) == len(cb) and len(ca) > 100
+        for f in ("x", "y", "response"):
+            assert np.array_equal(ca[f], cb[f]), ("candidates", l, f)
+    _assert_same(res, ref)
+    assert len(res[0]) >= 2000
+
+
+def test_lapping_area_mono_order(kitti):
+    img = synth.make_frame(1241, 376, step=2)
+    _assert_same(kitti.compute(img, (0, 1000)), orbo.Extractor(2000).compute(img, lap=(0, 1000)), "lap")
+
+
+def test_batch_equals_single_and_oracle(kitti):
+    imgs = [synth.make_frame(1241, 376, step=s, right=bool(s & 1)) for s in range(8)]
+    res = kitti.compute_batch(imgs)
+    e = orbo.Extractor(2000)
+    for s in range(8):
+        _assert_same(res[s], e.compute(imgs[s]), "slot %d" % s)
+    # a second, different batch on the same context (stateful pyramids must be fully rewritten)
+    imgs2 = [synth.make_frame(1241, 376, seed=99, step=s) for s in range(3)]
+    res2 = kitti.compute_batch(imgs2)
+    for s in range(3):
+        _assert_same(res2[s], e.compute(imgs2[s]), "second batch %d" % s)
+
+
+def test_device_resident_input_zero_copy(kitti):
+    import torch
+    imgs = [synth.make_frame(1241, 376, step=s) for s in range(2)]
+    pitch = 1280
+    dev = torch.zeros((2, 376, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(2):
+        dev[s, :, :1241] = torch.from_numpy(imgs[s]).cuda()
+    torch.cuda.synchronize()
+    res = kitti.compute_batch(None, device_ptrs=[dev[s].data_ptr() for s in range(2)], pitch=pitch)
+    e = orbo.Extractor(2000)
+    for s in range(2):
+        _assert_same(res[s], e.compute(imgs[s]), "zero-copy %d" % s)
+        assert np.array_equal(kitti.mvImagePyramid(0, slot=s), imgs[s])
+
+
+@pytest.mark.parametrize("cfg", [
+    (1241, 376, 1000, 20, 7),    # BASELINE config 2
+    (1920, 1080, 4000, 20, 7),   # BASELINE config 5
+    (752, 480, 500, 20, 7),      # hut_stereo size
+    (640, 480, 10000, 20, 7),    # 5 x nFeatures initialisation extractor (tracking.cpp:1093)
+    (321, 203, 300, 35, 12),     # odd size, other thresholds
+])
+def test_other_geometries(cfg):
+    w, h, nf, ini, mn = cfg
+    img = synth.make_frame(w, h, seed=w + nf)
+    fe = V.FExtractor(nf, 1.2, 8, ini, mn, w, h)
+    try:
+        _assert_same(fe.compute(img), orbo.Extractor(nf, ini_th=ini, min_th=mn).compute(img), str(cfg))
+    finally:
+        fe.close()
+
+
+def test_low_texture_cells_fall_back_to_min_threshold():
+    # faint texture only: no FAST corner at 20 anywhere, cells must rerun at 7 (fextractor.cpp:803-807)
+    rng = np.random.default_rng(8)
+    img = (128 + rng.integers(-9, 10, (240, 320))).astype(np.uint8)
+    img[100:140, 150:200] += 60  # one strong structure: its cells use iniTh, the rest fall back
+    fe = V.FExtractor(500, 1.2, 8, 20, 7, 320, 240)
+    try:
+        res = fe.compute(img)
+        _assert_same(res, orbo.Extractor(500).compute(img), "fallback")
+        assert (res[0]["response"] < 20).any() and (res[0]["response"] >= 20).any()
+    finally:
+        fe.close()
+
+
+def test_flat_image_gives_no_keypoints():
+    fe = V.FExtractor(500, 1.2, 8, 20, 7, 320, 240)
+    try:
+        k, d, m = fe.compute(np.full((240, 320), 100, np.uint8))
+        assert len(k) == 0 and d.shape == (0, 32) and m == 0
+    finally:
+        fe.close()
+
+
+def test_golden_real_image_crop(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pipeline_hut_320x240.npz"))
+    fe = V.FExtractor(500, 1.2, 8, 20, 7, 320, 240)
+    try:
+        k, d, m = fe.compute(g["L"])
+        assert kp_equal(k, g["kL"]) and np.array_equal(d, g["dL"])
+        assert np.array_equal(fe.mvImagePyramid(3), g["lvl3"])
+        assert np.array_equal(fe.mvImagePyramid(3, blurred=True), g["lvl3_blur"])
+        k, d, m = fe.compute(g["L"], (0, 1000))
+        assert kp_equal(k, g["kM"]) and np.array_equal(d, g["dM"]) and m == int(g["monoIndex"])
+    finally:
+        fe.close()
+
+
+def test_knobs_fma_and_legacy_gauss_taps():
+    img = synth.make_frame(640, 360, seed=5)
+    fe = V.FExtractor(800, 1.2, 8, 20, 7, 640, 360, flags=V.FLAG_ATAN_FMA, gauss_taps=[18, 34, 49, 55, 49, 34, 18])
+    try:
+        ref = orbo.Extractor(800, taps=[18, 34, 49, 55, 49, 34, 18], atan_fma=1).compute(img)
+        _assert_same(fe.compute(img), ref, "knobs")
+    finally:
+        fe.close()
+
+
+def test_device_trig_is_glibc_exact(kitti):
+    """Every float the rotation can see: angle(deg in [0,360]) * (float)(pi/180) plus a dense sweep."""
+    rng = np.random.default_rng(0)
+    deg = np.concatenate([np.linspace(0, 360, 200001, dtype=np.float32),
+                          rng.uniform(0, 360, 300000).astype(np.float32)])
+    x = deg * np.float32(np.pi / 180.0)
+    bits = rng.integers(0, np.float32(6.5).view(np.uint32), 500000, dtype=np.uint32).view(np.float32)
+    x = np.concatenate([x, bits])
+    s, c = V.dbg_sincos(kitti, x)
+    L = orbo.lib()
+    want_s = np.array([L.orbo_sinf(float(v)) for v in x[:20000]], np.float32)
+    want_c = np.array([L.orbo_cosf(float(v)) for v in x[:20000]], np.float32)
+    assert np.array_equal(s[:20000], want_s) and np.array_equal(c[:20000], want_c)
+    # numpy's float32 sin/cos call the same libm on this platform only loosely; check the rest to 1 ulp
+    assert np.all(np.abs(s - np.sin(x.astype(np.float64))) <= np.spacing(np.abs(s)) + 1e-45)
+    assert np.all(np.abs(c - np.cos(x.astype(np.float64))) <= np.spacing(np.abs(c)) + 1e-45)
+
+
+def test_device_fast_atan2_equals_oracle(kitti):
+    rng = np.random.default_rng(1)
+    y = rng.integers(-2_900_000, 2_900_000, 200000).astype(np.float32)
+    x = rng.integers(-2_900_000, 2_900_000, 200000).astype(np.float32)
+    y[:10] = 0
+    x[5:15] = 0
+    for fma in (0, 1):
+        a = V.dbg_fast_atan2(kitti, y, x, fma)
+        want = np.array([orbo.fast_atan2(float(yy), float(xx), fma) for yy, xx in zip(y[:30000], x[:30000])],
+                        np.float32)
+        assert np.array_equal(a[:30000], want)
+        assert np.all((a >= 0) & (a <= 360))
+
+
+def test_errors(kitti):
+    with pytest.raises(V.VslamError):
+        kitti.compute(np.zeros((100, 100), np.uint8))
+    with pytest.raises(V.VslamError):
+        kitti.compute_batch([np.zeros((376, 1241), np.uint8)] * 9)  # > max_batch
+    with pytest.raises(V.VslamError) as ei:
+        V.FExtractor(500, 1.2, 8, 20, 7, 200, 600)  # portrait: nIni == 0 in the reference
+    assert ei.value.code == V.ERR_UNSUPPORTED

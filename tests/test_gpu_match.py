@@ -1,0 +1,172 @@
+"""GPU (-m gpu): Hamming matcher kernels, stereo L<->R matching and the initialisation matcher vs the
+CPU oracle (bit-exact: indices, distances, mvuRight/mvDepth floats)."""
+import os
+
+import numpy as np
+import pytest
+
+import vi_slam_amd as V
+from oracle import orbo
+from vi_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    f = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=8)
+    yield f
+    f.close()
+
+
+def _dev(arr):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+def _top2_ref(q, t):
+    dm = orbo.hamming_matrix(q, t).astype(np.int64)
+    key = dm * 65536 + np.arange(t.shape[0])[None, :]
+    order = np.argsort(key, axis=1, kind="stable")[:, :2]
+    idx = order.astype(np.int32)
+    dist = np.take_along_axis(dm, order, 1).astype(np.int32)
+    return idx, dist
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (63, 257), (64, 256), (500, 300), (2011, 2013), (300, 5000)])
+def test_hamming_top2_and_matrix_random(fe, nq, nt):
+    rng = np.random.default_rng(nq * 7 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    t[rng.integers(0, nt, max(nt // 10, 1))] = q[rng.integers(0, nq, max(nt // 10, 1))]  # exact duplicates -> ties
+    dq, dt = _dev(q), _dev(t)
+    m = V.FMatcher(fe)
+    idx, dist = m.hamming_top2(dq.data_ptr(), nq, dt.data_ptr(), nt)
+    widx, wdist = _top2_ref(q, t)
+    if nt == 1:
+        assert np.array_equal(idx[:, 0], widx[:, 0]) and np.array_equal(dist[:, 0], wdist[:, 0])
+        assert np.all(idx[:, 1] == -1) and np.all(dist[:, 1] == 2**31 - 1)
+    else:
+        assert np.array_equal(idx, widx) and np.array_equal(dist, wdist)
+    dm = m.hamming_matrix(dq.data_ptr(), nq, dt.data_ptr(), nt)
+    assert np.array_equal(dm, np.minimum(orbo.hamming_matrix(q, t), 255).astype(np.uint8))
+
+
+def test_hamming_extremes_and_empty(fe):
+    m = V.FMatcher(fe)
+    q = np.zeros((3, 32), np.uint8)
+    t = np.full((2, 32), 255, np.uint8)
+    dq, dt = _dev(q), _dev(t)
+    idx, dist = m.hamming_top2(dq.data_ptr(), 3, dt.data_ptr(), 2)
+    assert np.all(dist == 256) and np.array_equal(idx, np.tile([0, 1], (3, 1)))
+    assert np.all(m.hamming_matrix(dq.data_ptr(), 3, dt.data_ptr(), 2) == 255)  # saturates
+    idx, dist = m.hamming_top2(dq.data_ptr(), 3, 0, 0)
+    assert np.all(idx == -1)
+    idx, dist = m.hamming_top2(0, 0, dt.data_ptr(), 2)
+    assert idx.shape == (0, 2)
+
+
+def test_hamming_on_real_descriptors_full_size(fe):
+    """BASELINE size (2000 x 2000): extractor output fed straight from HBM."""
+    L, R = synth.make_stereo_pair(1241, 376)
+    (kL, dL, _), (kR, dR, _) = fe.compute_batch([L, R])
+    pk0, pd0, n0 = fe.slot_buffers(0)
+    pk1, pd1, n1 = fe.slot_buffers(1)
+    assert (n0, n1) == (len(kL), len(kR))
+    idx, dist = V.FMatcher(fe).hamming_top2(pd0, n0, pd1, n1)
+    widx, wdist = _top2_ref(dL, dR)
+    assert np.array_equal(idx, widx) and np.array_equal(dist, wdist)
+    # size-independent properties: self-match is distance 0 at own index; symmetric matrix
+    idx, dist = V.FMatcher(fe).hamming_top2(pd0, n0, pd0, n0)
+    assert np.all(dist[:, 0] == 0)
+    dm = V.FMatcher(fe).hamming_matrix(pd0, n0, pd0, n0)
+    assert np.array_equal(dm, dm.T) and np.all(np.diag(dm) == 0)
+
+
+def _stereo_ref(L, R, nf, bf, fx):
+    eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
+    kL, dL, _ = eL.compute(L)
+    kR, dR, _ = eR.compute(R)
+    u, dep, bi, bs = orbo.stereo(eL, eR, kL, dL, kR, dR, bf, fx)
+    return kL, u, dep
+
+
+def test_stereo_matches_kitti_same_context(fe):
+    L, R = synth.make_stereo_pair(1241, 376, step=1)
+    fe.compute_batch([L, R])
+    u, d = V.ComputeStereoMatches(fe, 0, fe, 1, 386.1448, 718.856)
+    kL, wu, wd = _stereo_ref(L, R, 2000, 386.1448, 718.856)
+    assert np.array_equal(u, wu) and np.array_equal(d, wd)
+    ok = u >= 0
+    assert ok.sum() > 300
+    truth = synth.row_disparity(376)[kL["y"][ok].astype(int)]
+    assert np.mean(np.abs((kL["x"][ok] - u[ok]) - truth) < 1.5) > 0.95
+
+
+def test_stereo_two_contexts_like_left_right_extractors():
+    """The reference owns mpORBextractorLeft / mpORBextractorRight (tracking.cpp:1087-1090)."""
+    L, R = synth.make_stereo_pair(752, 480, seed=4)
+    feL = V.FExtractor(1200, 1.2, 8, 20, 7, 752, 480)
+    feR = V.FExtractor(1200, 1.2, 8, 20, 7, 752, 480)
+    try:
+        feL.compute(L)
+        feR.compute(R)
+        u, d = V.ComputeStereoMatches(feL, 0, feR, 0, 40.0, 435.2)
+        _, wu, wd = _stereo_ref(L, R, 1200, 40.0, 435.2)
+        assert np.array_equal(u, wu) and np.array_equal(d, wd) and (u >= 0).sum() > 100
+    finally:
+        feL.close()
+        feR.close()
+
+
+def test_stereo_batch_of_pairs(fe):
+    frames = [synth.make_stereo_pair(1241, 376, step=s) for s in range(4)]
+    imgs = [im for pair in frames for im in pair]
+    fe.compute_batch(imgs)
+    res = V.ComputeStereoMatchesBatch(fe, [0, 2, 4, 6], fe, [1, 3, 5, 7], 386.1448, 718.856)
+    for s in range(4):
+        _, wu, wd = _stereo_ref(frames[s][0], frames[s][1], 2000, 386.1448, 718.856)
+        assert np.array_equal(res[s][0], wu) and np.array_equal(res[s][1], wd), s
+
+
+def test_stereo_golden_real_images(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pipeline_hut_320x240.npz"))
+    f = V.FExtractor(500, 1.2, 8, 20, 7, 320, 240, max_batch=2)
+    try:
+        f.compute_batch([g["L"], g["R"]])
+        u, d = V.ComputeStereoMatches(f, 0, f, 1, 40.0, 400.0)
+        assert np.array_equal(u, g["uRight"]) and np.array_equal(d, g["depth"])
+    finally:
+        f.close()
+
+
+def test_stereo_no_matches_when_right_is_unrelated(fe):
+    L = synth.make_frame(1241, 376, seed=1)
+    R = np.full((376, 1241), 90, np.uint8)  # flat right image: no right keypoints at all
+    fe.compute_batch([L, R])
+    u, d = V.ComputeStereoMatches(fe, 0, fe, 1, 386.1448, 718.856)
+    assert len(u) > 1000 and np.all(u == -1) and np.all(d == -1)
+
+
+@pytest.mark.parametrize("nf,lap", [(1000, (0, 1000)), (2000, (0, 0))])
+def test_search_for_initialization(nf, lap):
+    a = synth.make_frame(1241, 376, step=0)
+    b = synth.make_frame(1241, 376, step=1)
+    f = V.FExtractor(nf, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    try:
+        (k1, d1, _), (k2, d2, _) = f.compute_batch([a, b], lap)
+        _, pd1, n1 = f.slot_buffers(0)
+        _, pd2, n2 = f.slot_buffers(1)
+        prev = np.stack([k1["x"], k1["y"]], 1)
+        m = V.FMatcher(f, 0.9, True)
+        nm, m12, pm = m.SearchForInitialization(k1, pd1, k2, pd2, prev, 100)
+        wn, wm, wp = orbo.search_for_initialization(k1, d1, k2, d2, 1241, 376, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp) and nm > 50
+        # second call with the updated vbPrevMatched and a tighter window (tracking.cpp:2323 loop)
+        nm2, m12b, _ = m.SearchForInitialization(k1, pd1, k2, pd2, pm, 20)
+        wn2, wm2, _ = orbo.search_for_initialization(k1, d1, k2, d2, 1241, 376, prev_matched=wp, window=20)
+        assert nm2 == wn2 and np.array_equal(m12b, wm2)
+    finally:
+        f.close()

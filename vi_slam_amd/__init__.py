@@ -30,7 +30,9 @@ ABI_SYMBOLS = [
     "vslam_fe_create", "vslam_fe_destroy", "vslam_last_error", "vslam_fe_tables", "vslam_fe_extract",
     "vslam_fe_extract_batch", "vslam_fe_level_size", "vslam_fe_level_copy", "vslam_fe_candidates",
     "vslam_fe_slot_buffers", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
-    "vslam_stereo_match", "vslam_search_for_initialization",
+    "vslam_stereo_match", "vslam_stereo_match_batch", "vslam_search_for_initialization",
+    "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
+    "vslam_fe_get_profile",
 ]
 
 
@@ -75,7 +77,13 @@ def lib():
         L.vslam_hamming_top2.argtypes = [vp, vp, i, vp, i, vp, vp]
         L.vslam_hamming_matrix.argtypes = [vp, vp, i, vp, i, vp]
         L.vslam_stereo_match.argtypes = [vp, i, vp, i, f, f, vp, vp]
+        L.vslam_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, f, f, vp, vp]
         L.vslam_search_for_initialization.argtypes = [vp, vp, vp, i, vp, vp, i, i, i, vp, vp, i, f, i, vp]
+        L.vslam_fe_pack_slots.argtypes = [vp, i, vp, C.c_size_t]
+        L.vslam_fe_set_profiling.argtypes = [vp, i]
+        L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
+        L.vslam_dbg_sincos.argtypes = [vp, vp, i, vp, vp]
+        L.vslam_dbg_fast_atan2.argtypes = [vp, vp, vp, i, i, vp]
         _lib = L
     return _lib
 
@@ -226,6 +234,24 @@ class FExtractor:
     def stream(self):
         return lib().vslam_fe_stream(self._h)
 
+    @property
+    def slot_bytes(self):
+        """Bytes of one packed result slot (see vslam_fe_pack_slots), rounded to 256."""
+        return (16 + self.cap * 60 + 255) & ~255
+
+    def pack_slots(self, nslots, dev_dst, slot_bytes=None):
+        _check(lib().vslam_fe_pack_slots(self._h, nslots, dev_dst, slot_bytes or self.slot_bytes))
+
+    def set_profiling(self, on=True):
+        _check(lib().vslam_fe_set_profiling(self._h, int(on)))
+
+    def get_profile(self):
+        ms = (C.c_double * 4)()
+        b, im = C.c_long(), C.c_long()
+        _check(lib().vslam_fe_get_profile(self._h, ms, C.byref(b), C.byref(im)))
+        return dict(pyramid_ms=ms[0], fast_ms=ms[1], blur_ms=ms[2], describe_ms=ms[3], batches=b.value,
+                    images=im.value)
+
 
 class FMatcher:
     """vi_slam::geometry::FMatcher (include/vi_slam/geometry/fmatcher.h:70-147), hot-path subset."""
@@ -275,3 +301,32 @@ def ComputeStereoMatches(feL, slotL, feR, slotR, bf, fx):
     d = np.full(max(n, 1), -1, np.float32)
     _check(lib().vslam_stereo_match(feL._h, slotL, feR._h, slotR, bf, fx, _p(u), _p(d)))
     return u[:n], d[:n]
+
+
+def ComputeStereoMatchesBatch(feL, slotsL, feR, slotsR, bf, fx):
+    """ComputeStereoMatches for several pairs in one pass of the kernels -> list of (mvuRight, mvDepth)."""
+    npairs = len(slotsL)
+    ns = [feL.slot_buffers(s)[2] for s in slotsL]
+    us = [np.full(max(n, 1), -1, np.float32) for n in ns]
+    ds = [np.full(max(n, 1), -1, np.float32) for n in ns]
+    sl = (C.c_int * npairs)(*slotsL)
+    sr = (C.c_int * npairs)(*slotsR)
+    up = (C.c_void_p * npairs)(*[u.ctypes.data for u in us])
+    dp = (C.c_void_p * npairs)(*[d.ctypes.data for d in ds])
+    _check(lib().vslam_stereo_match_batch(feL._h, feR._h, npairs, sl, sr, bf, fx, up, dp))
+    return [(us[j][:ns[j]], ds[j][:ns[j]]) for j in range(npairs)]
+
+
+def dbg_sincos(fe, x):
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    _check(lib().vslam_dbg_sincos(fe._h, _p(x), len(x), _p(s), _p(c)))
+    return s, c
+
+
+def dbg_fast_atan2(fe, y, x, fma=0):
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    a = np.zeros_like(x)
+    _check(lib().vslam_dbg_fast_atan2(fe._h, _p(y), _p(x), len(x), fma, _p(a)))
+    return a

@@ -1,0 +1,174 @@
+/* vslam_ctx.h -- private: the vslam_fe context (HBM layout, scratch, worker pool) shared by
+ * vslam_fe.hip (extractor ABI) and vslam_match.hip (matcher ABI). */
+#ifndef VSLAM_CTX_H
+#define VSLAM_CTX_H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vslam_orb_pattern.h"
+#include "vslam_host.h"
+#include "vslam_kernels.h"
+
+std::string& vslam_err();
+#define g_err (vslam_err())
+
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return VSLAM_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+/* ------------------------------------------------------------------ tiny worker pool */
+class WorkerPool {
+public:
+    explicit WorkerPool(int n) : stop_(false), next_(0), total_(0), pending_(0), gen_(0) {
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            next_.store(0);
+            total_ = n;
+            pending_ = n;
+            gen_++;
+        }
+        cv_.notify_all();
+        run();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= total_) break;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> l(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            run();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    bool stop_;
+    std::atomic<int> next_;
+    int total_, pending_;
+    unsigned long gen_;
+    const std::function<void(int)>* fn_ = nullptr;
+};
+
+/* ------------------------------------------------------------------ context */
+struct vslam_fe {
+    vslam_fe_params p;
+    vslam::ExtractorTables tab;
+    PyramidGeom geom;
+    size_t slot_stride = 0; /* bytes per slot in d_pyr / d_blur */
+    int B = 1, cap = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_cand = nullptr;
+
+    uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;
+    /* resize tables, one set per destination level >= 1 */
+    uint16_t* d_xtab[VSLAM_MAX_LEVELS] = {};
+    int16_t* d_xa[VSLAM_MAX_LEVELS] = {};
+    uint16_t* d_ytab[VSLAM_MAX_LEVELS] = {};
+    int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
+    /* FAST cells */
+    std::vector<vslam::HostCell> cells;
+    int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};
+    CellDesc* d_cells = nullptr;
+    int tile_pitch = 0, tile_rows = 0, max_px = 0;
+    /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
+    uint8_t* d_cand = nullptr;
+    uint8_t* h_cand = nullptr; /* pinned */
+    size_t cand_stride = 0;
+    int cand_cap = 0;
+    /* blur tiles */
+    uint32_t* d_blur_tiles = nullptr;
+    int n_blur_tiles = 0;
+    int32_t taps[7];
+    /* selection + outputs */
+    SelKp* d_sel = nullptr;
+    SelKp* h_sel = nullptr; /* pinned, B*cap */
+    vslam_kp* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    vslam_kp* h_kps = nullptr; /* pinned staging, B*cap */
+    uint8_t* h_desc = nullptr;
+    int8_t* d_pattern = nullptr;
+    BatchSrc src;
+    int n_out[VSLAM_MAX_BATCH] = {};
+    int mono_out[VSLAM_MAX_BATCH] = {};
+    std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
+    std::vector<std::vector<vslam::Cand>> cand_level;
+    /* matcher scratch (grown on demand) */
+    uint32_t* d_part = nullptr;
+    size_t part_bytes = 0;
+    int32_t* d_idx2 = nullptr;
+    int32_t* d_dist2 = nullptr;
+    size_t top2_cap = 0;
+    uint8_t* d_dmat = nullptr;
+    size_t dmat_bytes = 0;
+    uint8_t* d_tmp_desc[2] = {nullptr, nullptr};
+    size_t tmp_desc_bytes[2] = {0, 0};
+    /* stereo scratch */
+    void* d_stereo = nullptr;
+    size_t stereo_bytes = 0;
+
+    /* optional HIP-event timing of the kernel stages (bench.py roofline): resize x7, fast, blur, describe */
+    bool profiling = false;
+    hipEvent_t ev_prof[8] = {};
+    double prof_ms[4] = {0, 0, 0, 0};
+    long prof_batches = 0, prof_images = 0;
+
+    WorkerPool* pool = nullptr;
+};
+
+
+int vslam_ensure(void** p, size_t* have, size_t want);
+
+#endif

@@ -53,4 +53,17 @@ struct SelKp {
     uint32_t out;      /* index into the slot's output arrays (lapping-area order, fextractor.cpp:1118-1127) */
 };
 
+/* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */
+struct StereoJob {
+    const vslam_kp* kpsL;
+    const uint8_t* descL;
+    const vslam_kp* kpsR;
+    const uint8_t* descR;
+    int32_t nL, nR, slotL, slotR;
+};
+#define VSLAM_MAX_STEREO_JOBS 16
+struct StereoJobs {
+    StereoJob job[VSLAM_MAX_STEREO_JOBS];
+};
+
 #endif

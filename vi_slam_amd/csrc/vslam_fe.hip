@@ -7,165 +7,13 @@
  * The quadtree distribution (FExtractor::DistributeOctTree) is sequential by construction and runs on
  * the host, one task per (slot, level), on a small worker pool.
  */
-#include <hip/hip_runtime.h>
+#include "vslam_ctx.h"
 
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <condition_variable>
-#include <cstdio>
-#include <cstring>
-#include <functional>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/vslam_orb_pattern.h"
-#include "vslam_host.h"
-#include "vslam_kernels.h"
-
-static thread_local std::string g_err;
-extern "C" const char* vslam_last_error(void) { return g_err.c_str(); }
-
-#define HIPCHK(call)                                                                             \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
-            return VSLAM_ERR_HIP;                                                                \
-        }                                                                                        \
-    } while (0)
-
-/* ------------------------------------------------------------------ tiny worker pool */
-class WorkerPool {
-public:
-    explicit WorkerPool(int n) : stop_(false), next_(0), total_(0), pending_(0), gen_(0) {
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-            gen_++;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    void parallel_for(int n, const std::function<void(int)>& fn) {
-        if (n <= 0) return;
-        if (th_.empty() || n == 1) {
-            for (int i = 0; i < n; i++) fn(i);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn;
-            next_.store(0);
-            total_ = n;
-            pending_ = n;
-            gen_++;
-        }
-        cv_.notify_all();
-        run();
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-private:
-    void run() {
-        for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= total_) break;
-            (*fn_)(i);
-            std::lock_guard<std::mutex> l(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-            }
-            run();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    bool stop_;
-    std::atomic<int> next_;
-    int total_, pending_;
-    unsigned long gen_;
-    const std::function<void(int)>* fn_ = nullptr;
-};
-
-/* ------------------------------------------------------------------ context */
-struct vslam_fe {
-    vslam_fe_params p;
-    vslam::ExtractorTables tab;
-    PyramidGeom geom;
-    size_t slot_stride = 0; /* bytes per slot in d_pyr / d_blur */
-    int B = 1, cap = 0;
-
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_cand = nullptr;
-
-    uint8_t* d_pyr = nullptr;
-    uint8_t* d_blur = nullptr;
-    /* resize tables, one set per destination level >= 1 */
-    uint16_t* d_xtab[VSLAM_MAX_LEVELS] = {};
-    int16_t* d_xa[VSLAM_MAX_LEVELS] = {};
-    uint16_t* d_ytab[VSLAM_MAX_LEVELS] = {};
-    int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
-    /* FAST cells */
-    std::vector<vslam::HostCell> cells;
-    int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};
-    CellDesc* d_cells = nullptr;
-    int tile_pitch = 0, tile_rows = 0, max_px = 0;
-    /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
-    uint8_t* d_cand = nullptr;
-    uint8_t* h_cand = nullptr; /* pinned */
-    size_t cand_stride = 0;
-    int cand_cap = 0;
-    /* blur tiles */
-    uint32_t* d_blur_tiles = nullptr;
-    int n_blur_tiles = 0;
-    int32_t taps[7];
-    /* selection + outputs */
-    SelKp* d_sel = nullptr;
-    SelKp* h_sel = nullptr; /* pinned, B*cap */
-    vslam_kp* d_kps = nullptr;
-    uint8_t* d_desc = nullptr;
-    vslam_kp* h_kps = nullptr; /* pinned staging, B*cap */
-    uint8_t* h_desc = nullptr;
-    int8_t* d_pattern = nullptr;
-    BatchSrc src;
-    int n_out[VSLAM_MAX_BATCH] = {};
-    int mono_out[VSLAM_MAX_BATCH] = {};
-    std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
-    std::vector<std::vector<vslam::Cand>> cand_level;
-    /* matcher scratch (grown on demand) */
-    uint32_t* d_part = nullptr;
-    size_t part_bytes = 0;
-    int32_t* d_idx2 = nullptr;
-    int32_t* d_dist2 = nullptr;
-    size_t top2_cap = 0;
-    uint8_t* d_dmat = nullptr;
-    size_t dmat_bytes = 0;
-    uint8_t* d_tmp_desc[2] = {nullptr, nullptr};
-    size_t tmp_desc_bytes[2] = {0, 0};
-    /* stereo scratch */
-    void* d_stereo = nullptr;
-    size_t stereo_bytes = 0;
-
-    WorkerPool* pool = nullptr;
-};
+std::string& vslam_err() {
+    static thread_local std::string e;
+    return e;
+}
+extern "C" const char* vslam_last_error(void) { return vslam_err().c_str(); }
 
 static void free_ctx(vslam_fe* fe) {
     if (!fe) return;
@@ -198,6 +46,8 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_tmp_desc[1]);
     hipFree(fe->d_stereo);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
+    for (int i = 0; i < 8; i++)
+        if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
     delete fe;
 }
@@ -383,6 +233,46 @@ extern "C" int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scal
 
 extern "C" void* vslam_fe_stream(vslam_fe* fe) { return fe ? (void*)fe->stream : nullptr; }
 
+extern "C" int vslam_fe_set_profiling(vslam_fe* fe, int on) {
+    if (!fe) return VSLAM_ERR_INVALID;
+    HIPCHK(hipSetDevice(fe->p.device));
+    if (on && !fe->ev_prof[0])
+        for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&fe->ev_prof[i]));
+    fe->profiling = on != 0;
+    for (int i = 0; i < 4; i++) fe->prof_ms[i] = 0;
+    fe->prof_batches = fe->prof_images = 0;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[4], long* batches, long* images) {
+    if (!fe || !stage_ms) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < 4; i++) stage_ms[i] = fe->prof_ms[i];
+    if (batches) *batches = fe->prof_batches;
+    if (images) *images = fe->prof_images;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes) {
+    if (!fe || nslots < 0 || nslots > fe->B || !dev_dst || slot_bytes < 16 + (size_t)fe->cap * 60) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    for (int s = 0; s < nslots; s++) {
+        uint8_t* d = (uint8_t*)dev_dst + (size_t)s * slot_bytes;
+        int32_t hdr[4] = {fe->n_out[s], fe->mono_out[s], fe->cap, 0};
+        HIPCHK(hipMemcpyAsync(d, hdr, 16, hipMemcpyHostToDevice, fe->stream));
+        if (fe->n_out[s]) {
+            HIPCHK(hipMemcpyAsync(d + 16, fe->d_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp),
+                                  hipMemcpyDeviceToDevice, fe->stream));
+            HIPCHK(hipMemcpyAsync(d + 16 + (size_t)fe->cap * sizeof(vslam_kp), fe->d_desc + (size_t)s * fe->cap * 32,
+                                  (size_t)fe->n_out[s] * 32, hipMemcpyDeviceToDevice, fe->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h) {
     if (!fe || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
     if (w) *w = fe->geom.lv[level].w;
@@ -438,15 +328,19 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
     }
     /* 2. candidate headers (total, overflow) */
     HIPCHK(hipMemset2DAsync(fe->d_cand, fe->cand_stride, 0, 8, nimg, st));
+    const bool prof = fe->profiling;
     /* 3. pyramid */
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
     for (int l = 1; l < L; l++)
         vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
                         fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
     /* 4. FAST */
     const int ncells = (int)fe->cells.size();
     vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, ncells, fe->d_cand,
                   fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch, fe->tile_rows,
                   fe->max_px, nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     /* 5. candidates to the host; first chunk speculatively, the rest only if a slot needs it */
     const size_t hdr_bytes = 8 + (size_t)ncells * sizeof(CellOut);
     const size_t first_cands = std::min<size_t>((size_t)fe->cand_cap, 40960);
@@ -454,8 +348,10 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
                             hdr_bytes + first_cands * 4, nimg, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(fe->ev_cand, st));
     /* 6. blur runs while the host distributes */
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
     vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
              fe->taps, nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(fe->ev_cand));
     bool need_more = false;
@@ -536,11 +432,29 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
     /* 9. orientation + descriptors */
     if (nsel) {
         HIPCHK(hipMemcpyAsync(fe->d_sel, fe->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
+        if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
         vk_orient_describe(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, nsel,
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap,
                            (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0);
+        if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
     }
     HIPCHK(hipGetLastError());
+    if (prof) {
+        HIPCHK(hipStreamSynchronize(st));
+        float ms;
+        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[0], fe->ev_prof[1]));
+        fe->prof_ms[0] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[1], fe->ev_prof[2]));
+        fe->prof_ms[1] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[3], fe->ev_prof[4]));
+        fe->prof_ms[2] += ms;
+        if (nsel) {
+            HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[5], fe->ev_prof[6]));
+            fe->prof_ms[3] += ms;
+        }
+        fe->prof_batches++;
+        fe->prof_images += nimg;
+    }
     return VSLAM_OK;
 }
 
@@ -622,7 +536,7 @@ extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** de
 }
 
 /* ------------------------------------------------------------------ matcher */
-static int ensure(void** p, size_t* have, size_t want) {
+int vslam_ensure(void** p, size_t* have, size_t want) {
     if (*have >= want) return VSLAM_OK;
     if (*p) HIPCHK(hipFree(*p));
     *p = nullptr;
@@ -642,7 +556,7 @@ extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, co
     HIPCHK(hipSetDevice(fe->p.device));
     const int ntiles = std::max(vk_hamming_top2_tiles(nt), 1);
     int rc;
-    if ((rc = ensure((void**)&fe->d_part, &fe->part_bytes, (size_t)nq * ntiles * 8))) return rc;
+    if ((rc = vslam_ensure((void**)&fe->d_part, &fe->part_bytes, (size_t)nq * ntiles * 8))) return rc;
     if (fe->top2_cap < (size_t)nq) {
         hipFree(fe->d_idx2);
         hipFree(fe->d_dist2);
@@ -670,7 +584,7 @@ extern "C" int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, 
     if (nq == 0 || nt == 0) return VSLAM_OK;
     HIPCHK(hipSetDevice(fe->p.device));
     int rc;
-    if ((rc = ensure((void**)&fe->d_dmat, &fe->dmat_bytes, (size_t)nq * nt))) return rc;
+    if ((rc = vslam_ensure((void**)&fe->d_dmat, &fe->dmat_bytes, (size_t)nq * nt))) return rc;
     vk_hamming_matrix(fe->stream, dev_q, nq, dev_t, nt, fe->d_dmat);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, fe->d_dmat, (size_t)nq * nt, hipMemcpyDeviceToHost, fe->stream));
@@ -678,14 +592,3 @@ extern "C" int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, 
     return VSLAM_OK;
 }
 
-/* TEMP stubs (replaced by vslam_match.hip in the next commit) */
-extern "C" int vslam_stereo_match(vslam_fe*, int, vslam_fe*, int, float, float, float*, float*) {
-    g_err = "not implemented yet";
-    return VSLAM_ERR_UNSUPPORTED;
-}
-extern "C" int vslam_search_for_initialization(vslam_fe*, const vslam_kp*, const uint8_t*, int, const vslam_kp*,
-                                               const uint8_t*, int, int, int, float*, int32_t*, int, float, int,
-                                               int*) {
-    g_err = "not implemented yet";
-    return VSLAM_ERR_UNSUPPORTED;
-}

@@ -28,4 +28,13 @@ int vk_hamming_top2_tiles(int nt);
 void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
                      int32_t* idx2, int32_t* dist2);
 
+void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c);
+void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma, float* a);
+
+void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
+               const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
+               const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
+               int32_t* sad, int cap);
+void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);
+
 #endif

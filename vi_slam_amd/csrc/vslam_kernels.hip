@@ -506,6 +506,24 @@ __global__ void k_hamming_top2_merge(const uint32_t* __restrict__ part, int nq, 
     dist2[2 * qi + 1] = b2 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(b2 >> 16);
 }
 
+/* diagnostics: evaluate the device float helpers on arrays (tests pin them against glibc / the oracle) */
+__global__ void k_dbg_sincos(const float* __restrict__ x, int n, float* s, float* c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = vslam_trig::glibc_sinf(x[i]);
+    c[i] = vslam_trig::glibc_cosf(x[i]);
+}
+__global__ void k_dbg_atan2(const float* __restrict__ y, const float* __restrict__ x, int n, int fma, float* a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = fast_atan2_deg(y[i], x[i], fma);
+}
+void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c) {
+    if (n > 0) hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, st, x, n, s, c);
+}
+void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma, float* a) {
+    if (n > 0) hipLaunchKernelGGL(k_dbg_atan2, dim3((n + 255) / 256), dim3(256), 0, st, y, x, n, fma, a);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * launch wrappers (plain functions so the host file needs no kernel syntax)
  * ---------------------------------------------------------------------------------------------- */

@@ -1,1 +1,288 @@
-/* placeholder until matcher kernels land */
+/* vslam_match_kernels.hip -- stereo L<->R matching (Frame::ComputeStereoMatches, frame.cpp:823-997) and
+ * helpers for the host-replayed matchers.  Integer stages exact; the float tail (parabola, disparity,
+ * depth) uses explicit round-to-nearest intrinsics, no fusion.
+ */
+#include "vslam_kernels.h"
+
+__device__ __forceinline__ const uint8_t* level_base2(const uint8_t* pyr, size_t slot_stride,
+                                                      const BatchSrc& src, const LevelGeom& lg, int level,
+                                                      int slot, int* pitch) {
+    if (level == 0) {
+        *pitch = (int)src.pitch0[slot];
+        return src.l0[slot];
+    }
+    *pitch = lg.pitch;
+    return pyr + (size_t)slot * slot_stride + lg.off;
+}
+
+__device__ __forceinline__ int refl101(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return min(max(p, 0), len - 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S0  reset the per-left-keypoint best keys: bestDist = TH_HIGH (100), bestIdxR = 0 (frame.cpp:879-880)
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void k_stereo_init(StereoJobs jobs, uint32_t* best, int cap) {
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < jobs.job[j].nL) best[(size_t)j * cap + i] = 100u << 16;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S1  masked all-pairs Hamming arg-min (frame.cpp:861-906).  64 left keypoints per workgroup (one per
+ *     lane, descriptor in 8 VGPRs); a 256-keypoint right tile with its row band [minr,maxr], octave and
+ *     uR staged in LDS; every lane reads the same right entry (LDS broadcast).  Gate per pair:
+ *     row(vL) in [floor(yR - 2 s_R), ceil(yR + 2 s_R)], |octR - octL| <= 1, uL - maxD <= uR <= uL.
+ *     Tiles combine through atomicMin on key = dist << 16 | iR (first-wins == lowest iR on ties).
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_stereo_best(StereoJobs jobs, PyramidGeom g, float maxD, uint32_t* best, int cap) {
+    __shared__ uint4 s_t[256 * 2];
+    __shared__ int s_minr[256], s_maxr[256], s_oct[256];
+    __shared__ float s_u[256];
+    const StereoJob jb = jobs.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int iL = blockIdx.x * 64 + lane;
+    const int t0 = blockIdx.y * 256;
+    if (blockIdx.x * 64 >= jb.nL || t0 >= jb.nR) return; /* block-uniform */
+    {
+        const int iR = t0 + tid;
+        if (iR < jb.nR) {
+            const vslam_kp k = jb.kpsR[iR];
+            const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
+            s_maxr[tid] = (int)ceilf(__fadd_rn(k.y, r));
+            s_minr[tid] = (int)floorf(__fsub_rn(k.y, r));
+            s_oct[tid] = k.octave;
+            s_u[tid] = k.x;
+            s_t[2 * tid] = ((const uint4*)jb.descR)[(size_t)iR * 2];
+            s_t[2 * tid + 1] = ((const uint4*)jb.descR)[(size_t)iR * 2 + 1];
+        } else {
+            s_minr[tid] = 1 << 30;
+            s_maxr[tid] = -(1 << 30);
+            s_oct[tid] = 1000;
+            s_u[tid] = 0.f;
+        }
+    }
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    int row = -(1 << 29), octL = -1000;
+    float minU = 1.f, maxU = 0.f;
+    if (iL < jb.nL) {
+        const vslam_kp k = jb.kpsL[iL];
+        qa = ((const uint4*)jb.descL)[(size_t)iL * 2];
+        qb = ((const uint4*)jb.descL)[(size_t)iL * 2 + 1];
+        row = (int)k.y; /* vRowIndices[vL]: float -> size_t truncation */
+        octL = k.octave;
+        minU = __fsub_rn(k.x, maxD);
+        maxU = __fsub_rn(k.x, 0.f);
+        if (maxU < 0) row = -(1 << 29); /* frame.cpp:876-877 */
+    }
+    __syncthreads();
+    uint32_t bestKey = 0xFFFFFFFFu;
+    for (int j = wv * 64; j < wv * 64 + 64; j++) {
+        const int oR = s_oct[j];
+        const float uR = s_u[j];
+        const bool gate = row >= s_minr[j] && row <= s_maxr[j] && oR >= octL - 1 && oR <= octL + 1 &&
+                          uR >= minU && uR <= maxU;
+        if (gate) {
+            const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
+            const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) +
+                               __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) +
+                               __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+            const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
+            bestKey = min(bestKey, key);
+        }
+    }
+    if (iL < jb.nL && bestKey < (100u << 16)) atomicMin(&best[(size_t)blockIdx.z * cap + iL], bestKey);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S2  sub-pixel refinement (frame.cpp:908-980): 11x11 centre-subtracted L1 patch distance for
+ *     incR in [-5,5] at the left keypoint's octave, parabola fit, disparity / depth.
+ *     16 lanes per keypoint: lane s < 11 evaluates shift s-5.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t strideL, BatchSrc srcL,
+                const uint8_t* pyrR, size_t strideR, BatchSrc srcR, float mbf, float maxD,
+                const uint32_t* best, float* uRight, float* depth, int32_t* sad, int cap) {
+    __shared__ float s_d[16][12];
+    const StereoJob jb = jobs.job[blockIdx.y];
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int iL = blockIdx.x * 16 + grp;
+    const bool live = iL < jb.nL;
+    const size_t o = (size_t)blockIdx.y * cap + (live ? iL : 0);
+    uint32_t key = live ? best[o] : 0xFFFFFFFFu;
+    const int bestDist = (int)(key >> 16);
+    const bool refine = live && bestDist < 75; /* thOrbDist = (TH_HIGH+TH_LOW)/2, frame.cpp:828 */
+    vslam_kp kL;
+    float scaleduL = 0, scaledvL = 0, scaleduR0 = 0;
+    bool inside = false;
+    int oct = 0;
+    if (refine) {
+        kL = jb.kpsL[iL];
+        oct = kL.octave;
+        const float uR0 = jb.kpsR[key & 0xFFFF].x;
+        const float sf = __fdiv_rn(1.0f, g.lv[oct].scale); /* mvInvScaleFactors[octave] = 1.0f/scale */
+        scaleduL = roundf(__fmul_rn(kL.x, sf));
+        scaledvL = roundf(__fmul_rn(kL.y, sf));
+        scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const float iniu = __fsub_rn(__fadd_rn(scaleduR0, 5.f), 5.f);
+        const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, 5.f), 5.f), 1.f);
+        inside = !(iniu < 0 || endu >= (float)g.lv[oct].w);
+    }
+    if (refine && inside && sub < 11) {
+        const LevelGeom lg = g.lv[oct];
+        int pL, pR;
+        const uint8_t* imL = level_base2(pyrL, strideL, srcL, lg, oct, jb.slotL, &pL);
+        const uint8_t* imR = level_base2(pyrR, strideR, srcR, lg, oct, jb.slotR, &pR);
+        const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR = (int)scaleduR0 + sub - 5;
+        const int cL = imL[(size_t)refl101(cy, lg.h) * pL + refl101(cxL, lg.w)];
+        const int cR = imR[(size_t)refl101(cy, lg.h) * pR + refl101(cxR, lg.w)];
+        int acc = 0;
+        for (int dy = -5; dy <= 5; dy++) {
+            const int yy = refl101(cy + dy, lg.h);
+            const uint8_t* rl = imL + (size_t)yy * pL;
+            const uint8_t* rr = imR + (size_t)yy * pR;
+#pragma unroll
+            for (int dx = -5; dx <= 5; dx++) {
+                const int a = (int)rl[refl101(cxL + dx, lg.w)] - cL;
+                const int b = (int)rr[refl101(cxR + dx, lg.w)] - cR;
+                acc += abs(a - b);
+            }
+        }
+        s_d[grp][sub] = (float)acc;
+    }
+    __syncthreads();
+    if (!live || sub != 0) return;
+    float ur = -1.f, dp = -1.f;
+    int sd = -1;
+    if (refine && inside) {
+        int bestSad = 0x7FFFFFFF, bestinc = 0;
+        for (int i = 0; i < 11; i++) {
+            const float dist = s_d[grp][i];
+            if (dist < (float)bestSad) {
+                bestSad = (int)dist;
+                bestinc = i - 5;
+            }
+        }
+        if (bestinc != -5 && bestinc != 5) {
+            const float dist1 = s_d[grp][5 + bestinc - 1], dist2 = s_d[grp][5 + bestinc],
+                        dist3 = s_d[grp][5 + bestinc + 1];
+            const float num = __fsub_rn(dist1, dist3);
+            const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2)));
+            const float deltaR = __fdiv_rn(num, den);
+            if (!(deltaR < -1 || deltaR > 1)) {
+                float bestuR = __fmul_rn(g.lv[oct].scale,
+                                         __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                float disparity = __fsub_rn(kL.x, bestuR);
+                if (disparity >= 0 && disparity < maxD) {
+                    if (disparity <= 0) {
+                        disparity = 0.01f;
+                        bestuR = (float)((double)kL.x - 0.01);
+                    }
+                    dp = __fdiv_rn(mbf, disparity);
+                    ur = bestuR;
+                    sd = bestSad;
+                }
+            }
+        }
+    }
+    uRight[o] = ur;
+    depth[o] = dp;
+    sad[o] = sd;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S3  outlier cut (frame.cpp:983-996): median of the accepted SADs (element size/2 of the ascending
+ *     list) by a two-level byte histogram, then reject every match with SAD >= 1.5*1.4*median.
+ *     One workgroup per stereo pair.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(1024)
+k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t* sad, int cap) {
+    __shared__ int s_hist[256];
+    __shared__ int s_sel, s_rank, s_total;
+    const StereoJob jb = jobs.job[blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * cap;
+    const int tid = threadIdx.x;
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < jb.nL; i += 1024) {
+        const int s = sad[base + i];
+        if (s >= 0) {
+            atomicAdd(&s_hist[(s >> 8) & 255], 1);
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    const int total = s_total;
+    if (total == 0) return; /* the reference indexes an empty vector here (UB); nothing to cut */
+    if (tid == 0) {
+        int k = total / 2, acc = 0, b = 0;
+        for (; b < 256; b++) {
+            if (acc + s_hist[b] > k) break;
+            acc += s_hist[b];
+        }
+        s_sel = b;
+        s_rank = k - acc;
+    }
+    __syncthreads();
+    const int hi = s_sel, rank = s_rank;
+    __syncthreads();
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < jb.nL; i += 1024) {
+        const int s = sad[base + i];
+        if (s >= 0 && ((s >> 8) & 255) == hi) atomicAdd(&s_hist[s & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) {
+            if (acc + s_hist[b] > rank) break;
+            acc += s_hist[b];
+        }
+        s_sel = (hi << 8) | b;
+    }
+    __syncthreads();
+    const float median = (float)s_sel;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    for (int i = tid; i < jb.nL; i += 1024) {
+        const int s = sad[base + i];
+        if (s >= 0 && !((float)s < thDist)) {
+            uRight[base + i] = -1.f;
+            depth[base + i] = -1.f;
+        }
+    }
+}
+
+/* gather 32-byte descriptor rows by index (octave-0 subsets for SearchForInitialization) */
+__global__ void k_gather_rows32(const uint8_t* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                                uint8_t* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 2) return;
+    ((uint4*)dst)[i] = ((const uint4*)src)[(size_t)idx[i >> 1] * 2 + (i & 1)];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
+               const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
+               const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
+               int32_t* sad, int cap) {
+    if (njobs <= 0 || maxNL <= 0) return;
+    hipLaunchKernelGGL(k_stereo_init, dim3((maxNL + 255) / 256, njobs), dim3(256), 0, st, jobs, best, cap);
+    if (maxNR > 0)
+        hipLaunchKernelGGL(k_stereo_best, dim3((maxNL + 63) / 64, (maxNR + 255) / 256, njobs), dim3(256), 0, st,
+                           jobs, g, maxD, best, cap);
+    hipLaunchKernelGGL(k_stereo_refine, dim3((maxNL + 15) / 16, njobs), dim3(256), 0, st, jobs, g, pyrL, strideL,
+                       srcL, pyrR, strideR, srcR, mbf, maxD, best, uRight, depth, sad, cap);
+    hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(1024), 0, st, jobs, uRight, depth, sad, cap);
+}
+
+void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_rows32, dim3((2 * n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
+}

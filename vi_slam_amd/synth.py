@@ -1,8 +1,8 @@
 """Deterministic synthetic frames for tests and bench (no dataset is available on either box).
 
 SURVEY.md 8(d): KITTI-shaped (1241x376) or 1080p u8 images made of random axis-aligned rectangles
-(sharp FAST corners) plus 3x3 box-smoothed noise.  A stereo right view shifts every rectangle left by
-its own integer disparity in [2,64]; a "next" frame shifts the whole scene by (+3,+1) px per step.
+(sharp FAST corners) over a box-smoothed noise texture that belongs to the scene, plus sensor noise.  A stereo right view shifts every image row left
+by an integer disparity (8 bands, 4..60 px); a "next" frame shifts the whole scene by (+3,+1) px per step.
 Everything derives from splitmix64(seed, counter) so numpy versions cannot change the pixels.
 """
 import numpy as np
@@ -31,42 +31,69 @@ def _uniform_int(r, lo, hi):
     return (lo + (r % np.uint64(hi - lo + 1)).astype(np.int64)).astype(np.int64)
 
 
-def make_frame(width, height, seed=20250215, step=0, right=False, n_rects=None, noise_amp=12):
+def _texture(seed, width, height, salt, amp, box):
+    """Box-smoothed uniform noise field of the given size, values in about [-amp, amp]."""
+    pad = box - 1
+    nz = _stream(seed, (width + pad) * (height + pad), salt).reshape(height + pad, width + pad)
+    nz = (nz % np.uint64(2 * amp * box + 1)).astype(np.int32) - amp * box
+    sm = np.zeros((height, width), dtype=np.int32)
+    for oy in range(box):
+        for ox in range(box):
+            sm += nz[oy:oy + height, ox:ox + width]
+    return sm // (box * box // 2 + 1)
+
+
+N_DISP_BANDS = 8
+
+
+def row_disparity(height):
+    """Integer disparity of every image row: 8 horizontal bands, 4..60 px, larger towards the bottom
+    (a coarse ground plane).  The right view shows scene column x + d(y) at column x."""
+    rows = np.arange(height)
+    return 4 + 8 * (rows * N_DISP_BANDS // height)
+
+
+def make_frame(width, height, seed=20250215, step=0, right=False, n_rects=None, noise_amp=3):
     """Return an (height, width) uint8 image.
 
-    step   -- frame index: the scene is translated by (+3*step, +1*step) px, fresh noise per step.
-    right  -- stereo right view: each rectangle moves left by its disparity.
+    Scene = box-smoothed noise texture + additive random rectangles, rendered 64 px wider than the image.
+    step : frame index; the scene is translated by (+3*step, +1*step) px, fresh sensor noise per frame.
+    right: stereo right view = every row of the scene shifted left by row_disparity(row).
     """
+    sw = width + 64
     if n_rects is None:
-        n_rects = max(200, (width * height) // 330)
-    r = _stream(seed, n_rects * 6, 1).reshape(n_rects, 6)
+        n_rects = max(200, (sw * height) // 330)
+    r = _stream(seed, n_rects * 5, 1).reshape(n_rects, 5)
     margin = 96
-    x0 = _uniform_int(r[:, 0], -margin, width + margin)
+    x0 = _uniform_int(r[:, 0], -margin, sw + margin)
     y0 = _uniform_int(r[:, 1], -margin, height + margin)
     rw = _uniform_int(r[:, 2], 5, 72)
     rh = _uniform_int(r[:, 3], 5, 56)
     amp = _uniform_int(r[:, 4], 14, 80)
     sign = np.where((r[:, 4] >> np.uint64(33)) & np.uint64(1), 1, -1)
-    disp = _uniform_int(r[:, 5], 2, 64)
-    acc = np.full((height, width), 128, dtype=np.int32)
     dx, dy = 3 * step, 1 * step
+    span = 3 * 64 + 16
+    tex = _texture(seed, sw + span + 8, height + 80, 7, 9, 3)
+    bx = span - dx % span
+    by = 70 - dy % 64
+    acc = 128 + tex[by:by + height, bx:bx + sw].astype(np.int32)
     for k in range(n_rects):
-        xa = int(x0[k]) + dx - (int(disp[k]) if right else 0)
+        xa = int(x0[k]) + dx
         ya = int(y0[k]) + dy
         xb, yb = xa + int(rw[k]), ya + int(rh[k])
         xa, ya = max(xa, 0), max(ya, 0)
-        xb, yb = min(xb, width), min(yb, height)
+        xb, yb = min(xb, sw), min(yb, height)
         if xa < xb and ya < yb:
             acc[ya:yb, xa:xb] += int(sign[k]) * int(amp[k])
+    if right:
+        cols = np.arange(width)[None, :] + row_disparity(height)[:, None]
+        acc = np.take_along_axis(acc, cols, axis=1)
+    else:
+        acc = acc[:, :width]
     if noise_amp > 0:
         salt = 1000 + 2 * step + (1 if right else 0)
-        nz = _stream(seed, (width + 2) * (height + 2), salt).reshape(height + 2, width + 2)
-        nz = (nz % np.uint64(2 * noise_amp + 1)).astype(np.int32) - noise_amp
-        sm = np.zeros((height, width), dtype=np.int32)
-        for oy in range(3):
-            for ox in range(3):
-                sm += nz[oy:oy + height, ox:ox + width]
-        acc += sm // 3
+        nz = _stream(seed, width * height, salt).reshape(height, width)
+        acc = acc + (nz % np.uint64(2 * noise_amp + 1)).astype(np.int32) - noise_amp
     return np.clip(acc, 0, 255).astype(np.uint8)
 
 
