@@ -35,6 +35,9 @@ extern "C" {
 
 /* flags for vslam_fe_params.flags: OpenCV build-dependent arithmetic the reference inherits */
 #define VSLAM_FLAG_ATAN_FMA 1u /* cv::fastAtan2 Horner polynomial FMA-contracted (AVX2/FMA3 dispatch, aarch64) */
+/* Run FExtractor::DistributeOctTree on the host worker pool instead of the GPU kernel (k_octree).  The
+ * library picks this by itself only when a level's node list cannot fit LDS (nfeatures > ~11000). */
+#define VSLAM_FLAG_HOST_OCTREE 2u
 
 /* Same 28-byte layout and field order as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave,
  * class_id) so std::vector<cv::KeyPoint> storage can be handed over directly. */
@@ -88,6 +91,16 @@ int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, s
                            int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
                            uint8_t* const* desc, int cap, int* n, int* mono_index);
 
+/* The same in two halves, so a caller can keep several contexts (streams) in flight: _async enqueues the
+ * whole pass and returns without waiting for the GPU (with the device quadtree nothing in it touches the
+ * host); _wait blocks until that pass is done and delivers the results like vslam_fe_extract_batch.
+ * want_host != 0 also enqueues the D2H of keypoints and descriptors.  Device images passed to _async must
+ * stay valid until _wait returns. */
+int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
+                                 int imgs_on_device, int lap0, int lap1, int want_host);
+int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                          int* mono_index);
+
 /* FExtractor::mvImagePyramid[level] (fextractor.h:64; read by frame.cpp:830,920,932,937).  Copies the
  * borderless level image of a slot into dst (dst_pitch >= level width).  blurred != 0 returns the
  * GaussianBlur'ed clone used for the descriptors (fextractor.cpp:1085-1086). */
@@ -114,11 +127,11 @@ void* vslam_fe_stream(vslam_fe* fe);
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
 
 /* Stage timing with HIP events on the context's stream (the reference's REGISTER_TIMES spans,
- * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..3] = pyramid (7 launches), FAST cells,
- * Gaussian blur, orientation+descriptor, accumulated over `batches` batched calls / `images` images since
- * profiling was switched on.  Profiling adds one stream synchronisation per extract call. */
+ * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..4] = pyramid (7 launches), FAST cells,
+ * Gaussian blur, orientation+descriptor, quadtree distribution + output order (0 with the host quadtree),
+ * accumulated over `batches` batched calls / `images` images since profiling was switched on. */
 int vslam_fe_set_profiling(vslam_fe* fe, int on);
-int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[4], long* batches, long* images);
+int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batches, long* images);
 
 /* ---------------------------------------------------------------- matcher (FMatcher / Frame) */
 

@@ -194,3 +194,50 @@ def test_errors(kitti):
     with pytest.raises(V.VslamError) as ei:
         V.FExtractor(500, 1.2, 8, 20, 7, 200, 600)  # portrait: nIni == 0 in the reference
     assert ei.value.code == V.ERR_UNSUPPORTED
+
+
+def test_host_quadtree_fallback_path_matches_too():
+    """VSLAM_FLAG_HOST_OCTREE keeps DistributeOctTree on the host worker pool (the path taken when a
+    level's node list cannot fit LDS); both placements must give the reference's result."""
+    imgs = [synth.make_frame(1241, 376, step=s) for s in range(3)]
+    fe = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=3, flags=V.FLAG_HOST_OCTREE)
+    try:
+        res = fe.compute_batch(imgs, (0, 1000))
+        e = orbo.Extractor(2000)
+        for s in range(3):
+            _assert_same(res[s], e.compute(imgs[s], lap=(0, 1000)), "host quadtree %d" % s)
+    finally:
+        fe.close()
+
+
+def test_async_split_api_two_contexts_in_flight():
+    import torch
+    imgs = [synth.make_frame(1241, 376, step=s) for s in range(4)]
+    pitch = 1280
+    dev = torch.zeros((4, 376, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(4):
+        dev[s, :, :1241] = torch.from_numpy(imgs[s]).cuda()
+    torch.cuda.synchronize()
+    a = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    b = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    try:
+        a.compute_batch_async([dev[0].data_ptr(), dev[1].data_ptr()], pitch, (0, 1000))
+        b.compute_batch_async([dev[2].data_ptr(), dev[3].data_ptr()], pitch, (0, 1000))
+        ra = a.wait(copy=True)
+        rb = b.wait(copy=True)
+        e = orbo.Extractor(1000)
+        for s, r in enumerate(ra + rb):
+            _assert_same(r, e.compute(imgs[s], lap=(0, 1000)), "async %d" % s)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_large_feature_count_uses_a_big_node_list():
+    # 5 x nFeatures initialisation extractor at KITTI size: level-0 quota 2170 -> ~2.2k list entries in LDS
+    img = synth.make_frame(1241, 376, seed=21)
+    fe = V.FExtractor(10000, 1.2, 8, 20, 7, 1241, 376)
+    try:
+        _assert_same(fe.compute(img, (0, 1000)), orbo.Extractor(10000).compute(img, lap=(0, 1000)), "n10000")
+    finally:
+        fe.close()

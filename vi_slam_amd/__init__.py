@@ -19,6 +19,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libvslam_host.so")
 VSLAM_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 FLAG_ATAN_FMA = 1
+FLAG_HOST_OCTREE = 2
 MAX_BATCH = 32
 
 #: numpy view of vslam_kp == cv::KeyPoint (28 bytes)
@@ -32,7 +33,7 @@ ABI_SYMBOLS = [
     "vslam_fe_slot_buffers", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
     "vslam_stereo_match", "vslam_stereo_match_batch", "vslam_search_for_initialization",
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
-    "vslam_fe_get_profile",
+    "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
 ]
 
 
@@ -82,6 +83,8 @@ def lib():
         L.vslam_fe_pack_slots.argtypes = [vp, i, vp, C.c_size_t]
         L.vslam_fe_set_profiling.argtypes = [vp, i]
         L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
+        L.vslam_fe_extract_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, i, i, i]
+        L.vslam_fe_extract_wait.argtypes = [vp, vp, vp, i, vp, vp]
         L.vslam_dbg_sincos.argtypes = [vp, vp, i, vp, vp]
         L.vslam_dbg_fast_atan2.argtypes = [vp, vp, vp, i, i, vp]
         _lib = L
@@ -204,6 +207,36 @@ class FExtractor:
             return [(n[i], mono[i]) for i in range(nimg)]
         return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
 
+    def compute_batch_async(self, device_ptrs, pitch, vLappingArea=(0, 0), to_host=True):
+        """Enqueue one batched pass on HBM-resident images and return immediately (see
+        vslam_fe_extract_batch_async); collect with wait()."""
+        nimg = len(device_ptrs)
+        ptrs = (C.c_void_p * nimg)(*device_ptrs)
+        self._pending = (nimg, to_host)
+        _check(lib().vslam_fe_extract_batch_async(self._h, nimg, ptrs, pitch, 1, vLappingArea[0], vLappingArea[1],
+                                                  int(to_host)))
+
+    def wait(self, copy=False):
+        """Block until the enqueued pass is done.  Returns a list of (keypoints, descriptors, monoIndex);
+        the arrays are views into per-context staging that the next wait() overwrites unless copy=True."""
+        nimg, to_host = self._pending
+        n = (C.c_int * nimg)()
+        mono = (C.c_int * nimg)()
+        if not to_host:
+            _check(lib().vslam_fe_extract_wait(self._h, None, None, 0, n, mono))
+            return [(n[i], mono[i]) for i in range(nimg)]
+        if getattr(self, "_out_kps", None) is None or self._out_kps.shape[0] < nimg:
+            self._out_kps = np.zeros((self.max_batch, self.cap), KP_DTYPE)
+            self._out_desc = np.zeros((self.max_batch, self.cap, 32), np.uint8)
+            self._out_kp_ptrs = (C.c_void_p * self.max_batch)(*[self._out_kps[i].ctypes.data
+                                                                for i in range(self.max_batch)])
+            self._out_d_ptrs = (C.c_void_p * self.max_batch)(*[self._out_desc[i].ctypes.data
+                                                               for i in range(self.max_batch)])
+        _check(lib().vslam_fe_extract_wait(self._h, self._out_kp_ptrs, self._out_d_ptrs, self.cap, n, mono))
+        if copy:
+            return [(self._out_kps[i, :n[i]].copy(), self._out_desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
+        return [(self._out_kps[i, :n[i]], self._out_desc[i, :n[i]], mono[i]) for i in range(nimg)]
+
     # ---- mvImagePyramid (fextractor.h:64)
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
@@ -246,11 +279,11 @@ class FExtractor:
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))
 
     def get_profile(self):
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * 5)()
         b, im = C.c_long(), C.c_long()
         _check(lib().vslam_fe_get_profile(self._h, ms, C.byref(b), C.byref(im)))
-        return dict(pyramid_ms=ms[0], fast_ms=ms[1], blur_ms=ms[2], describe_ms=ms[3], batches=b.value,
-                    images=im.value)
+        return dict(pyramid_ms=ms[0], fast_ms=ms[1], blur_ms=ms[2], describe_ms=ms[3], octree_ms=ms[4],
+                    batches=b.value, images=im.value)
 
 
 class FMatcher:

@@ -159,10 +159,23 @@ struct vslam_fe {
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;
 
-    /* optional HIP-event timing of the kernel stages (bench.py roofline): resize x7, fast, blur, describe */
+    /* GPU quadtree distribution */
+    bool dev_octree = false;
+    OctParams oct;
+    uint32_t* d_pts[2] = {nullptr, nullptr};  /* key ping-pong arrays, B x cand_cap */
+    uint16_t* d_nid[2] = {nullptr, nullptr};  /* node (list index) of every key */
+    uint32_t* d_sel_xyr = nullptr;            /* per slot / level result lists */
+    int32_t* d_sel_cnt = nullptr;
+    int32_t* d_counts = nullptr;              /* [slot][4] = n, monoIndex, -, - ; then [B*4] = error flags */
+    int32_t* h_counts = nullptr;              /* pinned mirror */
+    bool cand_on_host = false;                /* h_cand holds the last batch's candidates */
+    int last_nimg = 0;
+
+    /* optional HIP-event timing of the kernel stages (bench.py roofline): resize x7, fast, blur, describe,
+     * quadtree (+ output order) */
     bool profiling = false;
-    hipEvent_t ev_prof[8] = {};
-    double prof_ms[4] = {0, 0, 0, 0};
+    hipEvent_t ev_prof[10] = {};
+    double prof_ms[5] = {0, 0, 0, 0, 0};
     long prof_batches = 0, prof_images = 0;
 
     WorkerPool* pool = nullptr;

@@ -53,6 +53,20 @@ struct SelKp {
     uint32_t out;      /* index into the slot's output arrays (lapping-area order, fextractor.cpp:1118-1127) */
 };
 
+/* Per-level parameters of the GPU quadtree distribution (k_octree). */
+struct OctParams {
+    int32_t N[VSLAM_MAX_LEVELS];      /* mnFeaturesPerLevel */
+    int32_t H[VSLAM_MAX_LEVELS];      /* maxBorderY - minBorderY */
+    int32_t nIni[VSLAM_MAX_LEVELS];   /* round(W/H) initial nodes */
+    float hX[VSLAM_MAX_LEVELS];       /* (float)W / nIni */
+    int32_t cellFirst[VSLAM_MAX_LEVELS + 1];
+    int32_t selOff[VSLAM_MAX_LEVELS]; /* offset of the level's result list inside a slot's sel_xyr */
+    int32_t selStride;                /* entries per slot in sel_xyr */
+    int32_t maxNodes;                 /* list capacity (LDS) */
+    int32_t ptsCap;                   /* entries per slot in the key ping-pong arrays */
+    int32_t pad;
+};
+
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */
 struct StereoJob {
     const vslam_kp* kpsL;

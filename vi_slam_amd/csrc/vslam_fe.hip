@@ -45,8 +45,16 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_tmp_desc[0]);
     hipFree(fe->d_tmp_desc[1]);
     hipFree(fe->d_stereo);
+    hipFree(fe->d_pts[0]);
+    hipFree(fe->d_pts[1]);
+    hipFree(fe->d_nid[0]);
+    hipFree(fe->d_nid[1]);
+    hipFree(fe->d_sel_xyr);
+    hipFree(fe->d_sel_cnt);
+    hipFree(fe->d_counts);
+    if (fe->h_counts) hipHostFree(fe->h_counts);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
     delete fe;
@@ -183,6 +191,50 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     HIPCHK(hipMemset(fe->d_kps, 0, nk * sizeof(vslam_kp)));
     HIPCHK(hipMemset(fe->d_desc, 0, nk * 32));
 
+    /* GPU quadtree distribution (k_octree): per-level parameters, key ping-pong arrays, result lists */
+    {
+        OctParams& O = fe->oct;
+        memset(&O, 0, sizeof(O));
+        int maxNodes = 16, selOff = 0;
+        bool ok = !(p.flags & VSLAM_FLAG_HOST_OCTREE);
+        for (int l = 0; l < p.nlevels; l++) {
+            const int W = fe->geom.lv[l].w - 2 * VSLAM_FAST_BORDER, H = fe->geom.lv[l].h - 2 * VSLAM_FAST_BORDER;
+            const int nIni = (int)std::round((float)W / (float)H);
+            O.N[l] = fe->tab.quota[l];
+            O.H[l] = H;
+            O.nIni[l] = nIni;
+            O.hX[l] = (float)W / nIni;
+            O.cellFirst[l] = fe->level_cell_first[l];
+            O.selOff[l] = selOff;
+            const int cap_l = std::max(O.N[l] + 3, 4 * nIni) + 1;
+            selOff += cap_l;
+            maxNodes = std::max(maxNodes, cap_l);
+            if (nIni > 64) ok = false;
+        }
+        O.cellFirst[p.nlevels] = fe->level_cell_first[p.nlevels];
+        O.selStride = selOff;
+        O.maxNodes = (maxNodes + 15) & ~15;
+        O.ptsCap = fe->cand_cap;
+        if (vk_octree_lds_bytes(O.maxNodes) > 150 * 1024) ok = false; /* list does not fit LDS: host quadtree */
+        fe->dev_octree = ok;
+        if (ok) {
+            if (vk_octree_set_max_lds(vk_octree_lds_bytes(O.maxNodes)) != 0) {
+                g_err = "hipFuncSetAttribute(k_octree, max dynamic LDS) failed";
+                return VSLAM_ERR_HIP;
+            }
+            const size_t np = (size_t)fe->B * fe->cand_cap;
+            HIPCHK(hipMalloc((void**)&fe->d_pts[0], np * 4));
+            HIPCHK(hipMalloc((void**)&fe->d_pts[1], np * 4));
+            HIPCHK(hipMalloc((void**)&fe->d_nid[0], np * 2));
+            HIPCHK(hipMalloc((void**)&fe->d_nid[1], np * 2));
+            HIPCHK(hipMalloc((void**)&fe->d_sel_xyr, (size_t)fe->B * O.selStride * 4));
+            HIPCHK(hipMalloc((void**)&fe->d_sel_cnt, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
+            HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
+            HIPCHK(hipHostMalloc((void**)&fe->h_counts, (size_t)(fe->B * 4 + 4) * 4, hipHostMallocDefault));
+            HIPCHK(hipMemset(fe->d_counts, 0, (size_t)(fe->B * 4 + 4) * 4));
+        }
+    }
+
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     fe->sel_level.resize((size_t)fe->B * p.nlevels);
@@ -237,16 +289,16 @@ extern "C" int vslam_fe_set_profiling(vslam_fe* fe, int on) {
     if (!fe) return VSLAM_ERR_INVALID;
     HIPCHK(hipSetDevice(fe->p.device));
     if (on && !fe->ev_prof[0])
-        for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&fe->ev_prof[i]));
+        for (int i = 0; i < 10; i++) HIPCHK(hipEventCreate(&fe->ev_prof[i]));
     fe->profiling = on != 0;
-    for (int i = 0; i < 4; i++) fe->prof_ms[i] = 0;
+    for (int i = 0; i < 5; i++) fe->prof_ms[i] = 0;
     fe->prof_batches = fe->prof_images = 0;
     return VSLAM_OK;
 }
 
-extern "C" int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[4], long* batches, long* images) {
+extern "C" int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batches, long* images) {
     if (!fe || !stage_ms) return VSLAM_ERR_INVALID;
-    for (int i = 0; i < 4; i++) stage_ms[i] = fe->prof_ms[i];
+    for (int i = 0; i < 5; i++) stage_ms[i] = fe->prof_ms[i];
     if (batches) *batches = fe->prof_batches;
     if (images) *images = fe->prof_images;
     return VSLAM_OK;
@@ -302,14 +354,31 @@ extern "C" int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurre
 }
 
 /* ------------------------------------------------------------------ extraction */
-static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                       int lap0, int lap1) {
+static void decode_candidates(vslam_fe* fe, int s, int l) {
+    const int ncells = (int)fe->cells.size();
+    const size_t hdr_bytes = 8 + (size_t)ncells * sizeof(CellOut);
+    const uint8_t* base = fe->h_cand + (size_t)s * fe->cand_stride;
+    const CellOut* co = (const CellOut*)(base + 8);
+    const uint32_t* cand = (const uint32_t*)(base + hdr_bytes);
+    std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)s * fe->p.nlevels + l];
+    cl.clear();
+    for (int c = fe->level_cell_first[l]; c < fe->level_cell_first[l + 1]; c++) {
+        const uint32_t* q = cand + co[c].base;
+        for (uint32_t k = 0; k < co[c].count; k++) {
+            vslam::Cand cd;
+            cd.x = (int16_t)(q[k] & 0xFFF);
+            cd.y = (int16_t)((q[k] >> 12) & 0xFFF);
+            cd.response = (uint8_t)(q[k] >> 24);
+            cl.push_back(cd);
+        }
+    }
+}
+
+/* steps shared by both quadtree placements: level 0, pyramid, FAST */
+static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device) {
     const vslam_fe_params& p = fe->p;
     const int L = p.nlevels;
     hipStream_t st = fe->stream;
-    HIPCHK(hipSetDevice(p.device));
-
-    /* 1. level 0 */
     for (int s = 0; s < nimg; s++) {
         if (!imgs[s]) {
             g_err = "null image";
@@ -326,33 +395,37 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
             fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
         }
     }
-    /* 2. candidate headers (total, overflow) */
-    HIPCHK(hipMemset2DAsync(fe->d_cand, fe->cand_stride, 0, 8, nimg, st));
+    fe->last_nimg = nimg;
+    fe->cand_on_host = false;
+    HIPCHK(hipMemset2DAsync(fe->d_cand, fe->cand_stride, 0, 8, nimg, st)); /* total, overflow */
     const bool prof = fe->profiling;
-    /* 3. pyramid */
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
     for (int l = 1; l < L; l++)
         vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
                         fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    /* 4. FAST */
-    const int ncells = (int)fe->cells.size();
-    vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, ncells, fe->d_cand,
+    vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
                   fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch, fe->tile_rows,
                   fe->max_px, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
-    /* 5. candidates to the host; first chunk speculatively, the rest only if a slot needs it */
-    const size_t hdr_bytes = 8 + (size_t)ncells * sizeof(CellOut);
-    const size_t first_cands = std::min<size_t>((size_t)fe->cand_cap, 40960);
-    HIPCHK(hipMemcpy2DAsync(fe->h_cand, fe->cand_stride, fe->d_cand, fe->cand_stride,
-                            hdr_bytes + first_cands * 4, nimg, hipMemcpyDeviceToHost, st));
+    return VSLAM_OK;
+}
+
+static int fetch_candidates(vslam_fe* fe, int nimg, bool everything) {
+    /* header + cell table + a first chunk speculatively; the rest only if a slot needs it */
+    hipStream_t st = fe->stream;
+    const size_t hdr_bytes = 8 + fe->cells.size() * sizeof(CellOut);
+    const size_t first_cands = everything ? (size_t)fe->cand_cap : std::min<size_t>((size_t)fe->cand_cap, 40960);
+    HIPCHK(hipMemcpy2DAsync(fe->h_cand, fe->cand_stride, fe->d_cand, fe->cand_stride, hdr_bytes + first_cands * 4,
+                            nimg, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(fe->ev_cand, st));
-    /* 6. blur runs while the host distributes */
-    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
-    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
-             fe->taps, nimg);
-    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
-    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
+}
+
+static int wait_candidates(vslam_fe* fe, int nimg) {
+    hipStream_t st = fe->stream;
+    const size_t hdr_bytes = 8 + fe->cells.size() * sizeof(CellOut);
+    const size_t first_cands = std::min<size_t>((size_t)fe->cand_cap, 40960);
     HIPCHK(hipEventSynchronize(fe->ev_cand));
     bool need_more = false;
     for (int s = 0; s < nimg; s++) {
@@ -363,32 +436,35 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
         }
         if (hdr[0] > first_cands) need_more = true;
     }
-    if (need_more) {
+    if (need_more && first_cands < (size_t)fe->cand_cap) {
         HIPCHK(hipMemcpy2DAsync(fe->h_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
                                 fe->d_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
                                 ((size_t)fe->cand_cap - first_cands) * 4, nimg, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
+    fe->cand_on_host = true;
+    return VSLAM_OK;
+}
 
-    /* 7. host: gather per level in cell order, distribute */
+/* quadtree on the host (fallback when the node list does not fit LDS, or VSLAM_FLAG_HOST_OCTREE) */
+static int enqueue_back_host(vslam_fe* fe, int nimg, int lap0, int lap1) {
+    const vslam_fe_params& p = fe->p;
+    const int L = p.nlevels;
+    hipStream_t st = fe->stream;
+    const bool prof = fe->profiling;
+    int rc = fetch_candidates(fe, nimg, false);
+    if (rc) return rc;
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
+    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
+             fe->taps, nimg); /* runs while the host distributes */
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
+    HIPCHK(hipGetLastError());
+    if ((rc = wait_candidates(fe, nimg))) return rc;
     std::atomic<int> bad(0);
     fe->pool->parallel_for(nimg * L, [&](int task) {
         const int s = task / L, l = task % L;
-        const uint8_t* base = fe->h_cand + (size_t)s * fe->cand_stride;
-        const CellOut* co = (const CellOut*)(base + 8);
-        const uint32_t* cand = (const uint32_t*)(base + hdr_bytes);
-        std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)s * L + l];
-        cl.clear();
-        for (int c = fe->level_cell_first[l]; c < fe->level_cell_first[l + 1]; c++) {
-            const uint32_t* q = cand + co[c].base;
-            for (uint32_t k = 0; k < co[c].count; k++) {
-                vslam::Cand cd;
-                cd.x = (int16_t)(q[k] & 0xFFF);
-                cd.y = (int16_t)((q[k] >> 12) & 0xFFF);
-                cd.response = (uint8_t)(q[k] >> 24);
-                cl.push_back(cd);
-            }
-        }
+        decode_candidates(fe, s, l);
+        const std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)s * L + l];
         const LevelGeom& g = fe->geom.lv[l];
         if (!vslam::distribute_octree(cl.data(), (int)cl.size(), g.w - 2 * VSLAM_FAST_BORDER,
                                       g.h - 2 * VSLAM_FAST_BORDER, fe->tab.quota[l],
@@ -399,7 +475,7 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
         g_err = "DistributeOctTree: nIni == 0";
         return VSLAM_ERR_UNSUPPORTED;
     }
-    /* 8. output order (fextractor.cpp:1071-1129): level-major, lapping-area keypoints from the tail */
+    /* output order (fextractor.cpp:1071-1129): level-major, lapping-area keypoints from the tail */
     int nsel = 0;
     for (int s = 0; s < nimg; s++) {
         int nk = 0;
@@ -429,31 +505,113 @@ static int run_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_
         fe->n_out[s] = nk;
         fe->mono_out[s] = monoIndex;
     }
-    /* 9. orientation + descriptors */
     if (nsel) {
         HIPCHK(hipMemcpyAsync(fe->d_sel, fe->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
         if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
         vk_orient_describe(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, nsel,
-                           fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap,
-                           (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0);
+                           fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0);
         if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
+    } else if (prof) {
+        HIPCHK(hipEventRecord(fe->ev_prof[5], st));
+        HIPCHK(hipEventRecord(fe->ev_prof[6], st));
+    }
+    if (prof) {
+        HIPCHK(hipEventRecord(fe->ev_prof[7], st));
+        HIPCHK(hipEventRecord(fe->ev_prof[8], st));
     }
     HIPCHK(hipGetLastError());
-    if (prof) {
-        HIPCHK(hipStreamSynchronize(st));
+    return VSLAM_OK;
+}
+
+/* quadtree on the device: nothing returns to the host until the results do */
+static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
+    const vslam_fe_params& p = fe->p;
+    hipStream_t st = fe->stream;
+    const bool prof = fe->profiling;
+    int32_t* d_err = fe->d_counts + (size_t)fe->B * 4;
+    HIPCHK(hipMemsetAsync(d_err, 0, 16, st));
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
+    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
+             fe->taps, nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
+    vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
+              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg);
+    vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
+                  d_err, nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
+    vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
+                           fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
+                           nimg);
+    if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
+    HIPCHK(hipMemcpyAsync(fe->h_counts, fe->d_counts, (size_t)(fe->B * 4 + 4) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
+}
+
+static int enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                           int lap0, int lap1, bool want_host) {
+    HIPCHK(hipSetDevice(fe->p.device));
+    int rc = enqueue_front(fe, nimg, imgs, pitch, on_device);
+    if (rc) return rc;
+    rc = fe->dev_octree ? enqueue_back_dev(fe, nimg, lap0, lap1) : enqueue_back_host(fe, nimg, lap0, lap1);
+    if (rc) return rc;
+    hipStream_t st = fe->stream;
+    if (want_host) { /* whole blocks: counts are not known on the host yet in the device-quadtree path */
+        HIPCHK(hipMemcpyAsync(fe->h_kps, fe->d_kps, (size_t)nimg * fe->cap * sizeof(vslam_kp),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(fe->h_desc, fe->d_desc, (size_t)nimg * fe->cap * 32, hipMemcpyDeviceToHost, st));
+    }
+    return VSLAM_OK;
+}
+
+static int finish_extract(vslam_fe* fe, int nimg) {
+    hipStream_t st = fe->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    if (fe->dev_octree) {
+        const int32_t* err = fe->h_counts + (size_t)fe->B * 4;
+        if (err[0] & 1) {
+            g_err = "FAST candidate buffer overflow (or > 65535 candidates on one level)";
+            return VSLAM_ERR_CAPACITY;
+        }
+        if (err[0] & 2) {
+            g_err = "internal keypoint capacity exceeded";
+            return VSLAM_ERR_CAPACITY;
+        }
+        for (int s = 0; s < nimg; s++) {
+            fe->n_out[s] = fe->h_counts[s * 4];
+            fe->mono_out[s] = fe->h_counts[s * 4 + 1];
+        }
+    }
+    if (fe->profiling) {
         float ms;
-        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[0], fe->ev_prof[1]));
-        fe->prof_ms[0] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[1], fe->ev_prof[2]));
-        fe->prof_ms[1] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[3], fe->ev_prof[4]));
-        fe->prof_ms[2] += ms;
-        if (nsel) {
-            HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[5], fe->ev_prof[6]));
-            fe->prof_ms[3] += ms;
+        static const int span[5][2] = {{0, 1}, {1, 2}, {3, 4}, {5, 6}, {7, 8}};
+        for (int i = 0; i < 5; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, fe->ev_prof[span[i][0]], fe->ev_prof[span[i][1]]));
+            fe->prof_ms[i] += ms;
         }
         fe->prof_batches++;
         fe->prof_images += nimg;
+    }
+    return VSLAM_OK;
+}
+
+static int deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                   int* mono_index) {
+    for (int s = 0; s < nimg; s++) {
+        if (kps && desc) {
+            if (fe->n_out[s] > cap) {
+                g_err = "caller keypoint capacity too small";
+                return VSLAM_ERR_CAPACITY;
+            }
+            if (fe->n_out[s]) {
+                memcpy(kps[s], fe->h_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp));
+                memcpy(desc[s], fe->h_desc + (size_t)s * fe->cap * 32, (size_t)fe->n_out[s] * 32);
+            }
+        }
+        if (n) n[s] = fe->n_out[s];
+        if (mono_index) mono_index[s] = fe->mono_out[s];
     }
     return VSLAM_OK;
 }
@@ -465,37 +623,36 @@ extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* con
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
-    int rc = run_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1);
+    int rc = enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, kps && desc);
+    if (rc == VSLAM_OK) rc = finish_extract(fe, nimg);
     if (rc != VSLAM_OK) {
         hipStreamSynchronize(fe->stream);
         return rc;
     }
-    hipStream_t st = fe->stream;
-    const bool want_host = kps && desc;
-    if (want_host) {
-        for (int s = 0; s < nimg; s++) {
-            if (fe->n_out[s] > cap) {
-                hipStreamSynchronize(st);
-                g_err = "caller keypoint capacity too small";
-                return VSLAM_ERR_CAPACITY;
-            }
-            if (fe->n_out[s] == 0) continue;
-            HIPCHK(hipMemcpyAsync(fe->h_kps + (size_t)s * fe->cap, fe->d_kps + (size_t)s * fe->cap,
-                                  (size_t)fe->n_out[s] * sizeof(vslam_kp), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(fe->h_desc + (size_t)s * fe->cap * 32, fe->d_desc + (size_t)s * fe->cap * 32,
-                                  (size_t)fe->n_out[s] * 32, hipMemcpyDeviceToHost, st));
-        }
+    return deliver(fe, nimg, kps, desc, cap, n, mono_index);
+}
+
+/* split form: enqueue everything (no host synchronisation in the device-quadtree path), collect later */
+extern "C" int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
+                                            int imgs_on_device, int lap0, int lap1, int want_host) {
+    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
     }
-    HIPCHK(hipStreamSynchronize(st));
-    for (int s = 0; s < nimg; s++) {
-        if (want_host && fe->n_out[s]) {
-            memcpy(kps[s], fe->h_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp));
-            memcpy(desc[s], fe->h_desc + (size_t)s * fe->cap * 32, (size_t)fe->n_out[s] * 32);
-        }
-        if (n) n[s] = fe->n_out[s];
-        if (mono_index) mono_index[s] = fe->mono_out[s];
+    int rc = enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, want_host != 0);
+    if (rc != VSLAM_OK) hipStreamSynchronize(fe->stream);
+    return rc;
+}
+
+extern "C" int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                                     int* mono_index) {
+    if (!fe || fe->last_nimg < 1) {
+        g_err = "nothing enqueued";
+        return VSLAM_ERR_INVALID;
     }
-    return VSLAM_OK;
+    int rc = finish_extract(fe, fe->last_nimg);
+    if (rc != VSLAM_OK) return rc;
+    return deliver(fe, fe->last_nimg, kps, desc, cap, n, mono_index);
 }
 
 extern "C" int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, int lap1,
@@ -512,7 +669,15 @@ extern "C" int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, 
 }
 
 extern "C" int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int cap) {
-    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
+    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels || slot >= fe->last_nimg)
+        return VSLAM_ERR_INVALID;
+    if (!fe->cand_on_host) { /* device-quadtree path: the candidates never left HBM; fetch them now */
+        HIPCHK(hipSetDevice(fe->p.device));
+        int rc = fetch_candidates(fe, fe->last_nimg, true);
+        if (rc == VSLAM_OK) rc = wait_candidates(fe, fe->last_nimg);
+        if (rc) return rc;
+    }
+    if (fe->dev_octree || true) decode_candidates(fe, slot, level);
     const std::vector<vslam::Cand>& cl = fe->cand_level[(size_t)slot * fe->p.nlevels + level];
     for (int i = 0; i < (int)cl.size() && i < cap && out; i++) {
         out[i].x = (float)cl[i].x;

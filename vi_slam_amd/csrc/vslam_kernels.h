@@ -28,6 +28,19 @@ int vk_hamming_top2_tiles(int nt);
 void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
                      int32_t* idx2, int32_t* dist2);
 
+size_t vk_octree_lds_bytes(int maxNodes);
+int vk_octree_set_max_lds(size_t bytes);
+void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
+               uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots);
+void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
+                   const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
+                   int32_t* err_flag, int nslots);
+void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
+                            const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
+                            const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
+                            int cap, int atan_fma, int nslots);
+
 void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c);
 void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma, float* a);
 

@@ -340,14 +340,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
     return a;
 }
 
-__global__ void __launch_bounds__(256)
-k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
-                  BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel, int nsel,
-                  const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma) {
+__device__ __forceinline__ void orient_describe_one(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                    size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                                                    const SelKp s, const int8_t* __restrict__ pattern, vslam_kp* kps,
+                                                    uint8_t* desc, int cap, int atan_fma) {
     const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= nsel) return; /* wave-uniform */
-    const SelKp s = sel[k];
     const LevelGeom lg = g.lv[s.level];
     int pitch;
     const uint8_t* img = level_base(pyr, slot_stride, src, lg, s.level, s.slot, &pitch);
@@ -401,6 +398,29 @@ k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ b
         unsigned long long* od = (unsigned long long*)(desc + ((size_t)s.slot * cap + s.out) * 32);
         od[lane] = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
     }
+}
+
+/* host-selected keypoints (quadtree on the host): one flat list for the batch */
+__global__ void __launch_bounds__(256)
+k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
+                  BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel, int nsel,
+                  const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= nsel) return; /* wave-uniform */
+    orient_describe_one(pyr, blur, slot_stride, src, g, sel[k], pattern, kps, desc, cap, atan_fma);
+}
+
+/* device-selected keypoints (k_octree + k_assign_out): per-slot lists, counts read from HBM */
+__global__ void __launch_bounds__(256)
+k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
+                      BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
+                      const int32_t* __restrict__ slot_counts, const int8_t* __restrict__ pattern, vslam_kp* kps,
+                      uint8_t* desc, int cap, int atan_fma) {
+    const int slot = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= slot_counts[slot * 4]) return; /* wave-uniform */
+    orient_describe_one(pyr, blur, slot_stride, src, g, sel[(size_t)slot * cap + k], pattern, kps, desc, cap,
+                        atan_fma);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -559,6 +579,14 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
     if (nsel <= 0) return;
     hipLaunchKernelGGL(k_orient_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, pyr, blur, slot_stride, src, g,
                        sel, nsel, pattern, kps, desc, cap, atan_fma);
+}
+
+void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
+                            const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
+                            const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
+                            int cap, int atan_fma, int nslots) {
+    hipLaunchKernelGGL(k_orient_describe_dev, dim3((cap + 3) / 4, nslots), dim3(256), 0, st, pyr, blur, slot_stride,
+                       src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma);
 }
 
 void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out) {

@@ -1,0 +1,510 @@
+/* vslam_octree_kernel.hip -- FExtractor::DistributeOctTree (fextractor.cpp:530-754) on the GPU.
+ *
+ * One 1024-thread workgroup per (image slot, pyramid level).  The reference algorithm is a sequential
+ * walk over a std::list, but every pass of it splits a whole generation of nodes, and the only
+ * order-dependent facts are (a) the relative order of the keys inside a node (DivideNode keeps it),
+ * (b) the order of the list and (c) the "largest node first, stop at N" rule.  All three are prefix sums:
+ *
+ *  - keys live in one array, each node owns a contiguous range; a split is a STABLE 4-way partition of
+ *    the range, done for all nodes of a pass at once with one block-wide scan of packed 4x16-bit
+ *    quadrant counters (rank of a key = scan value minus the scan value at its node's first key);
+ *  - children are push_front'ed in creation order and survivors keep their relative order, so after a
+ *    pass   list = reverse(children in creation order) ++ survivors.  Nodes are stored IN LIST ORDER and
+ *    rebuilt each pass from two scans (children created before me / survivors before me);
+ *  - phase 2 (fextractor.cpp:664-729) sorts the expandable nodes by (size, node address) and stops once
+ *    lNodes.size() >= N: rank by counting, prefix sum of (children-1) in that order, cut where the
+ *    running list size reaches N.  Heap addresses are not reproducible; the tie-break is "created later
+ *    first" == smaller list index first (same rule as the CPU oracle and vslam_host.cpp).
+ *
+ * Integer arithmetic only, except the initial bucket index (int)(x / hX) which is an IEEE float division
+ * exactly as in the reference (fextractor.cpp:560).
+ */
+#include "vslam_kernels.h"
+
+#define OT 1024
+typedef unsigned long long u64;
+
+struct ONode { /* 16 bytes, one entry of the list */
+    int16_t x0, y0, x1, y1;
+    uint16_t begin, count;
+    uint16_t flags; /* bit0 noMore */
+    uint16_t pad;
+};
+
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T* s_wave, T* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    T woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < OT / 64; k++) {
+        const T x = s_wave[k];
+        if (k < wv) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+__device__ __forceinline__ int quadrant(uint32_t pt, const ONode& nd) {
+    /* DivideNode, fextractor.cpp:474-517: halfX = ceil((UR.x-UL.x)/2); kp.x < n1.UR.x, kp.y < n1.BR.y */
+    const int x = pt & 0xFFF, y = (pt >> 12) & 0xFFF;
+    const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+    return (x < mx ? 0 : 1) | (y < my ? 0 : 2);
+}
+
+__global__ void __launch_bounds__(OT)
+k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
+         uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
+         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag) {
+    extern __shared__ __align__(16) uint8_t osm[];
+    const int MAXN = P.maxNodes;
+    ONode* cur = (ONode*)osm;
+    ONode* nxt = cur + MAXN;
+    u64* Sbeg = (u64*)(nxt + MAXN);
+    u64* Cnt = Sbeg + MAXN;               /* Send during a pass, then quadrant counts */
+    uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
+    uint16_t* newIdx = cb + MAXN;             /* list index of a survivor after the pass */
+    uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
+    uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
+    __shared__ u64 s_w64[OT / 64];
+    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ int s_size, s_M, s_nexp, s_cut;
+
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, slot = blockIdx.y;
+    const int N = P.N[level];
+    const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    const CellOut* cout = (const CellOut*)(hdr + 2);
+    const uint32_t* cand = (const uint32_t*)(cout + ncells);
+    uint32_t* pa = pts_a + (size_t)slot * pts_stride;
+    uint32_t* pb = pts_b + (size_t)slot * pts_stride;
+    uint16_t* na = nid_a + (size_t)slot * pts_stride;
+    uint16_t* nb = nid_b + (size_t)slot * pts_stride;
+    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
+    int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
+
+    /* ---- 0. gather this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817) */
+    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
+    uint32_t before = 0;
+    for (int c = tid; c < c0; c += OT) before += cout[c].count;
+    uint32_t off0;
+    {
+        uint32_t tot;
+        block_excl_scan<uint32_t>(before, s_w32, &tot);
+        off0 = tot;
+    }
+    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
+    uint32_t mine = 0;
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) mine += cout[c].count;
+    }
+    uint32_t ntot;
+    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
+    const int n = (int)ntot;
+    if (off0 + ntot > (uint32_t)P.ptsCap || n > 65535 || hdr[1] != 0) {
+        if (tid == 0) {
+            atomicOr(err_flag, 1);
+            *ocnt = 0;
+        }
+        return;
+    }
+    pa += off0; pb += off0; na += off0; nb += off0;
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) {
+            const uint32_t* q = cand + cout[c].base;
+            const uint32_t cnt = cout[c].count;
+            for (uint32_t e = 0; e < cnt; e++) pa[woff + e] = q[e];
+            woff += cnt;
+        }
+    }
+    if (n == 0) {
+        if (tid == 0) *ocnt = 0;
+        return;
+    }
+    __syncthreads();
+
+    const int C = (n + OT - 1) / OT;
+    const int i0 = min(tid * C, n), i1 = min(i0 + C, n);
+
+    /* ---- 1. initial nodes: stable bucketing by (int)(x / hX) (fextractor.cpp:534-576) */
+    const int nIni = P.nIni[level];
+    const float hX = P.hX[level];
+    const int Hh = P.H[level];
+    __shared__ uint32_t s_bcnt[64], s_bbeg[64], s_bidx[64];
+    if (tid < 64) s_bcnt[tid] = 0;
+    __syncthreads();
+    for (int g = 0; g * 4 < nIni; g++) {
+        u64 loc = 0;
+        for (int i = i0; i < i1; i++) {
+            int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+            b = min(b, nIni - 1);
+            if ((b >> 2) == g) loc += 1ull << (16 * (b & 3));
+        }
+        u64 tot;
+        block_excl_scan<u64>(loc, s_w64, &tot);
+        if (tid < 4 && g * 4 + tid < nIni) s_bcnt[g * 4 + tid] = (uint32_t)((tot >> (16 * tid)) & 0xFFFF);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t acc = 0;
+        int li = 0;
+        for (int b = 0; b < nIni; b++) {
+            const uint32_t cb0 = s_bcnt[b];
+            s_bbeg[b] = acc;
+            s_bidx[b] = (uint32_t)li;
+            if (cb0) { /* empty initial nodes are erased (fextractor.cpp:572-573) */
+                ONode nd;
+                nd.x0 = (int16_t)(int)__fmul_rn(hX, (float)b);
+                nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
+                nd.y0 = 0;
+                nd.y1 = (int16_t)Hh;
+                nd.begin = (uint16_t)acc;
+                nd.count = (uint16_t)cb0;
+                nd.flags = cb0 == 1 ? 1 : 0;
+                nd.pad = 0;
+                cur[li++] = nd;
+            }
+            acc += cb0;
+        }
+        s_size = li;
+    }
+    __syncthreads();
+    for (int g = 0; g * 4 < nIni; g++) {
+        u64 loc = 0;
+        for (int i = i0; i < i1; i++) {
+            int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+            b = min(b, nIni - 1);
+            if ((b >> 2) == g) loc += 1ull << (16 * (b & 3));
+        }
+        u64 tot;
+        u64 run = block_excl_scan<u64>(loc, s_w64, &tot);
+        for (int i = i0; i < i1; i++) {
+            const uint32_t pt = pa[i];
+            int b = (int)__fdiv_rn((float)(pt & 0xFFF), hX);
+            b = min(b, nIni - 1);
+            if ((b >> 2) == g) {
+                const uint32_t pos = s_bbeg[b] + (uint32_t)((run >> (16 * (b & 3))) & 0xFFFF);
+                pb[pos] = pt;
+                nb[pos] = (uint16_t)s_bidx[b];
+                run += 1ull << (16 * (b & 3));
+            }
+        }
+        __syncthreads();
+    }
+    { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
+
+    /* ---- 2. split passes */
+    int phase = 1;
+    const int KN = (MAXN + OT - 1) / OT;
+    for (int iter = 0; iter < 64; iter++) {
+        const int size0 = s_size;
+        /* A. classify keys of expandable nodes, thread totals */
+        u64 loc = 0;
+        for (int i = i0; i < i1; i++) {
+            const ONode nd = cur[na[i]];
+            if (!(nd.flags & 1)) loc += 1ull << (16 * quadrant(pa[i], nd));
+        }
+        u64 tot64;
+        const u64 S0 = block_excl_scan<u64>(loc, s_w64, &tot64);
+        /* C. scan value at each node's first key and after its last key */
+        {
+            u64 run = S0;
+            for (int i = i0; i < i1; i++) {
+                const int v = na[i];
+                const ONode nd = cur[v];
+                if (nd.flags & 1) continue;
+                if (i == nd.begin) Sbeg[v] = run;
+                run += 1ull << (16 * quadrant(pa[i], nd));
+                if (i == nd.begin + nd.count - 1) Cnt[v] = run;
+            }
+        }
+        __syncthreads();
+        /* D. node level */
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0 && !(cur[v].flags & 1)) Cnt[v] -= Sbeg[v];
+        }
+        __syncthreads();
+        /* D1. processing rank of every expandable node */
+        uint32_t nexp_mine = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0 && !(cur[v].flags & 1)) nexp_mine++;
+        }
+        uint32_t nexp;
+        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
+        if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
+        if (phase == 1) {
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !(cur[v].flags & 1)) {
+                    prank[v] = (uint16_t)rbase;
+                    ordv[rbase] = (uint16_t)v;
+                    rbase++;
+                }
+            }
+        } else {
+            /* descending (count, "created later" == smaller list index) */
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !(cur[v].flags & 1)) {
+                    const uint32_t cv = cur[v].count;
+                    uint32_t r = 0;
+                    for (int u = 0; u < size0; u++) {
+                        const ONode nu = cur[u];
+                        if (!(nu.flags & 1) && (nu.count > cv || (nu.count == cv && u < v))) r++;
+                    }
+                    prank[v] = (uint16_t)r;
+                    ordv[r] = (uint16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        /* D2. in processing order: children created before me, running list size -> cut */
+        const int KE = ((int)nexp + OT - 1) / OT;
+        uint32_t chl = 0;
+        for (int k = 0; k < KE; k++) {
+            const int r = tid * KE + k;
+            if (r < (int)nexp) {
+                const u64 c = Cnt[ordv[r]];
+                chl += ((c & 0xFFFF) != 0) + (((c >> 16) & 0xFFFF) != 0) + (((c >> 32) & 0xFFFF) != 0) + ((c >> 48) != 0);
+            }
+        }
+        uint32_t chtot;
+        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
+        if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
+        __syncthreads();
+        {
+            /* parent r is processed iff size0 + sum_{r'<r}(nch-1) < N (phase 2); phase 1: all */
+            uint32_t cb_run = chbase;
+            for (int k = 0; k < KE; k++) {
+                const int r = tid * KE + k;
+                if (r < (int)nexp) {
+                    const int v = ordv[r];
+                    const u64 c = Cnt[v];
+                    const uint32_t nch = ((c & 0xFFFF) != 0) + (((c >> 16) & 0xFFFF) != 0) +
+                                         (((c >> 32) & 0xFFFF) != 0) + ((c >> 48) != 0);
+                    if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
+                    cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
+                    cb_run += nch;
+                }
+            }
+        }
+        __syncthreads();
+        const int ncut = s_cut;
+        /* M = children of processed parents; new size */
+        if (tid == 0) {
+            int M;
+            if (ncut >= (int)nexp) M = (int)chtot;
+            else M = cb[ordv[ncut]];
+            s_M = M;
+            s_size = size0 + M - ncut;
+            s_nexp = 0;
+        }
+        __syncthreads();
+        const int M = s_M;
+        /* D3. survivors: list index after the pass */
+        uint32_t sv = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0) {
+                const bool processed = !(cur[v].flags & 1) && prank[v] < ncut;
+                if (!processed) sv++;
+            }
+        }
+        uint32_t svtot;
+        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
+        int nexp_children = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v >= size0) continue;
+            const ONode nd = cur[v];
+            const bool processed = !(nd.flags & 1) && prank[v] < ncut;
+            if (!processed) {
+                newIdx[v] = (uint16_t)(M + svbase);
+                nxt[M + svbase] = nd;
+                svbase++;
+            } else {
+                const u64 c = Cnt[v];
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                int kq = 0;
+                uint32_t beg = nd.begin;
+                const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cq = (uint32_t)((c >> (16 * q)) & 0xFFFF);
+                    if (!cq) continue;
+                    ONode ch;
+                    ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
+                    ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
+                    ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
+                    ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
+                    ch.begin = (uint16_t)beg;
+                    ch.count = (uint16_t)cq;
+                    ch.flags = cq == 1 ? 1 : 0;
+                    ch.pad = 0;
+                    nxt[first - kq] = ch;
+                    if (cq > 1) nexp_children++;
+                    beg += cq;
+                    kq++;
+                }
+                cb[v] = (uint16_t)first;
+            }
+        }
+        if (nexp_children) atomicAdd(&s_nexp, nexp_children);
+        __syncthreads();
+        /* E. move the keys of processed parents (stable), relabel every key with its node's new index */
+        {
+            u64 run = S0;
+            for (int i = i0; i < i1; i++) {
+                const uint32_t pt = pa[i];
+                const int v = na[i];
+                const ONode nd = cur[v];
+                if (nd.flags & 1) {
+                    pb[i] = pt;
+                    nb[i] = newIdx[v];
+                    continue;
+                }
+                const int q = quadrant(pt, nd);
+                if (prank[v] < ncut) {
+                    const u64 c = Cnt[v];
+                    const u64 rk = run - Sbeg[v];
+                    uint32_t pos = nd.begin + (uint32_t)((rk >> (16 * q)) & 0xFFFF);
+                    int kq = 0;
+                    for (int q2 = 0; q2 < q; q2++) {
+                        const uint32_t cq = (uint32_t)((c >> (16 * q2)) & 0xFFFF);
+                        pos += cq;
+                        kq += cq != 0;
+                    }
+                    pb[pos] = pt;
+                    nb[pos] = (uint16_t)(cb[v] - kq);
+                } else {
+                    pb[i] = pt;
+                    nb[i] = newIdx[v];
+                }
+                run += 1ull << (16 * q);
+            }
+        }
+        __syncthreads();
+        { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
+        { ONode* t = cur; cur = nxt; nxt = t; }
+        /* F. loop control (fextractor.cpp:658-729) */
+        const int size = s_size, nToExpand = s_nexp;
+        __syncthreads();
+        if (size >= N || size == size0) break;
+        if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
+    }
+
+    /* ---- 3. best response per node, first wins (fextractor.cpp:732-751); output in list order */
+    const int size = s_size;
+    for (int v = tid; v < size; v += OT) {
+        const ONode nd = cur[v];
+        uint32_t best = pa[nd.begin];
+        for (int k = 1; k < nd.count; k++) {
+            const uint32_t p = pa[nd.begin + k];
+            if ((p >> 24) > (best >> 24)) best = p;
+        }
+        out[v] = best;
+    }
+    if (tid == 0) *ocnt = size;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * output order of a slot (fextractor.cpp:1071-1129): level-major; a keypoint whose scaled x lies in
+ * [lap0, lap1] takes the next free index from the tail, the others from the head.  One workgroup per
+ * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(OT)
+k_assign_out(OctParams P, PyramidGeom g, const uint32_t* __restrict__ sel_xyr, const int32_t* __restrict__ sel_cnt,
+             int lap0, int lap1, SelKp* sel, int32_t* slot_counts /* [slot][4]: n, mono, 0, 0 */, int cap,
+             int32_t* err_flag) {
+    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
+    const int tid = threadIdx.x, slot = blockIdx.x;
+    const int L = g.nlevels;
+    if (tid == 0) {
+        int acc = 0;
+        for (int l = 0; l < L; l++) {
+            s_lvl_off[l] = acc;
+            acc += sel_cnt[slot * VSLAM_MAX_LEVELS + l];
+        }
+        s_lvl_off[L] = acc;
+    }
+    __syncthreads();
+    const int nk = s_lvl_off[L];
+    if (nk > cap) {
+        if (tid == 0) {
+            atomicOr(err_flag, 2);
+            slot_counts[slot * 4] = 0;
+            slot_counts[slot * 4 + 1] = 0;
+        }
+        return;
+    }
+    const int Cc = (nk + OT - 1) / OT;
+    const int i0 = min(tid * Cc, nk), i1 = min(i0 + Cc, nk);
+    const uint32_t* base = sel_xyr + (size_t)slot * P.selStride;
+    uint32_t lapc = 0;
+    int l = 0;
+    for (int i = i0; i < i1; i++) {
+        while (i >= s_lvl_off[l + 1]) l++;
+        const uint32_t p = base[P.selOff[l] + (i - s_lvl_off[l])];
+        float px = (float)((int)(p & 0xFFF) + VSLAM_BORDER);
+        if (l) px = __fmul_rn(px, g.lv[l].scale);
+        lapc += (px >= (float)lap0 && px <= (float)lap1) ? 1u : 0u;
+    }
+    uint32_t laptot;
+    uint32_t lapbefore = block_excl_scan<uint32_t>(lapc, s_w32, &laptot);
+    l = 0;
+    for (int i = i0; i < i1; i++) {
+        while (i >= s_lvl_off[l + 1]) l++;
+        const uint32_t p = base[P.selOff[l] + (i - s_lvl_off[l])];
+        const int lx = (int)(p & 0xFFF) + VSLAM_BORDER, ly = (int)((p >> 12) & 0xFFF) + VSLAM_BORDER;
+        float px = (float)lx;
+        if (l) px = __fmul_rn(px, g.lv[l].scale);
+        const bool inlap = px >= (float)lap0 && px <= (float)lap1;
+        SelKp k;
+        k.x = (uint16_t)lx;
+        k.y = (uint16_t)ly;
+        k.level = (uint8_t)l;
+        k.slot = (uint8_t)slot;
+        k.response = (uint8_t)(p >> 24);
+        k.pad = 0;
+        k.out = inlap ? (uint32_t)(nk - 1 - (int)lapbefore) : (uint32_t)(i - (int)lapbefore);
+        if (inlap) lapbefore++;
+        sel[(size_t)slot * cap + i] = k;
+    }
+    if (tid == 0) {
+        slot_counts[slot * 4] = nk;
+        slot_counts[slot * 4 + 1] = nk - (int)laptot; /* monoIndex */
+    }
+}
+
+size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 8 + 8 + 2 + 2 + 2 + 2) + 64; }
+
+void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
+               uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots) {
+    hipLaunchKernelGGL(k_octree, dim3(nlevels, nslots), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
+                       cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag);
+}
+
+void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
+                   const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
+                   int32_t* err_flag, int nslots) {
+    hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(OT), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
+                       slot_counts, cap, err_flag);
+}
+
+int vk_octree_set_max_lds(size_t bytes) {
+    return (int)hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
