@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
+    ap.add_argument("--inflight", type=int, default=3, help="extractor contexts (HIP streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,8 +126,10 @@ def main():
     B = args.batch
     if stereo and B % 2:
         B += 1
-    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B)
-    matcher = V.FMatcher(fe, 0.9, True)
+    NCTX = max(2, args.inflight)  # extractor contexts (streams) kept in flight per GPU
+    ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B) for _ in range(NCTX)]
+    fe = ctxs[0]
+    matchers = [V.FMatcher(c, 0.9, True) for c in ctxs]
     lap = (0, 0) if stereo else (0, 1000)  # frame.cpp:107-108 vs :289
 
     # ---- synthetic frames, resident in HBM before the timed region
@@ -140,6 +143,7 @@ def main():
         dev_frames[s, :, :w] = torch.from_numpy(fr).cuda()
     ptrs = [dev_frames[s].data_ptr() for s in range(B)]
     slot_bytes = fe.slot_bytes
+    desc_off = 16 + fe.cap * 28
     packed = torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda")
     gathered = torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
     carry = torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda")
@@ -149,39 +153,60 @@ def main():
     def slot_host_kps(view):
         hdr = view[:16].cpu().numpy().view(np.int32)
         n = int(hdr[0])
-        kp = view[16:16 + n * 28].cpu().numpy().view(V.KP_DTYPE)
-        return kp
+        return view[16:16 + n * 28].cpu().numpy().view(V.KP_DTYPE)
 
-    def step():
-        res = fe.compute_batch(None, lap, device_ptrs=ptrs, pitch=pitch)
+    def enqueue(t):
+        c = ctxs[t % NCTX]
         if stereo:
-            out = V.ComputeStereoMatchesBatch(fe, list(range(0, B, 2)), fe, list(range(1, B, 2)), BF, FX)
-            state["matches"] = sum(int((u >= 0).sum()) for u, _ in out)
+            c.frame_stereo_async(ptrs, pitch, BF, FX)
+        else:
+            c.compute_batch_async(ptrs, pitch, lap)
+
+    def collect(t):
+        """Finish step t: results to the host, then (mono) match every frame against its predecessor."""
+        c = ctxs[t % NCTX]
+        if stereo:
+            feats, st = c.frame_stereo_wait()
+            state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
             return
-        fe.pack_slots(B, packed.data_ptr(), slot_bytes)
-        vd.exchange_slots(packed, gathered)
-        nm_total = 0
+        res = c.wait()
+        if world > 1:
+            c.pack_slots(B, packed.data_ptr(), slot_bytes)
+            vd.exchange_slots(packed, gathered)
+        pairs = []
         for s in range(B):
             pr, ps, prev_step = vd.predecessor(rank, s, world, B)
             if prev_step:
                 if state["carry_kps"] is None:
                     continue
-                pview, k_prev = carry, state["carry_kps"]
+                k_prev, d_prev = state["carry_kps"], carry.data_ptr() + desc_off
+            elif world == 1:
+                k_prev, d_prev = res[ps][0], c.slot_buffers(ps)[1]
             else:
                 pview = vd.slot_view(gathered, pr, ps, B, slot_bytes)
                 k_prev = res[ps][0] if pr == rank else slot_host_kps(pview)
-            k_cur = res[s][0]
-            cview = vd.slot_view(gathered, rank, s, B, slot_bytes)
-            d_prev = pview.data_ptr() + 16 + fe.cap * 28
-            d_cur = cview.data_ptr() + 16 + fe.cap * 28
-            prevm = np.stack([k_prev["x"], k_prev["y"]], 1)
-            nm, _, _ = matcher.SearchForInitialization(k_prev, d_prev, k_cur, d_cur, prevm, 100, (w, h))
-            nm_total += nm
+                d_prev = pview.data_ptr() + desc_off
+            k_cur, d_cur = res[s][0], c.slot_buffers(s)[1]
+            pairs.append((k_prev, d_prev, k_cur, d_cur, np.stack([k_prev["x"], k_prev["y"]], 1)))
+        out = matchers[t % NCTX].SearchForInitializationBatch(pairs, 100, (w, h)) if pairs else []
+        state["matches"] = sum(o[0] for o in out)
         # the last frame of this step precedes the first frame of the next one
-        lastv = vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes)
-        carry.copy_(lastv)
-        state["carry_kps"] = res[B - 1][0] if rank == world - 1 else slot_host_kps(lastv)
-        state["matches"] = nm_total
+        if world == 1:
+            c.pack_slots(1, carry.data_ptr(), slot_bytes, first=B - 1)
+            state["carry_kps"] = res[B - 1][0].copy()
+        else:
+            lastv = vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes)
+            carry.copy_(lastv)
+            state["carry_kps"] = res[B - 1][0].copy() if rank == world - 1 else slot_host_kps(lastv)
+
+    def run(nsteps):
+        depth = NCTX - 1
+        for t in range(nsteps):
+            enqueue(t)
+            if t >= depth:
+                collect(t - depth)
+        for t in range(max(nsteps - depth, 0), nsteps):
+            collect(t)
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,17 +214,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fe.set_profiling(True)
+    run(args.warmup)
+    for c in ctxs:
+        c.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = fe.get_profile()
-    fe.set_profiling(False)
+    prof = {}
+    for c in ctxs:
+        for k, v in c.get_profile().items():
+            prof[k] = prof.get(k, 0) + v
+        c.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -212,10 +239,11 @@ def main():
         ab = algorithmic_bytes(fe, nf)
         nb = max(prof["batches"], 1)
         stage_ms = {"pyramid": prof["pyramid_ms"] / nb, "fast": prof["fast_ms"] / nb, "blur": prof["blur_ms"] / nb,
-                    "describe": prof["describe_ms"] / nb}
-        dom = max(stage_ms, key=stage_ms.get)
+                    "describe": prof["describe_ms"] / nb, "octree": prof["octree_ms"] / nb}
+        streaming = {k: v for k, v in stage_ms.items() if k != "octree"}  # the quadtree moves no image bytes
+        dom = max(streaming, key=streaming.get)
         kernel = {"pyramid": "k_resize_level(x7)", "fast": "k_fast_cells", "blur": "k_blur7",
-                  "describe": "k_orient_describe"}[dom]
+                  "describe": "k_orient_describe_dev"}[dom]
         bytes_per_launch = ab[dom] * B
         achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         out = {
@@ -236,7 +264,7 @@ def main():
                        "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100",
                        "sharding": "frames round-robin over ranks; one all-gather of result slots per step"
                        if not stereo else "stereo frames independent per rank, no collective",
-                       "matches_last_step_rank0": state["matches"]},
+                       "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"]},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -245,7 +273,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    fe.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -125,6 +125,8 @@ void* vslam_fe_stream(vslam_fe* fe);
  *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = nfeatures + 4*nlevels + 8)
  * Returns after the copies have completed. */
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
+/* the same for slots first .. first+nslots-1 (packed from offset 0 of dev_dst) */
+int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes);
 
 /* Stage timing with HIP events on the context's stream (the reference's REGISTER_TIMES spans,
  * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..4] = pyramid (7 launches), FAST cells,
@@ -159,6 +161,16 @@ int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, float bf, f
 int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL, const int* slotsR,
                              float bf, float fx, float* const* u_right, float* const* depth);
 
+/* The extraction + stereo-match section of Frame::Frame(imLeft, imRight, ...) (frame.cpp:102-132) for
+ * npairs (<= 16, 2*npairs <= max_batch) stereo frames in ONE enqueue on fe's stream: imgs = L0,R0,L1,R1,...
+ * (slot 2j = left, 2j+1 = right of frame j; vLappingArea {0,0} as the reference passes, frame.cpp:107-108).
+ * _async returns without waiting; _wait delivers keypoints/descriptors of all 2*npairs images (arrays of
+ * 2*npairs entries, may be NULL) and mvuRight/mvDepth of the npairs left images. */
+int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const uint8_t* const* imgs, size_t pitch,
+                                   int imgs_on_device, float bf, float fx, int want_host);
+int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                            float* const* u_right, float* const* depth);
+
 /* FMatcher::SearchForInitialization (fmatcher.h:106, fmatcher.cpp:983-1098).  Frame 1 / frame 2
  * keypoints+descriptors are device arrays (e.g. from vslam_fe_slot_buffers, or a slot of an RCCL
  * all-gather buffer); kps1_host/kps2_host are the same keypoints on the host.  prev_matched: 2*n1 floats
@@ -167,6 +179,16 @@ int vslam_search_for_initialization(vslam_fe* fe, const vslam_kp* kps1_host, con
                                     int n1, const vslam_kp* kps2_host, const uint8_t* dev_desc2, int n2,
                                     int img_w, int img_h, float* prev_matched, int32_t* matches12,
                                     int window, float nnratio, int check_orientation, int* nmatches);
+
+/* npairs (<= 32) independent SearchForInitialization problems in one pass: the dense distance matrices of
+ * all pairs come from one kernel launch, the order-dependent replays run in parallel on the host pool.
+ * Every per-pair argument of the single form becomes an array of npairs entries. */
+int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_kp* const* kps1_host,
+                                          const uint8_t* const* dev_desc1, const int* n1,
+                                          const vslam_kp* const* kps2_host, const uint8_t* const* dev_desc2,
+                                          const int* n2, int img_w, int img_h, float* const* prev_matched,
+                                          int32_t* const* matches12, int window, float nnratio,
+                                          int check_orientation, int* nmatches);
 
 /* ---------------------------------------------------------------- diagnostics */
 

@@ -170,3 +170,41 @@ def test_search_for_initialization(nf, lap):
         assert nm2 == wn2 and np.array_equal(m12b, wm2)
     finally:
         f.close()
+
+
+def test_search_for_initialization_batch_equals_single(fe):
+    frames = [synth.make_frame(1241, 376, step=s) for s in range(5)]
+    res = fe.compute_batch(frames, (0, 1000))
+    bufs = [fe.slot_buffers(s) for s in range(5)]
+    m = V.FMatcher(fe, 0.9, True)
+    pairs = [(res[s][0], bufs[s][1], res[s + 1][0], bufs[s + 1][1], np.stack([res[s][0]["x"], res[s][0]["y"]], 1))
+             for s in range(4)]
+    out = m.SearchForInitializationBatch(pairs, 100)
+    for s in range(4):
+        wn, wm, wp = orbo.search_for_initialization(res[s][0], res[s][1], res[s + 1][0], res[s + 1][1], 1241, 376,
+                                                    window=100, nnratio=0.9)
+        assert out[s][0] == wn and np.array_equal(out[s][1], wm) and np.array_equal(out[s][2], wp), s
+        assert wn > 50
+
+
+def test_frame_stereo_async_pipeline(fe):
+    """Frame::Frame(stereo) hot section in one enqueue: extraction of L,R and ComputeStereoMatches."""
+    import torch
+    frames = [synth.make_stereo_pair(1241, 376, step=s) for s in range(3)]
+    pitch = 1280
+    dev = torch.zeros((6, 376, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(3):
+        dev[2 * s, :, :1241] = torch.from_numpy(frames[s][0]).cuda()
+        dev[2 * s + 1, :, :1241] = torch.from_numpy(frames[s][1]).cuda()
+    torch.cuda.synchronize()
+    fe.frame_stereo_async([dev[i].data_ptr() for i in range(6)], pitch, 386.1448, 718.856)
+    feats, st = fe.frame_stereo_wait()
+    for s in range(3):
+        eL, eR = orbo.Extractor(2000), orbo.Extractor(2000)
+        kL, dL, _ = eL.compute(frames[s][0])
+        kR, dR, _ = eR.compute(frames[s][1])
+        wu, wd, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, 386.1448, 718.856)
+        assert all(np.array_equal(feats[2 * s][0][f], kL[f]) for f in kL.dtype.names)
+        assert np.array_equal(feats[2 * s][1], dL) and np.array_equal(feats[2 * s + 1][1], dR)
+        assert np.array_equal(st[s][0], wu) and np.array_equal(st[s][1], wd)
+        assert (wu >= 0).sum() > 300

@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "vslam_stereo_match", "vslam_stereo_match_batch", "vslam_search_for_initialization",
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
+    "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
+    "vslam_fe_pack_slot_range",
 ]
 
 
@@ -81,10 +83,15 @@ def lib():
         L.vslam_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, f, f, vp, vp]
         L.vslam_search_for_initialization.argtypes = [vp, vp, vp, i, vp, vp, i, i, i, vp, vp, i, f, i, vp]
         L.vslam_fe_pack_slots.argtypes = [vp, i, vp, C.c_size_t]
+        L.vslam_fe_pack_slot_range.argtypes = [vp, i, i, vp, C.c_size_t]
         L.vslam_fe_set_profiling.argtypes = [vp, i]
         L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
         L.vslam_fe_extract_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, i, i, i]
         L.vslam_fe_extract_wait.argtypes = [vp, vp, vp, i, vp, vp]
+        L.vslam_frame_stereo_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, f, f, i]
+        L.vslam_frame_stereo_wait.argtypes = [vp, vp, vp, i, vp, vp, vp]
+        L.vslam_search_for_initialization_batch.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, vp, i, f, i,
+                                                            vp]
         L.vslam_dbg_sincos.argtypes = [vp, vp, i, vp, vp]
         L.vslam_dbg_fast_atan2.argtypes = [vp, vp, vp, i, i, vp]
         _lib = L
@@ -237,6 +244,42 @@ class FExtractor:
             return [(self._out_kps[i, :n[i]].copy(), self._out_desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
         return [(self._out_kps[i, :n[i]], self._out_desc[i, :n[i]], mono[i]) for i in range(nimg)]
 
+    # ---- Frame::Frame(stereo) hot section (frame.cpp:102-132), several frames per enqueue
+    def frame_stereo_async(self, device_ptrs, pitch, bf, fx, to_host=True):
+        """device_ptrs = [L0, R0, L1, R1, ...] HBM-resident images.  Enqueues extraction of all images and
+        ComputeStereoMatches of every (L,R) pair; returns immediately.  Collect with frame_stereo_wait()."""
+        nimg = len(device_ptrs)
+        ptrs = (C.c_void_p * nimg)(*device_ptrs)
+        self._pending = (nimg, to_host)
+        _check(lib().vslam_frame_stereo_batch_async(self._h, nimg // 2, ptrs, pitch, 1, bf, fx, int(to_host)))
+
+    def frame_stereo_wait(self):
+        """-> (list of (keypoints, descriptors) per image, list of (mvuRight, mvDepth) per stereo frame);
+        views into per-context staging, overwritten by the next wait."""
+        nimg, to_host = self._pending
+        npairs = nimg // 2
+        n = (C.c_int * nimg)()
+        if getattr(self, "_out_kps", None) is None:
+            self._out_kps = np.zeros((self.max_batch, self.cap), KP_DTYPE)
+            self._out_desc = np.zeros((self.max_batch, self.cap, 32), np.uint8)
+            self._out_kp_ptrs = (C.c_void_p * self.max_batch)(*[self._out_kps[i].ctypes.data
+                                                                for i in range(self.max_batch)])
+            self._out_d_ptrs = (C.c_void_p * self.max_batch)(*[self._out_desc[i].ctypes.data
+                                                               for i in range(self.max_batch)])
+        if getattr(self, "_out_u", None) is None:
+            self._out_u = np.zeros((self.max_batch, self.cap), np.float32)
+            self._out_dep = np.zeros((self.max_batch, self.cap), np.float32)
+            self._out_u_ptrs = (C.c_void_p * self.max_batch)(*[self._out_u[i].ctypes.data
+                                                               for i in range(self.max_batch)])
+            self._out_dep_ptrs = (C.c_void_p * self.max_batch)(*[self._out_dep[i].ctypes.data
+                                                                 for i in range(self.max_batch)])
+        kp, dp = (self._out_kp_ptrs, self._out_d_ptrs) if to_host else (None, None)
+        _check(lib().vslam_frame_stereo_wait(self._h, kp, dp, self.cap, n, self._out_u_ptrs, self._out_dep_ptrs))
+        feats = [(self._out_kps[i, :n[i]], self._out_desc[i, :n[i]]) for i in range(nimg)] if to_host else \
+            [(n[i], None) for i in range(nimg)]
+        stereo = [(self._out_u[j, :n[2 * j]], self._out_dep[j, :n[2 * j]]) for j in range(npairs)]
+        return feats, stereo
+
     # ---- mvImagePyramid (fextractor.h:64)
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
@@ -272,8 +315,8 @@ class FExtractor:
         """Bytes of one packed result slot (see vslam_fe_pack_slots), rounded to 256."""
         return (16 + self.cap * 60 + 255) & ~255
 
-    def pack_slots(self, nslots, dev_dst, slot_bytes=None):
-        _check(lib().vslam_fe_pack_slots(self._h, nslots, dev_dst, slot_bytes or self.slot_bytes))
+    def pack_slots(self, nslots, dev_dst, slot_bytes=None, first=0):
+        _check(lib().vslam_fe_pack_slot_range(self._h, first, nslots, dev_dst, slot_bytes or self.slot_bytes))
 
     def set_profiling(self, on=True):
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))
@@ -325,6 +368,32 @@ class FMatcher:
                                                      self.mfNNratio, int(self.mbCheckOrientation),
                                                      C.byref(nm)))
         return nm.value, m[:len(kps1)], pm
+
+    def SearchForInitializationBatch(self, pairs, windowSize=10, img_size=None):
+        """Several independent SearchForInitialization problems in one pass of the kernels.
+        pairs: list of (kps1, dev_desc1, kps2, dev_desc2, vbPrevMatched).  Returns a list of
+        (nmatches, vnMatches12, vbPrevMatched)."""
+        npairs = len(pairs)
+        k1 = [np.ascontiguousarray(p[0], KP_DTYPE) for p in pairs]
+        k2 = [np.ascontiguousarray(p[2], KP_DTYPE) for p in pairs]
+        pm = [np.ascontiguousarray(p[4], np.float32).copy().reshape(-1, 2) for p in pairs]
+        for j in range(npairs):  # ctypes needs a valid address even for empty frames
+            if len(k1[j]) == 0:
+                pm[j] = np.zeros((1, 2), np.float32)
+        m = [np.full(max(len(k), 1), -1, np.int32) for k in k1]
+        vpa = C.c_void_p * npairs
+        ia = C.c_int * npairs
+        nm = ia()
+        w, h = img_size or (self.fe.width, self.fe.height)
+        dummy = np.zeros(1, KP_DTYPE)
+        _check(lib().vslam_search_for_initialization_batch(
+            self.fe._h, npairs, vpa(*[(k if len(k) else dummy).ctypes.data for k in k1]),
+            vpa(*[(p[1] or dummy.ctypes.data) for p in pairs]), ia(*[len(k) for k in k1]),
+            vpa(*[(k if len(k) else dummy).ctypes.data for k in k2]),
+            vpa(*[(p[3] or dummy.ctypes.data) for p in pairs]), ia(*[len(k) for k in k2]), w, h,
+            vpa(*[a.ctypes.data for a in pm]), vpa(*[a.ctypes.data for a in m]), windowSize, self.mfNNratio,
+            int(self.mbCheckOrientation), nm))
+        return [(nm[j], m[j][:len(k1[j])], pm[j][:len(k1[j])]) for j in range(npairs)]
 
 
 def ComputeStereoMatches(feL, slotL, feR, slotR, bf, fx):

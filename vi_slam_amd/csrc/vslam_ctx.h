@@ -143,6 +143,7 @@ struct vslam_fe {
     BatchSrc src;
     int n_out[VSLAM_MAX_BATCH] = {};
     int mono_out[VSLAM_MAX_BATCH] = {};
+    int32_t pack_hdr[VSLAM_MAX_BATCH][4] = {}; /* headers of vslam_fe_pack_slots while the copy is in flight */
     std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
     std::vector<std::vector<vslam::Cand>> cand_level;
     /* matcher scratch (grown on demand) */
@@ -158,6 +159,10 @@ struct vslam_fe {
     /* stereo scratch */
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;
+    float* h_stereo = nullptr; /* pinned: [uRight | depth] x pairs x cap */
+    size_t h_stereo_bytes = 0;
+    int stereo_pairs = 0;
+    int stereo_slotL[VSLAM_MAX_STEREO_JOBS] = {};
 
     /* GPU quadtree distribution */
     bool dev_octree = false;
@@ -183,5 +188,10 @@ struct vslam_fe {
 
 
 int vslam_ensure(void** p, size_t* have, size_t want);
+int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                          int lap0, int lap1, bool want_host);
+int vslam_finish_extract(vslam_fe* fe, int nimg);
+int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                  int* mono_index);
 
 #endif

@@ -73,11 +73,27 @@ struct StereoJob {
     const uint8_t* descL;
     const vslam_kp* kpsR;
     const uint8_t* descR;
-    int32_t nL, nR, slotL, slotR;
+    const int32_t* cntL; /* device: number of left / right keypoints */
+    const int32_t* cntR;
+    int32_t slotL, slotR;
 };
 #define VSLAM_MAX_STEREO_JOBS 16
 struct StereoJobs {
     StereoJob job[VSLAM_MAX_STEREO_JOBS];
+};
+
+/* One (frame 1, frame 2) pair of the batched dense-distance kernel. */
+struct MatJob {
+    const uint8_t* desc1;
+    const uint8_t* desc2;
+    int32_t nr, nc;             /* octave-0 keypoints of frame 1 / frame 2 */
+    uint32_t idx_off1, idx_off2; /* offsets into the uploaded index list */
+    uint32_t q_off, t_off;       /* row offsets of the gathered descriptors in the scratch buffer */
+    size_t out_off;              /* byte offset of this pair's nr x nc matrix */
+};
+#define VSLAM_MAX_MAT_JOBS 32
+struct MatJobs {
+    MatJob job[VSLAM_MAX_MAT_JOBS];
 };
 
 #endif

@@ -53,6 +53,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_sel_cnt);
     hipFree(fe->d_counts);
     if (fe->h_counts) hipHostFree(fe->h_counts);
+    if (fe->h_stereo) hipHostFree(fe->h_stereo);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
@@ -229,10 +230,11 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             HIPCHK(hipMalloc((void**)&fe->d_nid[1], np * 2));
             HIPCHK(hipMalloc((void**)&fe->d_sel_xyr, (size_t)fe->B * O.selStride * 4));
             HIPCHK(hipMalloc((void**)&fe->d_sel_cnt, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
-            HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
-            HIPCHK(hipHostMalloc((void**)&fe->h_counts, (size_t)(fe->B * 4 + 4) * 4, hipHostMallocDefault));
-            HIPCHK(hipMemset(fe->d_counts, 0, (size_t)(fe->B * 4 + 4) * 4));
         }
+        HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
+        HIPCHK(hipHostMalloc((void**)&fe->h_counts, (size_t)(fe->B * 4 + 4) * 4, hipHostMallocDefault));
+        HIPCHK(hipMemset(fe->d_counts, 0, (size_t)(fe->B * 4 + 4) * 4));
+        memset(fe->h_counts, 0, (size_t)(fe->B * 4 + 4) * 4);
     }
 
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
@@ -304,15 +306,21 @@ extern "C" int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batc
     return VSLAM_OK;
 }
 
-extern "C" int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes) {
-    if (!fe || nslots < 0 || nslots > fe->B || !dev_dst || slot_bytes < 16 + (size_t)fe->cap * 60) {
+extern "C" int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes) {
+    if (!fe || first < 0 || nslots < 0 || first + nslots > fe->B || !dev_dst ||
+        slot_bytes < 16 + (size_t)fe->cap * 60) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
     HIPCHK(hipSetDevice(fe->p.device));
-    for (int s = 0; s < nslots; s++) {
-        uint8_t* d = (uint8_t*)dev_dst + (size_t)s * slot_bytes;
-        int32_t hdr[4] = {fe->n_out[s], fe->mono_out[s], fe->cap, 0};
+    for (int k = 0; k < nslots; k++) {
+        const int s = first + k;
+        uint8_t* d = (uint8_t*)dev_dst + (size_t)k * slot_bytes;
+        int32_t* hdr = fe->pack_hdr[s];
+        hdr[0] = fe->n_out[s];
+        hdr[1] = fe->mono_out[s];
+        hdr[2] = fe->cap;
+        hdr[3] = 0;
         HIPCHK(hipMemcpyAsync(d, hdr, 16, hipMemcpyHostToDevice, fe->stream));
         if (fe->n_out[s]) {
             HIPCHK(hipMemcpyAsync(d + 16, fe->d_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp),
@@ -325,32 +333,8 @@ extern "C" int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size
     return VSLAM_OK;
 }
 
-extern "C" int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h) {
-    if (!fe || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
-    if (w) *w = fe->geom.lv[level].w;
-    if (h) *h = fe->geom.lv[level].h;
-    return VSLAM_OK;
-}
-
-extern "C" int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurred, uint8_t* dst,
-                                   size_t dst_pitch) {
-    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels || !dst) return VSLAM_ERR_INVALID;
-    const LevelGeom& g = fe->geom.lv[level];
-    if (dst_pitch < (size_t)g.w) return VSLAM_ERR_INVALID;
-    HIPCHK(hipSetDevice(fe->p.device));
-    const uint8_t* s;
-    size_t spitch;
-    if (!blurred && level == 0) {
-        s = fe->src.l0[slot];
-        spitch = fe->src.pitch0[slot];
-        if (!s) return VSLAM_ERR_INVALID;
-    } else {
-        s = (blurred ? fe->d_blur : fe->d_pyr) + (size_t)slot * fe->slot_stride + g.off;
-        spitch = g.pitch;
-    }
-    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, s, spitch, g.w, g.h, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
-    return VSLAM_OK;
+extern "C" int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes) {
+    return vslam_fe_pack_slot_range(fe, 0, nslots, dev_dst, slot_bytes);
 }
 
 /* ------------------------------------------------------------------ extraction */
@@ -504,7 +488,11 @@ static int enqueue_back_host(vslam_fe* fe, int nimg, int lap0, int lap1) {
         }
         fe->n_out[s] = nk;
         fe->mono_out[s] = monoIndex;
+        fe->h_counts[s * 4] = nk;
+        fe->h_counts[s * 4 + 1] = monoIndex;
     }
+    /* device-side consumers (stereo matcher) read the counts from HBM */
+    HIPCHK(hipMemcpyAsync(fe->d_counts, fe->h_counts, (size_t)nimg * 16, hipMemcpyHostToDevice, st));
     if (nsel) {
         HIPCHK(hipMemcpyAsync(fe->d_sel, fe->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
         if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
@@ -550,8 +538,8 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     return VSLAM_OK;
 }
 
-static int enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                           int lap0, int lap1, bool want_host) {
+int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                          int lap0, int lap1, bool want_host) {
     HIPCHK(hipSetDevice(fe->p.device));
     int rc = enqueue_front(fe, nimg, imgs, pitch, on_device);
     if (rc) return rc;
@@ -566,7 +554,7 @@ static int enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, s
     return VSLAM_OK;
 }
 
-static int finish_extract(vslam_fe* fe, int nimg) {
+int vslam_finish_extract(vslam_fe* fe, int nimg) {
     hipStream_t st = fe->stream;
     HIPCHK(hipStreamSynchronize(st));
     if (fe->dev_octree) {
@@ -597,8 +585,8 @@ static int finish_extract(vslam_fe* fe, int nimg) {
     return VSLAM_OK;
 }
 
-static int deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
-                   int* mono_index) {
+int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                  int* mono_index) {
     for (int s = 0; s < nimg; s++) {
         if (kps && desc) {
             if (fe->n_out[s] > cap) {
@@ -623,13 +611,13 @@ extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* con
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
-    int rc = enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, kps && desc);
-    if (rc == VSLAM_OK) rc = finish_extract(fe, nimg);
+    int rc = vslam_enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, kps && desc);
+    if (rc == VSLAM_OK) rc = vslam_finish_extract(fe, nimg);
     if (rc != VSLAM_OK) {
         hipStreamSynchronize(fe->stream);
         return rc;
     }
-    return deliver(fe, nimg, kps, desc, cap, n, mono_index);
+    return vslam_deliver(fe, nimg, kps, desc, cap, n, mono_index);
 }
 
 /* split form: enqueue everything (no host synchronisation in the device-quadtree path), collect later */
@@ -639,7 +627,7 @@ extern "C" int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
-    int rc = enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, want_host != 0);
+    int rc = vslam_enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, want_host != 0);
     if (rc != VSLAM_OK) hipStreamSynchronize(fe->stream);
     return rc;
 }
@@ -650,9 +638,9 @@ extern "C" int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t
         g_err = "nothing enqueued";
         return VSLAM_ERR_INVALID;
     }
-    int rc = finish_extract(fe, fe->last_nimg);
+    int rc = vslam_finish_extract(fe, fe->last_nimg);
     if (rc != VSLAM_OK) return rc;
-    return deliver(fe, fe->last_nimg, kps, desc, cap, n, mono_index);
+    return vslam_deliver(fe, fe->last_nimg, kps, desc, cap, n, mono_index);
 }
 
 extern "C" int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, int lap1,

@@ -48,6 +48,8 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
                const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
                const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
                int32_t* sad, int cap);
+void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
+                             uint8_t* tmp, uint8_t* out);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);
 
 #endif

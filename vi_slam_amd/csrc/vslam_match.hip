@@ -18,25 +18,27 @@ static int stereo_scratch(vslam_fe* fe, int njobs, StereoScratch* s) {
     s->uRight = (float*)(s->best + n);
     s->depth = s->uRight + n;
     s->sad = (int32_t*)(s->depth + n);
+    if (fe->h_stereo_bytes < n * 8) {
+        if (fe->h_stereo) HIPCHK(hipHostFree(fe->h_stereo));
+        fe->h_stereo = nullptr;
+        fe->h_stereo_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_stereo, n * 8, hipHostMallocDefault));
+        fe->h_stereo_bytes = n * 8;
+    }
     return VSLAM_OK;
 }
 
-extern "C" int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL,
-                                        const int* slotsR, float bf, float fx, float* const* u_right,
-                                        float* const* depth) {
-    if (!feL || !feR || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || !slotsL || !slotsR || !u_right || !depth) {
-        g_err = "invalid arguments";
-        return VSLAM_ERR_INVALID;
-    }
+/* enqueue the matcher kernels and the D2H of mvuRight/mvDepth (whole capacity: the keypoint counts may
+ * not be known on the host yet); nothing waits */
+static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL, const int* slotsR,
+                          float bf, float fx) {
     if (feL->p.device != feR->p.device || feL->p.width != feR->p.width || feL->p.height != feR->p.height ||
         feL->p.nlevels != feR->p.nlevels || feL->p.scale_factor != feR->p.scale_factor) {
         g_err = "left/right extractors must share device and geometry";
         return VSLAM_ERR_INVALID;
     }
-    HIPCHK(hipSetDevice(feL->p.device));
     StereoJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
-    int maxNL = 0, maxNR = 0;
     for (int j = 0; j < npairs; j++) {
         const int sL = slotsL[j], sR = slotsR[j];
         if (sL < 0 || sL >= feL->B || sR < 0 || sR >= feR->B || !feL->src.l0[sL] || !feR->src.l0[sR]) {
@@ -48,12 +50,10 @@ extern "C" int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs
         jb.descL = feL->d_desc + (size_t)sL * feL->cap * 32;
         jb.kpsR = feR->d_kps + (size_t)sR * feR->cap;
         jb.descR = feR->d_desc + (size_t)sR * feR->cap * 32;
-        jb.nL = feL->n_out[sL];
-        jb.nR = feR->n_out[sR];
+        jb.cntL = feL->d_counts + sL * 4;
+        jb.cntR = feR->d_counts + sR * 4;
         jb.slotL = sL;
         jb.slotR = sR;
-        maxNL = std::max(maxNL, jb.nL);
-        maxNR = std::max(maxNR, jb.nR);
     }
     if (feL != feR) HIPCHK(hipStreamSynchronize(feR->stream)); /* right results must be complete */
     StereoScratch sc;
@@ -63,19 +63,38 @@ extern "C" int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs
     const float mb = bf / fx;
     const float maxD = bf / mb;
     hipStream_t st = feL->stream;
-    if (maxNL > 0) {
-        vk_stereo(st, jobs, npairs, maxNL, maxNR, feL->geom, feL->d_pyr, feL->slot_stride, feL->src, feR->d_pyr,
-                  feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap);
-        HIPCHK(hipGetLastError());
-        for (int j = 0; j < npairs; j++) {
-            if (!jobs.job[j].nL) continue;
-            HIPCHK(hipMemcpyAsync(u_right[j], sc.uRight + (size_t)j * feL->cap, (size_t)jobs.job[j].nL * 4,
-                                  hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(depth[j], sc.depth + (size_t)j * feL->cap, (size_t)jobs.job[j].nL * 4,
-                                  hipMemcpyDeviceToHost, st));
-        }
+    vk_stereo(st, jobs, npairs, feL->cap, feR->cap, feL->geom, feL->d_pyr, feL->slot_stride, feL->src, feR->d_pyr,
+              feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap);
+    HIPCHK(hipGetLastError());
+    const size_t n = (size_t)npairs * feL->cap;
+    HIPCHK(hipMemcpyAsync(feL->h_stereo, sc.uRight, n * 8, hipMemcpyDeviceToHost, st)); /* uRight | depth */
+    feL->stereo_pairs = npairs;
+    for (int j = 0; j < npairs; j++) feL->stereo_slotL[j] = slotsL[j];
+    return VSLAM_OK;
+}
+
+static void deliver_stereo(vslam_fe* feL, float* const* u_right, float* const* depth) {
+    const size_t n = (size_t)feL->stereo_pairs * feL->cap;
+    for (int j = 0; j < feL->stereo_pairs; j++) {
+        const int nL = feL->n_out[feL->stereo_slotL[j]];
+        if (!nL) continue;
+        if (u_right && u_right[j]) memcpy(u_right[j], feL->h_stereo + (size_t)j * feL->cap, (size_t)nL * 4);
+        if (depth && depth[j]) memcpy(depth[j], feL->h_stereo + n + (size_t)j * feL->cap, (size_t)nL * 4);
     }
-    HIPCHK(hipStreamSynchronize(st));
+}
+
+extern "C" int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL,
+                                        const int* slotsR, float bf, float fx, float* const* u_right,
+                                        float* const* depth) {
+    if (!feL || !feR || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || !slotsL || !slotsR || !u_right || !depth) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(feL->p.device));
+    int rc = enqueue_stereo(feL, feR, npairs, slotsL, slotsR, bf, fx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(feL->stream));
+    deliver_stereo(feL, u_right, depth);
     return VSLAM_OK;
 }
 
@@ -86,51 +105,137 @@ extern "C" int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, 
     return vslam_stereo_match_batch(feL, feR, 1, &sL, &sR, bf, fx, u, d);
 }
 
+/* The extraction + stereo section of Frame::Frame(stereo) (frame.cpp:102-132) for npairs frames in one
+ * enqueue: images are L0,R0,L1,R1,...; slot 2j = left, 2j+1 = right of pair j. */
+extern "C" int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const uint8_t* const* imgs, size_t pitch,
+                                              int imgs_on_device, float bf, float fx, int want_host) {
+    if (!fe || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || 2 * npairs > fe->B || !imgs ||
+        pitch < (size_t)fe->p.width) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    int rc = vslam_enqueue_extract(fe, 2 * npairs, imgs, pitch, imgs_on_device, 0, 0, want_host != 0);
+    if (rc == VSLAM_OK) {
+        int sl[VSLAM_MAX_STEREO_JOBS], sr[VSLAM_MAX_STEREO_JOBS];
+        for (int j = 0; j < npairs; j++) {
+            sl[j] = 2 * j;
+            sr[j] = 2 * j + 1;
+        }
+        rc = enqueue_stereo(fe, fe, npairs, sl, sr, bf, fx);
+    }
+    if (rc != VSLAM_OK) hipStreamSynchronize(fe->stream);
+    return rc;
+}
+
+extern "C" int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
+                                       float* const* u_right, float* const* depth) {
+    if (!fe || fe->last_nimg < 2) {
+        g_err = "nothing enqueued";
+        return VSLAM_ERR_INVALID;
+    }
+    int rc = vslam_finish_extract(fe, fe->last_nimg);
+    if (rc != VSLAM_OK) return rc;
+    rc = vslam_deliver(fe, fe->last_nimg, kps, desc, cap, n, nullptr);
+    if (rc != VSLAM_OK) return rc;
+    deliver_stereo(fe, u_right, depth);
+    return VSLAM_OK;
+}
+
 /* ------------------------------------------------------------------ SearchForInitialization */
+extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_kp* const* kps1,
+                                                     const uint8_t* const* dev_desc1, const int* n1,
+                                                     const vslam_kp* const* kps2, const uint8_t* const* dev_desc2,
+                                                     const int* n2, int img_w, int img_h,
+                                                     float* const* prev_matched, int32_t* const* matches12,
+                                                     int window, float nnratio, int check_orientation,
+                                                     int* nmatches) {
+    if (!fe || npairs < 1 || npairs > VSLAM_MAX_MAT_JOBS || !kps1 || !dev_desc1 || !n1 || !kps2 || !dev_desc2 ||
+        !n2 || !prev_matched || !matches12 || !nmatches) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    for (int j = 0; j < npairs; j++)
+        if (n1[j] < 0 || n2[j] < 0 || (n1[j] && (!kps1[j] || !dev_desc1[j] || !prev_matched[j] || !matches12[j])) ||
+            (n2[j] && (!kps2[j] || !dev_desc2[j]))) {
+            g_err = "invalid arguments";
+            return VSLAM_ERR_INVALID;
+        }
+    HIPCHK(hipSetDevice(fe->p.device));
+    /* only octave-0 keypoints take part (fmatcher.cpp:999-1003: level1 > 0 -> continue; window query
+     * restricted to [level1, level1]) */
+    std::vector<std::vector<int>> row_of(npairs), col_of(npairs);
+    std::vector<int32_t> idx;
+    MatJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    size_t rows_total = 0, out_total = 0;
+    int maxr = 0, maxc = 0;
+    for (int j = 0; j < npairs; j++) {
+        MatJob& jb = jobs.job[j];
+        row_of[j].assign(n1[j], -1);
+        col_of[j].assign(n2[j], -1);
+        jb.idx_off1 = (uint32_t)idx.size();
+        int nr = 0, nc = 0;
+        for (int i = 0; i < n1[j]; i++)
+            if (kps1[j][i].octave == 0) { row_of[j][i] = nr++; idx.push_back(i); }
+        jb.idx_off2 = (uint32_t)idx.size();
+        for (int i = 0; i < n2[j]; i++)
+            if (kps2[j][i].octave == 0) { col_of[j][i] = nc++; idx.push_back(i); }
+        jb.desc1 = dev_desc1[j];
+        jb.desc2 = dev_desc2[j];
+        jb.nr = nr;
+        jb.nc = nc;
+        jb.q_off = (uint32_t)rows_total;
+        jb.t_off = (uint32_t)(rows_total + nr);
+        jb.out_off = out_total;
+        rows_total += (size_t)nr + nc;
+        out_total += ((size_t)nr * nc + 15) & ~(size_t)15;
+        maxr = std::max(maxr, nr);
+        maxc = std::max(maxc, nc);
+    }
+    std::vector<uint8_t> dmat(std::max<size_t>(out_total, 16));
+    if (maxr && maxc) {
+        int rc;
+        const size_t ib = (idx.size() * 4 + 255) & ~(size_t)255;
+        if ((rc = vslam_ensure((void**)&fe->d_tmp_desc[0], &fe->tmp_desc_bytes[0], ib + rows_total * 32))) return rc;
+        if ((rc = vslam_ensure((void**)&fe->d_dmat, &fe->dmat_bytes, out_total))) return rc;
+        int32_t* d_idx = (int32_t*)fe->d_tmp_desc[0];
+        uint8_t* d_rows = fe->d_tmp_desc[0] + ib;
+        hipStream_t st = fe->stream;
+        HIPCHK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+        vk_hamming_matrix_batch(st, jobs, npairs, maxr, maxc, d_idx, d_rows, fe->d_dmat);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(dmat.data(), fe->d_dmat, out_total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    /* the stealing / ratio / rotation-histogram logic is order dependent: replayed on the host, one
+     * pair per worker */
+    fe->pool->parallel_for(npairs, [&](int j) {
+        const MatJob& jb = jobs.job[j];
+        nmatches[j] = vslam::search_for_initialization_replay(
+            kps1[j], n1[j], kps2[j], n2[j], dmat.data() + jb.out_off, row_of[j].data(), col_of[j].data(),
+            std::max(jb.nc, 1), img_w, img_h, prev_matched[j], matches12[j], window, nnratio, check_orientation != 0);
+    });
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_search_for_initialization(vslam_fe* fe, const vslam_kp* kps1, const uint8_t* dev_desc1,
                                                int n1, const vslam_kp* kps2, const uint8_t* dev_desc2, int n2,
                                                int img_w, int img_h, float* prev_matched, int32_t* matches12,
                                                int window, float nnratio, int check_orientation,
                                                int* nmatches) {
-    if (!fe || n1 < 0 || n2 < 0 || (n1 && (!kps1 || !dev_desc1 || !prev_matched || !matches12)) ||
-        (n2 && (!kps2 || !dev_desc2)) || !nmatches) {
-        g_err = "invalid arguments";
-        return VSLAM_ERR_INVALID;
-    }
-    HIPCHK(hipSetDevice(fe->p.device));
-    /* only octave-0 keypoints take part (fmatcher.cpp:999-1003: level1 > 0 -> continue; window query
-     * restricted to [level1, level1]) */
-    std::vector<int> row_of(n1, -1), col_of(n2, -1);
-    std::vector<int32_t> rows, cols;
-    for (int i = 0; i < n1; i++)
-        if (kps1[i].octave == 0) { row_of[i] = (int)rows.size(); rows.push_back(i); }
-    for (int i = 0; i < n2; i++)
-        if (kps2[i].octave == 0) { col_of[i] = (int)cols.size(); cols.push_back(i); }
-    const int nr = (int)rows.size(), nc = (int)cols.size();
-    std::vector<uint8_t> dmat((size_t)std::max(nr, 1) * std::max(nc, 1));
-    if (nr && nc) {
-        int rc;
-        const size_t ib = (size_t)(nr + nc) * 4;
-        if ((rc = vslam_ensure((void**)&fe->d_tmp_desc[0], &fe->tmp_desc_bytes[0], (size_t)(nr + nc) * 32 + ib))) return rc;
-        uint8_t* d_q = fe->d_tmp_desc[0];
-        uint8_t* d_t = d_q + (size_t)nr * 32;
-        int32_t* d_idx = (int32_t*)(d_t + (size_t)nc * 32);
-        hipStream_t st = fe->stream;
-        HIPCHK(hipMemcpyAsync(d_idx, rows.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_idx + nr, cols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
-        vk_gather_rows32(st, dev_desc1, d_idx, nr, d_q);
-        vk_gather_rows32(st, dev_desc2, d_idx + nr, nc, d_t);
-        if ((rc = vslam_ensure((void**)&fe->d_dmat, &fe->dmat_bytes, (size_t)nr * nc))) return rc;
-        vk_hamming_matrix(st, d_q, nr, d_t, nc, fe->d_dmat);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(dmat.data(), fe->d_dmat, (size_t)nr * nc, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    *nmatches = vslam::search_for_initialization_replay(kps1, n1, kps2, n2, dmat.data(), row_of.data(),
-                                                        col_of.data(), std::max(nc, 1), img_w, img_h,
-                                                        prev_matched, matches12, window, nnratio,
-                                                        check_orientation != 0);
-    return VSLAM_OK;
+    /* the reference tolerates empty frames: nothing to match */
+    static const vslam_kp no_kp = {0, 0, 0, 0, 0, 0, 0};
+    static const uint8_t* no_desc = (const uint8_t*)&no_kp;
+    static float no_prev[2];
+    static int32_t no_match[1];
+    const vslam_kp* k1 = n1 ? kps1 : &no_kp;
+    const vslam_kp* k2 = n2 ? kps2 : &no_kp;
+    const uint8_t* d1 = n1 ? dev_desc1 : no_desc;
+    const uint8_t* d2 = n2 ? dev_desc2 : no_desc;
+    float* pm = n1 ? prev_matched : no_prev;
+    int32_t* m = n1 ? matches12 : no_match;
+    return vslam_search_for_initialization_batch(fe, 1, &k1, &d1, &n1, &k2, &d2, &n2, img_w, img_h, &pm, &m, window,
+                                                 nnratio, check_orientation, nmatches);
 }
 
 /* ------------------------------------------------------------------ diagnostics */

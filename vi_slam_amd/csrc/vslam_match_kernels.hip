@@ -15,6 +15,11 @@ __device__ __forceinline__ const uint8_t* level_base2(const uint8_t* pyr, size_t
     return pyr + (size_t)slot * slot_stride + lg.off;
 }
 
+/* keypoint counts of a stereo job live in HBM (written by k_assign_out or uploaded by the host quadtree
+ * path), so the whole frame can be enqueued before the host knows them */
+#define JNL(j) (*(j).cntL)
+#define JNR(j) (*(j).cntR)
+
 __device__ __forceinline__ int refl101(int p, int len) {
     if (p < 0) p = -p;
     if (p >= len) p = 2 * (len - 1) - p;
@@ -27,7 +32,7 @@ __device__ __forceinline__ int refl101(int p, int len) {
 __global__ void k_stereo_init(StereoJobs jobs, uint32_t* best, int cap) {
     const int j = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < jobs.job[j].nL) best[(size_t)j * cap + i] = 100u << 16;
+    if (i < JNL(jobs.job[j])) best[(size_t)j * cap + i] = 100u << 16;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -46,10 +51,10 @@ k_stereo_best(StereoJobs jobs, PyramidGeom g, float maxD, uint32_t* best, int ca
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int iL = blockIdx.x * 64 + lane;
     const int t0 = blockIdx.y * 256;
-    if (blockIdx.x * 64 >= jb.nL || t0 >= jb.nR) return; /* block-uniform */
+    if (blockIdx.x * 64 >= JNL(jb) || t0 >= JNR(jb)) return; /* block-uniform */
     {
         const int iR = t0 + tid;
-        if (iR < jb.nR) {
+        if (iR < JNR(jb)) {
             const vslam_kp k = jb.kpsR[iR];
             const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
             s_maxr[tid] = (int)ceilf(__fadd_rn(k.y, r));
@@ -68,7 +73,7 @@ k_stereo_best(StereoJobs jobs, PyramidGeom g, float maxD, uint32_t* best, int ca
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
     int row = -(1 << 29), octL = -1000;
     float minU = 1.f, maxU = 0.f;
-    if (iL < jb.nL) {
+    if (iL < JNL(jb)) {
         const vslam_kp k = jb.kpsL[iL];
         qa = ((const uint4*)jb.descL)[(size_t)iL * 2];
         qb = ((const uint4*)jb.descL)[(size_t)iL * 2 + 1];
@@ -94,7 +99,7 @@ k_stereo_best(StereoJobs jobs, PyramidGeom g, float maxD, uint32_t* best, int ca
             bestKey = min(bestKey, key);
         }
     }
-    if (iL < jb.nL && bestKey < (100u << 16)) atomicMin(&best[(size_t)blockIdx.z * cap + iL], bestKey);
+    if (iL < JNL(jb) && bestKey < (100u << 16)) atomicMin(&best[(size_t)blockIdx.z * cap + iL], bestKey);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -110,7 +115,7 @@ k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t stri
     const StereoJob jb = jobs.job[blockIdx.y];
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int iL = blockIdx.x * 16 + grp;
-    const bool live = iL < jb.nL;
+    const bool live = iL < JNL(jb);
     const size_t o = (size_t)blockIdx.y * cap + (live ? iL : 0);
     uint32_t key = live ? best[o] : 0xFFFFFFFFu;
     const int bestDist = (int)(key >> 16);
@@ -209,7 +214,7 @@ k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t*
     if (tid == 0) s_total = 0;
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < jb.nL; i += 1024) {
+    for (int i = tid; i < JNL(jb); i += 1024) {
         const int s = sad[base + i];
         if (s >= 0) {
             atomicAdd(&s_hist[(s >> 8) & 255], 1);
@@ -234,7 +239,7 @@ k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t*
     __syncthreads();
     if (tid < 256) s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < jb.nL; i += 1024) {
+    for (int i = tid; i < JNL(jb); i += 1024) {
         const int s = sad[base + i];
         if (s >= 0 && ((s >> 8) & 255) == hi) atomicAdd(&s_hist[s & 255], 1);
     }
@@ -250,7 +255,7 @@ k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t*
     __syncthreads();
     const float median = (float)s_sel;
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
-    for (int i = tid; i < jb.nL; i += 1024) {
+    for (int i = tid; i < JNL(jb); i += 1024) {
         const int s = sad[base + i];
         if (s >= 0 && !((float)s < thDist)) {
             uRight[base + i] = -1.f;
@@ -285,4 +290,62 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_gather_rows32, dim3((2 * n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * batched forms for SearchForInitialization: gather the octave-0 descriptor rows of every pair, then one
+ * launch computes all dense distance matrices (grid.z = pair).
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void k_gather_rows32_batch(MatJobs jobs, const int32_t* __restrict__ idx, uint8_t* __restrict__ tmp) {
+    const MatJob jb = jobs.job[blockIdx.y >> 1];
+    const int side = blockIdx.y & 1;
+    const int n = side ? jb.nc : jb.nr;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 2) return;
+    const uint8_t* src = side ? jb.desc2 : jb.desc1;
+    const int32_t* id = idx + (side ? jb.idx_off2 : jb.idx_off1);
+    uint4* dst = (uint4*)(tmp + (size_t)(side ? jb.t_off : jb.q_off) * 32);
+    dst[i] = ((const uint4*)src)[(size_t)id[i >> 1] * 2 + (i & 1)];
+}
+
+__global__ void __launch_bounds__(256)
+k_hamming_matrix_batch(MatJobs jobs, const uint8_t* __restrict__ tmp, uint8_t* __restrict__ out) {
+    __shared__ uint4 s_t[256 * 2];
+    const MatJob jb = jobs.job[blockIdx.z];
+    const int nq = jb.nr, nt = jb.nc;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qi = blockIdx.x * 64 + lane;
+    const int t0 = blockIdx.y * 256;
+    if (blockIdx.x * 64 >= nq || t0 >= nt) return; /* block-uniform */
+    const uint4* q = (const uint4*)(tmp + (size_t)jb.q_off * 32);
+    const uint4* t = (const uint4*)(tmp + (size_t)jb.t_off * 32);
+    for (int i = tid; i < 512; i += 256) {
+        const int ti = t0 + (i >> 1);
+        s_t[i] = ti < nt ? t[(size_t)ti * 2 + (i & 1)] : make_uint4(0, 0, 0, 0);
+    }
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (qi < nq) {
+        qa = q[(size_t)qi * 2];
+        qb = q[(size_t)qi * 2 + 1];
+    }
+    __syncthreads();
+    if (qi >= nq) return;
+    uint8_t* o = out + jb.out_off + (size_t)qi * nt;
+    for (int j = wv * 64; j < wv * 64 + 64; j++) {
+        const int ti = t0 + j;
+        if (ti >= nt) break;
+        const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
+        const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                      __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+        o[ti] = (uint8_t)min(d, 255);
+    }
+}
+
+void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
+                             uint8_t* tmp, uint8_t* out) {
+    if (njobs <= 0 || maxr <= 0 || maxc <= 0) return;
+    const int mx = maxr > maxc ? maxr : maxc;
+    hipLaunchKernelGGL(k_gather_rows32_batch, dim3((2 * mx + 255) / 256, 2 * njobs), dim3(256), 0, st, jobs, idx, tmp);
+    hipLaunchKernelGGL(k_hamming_matrix_batch, dim3((maxr + 63) / 64, (maxc + 255) / 256, njobs), dim3(256), 0, st,
+                       jobs, tmp, out);
 }

@@ -6,7 +6,7 @@
  * (b) the order of the list and (c) the "largest node first, stop at N" rule.  All three are prefix sums:
  *
  *  - keys live in one array, each node owns a contiguous range; a split is a STABLE 4-way partition of
- *    the range, done for all nodes of a pass at once with one block-wide scan of packed 4x16-bit
+ *    the range, done for all nodes of a pass at once with one block-wide scan of packed 3x21-bit
  *    quadrant counters (rank of a key = scan value minus the scan value at its node's first key);
  *  - children are push_front'ed in creation order and survivors keep their relative order, so after a
  *    pass   list = reverse(children in creation order) ++ survivors.  Nodes are stored IN LIST ORDER and
@@ -26,10 +26,23 @@ typedef unsigned long long u64;
 
 struct ONode { /* 16 bytes, one entry of the list */
     int16_t x0, y0, x1, y1;
-    uint16_t begin, count;
-    uint16_t flags; /* bit0 noMore */
-    uint16_t pad;
+    uint32_t begin; /* first key of the node in the key array */
+    uint32_t cf;    /* count << 1 | noMore */
 };
+#define ND_COUNT(nd) ((nd).cf >> 1)
+#define ND_NOMORE(nd) ((nd).cf & 1u)
+
+/* packed per-quadrant counters: quadrants 0..2 in three 21-bit fields of a u64 (up to 2M keys per level);
+ * quadrant 3 is what remains of the node */
+#define FB 21
+#define FMASK ((1ull << FB) - 1)
+__device__ __forceinline__ unsigned long long onehot(int q) { return q < 3 ? 1ull << (FB * q) : 0ull; }
+__device__ __forceinline__ uint32_t fld(unsigned long long v, int q) { return (uint32_t)((v >> (FB * q)) & FMASK); }
+/* number of non-empty children given the packed counts of quadrants 0..2 and the node's key count */
+__device__ __forceinline__ uint32_t nchildren(unsigned long long c, uint32_t count) {
+    const uint32_t c0 = fld(c, 0), c1 = fld(c, 1), c2 = fld(c, 2);
+    return (c0 != 0) + (c1 != 0) + (c2 != 0) + (count - c0 - c1 - c2 != 0);
+}
 
 template <typename T>
 __device__ __forceinline__ T block_excl_scan(T v, T* s_wave, T* total) {
@@ -111,7 +124,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     uint32_t ntot;
     uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
     const int n = (int)ntot;
-    if (off0 + ntot > (uint32_t)P.ptsCap || n > 65535 || hdr[1] != 0) {
+    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
         if (tid == 0) {
             atomicOr(err_flag, 1);
             *ocnt = 0;
@@ -144,16 +157,16 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     __shared__ uint32_t s_bcnt[64], s_bbeg[64], s_bidx[64];
     if (tid < 64) s_bcnt[tid] = 0;
     __syncthreads();
-    for (int g = 0; g * 4 < nIni; g++) {
+    for (int g = 0; g * 3 < nIni; g++) {
         u64 loc = 0;
         for (int i = i0; i < i1; i++) {
             int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
             b = min(b, nIni - 1);
-            if ((b >> 2) == g) loc += 1ull << (16 * (b & 3));
+            if (b / 3 == g) loc += 1ull << (FB * (b % 3));
         }
         u64 tot;
         block_excl_scan<u64>(loc, s_w64, &tot);
-        if (tid < 4 && g * 4 + tid < nIni) s_bcnt[g * 4 + tid] = (uint32_t)((tot >> (16 * tid)) & 0xFFFF);
+        if (tid < 3 && g * 3 + tid < nIni) s_bcnt[g * 3 + tid] = fld(tot, tid);
         __syncthreads();
     }
     if (tid == 0) {
@@ -169,10 +182,8 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
                 nd.y0 = 0;
                 nd.y1 = (int16_t)Hh;
-                nd.begin = (uint16_t)acc;
-                nd.count = (uint16_t)cb0;
-                nd.flags = cb0 == 1 ? 1 : 0;
-                nd.pad = 0;
+                nd.begin = acc;
+                nd.cf = (cb0 << 1) | (cb0 == 1 ? 1u : 0u);
                 cur[li++] = nd;
             }
             acc += cb0;
@@ -180,12 +191,12 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         s_size = li;
     }
     __syncthreads();
-    for (int g = 0; g * 4 < nIni; g++) {
+    for (int g = 0; g * 3 < nIni; g++) {
         u64 loc = 0;
         for (int i = i0; i < i1; i++) {
             int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
             b = min(b, nIni - 1);
-            if ((b >> 2) == g) loc += 1ull << (16 * (b & 3));
+            if (b / 3 == g) loc += 1ull << (FB * (b % 3));
         }
         u64 tot;
         u64 run = block_excl_scan<u64>(loc, s_w64, &tot);
@@ -193,11 +204,11 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             const uint32_t pt = pa[i];
             int b = (int)__fdiv_rn((float)(pt & 0xFFF), hX);
             b = min(b, nIni - 1);
-            if ((b >> 2) == g) {
-                const uint32_t pos = s_bbeg[b] + (uint32_t)((run >> (16 * (b & 3))) & 0xFFFF);
+            if (b / 3 == g) {
+                const uint32_t pos = s_bbeg[b] + fld(run, b % 3);
                 pb[pos] = pt;
                 nb[pos] = (uint16_t)s_bidx[b];
-                run += 1ull << (16 * (b & 3));
+                run += 1ull << (FB * (b % 3));
             }
         }
         __syncthreads();
@@ -213,7 +224,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         u64 loc = 0;
         for (int i = i0; i < i1; i++) {
             const ONode nd = cur[na[i]];
-            if (!(nd.flags & 1)) loc += 1ull << (16 * quadrant(pa[i], nd));
+            if (!ND_NOMORE(nd)) loc += onehot(quadrant(pa[i], nd));
         }
         u64 tot64;
         const u64 S0 = block_excl_scan<u64>(loc, s_w64, &tot64);
@@ -223,24 +234,24 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             for (int i = i0; i < i1; i++) {
                 const int v = na[i];
                 const ONode nd = cur[v];
-                if (nd.flags & 1) continue;
-                if (i == nd.begin) Sbeg[v] = run;
-                run += 1ull << (16 * quadrant(pa[i], nd));
-                if (i == nd.begin + nd.count - 1) Cnt[v] = run;
+                if (ND_NOMORE(nd)) continue;
+                if ((uint32_t)i == nd.begin) Sbeg[v] = run;
+                run += onehot(quadrant(pa[i], nd));
+                if ((uint32_t)i == nd.begin + ND_COUNT(nd) - 1) Cnt[v] = run;
             }
         }
         __syncthreads();
         /* D. node level */
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
-            if (v < size0 && !(cur[v].flags & 1)) Cnt[v] -= Sbeg[v];
+            if (v < size0 && !ND_NOMORE(cur[v])) Cnt[v] -= Sbeg[v];
         }
         __syncthreads();
         /* D1. processing rank of every expandable node */
         uint32_t nexp_mine = 0;
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
-            if (v < size0 && !(cur[v].flags & 1)) nexp_mine++;
+            if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
         }
         uint32_t nexp;
         uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
@@ -248,7 +259,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         if (phase == 1) {
             for (int k = 0; k < KN; k++) {
                 const int v = tid * KN + k;
-                if (v < size0 && !(cur[v].flags & 1)) {
+                if (v < size0 && !ND_NOMORE(cur[v])) {
                     prank[v] = (uint16_t)rbase;
                     ordv[rbase] = (uint16_t)v;
                     rbase++;
@@ -258,12 +269,12 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             /* descending (count, "created later" == smaller list index) */
             for (int k = 0; k < KN; k++) {
                 const int v = tid * KN + k;
-                if (v < size0 && !(cur[v].flags & 1)) {
-                    const uint32_t cv = cur[v].count;
+                if (v < size0 && !ND_NOMORE(cur[v])) {
+                    const uint32_t cv = ND_COUNT(cur[v]);
                     uint32_t r = 0;
                     for (int u = 0; u < size0; u++) {
                         const ONode nu = cur[u];
-                        if (!(nu.flags & 1) && (nu.count > cv || (nu.count == cv && u < v))) r++;
+                        if (!ND_NOMORE(nu) && (ND_COUNT(nu) > cv || (ND_COUNT(nu) == cv && u < v))) r++;
                     }
                     prank[v] = (uint16_t)r;
                     ordv[r] = (uint16_t)v;
@@ -277,8 +288,8 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         for (int k = 0; k < KE; k++) {
             const int r = tid * KE + k;
             if (r < (int)nexp) {
-                const u64 c = Cnt[ordv[r]];
-                chl += ((c & 0xFFFF) != 0) + (((c >> 16) & 0xFFFF) != 0) + (((c >> 32) & 0xFFFF) != 0) + ((c >> 48) != 0);
+                const int v = ordv[r];
+                chl += nchildren(Cnt[v], ND_COUNT(cur[v]));
             }
         }
         uint32_t chtot;
@@ -292,9 +303,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 const int r = tid * KE + k;
                 if (r < (int)nexp) {
                     const int v = ordv[r];
-                    const u64 c = Cnt[v];
-                    const uint32_t nch = ((c & 0xFFFF) != 0) + (((c >> 16) & 0xFFFF) != 0) +
-                                         (((c >> 32) & 0xFFFF) != 0) + ((c >> 48) != 0);
+                    const uint32_t nch = nchildren(Cnt[v], ND_COUNT(cur[v]));
                     if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
                     cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
                     cb_run += nch;
@@ -319,7 +328,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
             if (v < size0) {
-                const bool processed = !(cur[v].flags & 1) && prank[v] < ncut;
+                const bool processed = !ND_NOMORE(cur[v]) && prank[v] < ncut;
                 if (!processed) sv++;
             }
         }
@@ -330,7 +339,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             const int v = tid * KN + k;
             if (v >= size0) continue;
             const ONode nd = cur[v];
-            const bool processed = !(nd.flags & 1) && prank[v] < ncut;
+            const bool processed = !ND_NOMORE(nd) && prank[v] < ncut;
             if (!processed) {
                 newIdx[v] = (uint16_t)(M + svbase);
                 nxt[M + svbase] = nd;
@@ -341,18 +350,17 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 int kq = 0;
                 uint32_t beg = nd.begin;
                 const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
+                const uint32_t c3 = ND_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t cq = (uint32_t)((c >> (16 * q)) & 0xFFFF);
+                    const uint32_t cq = q < 3 ? fld(c, q) : c3;
                     if (!cq) continue;
                     ONode ch;
                     ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
                     ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
                     ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
                     ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
-                    ch.begin = (uint16_t)beg;
-                    ch.count = (uint16_t)cq;
-                    ch.flags = cq == 1 ? 1 : 0;
-                    ch.pad = 0;
+                    ch.begin = beg;
+                    ch.cf = (cq << 1) | (cq == 1 ? 1u : 0u);
                     nxt[first - kq] = ch;
                     if (cq > 1) nexp_children++;
                     beg += cq;
@@ -370,7 +378,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 const uint32_t pt = pa[i];
                 const int v = na[i];
                 const ONode nd = cur[v];
-                if (nd.flags & 1) {
+                if (ND_NOMORE(nd)) {
                     pb[i] = pt;
                     nb[i] = newIdx[v];
                     continue;
@@ -378,11 +386,12 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 const int q = quadrant(pt, nd);
                 if (prank[v] < ncut) {
                     const u64 c = Cnt[v];
-                    const u64 rk = run - Sbeg[v];
-                    uint32_t pos = nd.begin + (uint32_t)((rk >> (16 * q)) & 0xFFFF);
+                    const u64 rk = run - Sbeg[v]; /* keys of this node seen so far, quadrants 0..2 */
+                    const uint32_t r012 = fld(rk, 0) + fld(rk, 1) + fld(rk, 2);
+                    uint32_t pos = nd.begin + (q < 3 ? fld(rk, q) : ((uint32_t)i - nd.begin) - r012);
                     int kq = 0;
                     for (int q2 = 0; q2 < q; q2++) {
-                        const uint32_t cq = (uint32_t)((c >> (16 * q2)) & 0xFFFF);
+                        const uint32_t cq = fld(c, q2);
                         pos += cq;
                         kq += cq != 0;
                     }
@@ -392,7 +401,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                     pb[i] = pt;
                     nb[i] = newIdx[v];
                 }
-                run += 1ull << (16 * q);
+                run += onehot(q);
             }
         }
         __syncthreads();
@@ -410,7 +419,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     for (int v = tid; v < size; v += OT) {
         const ONode nd = cur[v];
         uint32_t best = pa[nd.begin];
-        for (int k = 1; k < nd.count; k++) {
+        for (uint32_t k = 1; k < ND_COUNT(nd); k++) {
             const uint32_t p = pa[nd.begin + k];
             if ((p >> 24) > (best >> 24)) best = p;
         }
