@@ -337,6 +337,34 @@ extern "C" int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size
     return vslam_fe_pack_slot_range(fe, 0, nslots, dev_dst, slot_bytes);
 }
 
+extern "C" int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h) {
+    if (!fe || level < 0 || level >= fe->p.nlevels) return VSLAM_ERR_INVALID;
+    if (w) *w = fe->geom.lv[level].w;
+    if (h) *h = fe->geom.lv[level].h;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurred, uint8_t* dst,
+                                   size_t dst_pitch) {
+    if (!fe || slot < 0 || slot >= fe->B || level < 0 || level >= fe->p.nlevels || !dst) return VSLAM_ERR_INVALID;
+    const LevelGeom& g = fe->geom.lv[level];
+    if (dst_pitch < (size_t)g.w) return VSLAM_ERR_INVALID;
+    HIPCHK(hipSetDevice(fe->p.device));
+    const uint8_t* s;
+    size_t spitch;
+    if (!blurred && level == 0) {
+        s = fe->src.l0[slot];
+        spitch = fe->src.pitch0[slot];
+        if (!s) return VSLAM_ERR_INVALID;
+    } else {
+        s = (blurred ? fe->d_blur : fe->d_pyr) + (size_t)slot * fe->slot_stride + g.off;
+        spitch = g.pitch;
+    }
+    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, s, spitch, g.w, g.h, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
 /* ------------------------------------------------------------------ extraction */
 static void decode_candidates(vslam_fe* fe, int s, int l) {
     const int ncells = (int)fe->cells.size();
