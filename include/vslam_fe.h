@@ -196,6 +196,9 @@ int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);
 int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, int fma, float* deg);
+/* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
+ * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */
+int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);
 
 #ifdef __cplusplus
 }

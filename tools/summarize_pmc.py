@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (tools/collect_pmc.sh) into one JSON: per kernel and per launch,
+FETCH_SIZE / WRITE_SIZE in bytes (raw counter x 1024; the gfx950 factor-2 under-count of FETCH_SIZE for wide
+coalesced streams, MI355X_MICROARCH.md 'HBM', is NOT applied here -- it is recorded as a separate field) and
+the SQ counters."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root = sys.argv[1]
+out = collections.defaultdict(dict)
+for sub in ("fetch", "write", "sq"):
+    files = glob.glob("%s/%s/*/*counter_collection.csv" % (root, sub))
+    if not files:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("k_"):
+            acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in acc.items():
+        out[k][c] = sum(v) / len(v)
+        out[k]["launches_" + sub] = len(v)
+res = {"workload": "run_extract_loop.py: 1241x376, 2000 features, 16 images per launch, 5 launches", "kernels": {}}
+for k, d in sorted(out.items()):
+    e = dict(d)
+    if "FETCH_SIZE" in d:
+        e["fetch_bytes_raw"] = d["FETCH_SIZE"] * 1024
+        e["fetch_bytes_x2_wide_stream_correction"] = d["FETCH_SIZE"] * 2048
+    if "WRITE_SIZE" in d:
+        e["write_bytes"] = d["WRITE_SIZE"] * 1024
+    res["kernels"][k] = e
+json.dump(res, open("%s/summary.json" % root, "w"), indent=1, sort_keys=True)
+print(json.dumps(res["kernels"], indent=1, sort_keys=True)[:3000])

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
-    "vslam_fe_pack_slot_range",
+    "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps",
 ]
 
 
@@ -62,6 +62,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C vi_slam_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        try:
+            # PyTorch bundles its own libamdhip64; if it is going to be used in this process it must be the
+            # first HIP runtime loaded, or torch.cuda later reports "No HIP GPUs are available".
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.vslam_fe_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]

@@ -132,6 +132,10 @@ struct vslam_fe {
     uint32_t* d_blur_tiles = nullptr;
     int n_blur_tiles = 0;
     int32_t taps[7];
+    /* v2 kernels (vslam_kernels_v2.hip); VSLAM_KERNELS=v1 in the environment selects the first generation */
+    bool use_v2_fast = false, use_v2_blur = false;
+    uint32_t* d_blur_tasks = nullptr;
+    int n_blur_tasks = 0;
     /* selection + outputs */
     SelKp* d_sel = nullptr;
     SelKp* h_sel = nullptr; /* pinned, B*cap */

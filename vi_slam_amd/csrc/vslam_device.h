@@ -35,10 +35,12 @@ struct BatchSrc {
 /* One executed FAST cell (fextractor.cpp:780-819): window [x0,x1) x [y0,y1) in level coordinates. */
 struct CellDesc {
     uint16_t level, x0, y0, x1, y1, pad;
+    uint32_t base; /* first entry of the cell's fixed candidate segment: capacity ceil(iw/2)*ceil(ih/2), the
+                      most strict 3x3 local maxima an iw x ih interior can hold -> no allocation atomics */
 };
 
 /* Per-slot candidate region, contiguous so one D2H moves header + cell table + candidates:
- *   uint32 total; uint32 overflow; CellOut cells[ncells]; uint32 cand[cap]
+ *   uint32 unused; uint32 overflow; CellOut cells[ncells]; uint32 cand[cap]
  * cand = (score << 24) | ((y-16) << 12) | (x-16), level coordinates. */
 struct CellOut {
     uint32_t base, count;
@@ -64,7 +66,8 @@ struct OctParams {
     int32_t selStride;                /* entries per slot in sel_xyr */
     int32_t maxNodes;                 /* list capacity (LDS) */
     int32_t ptsCap;                   /* entries per slot in the key ping-pong arrays */
-    int32_t pad;
+    int32_t maxIter;                  /* split passes allowed (64; lower only for timing experiments) */
+    void* dbg;                        /* timing stamps (diagnostic builds only) */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

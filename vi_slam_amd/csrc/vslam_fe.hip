@@ -31,6 +31,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_cand);
     if (fe->h_cand) hipHostFree(fe->h_cand);
     hipFree(fe->d_blur_tiles);
+    hipFree(fe->d_blur_tasks);
     hipFree(fe->d_sel);
     if (fe->h_sel) hipHostFree(fe->h_sel);
     hipFree(fe->d_kps);
@@ -141,10 +142,13 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
     fe->level_cell_first[p.nlevels] = (int)fe->cells.size();
     int maxw = 8, maxh = 8;
+    size_t cand_total = 0;
     std::vector<CellDesc> dc(fe->cells.size());
     for (size_t i = 0; i < fe->cells.size(); i++) {
         const vslam::HostCell& c = fe->cells[i];
         dc[i].level = c.level; dc[i].x0 = c.x0; dc[i].y0 = c.y0; dc[i].x1 = c.x1; dc[i].y1 = c.y1; dc[i].pad = 0;
+        dc[i].base = (uint32_t)cand_total;
+        cand_total += (size_t)((c.x1 - c.x0 - 6 + 1) / 2) * (size_t)((c.y1 - c.y0 - 6 + 1) / 2);
         maxw = std::max(maxw, c.x1 - c.x0);
         maxh = std::max(maxh, c.y1 - c.y0);
     }
@@ -160,9 +164,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if ((rc = upload(&fe->d_cells, dc.data(), dc.size() * sizeof(CellDesc)))) return rc;
     }
     const int ncells = (int)fe->cells.size();
-    /* a strict 3x3 local maximum needs its own 2x2 block at least: <= total_px/4 candidates; real images
-     * stay far below; size for 1/10 of the pixels and report overflow as an error */
-    fe->cand_cap = (int)std::max<size_t>(total_px / 10, 4096);
+    /* every cell owns a fixed segment sized by the exact upper bound of its NMS survivors */
+    fe->cand_cap = (int)std::max<size_t>(cand_total, 16);
     fe->cand_stride = (8 + (size_t)ncells * sizeof(CellOut) + (size_t)fe->cand_cap * 4 + 255) & ~(size_t)255;
     HIPCHK(hipMalloc((void**)&fe->d_cand, fe->cand_stride * fe->B));
     HIPCHK(hipHostMalloc((void**)&fe->h_cand, fe->cand_stride * fe->B, hipHostMallocDefault));
@@ -181,6 +184,22 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if ((rc = upload(&fe->d_pattern, VSLAM_ORB_PATTERN, 1024))) return rc;
     }
     vk_upload_disc(fe->tab.disc_u.data(), fe->tab.disc_v.data(), (int)fe->tab.disc_u.size());
+    {
+        /* marching-rows blur: one wave task per (level, 32-row chunk, 248-column strip) */
+        std::vector<uint32_t> tasks;
+        for (int l = 0; l < p.nlevels; l++) {
+            const int ns = std::max(1, (fe->geom.lv[l].w + 247) / 248), nc = (fe->geom.lv[l].h + 31) / 32;
+            for (int c = 0; c < nc; c++)
+                for (int s = 0; s < ns; s++) tasks.push_back(((uint32_t)l << 24) | ((uint32_t)c << 12) | (uint32_t)s);
+        }
+        fe->n_blur_tasks = (int)tasks.size();
+        int rc;
+        if ((rc = upload(&fe->d_blur_tasks, tasks.data(), tasks.size() * 4))) return rc;
+        const char* gen = getenv("VSLAM_KERNELS");
+        const bool v1 = gen && !strcmp(gen, "v1");
+        fe->use_v2_blur = !v1;
+        fe->use_v2_fast = !v1 && maxw <= vk_fast_v2_max_window() && maxh <= vk_fast_v2_max_rows();
+    }
 
     const size_t nk = (size_t)fe->B * fe->cap;
     HIPCHK(hipMalloc((void**)&fe->d_sel, nk * sizeof(SelKp)));
@@ -216,6 +235,12 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         O.selStride = selOff;
         O.maxNodes = (maxNodes + 15) & ~15;
         O.ptsCap = fe->cand_cap;
+        O.dbg = nullptr;
+        if (getenv("VSLAM_OCT_DBG")) {
+            HIPCHK(hipMalloc(&O.dbg, 64 * 8));
+            HIPCHK(hipMemset(O.dbg, 0, 64 * 8));
+        }
+        O.maxIter = getenv("VSLAM_OCT_MAXITER") ? atoi(getenv("VSLAM_OCT_MAXITER")) : 64;
         if (vk_octree_lds_bytes(O.maxNodes) > 150 * 1024) ok = false; /* list does not fit LDS: host quadtree */
         fe->dev_octree = ok;
         if (ok) {
@@ -283,6 +308,12 @@ extern "C" int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scal
         if (quota) quota[i] = fe->tab.quota[i];
     }
     return fe->p.nlevels;
+}
+
+extern "C" int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64) {
+    if (!fe || !fe->oct.dbg) return VSLAM_ERR_INVALID;
+    HIPCHK(hipMemcpy(out64, fe->oct.dbg, 64 * 8, hipMemcpyDeviceToHost));
+    return VSLAM_OK;
 }
 
 extern "C" void* vslam_fe_stream(vslam_fe* fe) { return fe ? (void*)fe->stream : nullptr; }
@@ -416,9 +447,13 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
         vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
                         fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
-                  fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch, fe->tile_rows,
-                  fe->max_px, nimg);
+    if (fe->use_v2_fast)
+        vk_fast_cells_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
+                         fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_rows, nimg);
+    else
+        vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
+                      fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch,
+                      fe->tile_rows, fe->max_px, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     return VSLAM_OK;
 }
@@ -427,7 +462,8 @@ static int fetch_candidates(vslam_fe* fe, int nimg, bool everything) {
     /* header + cell table + a first chunk speculatively; the rest only if a slot needs it */
     hipStream_t st = fe->stream;
     const size_t hdr_bytes = 8 + fe->cells.size() * sizeof(CellOut);
-    const size_t first_cands = everything ? (size_t)fe->cand_cap : std::min<size_t>((size_t)fe->cand_cap, 40960);
+    (void)everything; /* fixed per-cell segments: the used entries are scattered, copy the whole region */
+    const size_t first_cands = (size_t)fe->cand_cap;
     HIPCHK(hipMemcpy2DAsync(fe->h_cand, fe->cand_stride, fe->d_cand, fe->cand_stride, hdr_bytes + first_cands * 4,
                             nimg, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(fe->ev_cand, st));
@@ -436,26 +472,26 @@ static int fetch_candidates(vslam_fe* fe, int nimg, bool everything) {
 
 static int wait_candidates(vslam_fe* fe, int nimg) {
     hipStream_t st = fe->stream;
-    const size_t hdr_bytes = 8 + fe->cells.size() * sizeof(CellOut);
-    const size_t first_cands = std::min<size_t>((size_t)fe->cand_cap, 40960);
     HIPCHK(hipEventSynchronize(fe->ev_cand));
-    bool need_more = false;
     for (int s = 0; s < nimg; s++) {
         const uint32_t* hdr = (const uint32_t*)(fe->h_cand + (size_t)s * fe->cand_stride);
         if (hdr[1]) {
             g_err = "FAST candidate buffer overflow";
             return VSLAM_ERR_CAPACITY;
         }
-        if (hdr[0] > first_cands) need_more = true;
     }
-    if (need_more && first_cands < (size_t)fe->cand_cap) {
-        HIPCHK(hipMemcpy2DAsync(fe->h_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
-                                fe->d_cand + hdr_bytes + first_cands * 4, fe->cand_stride,
-                                ((size_t)fe->cand_cap - first_cands) * 4, nimg, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
+    (void)st;
     fe->cand_on_host = true;
     return VSLAM_OK;
+}
+
+static void enqueue_blur(vslam_fe* fe, int nimg) {
+    if (fe->use_v2_blur)
+        vk_blur7_v2(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks,
+                    fe->n_blur_tasks, fe->taps, nimg);
+    else
+        vk_blur7(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles,
+                 fe->n_blur_tiles, fe->taps, nimg);
 }
 
 /* quadtree on the host (fallback when the node list does not fit LDS, or VSLAM_FLAG_HOST_OCTREE) */
@@ -467,8 +503,7 @@ static int enqueue_back_host(vslam_fe* fe, int nimg, int lap0, int lap1) {
     int rc = fetch_candidates(fe, nimg, false);
     if (rc) return rc;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
-    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
-             fe->taps, nimg); /* runs while the host distributes */
+    enqueue_blur(fe, nimg); /* runs while the host distributes */
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     HIPCHK(hipGetLastError());
     if ((rc = wait_candidates(fe, nimg))) return rc;
@@ -547,8 +582,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     int32_t* d_err = fe->d_counts + (size_t)fe->B * 4;
     HIPCHK(hipMemsetAsync(d_err, 0, 16, st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
-    vk_blur7(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles, fe->n_blur_tiles,
-             fe->taps, nimg);
+    enqueue_blur(fe, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],

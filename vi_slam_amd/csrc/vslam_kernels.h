@@ -28,6 +28,14 @@ int vk_hamming_top2_tiles(int nt);
 void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
                      int32_t* idx2, int32_t* dist2);
 
+void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                 uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int nslots);
+void vk_fast_cells_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                      size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_rows, int nslots);
+int vk_fast_v2_max_window();
+int vk_fast_v2_max_rows();
+
 size_t vk_octree_lds_bytes(int maxNodes);
 int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,

@@ -113,7 +113,6 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     uint8_t* sc = win + tile_rows * tile_pitch;                       /* (tile_rows-4) x tile_pitch */
     uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * tile_pitch);  /* ceil(max_px/32) words */
     __shared__ uint32_t s_wave_tot[4];
-    __shared__ uint32_t s_base;
     __shared__ int s_any_ini;
 
     const int tid = threadIdx.x;
@@ -216,22 +215,13 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     CellOut* cout = (CellOut*)(hdr + 2);
     uint32_t* cand = (uint32_t*)(cout + ncells);
     if (tid == 0) {
-        uint32_t base = 0;
-        if (total) base = atomicAdd(&hdr[0], total);
-        if (base + total > (uint32_t)cand_cap) {
-            atomicOr(&hdr[1], 1u);
-            cout[blockIdx.x].base = base;
-            cout[blockIdx.x].count = 0;
-            s_base = 0xFFFFFFFFu;
-        } else {
-            cout[blockIdx.x].base = base;
-            cout[blockIdx.x].count = total;
-            s_base = base;
-        }
+        cout[blockIdx.x].base = cd.base;
+        cout[blockIdx.x].count = total;
     }
-    __syncthreads();
-    const uint32_t base = s_base;
-    if (base == 0xFFFFFFFFu || bits == 0) return;
+    (void)cand_cap;
+    (void)hdr;
+    const uint32_t base = cd.base;
+    if (bits == 0) return;
     uint32_t o = base + wave_off + incl - cnt;
     const int ox = cd.x0 + 3 - VSLAM_BORDER, oy = cd.y0 + 3 - VSLAM_BORDER;
     while (bits) {
@@ -415,9 +405,15 @@ __global__ void __launch_bounds__(256)
 k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
                       BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
                       const int32_t* __restrict__ slot_counts, const int8_t* __restrict__ pattern, vslam_kp* kps,
-                      uint8_t* desc, int cap, int atan_fma) {
-    const int slot = blockIdx.y;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+                      uint8_t* desc, int cap, int atan_fma, int bps, int nwork) {
+    /* XCD-aware order: workgroups b and b+8 share an XCD/L2.  The (slot, keypoint-block) work list is
+     * slot-major and level-major inside a slot, so handing XCD k the k-th contiguous eighth keeps one image
+     * (or a few of its levels) per L2 instead of streaming every pyramid through all eight. */
+    const int per_xcd = (nwork + 7) >> 3;
+    const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (w >= nwork) return;
+    const int slot = w / bps;
+    const int k = (w - slot * bps) * 4 + (threadIdx.x >> 6);
     if (k >= slot_counts[slot * 4]) return; /* wave-uniform */
     orient_describe_one(pyr, blur, slot_stride, src, g, sel[(size_t)slot * cap + k], pattern, kps, desc, cap,
                         atan_fma);
@@ -585,8 +581,9 @@ void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* b
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
                             int cap, int atan_fma, int nslots) {
-    hipLaunchKernelGGL(k_orient_describe_dev, dim3((cap + 3) / 4, nslots), dim3(256), 0, st, pyr, blur, slot_stride,
-                       src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma);
+    const int bps = (cap + 3) / 4, nwork = bps * nslots;
+    hipLaunchKernelGGL(k_orient_describe_dev, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
+                       src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
 }
 
 void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out) {

@@ -1,0 +1,379 @@
+/* vslam_kernels_v2.hip -- second-generation FAST and blur kernels (same results as v1, bit for bit).
+ *
+ * k_blur7_v2   marching-rows separable 7x7: one WAVE owns a 256-px-wide strip (64 lanes x 4 px, loaded as one
+ *              dword per lane = 256 B coalesced), gets its neighbours' dwords with two wave shuffles, does
+ *              the row pass with v_dot4_u32_u8 against packed tap constants (10 dot4 per 4 px, no byte
+ *              extraction) and keeps a 7-row ring of row-pass results in VGPRs for the column pass.  No LDS,
+ *              no barriers; every input byte is read once per strip (+6 halo rows per 32).
+ * k_fast_cells_v2  same algorithm as k_fast_cells, but the LDS tiles have a compile-time pitch (ring offsets
+ *              become ds_read immediates), pixel <-> thread mapping is 32x8 without any integer division,
+ *              and the keep mask is 2 words per interior row.
+ */
+#include "vslam_kernels.h"
+
+__device__ __forceinline__ const uint8_t* level_base_v2(const uint8_t* pyr, size_t slot_stride,
+                                                        const BatchSrc& src, const LevelGeom& lg, int level,
+                                                        int slot, int* pitch) {
+    if (level == 0) {
+        *pitch = (int)src.pitch0[slot];
+        return src.l0[slot];
+    }
+    *pitch = lg.pitch;
+    return pyr + (size_t)slot * slot_stride + lg.off;
+}
+
+__device__ __forceinline__ int refl101_v2(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return min(max(p, 0), len - 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * blur
+ * ---------------------------------------------------------------------------------------------- */
+#define BV_ROWS 32   /* output rows per wave task */
+#define BV_OUTW 248  /* output columns per strip: lanes 1..62 of 64, 4 px each */
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+
+/* row pass of the 4 pixels of one lane: L, C, R = dwords of the left neighbour, this lane, right neighbour
+ * (byte 0 = lowest x).  T* = taps packed per byte position; results are exact (<= 255*256). */
+struct BlurTapsV2 {
+    uint32_t l0, c0, l1, c1, r1, l2, c2, r2, c3, r3; /* packed byte weights */
+    uint32_t k[7];
+};
+
+__global__ void __launch_bounds__(256)
+k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
+           const uint32_t* __restrict__ tasks, int ntasks, int nslots, BlurTapsV2 T) {
+    const int lane = threadIdx.x & 63;
+    /* XCD-aware order (workgroups b, b+8 share an L2): the (slot, task) list is cut into 8 contiguous parts */
+    const int tpb = (ntasks + 3) >> 2, nwork = tpb * nslots, per_xcd = (nwork + 7) >> 3;
+    const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (wk >= nwork) return;
+    const int slot = wk / tpb;
+    const int task = (wk - slot * tpb) * 4 + (threadIdx.x >> 6);
+    if (task >= ntasks) return; /* wave-uniform */
+    const uint32_t td = tasks[task]; /* level << 24 | rowchunk << 12 | strip */
+    const int level = td >> 24, rc = (td >> 12) & 0xFFF, strip = td & 0xFFF;
+    const LevelGeom lg = g.lv[level];
+    int pitch;
+    const uint8_t* img = level_base_v2(pyr, slot_stride, src, lg, level, slot, &pitch);
+    uint8_t* out = blur + (size_t)slot * slot_stride + lg.off;
+    const int w = lg.w, h = lg.h;
+    /* the last strip is shifted left so that it ends at the image edge (overlap is rewritten identically) */
+    const int ox0 = min(strip * BV_OUTW, max(w - BV_OUTW, 0)); /* first output column of the strip */
+    const int x = ox0 - 4 + lane * 4;                          /* first of this lane's 4 columns */
+    const int y0 = rc * BV_ROWS;
+    const int nrows = min(BV_ROWS, h - y0);
+    const bool fast_x = x >= 0 && x + 3 < w;
+    /* columns of a border lane, reflected once */
+    int bx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) bx[k] = refl101_v2(x + k, w);
+
+    uint32_t hq[7][4]; /* ring of row-pass results, hq[r % 7] */
+    auto load_row = [&](int yy) -> uint32_t {
+        const uint8_t* row = img + (size_t)refl101_v2(yy, h) * pitch;
+        if (fast_x) return *(const uint32_t*)(row + x);
+        return (uint32_t)row[bx[0]] | ((uint32_t)row[bx[1]] << 8) | ((uint32_t)row[bx[2]] << 16) |
+               ((uint32_t)row[bx[3]] << 24);
+    };
+    auto hpass = [&](uint32_t Cw, uint32_t* o) {
+        const uint32_t Lw = __shfl_up(Cw, 1, 64), Rw = __shfl_down(Cw, 1, 64);
+        o[0] = udot4(Lw, T.l0, udot4(Cw, T.c0, 0));
+        o[1] = udot4(Lw, T.l1, udot4(Cw, T.c1, udot4(Rw, T.r1, 0)));
+        o[2] = udot4(Lw, T.l2, udot4(Cw, T.c2, udot4(Rw, T.r2, 0)));
+        o[3] = udot4(Cw, T.c3, udot4(Rw, T.r3, 0));
+    };
+    /* prologue: rows y0-3 .. y0+2 */
+#pragma unroll
+    for (int r = 0; r < 6; r++) hpass(load_row(y0 - 3 + r), hq[r]);
+    const bool writer = lane >= 1 && lane <= 62 && x < w; /* halo lanes and lanes past the image do not store */
+    uint32_t nextw = load_row(y0 + 3);
+    for (int rb = 0; rb < nrows; rb += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int r = rb + u;
+            if (r < nrows) { /* wave-uniform */
+                hpass(nextw, hq[(u + 6) % 7]);
+                nextw = load_row(y0 + r + 4);
+                uint32_t px[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    uint32_t acc = 32768u;
+#pragma unroll
+                    for (int k = 0; k < 7; k++) acc += __umul24(T.k[k], hq[(u + k) % 7][c]);
+                    px[c] = min(acc >> 16, 255u);
+                }
+                if (writer) {
+                    uint8_t* o = out + (size_t)(y0 + r) * lg.pitch + x;
+                    if (x + 3 < w) *(uint32_t*)o = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                    else {
+                        o[0] = (uint8_t)px[0];
+                        if (x + 1 < w) o[1] = (uint8_t)px[1];
+                        if (x + 2 < w) o[2] = (uint8_t)px[2];
+                    }
+                }
+            }
+        }
+    }
+}
+
+void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                 uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int nslots) {
+    BlurTapsV2 T;
+    const uint32_t k0 = taps[0], k1 = taps[1], k2 = taps[2], k3 = taps[3], k4 = taps[4], k5 = taps[5], k6 = taps[6];
+    auto pk = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); };
+    /* pixel j of the lane sits at byte j of C; its window covers bytes j-3 .. j+3 of the L|C|R stream */
+    T.l0 = pk(0, k0, k1, k2); T.c0 = pk(k3, k4, k5, k6);
+    T.l1 = pk(0, 0, k0, k1);  T.c1 = pk(k2, k3, k4, k5); T.r1 = pk(k6, 0, 0, 0);
+    T.l2 = pk(0, 0, 0, k0);   T.c2 = pk(k1, k2, k3, k4); T.r2 = pk(k5, k6, 0, 0);
+    T.c3 = pk(k0, k1, k2, k3); T.r3 = pk(k4, k5, k6, 0);
+    for (int i = 0; i < 7; i++) T.k[i] = taps[i];
+    const int nwork = ((ntasks + 3) / 4) * nslots;
+    hipLaunchKernelGGL(k_blur7_v2, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
+                       ntasks, nslots, T);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FAST cells
+ * ---------------------------------------------------------------------------------------------- */
+#define FP 72 /* LDS pitch in bytes; cell windows are at most 66 px wide (host checks) */
+
+/* hipcc splits min(a,min(b,c)) into shared two-input mins; the three-input forms halve the network */
+__device__ __forceinline__ int imin3v(int a, int b, int c) {
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int imax3v(int a, int b, int c) {
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+/* One polarity of the FAST score: max over the 16 nine-pixel arcs of min_k d_k, with d_k = sign*(v - ring_k).
+ * sign = +1 -> dark corners (cornerScore's a0), sign = -1 -> bright corners (its -b0).  The OpenCV score is
+ * max(dark, bright) - 1. */
+template <int SIGN>
+__device__ __forceinline__ int fast_half_score(const uint8_t* c) {
+    const int v = c[0];
+    int d[16];
+#define RD(k, off) d[k] = SIGN > 0 ? v - (int)c[off] : (int)c[off] - v
+    RD(0, 3 * FP);   RD(1, 3 * FP + 1);   RD(2, 2 * FP + 2);    RD(3, FP + 3);
+    RD(4, 3);        RD(5, -FP + 3);      RD(6, -2 * FP + 2);   RD(7, -3 * FP + 1);
+    RD(8, -3 * FP);  RD(9, -3 * FP - 1);  RD(10, -2 * FP - 2);  RD(11, -FP - 3);
+    RD(12, -3);      RD(13, FP - 3);      RD(14, 2 * FP - 2);   RD(15, 3 * FP - 1);
+#undef RD
+    int lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo3[k] = imin3v(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    int A = -256;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2)
+        A = imax3v(A, imin3v(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]),
+                   imin3v(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
+    return A;
+}
+
+__global__ void __launch_bounds__(256)
+k_fast_cells_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
+                const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
+                int cand_cap, int iniTh, int minTh, int tile_rows) {
+    extern __shared__ __align__(16) uint8_t smem2[];
+    uint8_t* win = smem2;                        /* tile_rows x FP */
+    uint8_t* sc = win + tile_rows * FP;          /* (tile_rows-4) x FP, interior at (1..ih, 1..iw) */
+    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * FP); /* 2 words per interior row */
+    uint16_t* plist = (uint16_t*)(keep + (tile_rows - 6) * 2); /* pixels passing the dark compass pre-test */
+    uint16_t* plistB = plist + (tile_rows - 6) * 64;            /* ... the bright one */
+    __shared__ int s_npass[2];
+    __shared__ uint32_t s_wave_tot[4];
+    __shared__ int s_any_ini;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = blockIdx.y;
+    /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2), so XCD k takes the k-th
+     * contiguous eighth of the cell list -- neighbouring cells, whose windows overlap by 6 px and share image
+     * rows, then hit the same L2 instead of being fetched by all eight. */
+    const int per_xcd = (ncells + 7) >> 3;
+    const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (cell >= ncells) return;
+    const CellDesc cd = cells[cell];
+    const int level = cd.level;
+    const LevelGeom lg = g.lv[level];
+    int pitch;
+    const uint8_t* img = level_base_v2(pyr, slot_stride, src, lg, level, slot, &pitch);
+    const int ww = cd.x1 - cd.x0, wh = cd.y1 - cd.y0;
+    const int iw = ww - 6, ih = wh - 6;
+    const int nwords = ih * 2;
+
+    /* stage the window with dword loads: 16 lanes x 4 bytes per row, 16 rows per sweep.  A lane's dword may
+     * run up to 3 bytes past the window, which is still inside the image row (windows end >= 16 px before it) */
+    {
+        const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0;
+        const int srow = tid >> 4, scol = (tid & 15) * 4;
+        for (int y = srow; y < wh; y += 16) {
+            if (scol < ww) *(uint32_t*)(win + y * FP + scol) = *(const uint32_t*)(gsrc + (size_t)y * pitch + scol);
+            if (scol + 64 < ww) win[y * FP + scol + 64] = gsrc[(size_t)y * pitch + scol + 64]; /* ww in 65..66 */
+            if (scol + 65 < ww && scol == 0) win[y * FP + 65] = gsrc[(size_t)y * pitch + 65];
+        }
+    }
+    /* zero frame of the score tile, keep mask */
+    if (tid < iw + 2) {
+        sc[tid] = 0;
+        sc[(ih + 1) * FP + tid] = 0;
+    }
+    if (tid < ih) {
+        sc[(tid + 1) * FP] = 0;
+        sc[(tid + 1) * FP + iw + 1] = 0;
+    }
+    if (tid < nwords) keep[tid] = 0;
+    if (tid == 0) {
+        s_any_ini = 0;
+        s_npass[0] = 0;
+        s_npass[1] = 0;
+    }
+    __syncthreads();
+
+    const int lx = tid & 31, lyb = tid >> 5; /* 32 columns x 8 rows per sweep */
+    /* Pre-test (exact necessary condition): a nine-pixel arc always contains two compass-adjacent ring
+     * pixels (0,4,8,12), so a pixel whose score can reach minTh has two adjacent compass pixels darker than
+     * v - minTh or two brighter than v + minTh.  Everything else scores 0 -- which cannot change the NMS
+     * (a suppressing neighbour needs a score >= the candidate's >= minTh).  The test is made per polarity:
+     * a pixel that can only be a dark corner runs only the dark half of the network (and vice versa); both
+     * survivor lists are compacted so the min3/max3 networks run on dense lanes. */
+    for (int xb = 0; xb < iw; xb += 32) {
+        const int x = xb + lx;
+        for (int ly0 = 0; ly0 < ih; ly0 += 8) { /* uniform trip count: the ballot below needs whole waves */
+            const int ly = ly0 + lyb;
+            bool passD = false, passB = false;
+            if (x < iw && ly < ih) {
+                const uint8_t* c = win + (ly + 3) * FP + x + 3;
+                const int v = c[0];
+                const int d0 = v - c[3 * FP], d4 = v - c[3], d8 = v - c[-3 * FP], d12 = v - c[-3];
+                const bool k0 = d0 > minTh, k4 = d4 > minTh, k8 = d8 > minTh, k12 = d12 > minTh;
+                const bool b0 = d0 < -minTh, b4 = d4 < -minTh, b8 = d8 < -minTh, b12 = d12 < -minTh;
+                passD = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
+                passB = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+                sc[(ly + 1) * FP + x + 1] = 0;
+            }
+            const uint16_t code = (uint16_t)(ly * 64 + x);
+            unsigned long long m = __ballot(passD);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_npass[0], __popcll(m));
+                base = __shfl(base, leader, 64);
+                if (passD) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
+            }
+            m = __ballot(passB);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_npass[1], __popcll(m));
+                base = __shfl(base, leader, 64);
+                if (passB) plistB[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
+            }
+        }
+    }
+    __syncthreads();
+    /* dark half on its list, then the bright half on its own (a pixel on both lists keeps the larger) */
+    const int nD = s_npass[0], nB = s_npass[1];
+    for (int i = tid; i < nD; i += 256) {
+        const int code = plist[i], ly = code >> 6, x = code & 63;
+        const int a = fast_half_score<1>(win + (ly + 3) * FP + x + 3) - 1;
+        sc[(ly + 1) * FP + x + 1] = (uint8_t)max(a, 0);
+    }
+    __syncthreads();
+    for (int i = tid; i < nB; i += 256) {
+        const int code = plistB[i], ly = code >> 6, x = code & 63;
+        const int a = fast_half_score<-1>(win + (ly + 3) * FP + x + 3) - 1;
+        uint8_t* q = sc + (ly + 1) * FP + x + 1;
+        if (a > (int)*q) *q = (uint8_t)a;
+    }
+    __syncthreads();
+
+    /* NMS only where a score exists: walk the two survivor lists (a pixel on both is visited twice) */
+    int any_ini = 0;
+    for (int i = tid; i < nD + nB; i += 256) {
+        const int code = i < nD ? plist[i] : plistB[i - nD], ly = code >> 6, x = code & 63;
+        const uint8_t* q = sc + (ly + 1) * FP + x + 1;
+        const int s = q[0];
+        if (s >= minTh) {
+            const int m = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
+                              max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
+            if (s > m) {
+                atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
+                if (s >= iniTh) any_ini = 1;
+            }
+        }
+    }
+    if (any_ini) s_any_ini = 1;
+    __syncthreads();
+    const int T = s_any_ini ? iniTh : minTh;
+
+    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..) */
+    uint32_t bits = 0;
+    const int kly = tid >> 1, kxb = (tid & 1) * 32;
+    if (tid < nwords) {
+        uint32_t b = keep[tid];
+        if (T != minTh) {
+            uint32_t r = b;
+            while (r) {
+                const int k = __ffs(r) - 1;
+                r &= r - 1;
+                if (sc[(kly + 1) * FP + kxb + k + 1] < T) b &= ~(1u << k);
+            }
+        }
+        bits = b;
+    }
+    const uint32_t cnt = __popc(bits);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < wv) wave_off += s_wave_tot[k];
+        total += s_wave_tot[k];
+    }
+    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    CellOut* cout = (CellOut*)(hdr + 2);
+    uint32_t* cand = (uint32_t*)(cout + ncells);
+    if (tid == 0) {
+        cout[cell].base = cd.base;
+        cout[cell].count = total;
+    }
+    (void)cand_cap;
+    (void)hdr;
+    const uint32_t base = cd.base;
+    if (bits == 0) return;
+    uint32_t o = base + wave_off + incl - cnt;
+    const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
+    while (bits) {
+        const int k = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
+        cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+    }
+}
+
+void vk_fast_cells_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                      size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_rows, int nslots) {
+    const size_t shm = (size_t)tile_rows * FP + (size_t)(tile_rows - 4) * FP + (size_t)(tile_rows - 6) * 8 +
+                       (size_t)(tile_rows - 6) * 64 * 2 * 2 + 16;
+    hipLaunchKernelGGL(k_fast_cells_v2, dim3(((ncells + 7) / 8) * 8, nslots), dim3(256), shm, st, pyr, slot_stride, src, g, cells,
+                       cand_region, cand_stride, ncells, cand_cap, iniTh, minTh, tile_rows);
+}
+
+int vk_fast_v2_max_window() { return 66; } /* widest window the fixed LDS pitch supports (needs x+3 < FP-3) */
+int vk_fast_v2_max_rows() { return 128 + 6; } /* keep mask: 2 words per interior row, <= 256 threads */

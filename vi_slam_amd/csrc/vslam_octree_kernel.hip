@@ -94,6 +94,15 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
 
     const int tid = threadIdx.x;
     const int level = blockIdx.x, slot = blockIdx.y;
+#ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
+                           of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
+    int dbgn = 0;
+    unsigned long long* DBG = (unsigned long long*)P.dbg;
+#define STAMP() do { if (DBG && tid == 0 && level == 0 && slot == 0 && dbgn < 60) DBG[dbgn++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
     const int N = P.N[level];
     const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
     const CellOut* cout = (const CellOut*)(hdr + 2);
@@ -147,6 +156,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     }
     __syncthreads();
 
+    STAMP();
     const int C = (n + OT - 1) / OT;
     const int i0 = min(tid * C, n), i1 = min(i0 + C, n);
 
@@ -215,22 +225,27 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     }
     { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
 
+    STAMP();
     /* ---- 2. split passes */
     int phase = 1;
     const int KN = (MAXN + OT - 1) / OT;
-    for (int iter = 0; iter < 64; iter++) {
+    for (int iter = 0; iter < P.maxIter; iter++) {
         const int size0 = s_size;
         /* A. classify keys of expandable nodes, thread totals */
         u64 loc = 0;
+#pragma unroll 8
         for (int i = i0; i < i1; i++) {
             const ONode nd = cur[na[i]];
             if (!ND_NOMORE(nd)) loc += onehot(quadrant(pa[i], nd));
         }
         u64 tot64;
+        STAMP();
         const u64 S0 = block_excl_scan<u64>(loc, s_w64, &tot64);
+        STAMP();
         /* C. scan value at each node's first key and after its last key */
         {
             u64 run = S0;
+#pragma unroll 8
             for (int i = i0; i < i1; i++) {
                 const int v = na[i];
                 const ONode nd = cur[v];
@@ -241,6 +256,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             }
         }
         __syncthreads();
+        STAMP();
         /* D. node level */
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
@@ -272,9 +288,10 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
                 if (v < size0 && !ND_NOMORE(cur[v])) {
                     const uint32_t cv = ND_COUNT(cur[v]);
                     uint32_t r = 0;
+#pragma unroll 8
                     for (int u = 0; u < size0; u++) {
-                        const ONode nu = cur[u];
-                        if (!ND_NOMORE(nu) && (ND_COUNT(nu) > cv || (ND_COUNT(nu) == cv && u < v))) r++;
+                        const uint32_t cfu = cur[u].cf; /* count << 1 | noMore */
+                        r += (!(cfu & 1u) && ((cfu >> 1) > cv || ((cfu >> 1) == cv && u < v))) ? 1u : 0u;
                     }
                     prank[v] = (uint16_t)r;
                     ordv[r] = (uint16_t)v;
@@ -282,6 +299,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
             }
         }
         __syncthreads();
+        STAMP();
         /* D2. in processing order: children created before me, running list size -> cut */
         const int KE = ((int)nexp + OT - 1) / OT;
         uint32_t chl = 0;
@@ -323,6 +341,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         }
         __syncthreads();
         const int M = s_M;
+        STAMP();
         /* D3. survivors: list index after the pass */
         uint32_t sv = 0;
         for (int k = 0; k < KN; k++) {
@@ -371,9 +390,11 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         }
         if (nexp_children) atomicAdd(&s_nexp, nexp_children);
         __syncthreads();
+        STAMP();
         /* E. move the keys of processed parents (stable), relabel every key with its node's new index */
         {
             u64 run = S0;
+#pragma unroll 8
             for (int i = i0; i < i1; i++) {
                 const uint32_t pt = pa[i];
                 const int v = na[i];
@@ -407,6 +428,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         __syncthreads();
         { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
         { ONode* t = cur; cur = nxt; nxt = t; }
+        STAMP();
         /* F. loop control (fextractor.cpp:658-729) */
         const int size = s_size, nToExpand = s_nexp;
         __syncthreads();
@@ -414,6 +436,7 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
     }
 
+    STAMP();
     /* ---- 3. best response per node, first wins (fextractor.cpp:732-751); output in list order */
     const int size = s_size;
     for (int v = tid; v < size; v += OT) {
@@ -425,6 +448,11 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
         }
         out[v] = best;
     }
+#ifdef VSLAM_OCT_STAMPS
+    __syncthreads();
+    STAMP();
+    if (DBG && tid == 0 && level == 0 && slot == 0) DBG[63] = dbgn;
+#endif
     if (tid == 0) *ocnt = size;
 }
 
