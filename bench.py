@@ -46,6 +46,22 @@ def algorithmic_bytes(fe, nf):
     return dict(pyramid=(P - px[-1]) + (P - px[0]), fast=P, blur=2 * P, describe=2 * P + 60 * nf, total_px=P)
 
 
+def pmc_traffic(kernel, cfg, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/collect_pmc.sh,
+    separate FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of
+    a coalesced stream (MI355X_MICROARCH.md 'HBM'): calibrated here on k_fast_cells_v2, whose unique input is
+    the 23.1 MB of pyramid pixels and whose raw FETCH_SIZE reads 11.1 MB -> the factor 2 is applied.
+    Only valid for the geometry/batch the profile was taken with; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_kitti_n2000_b16.json")
+    if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376 and batch == 16):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel.split("(")[0])
+    if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
+        return None
+    return {"bytes": 2 * k["fetch_bytes_raw"] + k["write_bytes"], "fetch_size_raw_bytes": k["fetch_bytes_raw"],
+            "write_size_bytes": k["write_bytes"], "source": "profiles/r01c_pmc_traffic_kitti_n2000_b16.json"}
+
+
 def cpu_baseline(cfg, seconds=12.0):
     """The oracle (a port of the reference's CPU path, oracle/) timed on this box's host cores: the same
     workload on a bounded sample of frames, reference-faithful threading (1 thread per image; the two
@@ -242,8 +258,9 @@ def main():
                     "describe": prof["describe_ms"] / nb, "octree": prof["octree_ms"] / nb}
         streaming = {k: v for k, v in stage_ms.items() if k != "octree"}  # the quadtree moves no image bytes
         dom = max(streaming, key=streaming.get)
-        kernel = {"pyramid": "k_resize_level(x7)", "fast": "k_fast_cells", "blur": "k_blur7",
+        kernel = {"pyramid": "k_resize_level(x7)", "fast": "k_fast_cells_v2", "blur": "k_blur7_v2",
                   "describe": "k_orient_describe_dev"}[dom]
+        tr = pmc_traffic(kernel, cfg, B)
         bytes_per_launch = ab[dom] * B
         achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         out = {
@@ -266,7 +283,8 @@ def main():
                        if not stereo else "stereo frames independent per rank, no collective",
                        "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"]},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
+                         "traffic_detail": tr,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": stage_ms[dom], "stage_ms_per_batch": stage_ms},
         }
