@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
-    ap.add_argument("--inflight", type=int, default=3, help="extractor contexts (HIP streams) in flight per GPU")
+    ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,7 +142,7 @@ def main():
     B = args.batch
     if stereo and B % 2:
         B += 1
-    NCTX = max(2, args.inflight)  # extractor contexts (streams) kept in flight per GPU
+    NCTX = max(3, args.inflight)  # extractor contexts (streams) kept in flight per GPU
     ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B) for _ in range(NCTX)]
     fe = ctxs[0]
     matchers = [V.FMatcher(c, 0.9, True) for c in ctxs]
@@ -178,51 +178,79 @@ def main():
         else:
             c.compute_batch_async(ptrs, pitch, lap)
 
-    def collect(t):
-        """Finish step t: results to the host, then (mono) match every frame against its predecessor."""
+    def mid(t):
+        """Step t's extraction is done: results to the host; (mono) enqueue the frame-to-frame matcher for
+        every frame of the step -- on the GPU, fed with device pointers only."""
         c = ctxs[t % NCTX]
         if stereo:
             feats, st = c.frame_stereo_wait()
             state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
             return
+        t_a = time.perf_counter()
         res = c.wait()
+        t_b = time.perf_counter()
         if world > 1:
             c.pack_slots(B, packed.data_ptr(), slot_bytes)
             vd.exchange_slots(packed, gathered)
-        pairs = []
+            torch.cuda.synchronize()
+        jobs, n1 = [], []
         for s in range(B):
             pr, ps, prev_step = vd.predecessor(rank, s, world, B)
             if prev_step:
-                if state["carry_kps"] is None:
+                if not state.get("have_carry"):
                     continue
-                k_prev, d_prev = state["carry_kps"], carry.data_ptr() + desc_off
+                base = carry.data_ptr()
+                prev_ptrs = (base + 16, base + desc_off, base)
+                n_prev = state["carry_n"]
             elif world == 1:
-                k_prev, d_prev = res[ps][0], c.slot_buffers(ps)[1]
+                prev_ptrs = c.slot_dev_ptrs(ps)
+                n_prev = len(res[ps][0])
             else:
-                pview = vd.slot_view(gathered, pr, ps, B, slot_bytes)
-                k_prev = res[ps][0] if pr == rank else slot_host_kps(pview)
-                d_prev = pview.data_ptr() + desc_off
-            k_cur, d_cur = res[s][0], c.slot_buffers(s)[1]
-            pairs.append((k_prev, d_prev, k_cur, d_cur, np.stack([k_prev["x"], k_prev["y"]], 1)))
-        out = matchers[t % NCTX].SearchForInitializationBatch(pairs, 100, (w, h)) if pairs else []
-        state["matches"] = sum(o[0] for o in out)
-        # the last frame of this step precedes the first frame of the next one
+                base = vd.slot_view(gathered, pr, ps, B, slot_bytes).data_ptr()
+                prev_ptrs = (base + 16, base + desc_off, base)
+                n_prev = fe.cap  # count lives in the packed header; deliver up to capacity
+            cur = c.slot_dev_ptrs(s)
+            jobs.append((prev_ptrs[0], prev_ptrs[1], prev_ptrs[2], cur[0], cur[1], cur[2], 0))
+            n1.append(n_prev)
+        if jobs:
+            matchers[t % NCTX].search_init_dev_async(jobs, 100, (w, h))
+        state["pending_n1"] = state.get("pending_n1", {})
+        state["pending_n1"][t] = n1
+        # the last frame of this step precedes the first frame of the next one: keep it in `carry`
         if world == 1:
-            c.pack_slots(1, carry.data_ptr(), slot_bytes, first=B - 1)
-            state["carry_kps"] = res[B - 1][0].copy()
+            c.pack_slots(1, carry.data_ptr(), slot_bytes, first=B - 1, sync=False)
+            state["carry_n"] = len(res[B - 1][0])
         else:
-            lastv = vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes)
-            carry.copy_(lastv)
-            state["carry_kps"] = res[B - 1][0].copy() if rank == world - 1 else slot_host_kps(lastv)
+            carry.copy_(vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes))
+            torch.cuda.synchronize()
+            state["carry_n"] = fe.cap
+        state["have_carry"] = True
+        t_c = time.perf_counter()
+        hs = state.setdefault("host_s", [0.0, 0.0, 0.0])
+        hs[0] += t_b - t_a
+        hs[1] += t_c - t_b
+
+    def fin(t):
+        """Collect step t's matches (synchronises that context's stream, which also orders its carry copy
+        before the next step's matcher reads it)."""
+        if stereo:
+            return
+        t_a = time.perf_counter()
+        n1 = state["pending_n1"].pop(t)
+        if n1:
+            out = matchers[t % NCTX].search_init_dev_wait(n1)
+            state["matches"] = sum(o[0] for o in out)
+        state.setdefault("host_s", [0.0, 0.0, 0.0])[2] += time.perf_counter() - t_a
 
     def run(nsteps):
-        depth = NCTX - 1
-        for t in range(nsteps):
-            enqueue(t)
-            if t >= depth:
-                collect(t - depth)
-        for t in range(max(nsteps - depth, 0), nsteps):
-            collect(t)
+        d1 = NCTX - 2  # enqueue(t) .. mid(t - d1) .. fin(t - d1 - 1): NCTX contexts busy at once
+        for t in range(nsteps + d1 + 1):
+            if t < nsteps:
+                enqueue(t)
+            if 0 <= t - d1 - 1 < nsteps:
+                fin(t - d1 - 1)
+            if 0 <= t - d1 < nsteps:
+                mid(t - d1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -231,6 +259,7 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
+    state.pop("host_s", None)
     for c in ctxs:
         c.set_profiling(True)
     barrier()
@@ -278,10 +307,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "frames_per_step_per_gpu": B // 2 if stereo else B,
                        "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
-                       "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100",
+                       "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100, on device",
                        "sharding": "frames round-robin over ranks; one all-gather of result slots per step"
                        if not stereo else "stereo frames independent per rank, no collective",
-                       "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"]},
+                       "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],
+                       "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in
+                                            zip(("wait_extract", "enqueue_match", "wait_match"),
+                                                state.get("host_s", [0, 0, 0]))}},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_detail": tr,

@@ -127,6 +127,9 @@ void* vslam_fe_stream(vslam_fe* fe);
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
 /* the same for slots first .. first+nslots-1 (packed from offset 0 of dev_dst) */
 int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes);
+/* enqueue-only variant: the copies run on fe's stream after the pass that produced the slots; the caller
+ * orders later readers (stream sync / event) itself */
+int vslam_fe_pack_slot_range_async(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes);
 
 /* Stage timing with HIP events on the context's stream (the reference's REGISTER_TIMES spans,
  * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..4] = pyramid (7 launches), FAST cells,
@@ -189,6 +192,29 @@ int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_
                                           const int* n2, int img_w, int img_h, float* const* prev_matched,
                                           int32_t* const* matches12, int window, float nnratio,
                                           int check_orientation, int* nmatches);
+
+/* Device-resident form: every pointer of a job is a DEVICE pointer -- keypoints/descriptors as returned by
+ * vslam_fe_slot_buffers (or a slot of an RCCL all-gather buffer packed by vslam_fe_pack_slots), the keypoint
+ * counts as int32 in HBM (vslam_fe_slot_count_ptr, or the header word of a packed slot).  The whole matcher
+ * (window query, Hamming distances, stealing, ratio test, rotation histogram) runs in one kernel, one wave per
+ * pair, on fe's stream; _async returns without waiting, _wait delivers n1[j] entries of vnMatches12 and the
+ * updated vbPrevMatched per pair plus the match counts.  dev_prev_matched == NULL means "frame 1's keypoint
+ * positions" (tracking.cpp:2281-2288 initialises vbPrevMatched that way). */
+typedef struct vslam_init_job {
+    const vslam_kp* dev_kps1;
+    const uint8_t* dev_desc1;
+    const int32_t* dev_n1;
+    const vslam_kp* dev_kps2;
+    const uint8_t* dev_desc2;
+    const int32_t* dev_n2;
+    const float* dev_prev_matched;
+} vslam_init_job;
+int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam_init_job* jobs, int img_w, int img_h,
+                                int window, float nnratio, int check_orientation);
+int vslam_search_init_dev_wait(vslam_fe* fe, const int* n1, int32_t* const* matches12, float* const* prev_matched,
+                               int* nmatches);
+/* device address of a slot's keypoint count (int32), valid for the life of the context */
+int vslam_fe_slot_count_ptr(vslam_fe* fe, int slot, const int32_t** dev_n);
 
 /* ---------------------------------------------------------------- diagnostics */
 

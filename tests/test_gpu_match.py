@@ -208,3 +208,62 @@ def test_frame_stereo_async_pipeline(fe):
         assert np.array_equal(feats[2 * s][1], dL) and np.array_equal(feats[2 * s + 1][1], dR)
         assert np.array_equal(st[s][0], wu) and np.array_equal(st[s][1], wd)
         assert (wu >= 0).sum() > 300
+
+
+def test_search_init_host_replay_path_agrees(monkeypatch):
+    """VSLAM_INIT_MATCH=host: distance matrices on the GPU, order-dependent replay on the host."""
+    monkeypatch.setenv("VSLAM_INIT_MATCH", "host")
+    a, b = synth.make_frame(1241, 376, step=3), synth.make_frame(1241, 376, step=4)
+    f = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    try:
+        (k1, d1, _), (k2, d2, _) = f.compute_batch([a, b], (0, 1000))
+        _, pd1, _ = f.slot_buffers(0)
+        _, pd2, _ = f.slot_buffers(1)
+        nm, m12, pm = V.FMatcher(f, 0.9, True).SearchForInitialization(k1, pd1, k2, pd2,
+                                                                       np.stack([k1["x"], k1["y"]], 1), 100)
+        wn, wm, wp = orbo.search_for_initialization(k1, d1, k2, d2, 1241, 376, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp)
+    finally:
+        f.close()
+
+
+def test_search_init_device_jobs_async(fe):
+    """Device-pointer jobs straight from the slot buffers: frame s-1 -> frame s for a whole batch, plus a
+    window-20 / ratio-0.6 / no-orientation variant; everything equals the oracle."""
+    frames = [synth.make_frame(1241, 376, step=s) for s in range(6)]
+    res = fe.compute_batch(frames, (0, 1000))
+    jobs = []
+    for s in range(1, 6):
+        p, c = fe.slot_dev_ptrs(s - 1), fe.slot_dev_ptrs(s)
+        jobs.append((p[0], p[1], p[2], c[0], c[1], c[2], 0))
+    m = V.FMatcher(fe, 0.9, True)
+    m.search_init_dev_async(jobs, 100)
+    out = m.search_init_dev_wait([len(res[s - 1][0]) for s in range(1, 6)], want_prev=True)
+    for j, s in enumerate(range(1, 6)):
+        wn, wm, wp = orbo.search_for_initialization(res[s - 1][0], res[s - 1][1], res[s][0], res[s][1], 1241, 376,
+                                                    window=100, nnratio=0.9)
+        assert out[j][0] == wn and np.array_equal(out[j][1], wm) and np.array_equal(out[j][2], wp), s
+        assert wn > 50
+    m2 = V.FMatcher(fe, 0.6, False)
+    m2.search_init_dev_async(jobs[:2], 20)
+    out = m2.search_init_dev_wait([len(res[0][0]), len(res[1][0])])
+    for j in range(2):
+        wn, wm, _ = orbo.search_for_initialization(res[j][0], res[j][1], res[j + 1][0], res[j + 1][1], 1241, 376,
+                                                   window=20, nnratio=0.6, check_ori=False)
+        assert out[j][0] == wn and np.array_equal(out[j][1], wm), j
+
+
+def test_search_init_large_feature_count():
+    """The mono initialisation extractor uses 5 x nFeatures (tracking.cpp:1093): 2170 octave-0 keypoints."""
+    a, b = synth.make_frame(1241, 376, seed=5, step=0), synth.make_frame(1241, 376, seed=5, step=1)
+    f = V.FExtractor(10000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    try:
+        (k1, d1, _), (k2, d2, _) = f.compute_batch([a, b], (0, 1000))
+        _, pd1, _ = f.slot_buffers(0)
+        _, pd2, _ = f.slot_buffers(1)
+        nm, m12, pm = V.FMatcher(f, 0.9, True).SearchForInitialization(k1, pd1, k2, pd2,
+                                                                       np.stack([k1["x"], k1["y"]], 1), 100)
+        wn, wm, wp = orbo.search_for_initialization(k1, d1, k2, d2, 1241, 376, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp) and nm > 300
+    finally:
+        f.close()

@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
-    "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps",
+    "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_search_init_dev_async",
+    "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async",
 ]
 
 
@@ -50,6 +51,12 @@ class _Params(C.Structure):
                 ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
                 ("min_th_fast", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),
                 ("flags", C.c_uint32), ("gauss_taps", C.c_int32 * 7)]
+
+
+class _InitJob(C.Structure):  # vslam_init_job
+    _fields_ = [("dev_kps1", C.c_void_p), ("dev_desc1", C.c_void_p), ("dev_n1", C.c_void_p),
+                ("dev_kps2", C.c_void_p), ("dev_desc2", C.c_void_p), ("dev_n2", C.c_void_p),
+                ("dev_prev_matched", C.c_void_p)]
 
 
 _lib = None
@@ -88,8 +95,12 @@ def lib():
         L.vslam_stereo_match.argtypes = [vp, i, vp, i, f, f, vp, vp]
         L.vslam_stereo_match_batch.argtypes = [vp, vp, i, vp, vp, f, f, vp, vp]
         L.vslam_search_for_initialization.argtypes = [vp, vp, vp, i, vp, vp, i, i, i, vp, vp, i, f, i, vp]
+        L.vslam_search_init_dev_async.argtypes = [vp, i, vp, i, i, i, f, i]
+        L.vslam_search_init_dev_wait.argtypes = [vp, vp, vp, vp, vp]
+        L.vslam_fe_slot_count_ptr.argtypes = [vp, i, vp]
         L.vslam_fe_pack_slots.argtypes = [vp, i, vp, C.c_size_t]
         L.vslam_fe_pack_slot_range.argtypes = [vp, i, i, vp, C.c_size_t]
+        L.vslam_fe_pack_slot_range_async.argtypes = [vp, i, i, vp, C.c_size_t]
         L.vslam_fe_set_profiling.argtypes = [vp, i]
         L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
         L.vslam_fe_extract_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, i, i, i]
@@ -313,6 +324,19 @@ class FExtractor:
         _check(lib().vslam_fe_slot_buffers(self._h, slot, C.byref(k), C.byref(d), C.byref(n)))
         return k.value, d.value, n.value
 
+    def slot_dev_ptrs(self, slot):
+        """(device address of the slot's vslam_kp array, of its descriptors, of its int32 keypoint count):
+        fixed for the life of the context, so they can be used before the results exist."""
+        if getattr(self, "_slot_ptrs", None) is None:
+            self._slot_ptrs = []
+            for s in range(self.max_batch):
+                k, d, n = C.c_void_p(), C.c_void_p(), C.c_int()
+                _check(lib().vslam_fe_slot_buffers(self._h, s, C.byref(k), C.byref(d), C.byref(n)))
+                c = C.c_void_p()
+                _check(lib().vslam_fe_slot_count_ptr(self._h, s, C.byref(c)))
+                self._slot_ptrs.append((k.value, d.value, c.value))
+        return self._slot_ptrs[slot]
+
     def stream(self):
         return lib().vslam_fe_stream(self._h)
 
@@ -321,8 +345,9 @@ class FExtractor:
         """Bytes of one packed result slot (see vslam_fe_pack_slots), rounded to 256."""
         return (16 + self.cap * 60 + 255) & ~255
 
-    def pack_slots(self, nslots, dev_dst, slot_bytes=None, first=0):
-        _check(lib().vslam_fe_pack_slot_range(self._h, first, nslots, dev_dst, slot_bytes or self.slot_bytes))
+    def pack_slots(self, nslots, dev_dst, slot_bytes=None, first=0, sync=True):
+        fn = lib().vslam_fe_pack_slot_range if sync else lib().vslam_fe_pack_slot_range_async
+        _check(fn(self._h, first, nslots, dev_dst, slot_bytes or self.slot_bytes))
 
     def set_profiling(self, on=True):
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))
@@ -374,6 +399,33 @@ class FMatcher:
                                                      self.mfNNratio, int(self.mbCheckOrientation),
                                                      C.byref(nm)))
         return nm.value, m[:len(kps1)], pm
+
+    # ---- device-resident form: nothing but device pointers go in, one kernel, results later
+    def search_init_dev_async(self, jobs, windowSize=10, img_size=None):
+        """jobs: list of (dev_kps1, dev_desc1, dev_n1, dev_kps2, dev_desc2, dev_n2, dev_prev_or_0) device
+        addresses.  Enqueues the whole matcher for all pairs on the extractor's stream and returns."""
+        n = len(jobs)
+        arr = (_InitJob * n)()
+        for j, t in enumerate(jobs):
+            arr[j] = _InitJob(*[C.c_void_p(v or None) for v in t])
+        w, h = img_size or (self.fe.width, self.fe.height)
+        self._init_n = n
+        _check(lib().vslam_search_init_dev_async(self.fe._h, n, arr, w, h, windowSize, self.mfNNratio,
+                                                 int(self.mbCheckOrientation)))
+
+    def search_init_dev_wait(self, n1, want_prev=False):
+        """-> list of (nmatches, vnMatches12[n1[j]], vbPrevMatched or None)."""
+        n = self._init_n
+        cap = self.fe.cap
+        if getattr(self, "_m_buf", None) is None or self._m_buf.shape[0] < n:
+            self._m_buf = np.zeros((MAX_BATCH, cap), np.int32)
+            self._p_buf = np.zeros((MAX_BATCH, cap, 2), np.float32)
+            self._m_ptrs = (C.c_void_p * MAX_BATCH)(*[self._m_buf[i].ctypes.data for i in range(MAX_BATCH)])
+            self._p_ptrs = (C.c_void_p * MAX_BATCH)(*[self._p_buf[i].ctypes.data for i in range(MAX_BATCH)])
+        nm = (C.c_int * n)()
+        _check(lib().vslam_search_init_dev_wait(self.fe._h, (C.c_int * n)(*n1), self._m_ptrs,
+                                                self._p_ptrs if want_prev else None, nm))
+        return [(nm[j], self._m_buf[j, :n1[j]], self._p_buf[j, :n1[j]] if want_prev else None) for j in range(n)]
 
     def SearchForInitializationBatch(self, pairs, windowSize=10, img_size=None):
         """Several independent SearchForInitialization problems in one pass of the kernels.

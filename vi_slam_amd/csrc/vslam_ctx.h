@@ -160,6 +160,13 @@ struct vslam_fe {
     size_t dmat_bytes = 0;
     uint8_t* d_tmp_desc[2] = {nullptr, nullptr};
     size_t tmp_desc_bytes[2] = {0, 0};
+    /* device SearchForInitialization: matches12 | prevMatched | nmatches of every pair */
+    uint8_t* d_init = nullptr;
+    size_t init_bytes = 0;
+    uint8_t* h_init = nullptr; /* pinned */
+    size_t h_init_bytes = 0;
+    int init_pairs = 0;
+    bool init_lds_set = false;
     /* stereo scratch */
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;

@@ -99,4 +99,18 @@ struct MatJobs {
     MatJob job[VSLAM_MAX_MAT_JOBS];
 };
 
+/* One (frame 1, frame 2) problem of k_search_init; every pointer is a device pointer. */
+struct InitJob {
+    const vslam_kp* k1;
+    const uint8_t* d1;
+    const int32_t* cnt1;
+    const vslam_kp* k2;
+    const uint8_t* d2;
+    const int32_t* cnt2;
+    const float* prev; /* vbPrevMatched (2*n1 floats) or NULL = frame 1's keypoint positions */
+};
+struct InitJobs {
+    InitJob job[VSLAM_MAX_MAT_JOBS];
+};
+
 #endif

@@ -55,6 +55,8 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_counts);
     if (fe->h_counts) hipHostFree(fe->h_counts);
     if (fe->h_stereo) hipHostFree(fe->h_stereo);
+    hipFree(fe->d_init);
+    if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
@@ -337,7 +339,19 @@ extern "C" int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batc
     return VSLAM_OK;
 }
 
+static int pack_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes, bool sync);
+
 extern "C" int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes) {
+    return pack_range(fe, first, nslots, dev_dst, slot_bytes, true);
+}
+
+/* same, but only enqueued on the context's stream (ordered after the extraction that produced the slots) */
+extern "C" int vslam_fe_pack_slot_range_async(vslam_fe* fe, int first, int nslots, void* dev_dst,
+                                              size_t slot_bytes) {
+    return pack_range(fe, first, nslots, dev_dst, slot_bytes, false);
+}
+
+static int pack_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes, bool sync) {
     if (!fe || first < 0 || nslots < 0 || first + nslots > fe->B || !dev_dst ||
         slot_bytes < 16 + (size_t)fe->cap * 60) {
         g_err = "invalid arguments";
@@ -360,7 +374,7 @@ extern "C" int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, voi
                                   (size_t)fe->n_out[s] * 32, hipMemcpyDeviceToDevice, fe->stream));
         }
     }
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    if (sync) HIPCHK(hipStreamSynchronize(fe->stream));
     return VSLAM_OK;
 }
 
@@ -739,6 +753,12 @@ extern "C" int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* 
         out[i].class_id = -1;
     }
     return (int)cl.size();
+}
+
+extern "C" int vslam_fe_slot_count_ptr(vslam_fe* fe, int slot, const int32_t** dev_n) {
+    if (!fe || slot < 0 || slot >= fe->B || !dev_n) return VSLAM_ERR_INVALID;
+    *dev_n = fe->d_counts + slot * 4;
+    return VSLAM_OK;
 }
 
 extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, const uint8_t** dev_desc,

@@ -141,6 +141,95 @@ extern "C" int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8
     return VSLAM_OK;
 }
 
+/* ------------------------------------------------------------------ SearchForInitialization on the device */
+static int init_scratch(vslam_fe* fe, int npairs) {
+    const size_t per = (size_t)fe->cap * 4 + (size_t)fe->cap * 8 + 16;
+    int rc = vslam_ensure((void**)&fe->d_init, &fe->init_bytes, per * npairs);
+    if (rc) return rc;
+    if (fe->h_init_bytes < per * npairs) {
+        if (fe->h_init) HIPCHK(hipHostFree(fe->h_init));
+        fe->h_init = nullptr;
+        fe->h_init_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_init, per * npairs, hipHostMallocDefault));
+        fe->h_init_bytes = per * npairs;
+    }
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam_init_job* jobs, int img_w,
+                                           int img_h, int window, float nnratio, int check_orientation) {
+    if (!fe || npairs < 1 || npairs > VSLAM_MAX_MAT_JOBS || !jobs) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    InitJobs J;
+    memset(&J, 0, sizeof(J));
+    for (int j = 0; j < npairs; j++) {
+        if (!jobs[j].dev_kps1 || !jobs[j].dev_desc1 || !jobs[j].dev_n1 || !jobs[j].dev_kps2 || !jobs[j].dev_desc2 ||
+            !jobs[j].dev_n2) {
+            g_err = "null device pointer in job";
+            return VSLAM_ERR_INVALID;
+        }
+        J.job[j].k1 = jobs[j].dev_kps1;
+        J.job[j].d1 = jobs[j].dev_desc1;
+        J.job[j].cnt1 = jobs[j].dev_n1;
+        J.job[j].k2 = jobs[j].dev_kps2;
+        J.job[j].d2 = jobs[j].dev_desc2;
+        J.job[j].cnt2 = jobs[j].dev_n2;
+        J.job[j].prev = jobs[j].dev_prev_matched;
+    }
+    int rc = init_scratch(fe, npairs);
+    if (rc) return rc;
+    /* octave-0 keypoints of frame 2 kept in LDS: the level-0 quota (+ the quadtree's overshoot) bounds them
+     * for extractor output; foreign inputs are clipped to the context's capacity */
+    const int max_c2 = std::min(fe->cap, std::max(fe->tab.quota[0] + 8, 64));
+    const size_t lds = vk_search_init_lds(fe->cap, max_c2);
+    if (lds > 150 * 1024) {
+        g_err = "SearchForInitialization: keypoint capacity too large for the LDS-resident matcher";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    if (!fe->init_lds_set) {
+        if (vk_search_init_set_max_lds(lds) != 0) {
+            g_err = "hipFuncSetAttribute(k_search_init) failed";
+            return VSLAM_ERR_HIP;
+        }
+        fe->init_lds_set = true;
+    }
+    const size_t nm = (size_t)npairs * fe->cap;
+    int32_t* d_m = (int32_t*)fe->d_init;
+    float* d_p = (float*)(d_m + nm);
+    int32_t* d_n = (int32_t*)(d_p + 2 * nm);
+    vk_search_init(fe->stream, J, npairs, fe->cap, img_w, img_h, window, nnratio, check_orientation, d_m, d_p, d_n,
+                   max_c2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(fe->h_init, fe->d_init, nm * 12 + (size_t)npairs * 4, hipMemcpyDeviceToHost, fe->stream));
+    fe->init_pairs = npairs;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_search_init_dev_wait(vslam_fe* fe, const int* n1, int32_t* const* matches12,
+                                          float* const* prev_matched, int* nmatches) {
+    if (!fe || fe->init_pairs < 1) {
+        g_err = "nothing enqueued";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    const int npairs = fe->init_pairs;
+    const size_t nm = (size_t)npairs * fe->cap;
+    const int32_t* h_m = (const int32_t*)fe->h_init;
+    const float* h_p = (const float*)(h_m + nm);
+    const int32_t* h_n = (const int32_t*)(h_p + 2 * nm);
+    for (int j = 0; j < npairs; j++) {
+        const int n = n1 ? std::min(n1[j], fe->cap) : 0;
+        if (matches12 && matches12[j] && n) memcpy(matches12[j], h_m + (size_t)j * fe->cap, (size_t)n * 4);
+        if (prev_matched && prev_matched[j] && n) memcpy(prev_matched[j], h_p + (size_t)j * fe->cap * 2, (size_t)n * 8);
+        if (nmatches) nmatches[j] = h_n[j];
+    }
+    return VSLAM_OK;
+}
+
 /* ------------------------------------------------------------------ SearchForInitialization */
 extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_kp* const* kps1,
                                                      const uint8_t* const* dev_desc1, const int* n1,
@@ -161,6 +250,46 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
             return VSLAM_ERR_INVALID;
         }
     HIPCHK(hipSetDevice(fe->p.device));
+    {
+        /* default: the whole matcher on the GPU (k_search_init).  VSLAM_INIT_MATCH=host keeps the distance
+         * matrices on the GPU and replays the order-dependent part on the host (cross-check path). */
+        const char* mode = getenv("VSLAM_INIT_MATCH");
+        bool fits = true;
+        for (int j = 0; j < npairs; j++) fits = fits && n1[j] <= fe->cap && n2[j] <= fe->cap;
+        if (!(mode && !strcmp(mode, "host")) && fits) {
+            /* upload keypoints, counts and vbPrevMatched of every pair, run, download */
+            size_t bytes = 0;
+            for (int j = 0; j < npairs; j++) bytes += ((size_t)(n1[j] + n2[j]) * sizeof(vslam_kp) + (size_t)n1[j] * 8 + 16 + 63) & ~(size_t)63;
+            int rc = vslam_ensure((void**)&fe->d_tmp_desc[1], &fe->tmp_desc_bytes[1], bytes + 64);
+            if (rc) return rc;
+            std::vector<uint8_t> stage(bytes + 64);
+            std::vector<vslam_init_job> jobs(npairs);
+            size_t off = 0;
+            for (int j = 0; j < npairs; j++) {
+                uint8_t* base = fe->d_tmp_desc[1] + off;
+                uint8_t* hb = stage.data() + off;
+                int32_t cnt[4] = {n1[j], n2[j], 0, 0};
+                memcpy(hb, cnt, 16);
+                memcpy(hb + 16, kps1[j], (size_t)n1[j] * sizeof(vslam_kp));
+                memcpy(hb + 16 + (size_t)n1[j] * sizeof(vslam_kp), kps2[j], (size_t)n2[j] * sizeof(vslam_kp));
+                const size_t poff = 16 + (size_t)(n1[j] + n2[j]) * sizeof(vslam_kp);
+                memcpy(hb + poff, prev_matched[j], (size_t)n1[j] * 8);
+                jobs[j].dev_n1 = (const int32_t*)base;
+                jobs[j].dev_n2 = (const int32_t*)base + 1;
+                jobs[j].dev_kps1 = (const vslam_kp*)(base + 16);
+                jobs[j].dev_kps2 = (const vslam_kp*)(base + 16 + (size_t)n1[j] * sizeof(vslam_kp));
+                jobs[j].dev_prev_matched = (const float*)(base + poff);
+                jobs[j].dev_desc1 = dev_desc1[j];
+                jobs[j].dev_desc2 = dev_desc2[j];
+                off += (poff + (size_t)n1[j] * 8 + 63) & ~(size_t)63;
+            }
+            HIPCHK(hipMemcpyAsync(fe->d_tmp_desc[1], stage.data(), off, hipMemcpyHostToDevice, fe->stream));
+            HIPCHK(hipStreamSynchronize(fe->stream)); /* stage is pageable and goes out of scope */
+            rc = vslam_search_init_dev_async(fe, npairs, jobs.data(), img_w, img_h, window, nnratio, check_orientation);
+            if (rc) return rc;
+            return vslam_search_init_dev_wait(fe, n1, matches12, prev_matched, nmatches);
+        }
+    }
     /* only octave-0 keypoints take part (fmatcher.cpp:999-1003: level1 > 0 -> continue; window query
      * restricted to [level1, level1]) */
     std::vector<std::vector<int>> row_of(npairs), col_of(npairs);
