@@ -213,6 +213,8 @@ def main():
             jobs.append((prev_ptrs[0], prev_ptrs[1], prev_ptrs[2], cur[0], cur[1], cur[2], 0))
             n1.append(n_prev)
         if jobs:
+            if world == 1 and t > 0:
+                c.wait_for(ctxs[(t - 1) % NCTX])  # the previous step's carry copy (its stream) precedes our matcher
             matchers[t % NCTX].search_init_dev_async(jobs, 100, (w, h))
         state["pending_n1"] = state.get("pending_n1", {})
         state["pending_n1"][t] = n1
@@ -243,12 +245,13 @@ def main():
         state.setdefault("host_s", [0.0, 0.0, 0.0])[2] += time.perf_counter() - t_a
 
     def run(nsteps):
-        d1 = NCTX - 2  # enqueue(t) .. mid(t - d1) .. fin(t - d1 - 1): NCTX contexts busy at once
-        for t in range(nsteps + d1 + 1):
+        # enqueue(t) .. mid(t - d1) .. fin(t - d2): a context is busy from enqueue to fin, NCTX = d2 + 1 of them
+        d1, d2 = (NCTX - 1, NCTX - 1) if stereo else (2, NCTX - 1)
+        for t in range(nsteps + d2):
             if t < nsteps:
                 enqueue(t)
-            if 0 <= t - d1 - 1 < nsteps:
-                fin(t - d1 - 1)
+            if 0 <= t - d2 < nsteps:
+                fin(t - d2)
             if 0 <= t - d1 < nsteps:
                 mid(t - d1)
 

@@ -117,6 +117,10 @@ int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int ca
 int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, const uint8_t** dev_desc,
                           int* n);
 
+/* GPU-side ordering between two contexts of one device: work enqueued on `waiter` after this call runs
+ * after everything enqueued on `signal` so far (event record + stream wait, no host synchronisation). */
+int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal);
+
 /* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */
 void* vslam_fe_stream(vslam_fe* fe);
 

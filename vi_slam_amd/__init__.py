@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
     "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_search_init_dev_async",
-    "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async",
+    "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
         L.vslam_fe_pack_slots.argtypes = [vp, i, vp, C.c_size_t]
         L.vslam_fe_pack_slot_range.argtypes = [vp, i, i, vp, C.c_size_t]
         L.vslam_fe_pack_slot_range_async.argtypes = [vp, i, i, vp, C.c_size_t]
+        L.vslam_fe_wait_for.argtypes = [vp, vp]
         L.vslam_fe_set_profiling.argtypes = [vp, i]
         L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
         L.vslam_fe_extract_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, i, i, i]
@@ -336,6 +337,10 @@ class FExtractor:
                 _check(lib().vslam_fe_slot_count_ptr(self._h, s, C.byref(c)))
                 self._slot_ptrs.append((k.value, d.value, c.value))
         return self._slot_ptrs[slot]
+
+    def wait_for(self, other):
+        """GPU-side: work enqueued on this context from now on runs after everything enqueued on `other`."""
+        _check(lib().vslam_fe_wait_for(self._h, other._h))
 
     def stream(self):
         return lib().vslam_fe_stream(self._h)

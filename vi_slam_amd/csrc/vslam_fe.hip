@@ -58,6 +58,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_init);
     if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
+    if (fe->ev_x) hipEventDestroy(fe->ev_x);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
@@ -319,6 +320,18 @@ extern "C" int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64) 
 }
 
 extern "C" void* vslam_fe_stream(vslam_fe* fe) { return fe ? (void*)fe->stream : nullptr; }
+
+/* GPU-side ordering between two contexts: everything enqueued on `waiter` after this call runs after
+ * everything enqueued on `signal` so far (hipEventRecord + hipStreamWaitEvent; no host synchronisation). */
+extern "C" int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal) {
+    if (!waiter || !signal || waiter->p.device != signal->p.device) return VSLAM_ERR_INVALID;
+    if (waiter == signal) return VSLAM_OK;
+    HIPCHK(hipSetDevice(waiter->p.device));
+    if (!signal->ev_x) HIPCHK(hipEventCreateWithFlags(&signal->ev_x, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(signal->ev_x, signal->stream));
+    HIPCHK(hipStreamWaitEvent(waiter->stream, signal->ev_x, 0));
+    return VSLAM_OK;
+}
 
 extern "C" int vslam_fe_set_profiling(vslam_fe* fe, int on) {
     if (!fe) return VSLAM_ERR_INVALID;

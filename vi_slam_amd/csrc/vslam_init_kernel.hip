@@ -20,40 +20,50 @@
 #define SI_GRID_COLS 64 /* FRAME_GRID_COLS, frame.h:42 */
 #define SI_GRID_ROWS 48 /* FRAME_GRID_ROWS, frame.h:43 */
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
+/* wave64 min-reduction on DPP (no LDS traffic, a few cycles per step instead of a ds_bpermute round trip):
+ * quad swaps, row rotations, then row_bcast:15 / row_bcast:31; the result sits in lane 63 and is returned
+ * wave-uniform through v_readlane. */
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
+    v = min(v, dpp_mov<0xb1, 0xf>(v));  /* quad_perm [1,0,3,2] */
+    v = min(v, dpp_mov<0x4e, 0xf>(v));  /* quad_perm [2,3,0,1] */
+    v = min(v, dpp_mov<0x124, 0xf>(v)); /* row_ror:4 */
+    v = min(v, dpp_mov<0x128, 0xf>(v)); /* row_ror:8 */
+    v = min(v, dpp_mov<0x142, 0xa>(v)); /* row_bcast:15 into rows 1,3 */
+    v = min(v, dpp_mov<0x143, 0xc>(v)); /* row_bcast:31 into rows 2,3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct SiCand { /* one octave-0 keypoint of frame 2 */
-    float x, y;
+    float x, y, angle;
     uint16_t cell; /* gridX * 64 + gridY (gridY < 48) */
     uint16_t idx;  /* index in frame 2 */
+};
+struct SiQuery { /* one octave-0 keypoint of frame 1 */
+    float px, py, angle; /* vbPrevMatched position, keypoint angle */
+    uint32_t idx;
 };
 
 __global__ void __launch_bounds__(64)
 k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
               int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
-              int32_t* nmatch_out /* [pair] */, int max_c2) {
+              int32_t* nmatch_out /* [pair] */, int max_c2, int lds_desc) {
     extern __shared__ __align__(16) uint8_t sism[];
     const InitJob jb = jobs.job[blockIdx.x];
     const int lane = threadIdx.x;
     const int n1 = min(*jb.cnt1, cap), n2 = min(*jb.cnt2, cap);
-    SiCand* cand = (SiCand*)sism;                       /* max_c2 */
-    int32_t* owner = (int32_t*)(cand + max_c2);          /* vnMatches21 (query index) */
-    int32_t* ownerDist = owner + max_c2;                 /* vMatchedDistance */
-    int32_t* m12 = ownerDist + max_c2;                   /* vnMatches12, cap */
-    uint16_t* q1 = (uint16_t*)(m12 + cap);               /* octave-0 queries of frame 1, ascending */
-    uint8_t* rotBin = (uint8_t*)(q1 + cap);              /* bin of an accepted query, 255 = none */
+    /* LDS: [desc2 | desc1] (only if lds_desc) | cand | query | owner | ownerDist | m12 | rotBin */
+    uint4* ldesc2 = (uint4*)sism;                                      /* max_c2 x 32 B */
+    uint4* ldesc1 = ldesc2 + (lds_desc ? 2 * max_c2 : 0);              /* max_c2 x 32 B */
+    SiCand* cand = (SiCand*)(ldesc1 + (lds_desc ? 2 * max_c2 : 0));    /* max_c2 */
+    SiQuery* qry = (SiQuery*)(cand + max_c2);                          /* max_c2 (frame 1 has the same quota) */
+    int32_t* owner = (int32_t*)(qry + max_c2);                         /* vnMatches21 (query index) */
+    int32_t* ownerDist = owner + max_c2;                               /* vMatchedDistance */
+    int32_t* m12 = ownerDist + max_c2;                                 /* vnMatches12, cap */
+    uint8_t* rotBin = (uint8_t*)(m12 + cap);                           /* bin of an accepted query, 255 = none */
     __shared__ int s_hist[SI_HISTO];
 
     int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
@@ -84,10 +94,15 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
             if (pos < max_c2) {
                 cand[pos].x = k.x;
                 cand[pos].y = k.y;
+                cand[pos].angle = k.angle;
                 cand[pos].cell = (uint16_t)(gx * 64 + gy);
                 cand[pos].idx = (uint16_t)i;
                 owner[pos] = -1;
                 ownerDist[pos] = 0x7FFFFFFF;
+                if (lds_desc) {
+                    ldesc2[2 * pos] = ((const uint4*)jb.d2)[(size_t)i * 2];
+                    ldesc2[2 * pos + 1] = ((const uint4*)jb.d2)[(size_t)i * 2 + 1];
+                }
             }
         }
         c2 += __popcll(m);
@@ -96,11 +111,29 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
     int c1 = 0;
     for (int b = 0; b < n1; b += 64) {
         const int i = b + lane;
-        const bool take = i < n1 && jb.k1[i].octave == 0; /* level1 > 0 -> continue, fmatcher.cpp:999-1001 */
+        vslam_kp k;
+        bool take = false;
+        if (i < n1) {
+            k = jb.k1[i];
+            take = k.octave == 0; /* level1 > 0 -> continue, fmatcher.cpp:999-1001 */
+        }
         const unsigned long long m = __ballot(take);
-        if (take) q1[c1 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (take) {
+            const int pos = c1 + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < max_c2) {
+                qry[pos].px = jb.prev ? jb.prev[2 * i] : k.x;
+                qry[pos].py = jb.prev ? jb.prev[2 * i + 1] : k.y;
+                qry[pos].angle = k.angle;
+                qry[pos].idx = (uint32_t)i;
+                if (lds_desc) {
+                    ldesc1[2 * pos] = ((const uint4*)jb.d1)[(size_t)i * 2];
+                    ldesc1[2 * pos + 1] = ((const uint4*)jb.d1)[(size_t)i * 2 + 1];
+                }
+            }
+        }
         c1 += __popcll(m);
     }
+    c1 = min(c1, max_c2);
     for (int i = lane; i < n1; i += 64) {
         m12[i] = -1;
         rotBin[i] = 255;
@@ -111,47 +144,65 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
     const float r = (float)window;
     const float factor = 1.0f / SI_HISTO;
     for (int t = 0; t < c1; t++) {
-        const int i1 = q1[t];
-        const vslam_kp kp1 = jb.k1[i1];
-        const float px = jb.prev ? jb.prev[2 * i1] : kp1.x, py = jb.prev ? jb.prev[2 * i1 + 1] : kp1.y;
+        const SiQuery qq = qry[t];
+        const int i1 = (int)qq.idx;
+        const float px = qq.px, py = qq.py;
         /* GetFeaturesInArea(x, y, r, 0, 0): cell range (frame.cpp:686-708) */
         const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(px, r), invW)));
         const int nMaxCellX = min(SI_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(px, r), invW)));
         const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(py, r), invH)));
         const int nMaxCellY = min(SI_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(py, r), invH)));
         if (nMinCellX >= SI_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SI_GRID_ROWS || nMaxCellY < 0) continue;
-        const uint4 da = ((const uint4*)jb.d1)[(size_t)i1 * 2], db = ((const uint4*)jb.d1)[(size_t)i1 * 2 + 1];
+        uint4 da, db;
+        if (lds_desc) {
+            da = ldesc1[2 * t];
+            db = ldesc1[2 * t + 1];
+        } else {
+            da = ((const uint4*)jb.d1)[(size_t)i1 * 2];
+            db = ((const uint4*)jb.d1)[(size_t)i1 * 2 + 1];
+        }
 
-        unsigned long long bestKey = ~0ull; /* dist << 28 | cell << 16 | slot */
-        uint32_t second = 0x7FFFFFFFu;      /* smallest distance among this lane's other candidates */
+        /* key = min(dist,63) << 24 | cell << 12 | slot: distances above TH_LOW are rejected anyway, so the
+         * clamp cannot change an accepted match; true distances are tracked beside the key */
+        uint32_t bestKey = 0xFFFFFFFFu, bestD = 0x7FFFFFFFu;
+        uint32_t second = 0x7FFFFFFFu; /* smallest distance among this lane's other candidates */
         for (int c = lane; c < c2; c += 64) {
             const SiCand cd = cand[c];
             const int gx = cd.cell >> 6, gy = cd.cell & 63;
             if (gx < nMinCellX || gx > nMaxCellX || gy < nMinCellY || gy > nMaxCellY) continue;
             const float distx = __fsub_rn(cd.x, px), disty = __fsub_rn(cd.y, py);
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            const uint4 ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2], tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
+            uint4 ta, tb;
+            if (lds_desc) {
+                ta = ldesc2[2 * c];
+                tb = ldesc2[2 * c + 1];
+            } else {
+                ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
+                tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
+            }
             const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) +
                                   __popc(da.w ^ ta.w) + __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) +
                                   __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
             if ((uint32_t)ownerDist[c] <= dist) continue; /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
-            const unsigned long long key = ((unsigned long long)dist << 28) | ((unsigned long long)cd.cell << 16) |
-                                           (unsigned long long)c;
-            if (key < bestKey) {
-                if (bestKey != ~0ull) second = min(second, (uint32_t)(bestKey >> 28));
+            const uint32_t key = (min(dist, 63u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+            /* compare on (true distance, grid order): identical to the key order whenever dist < 63 */
+            if (dist < bestD || (dist == bestD && key < bestKey)) {
+                second = min(second, bestD);
                 bestKey = key;
+                bestD = dist;
             } else {
                 second = min(second, dist);
             }
         }
-        const unsigned long long gBest = wave_min_u64(bestKey);
-        if (gBest == ~0ull) continue; /* vIndices2 empty or everything skipped: bestDist = INT_MAX */
+        const uint32_t gBest = wave_min_u32(bestKey);
+        if (gBest == 0xFFFFFFFFu) continue; /* vIndices2 empty or everything skipped: bestDist = INT_MAX */
+        if ((gBest >> 24) > SI_TH_LOW) continue; /* bestDist > TH_LOW (clamped distances are all > 50) */
         /* second minimum over the multiset: lanes that do not hold the winner contribute their own best */
         uint32_t contrib = second;
-        if (bestKey != gBest && bestKey != ~0ull) contrib = min(contrib, (uint32_t)(bestKey >> 28));
+        if (bestKey != gBest) contrib = min(contrib, bestD);
         const uint32_t bestDist2 = wave_min_u32(contrib); /* 0x7FFFFFFF == INT_MAX when there is none */
-        const int bestDist = (int)(gBest >> 28);
-        const int slot2 = (int)(gBest & 0xFFFF);
+        const int bestDist = (int)(gBest >> 24);
+        const int slot2 = (int)(gBest & 0xFFF);
         if (bestDist <= SI_TH_LOW && (float)bestDist < __fmul_rn((float)(int)bestDist2, nnratio)) {
             /* wave-uniform branch; lane 0 updates the shared state */
             if (lane == 0) {
@@ -161,7 +212,7 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
                 owner[slot2] = i1;
                 ownerDist[slot2] = bestDist;
                 if (checkOri) {
-                    float rot = __fsub_rn(kp1.angle, jb.k2[cand[slot2].idx].angle);
+                    float rot = __fsub_rn(qq.angle, cand[slot2].angle);
                     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                     int bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == SI_HISTO) bin = 0;
@@ -217,8 +268,8 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
     if (lane == 0) nmatch_out[blockIdx.x] = cnt;
 }
 
-size_t vk_search_init_lds(int cap, int max_c2) {
-    return (size_t)max_c2 * (sizeof(SiCand) + 8) + (size_t)cap * (4 + 2 + 1) + 64;
+size_t vk_search_init_lds(int cap, int max_c2, int lds_desc) {
+    return (size_t)max_c2 * (sizeof(SiCand) + sizeof(SiQuery) + 8 + (lds_desc ? 64 : 0)) + (size_t)cap * (4 + 1) + 64;
 }
 
 int vk_search_init_set_max_lds(size_t bytes) {
@@ -227,8 +278,8 @@ int vk_search_init_set_max_lds(size_t bytes) {
 
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2) {
+                    int max_c2, int lds_desc) {
     if (npairs <= 0) return;
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), vk_search_init_lds(cap, max_c2), st, jobs, cap, imgW,
-                       imgH, window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2);
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), vk_search_init_lds(cap, max_c2, lds_desc), st, jobs, cap,
+                       imgW, imgH, window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, lds_desc);
 }

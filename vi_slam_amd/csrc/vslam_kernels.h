@@ -58,11 +58,11 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
                int32_t* sad, int cap);
 void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
                              uint8_t* tmp, uint8_t* out);
-size_t vk_search_init_lds(int cap, int max_c2);
+size_t vk_search_init_lds(int cap, int max_c2, int lds_desc);
 int vk_search_init_set_max_lds(size_t bytes);
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2);
+                    int max_c2, int lds_desc);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);
 
 #endif

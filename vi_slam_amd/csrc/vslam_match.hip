@@ -184,7 +184,18 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
     /* octave-0 keypoints of frame 2 kept in LDS: the level-0 quota (+ the quadtree's overshoot) bounds them
      * for extractor output; foreign inputs are clipped to the context's capacity */
     const int max_c2 = std::min(fe->cap, std::max(fe->tab.quota[0] + 8, 64));
-    const size_t lds = vk_search_init_lds(fe->cap, max_c2);
+    if (max_c2 > 4096) { /* candidate slot is a 12-bit field of the ordering key */
+        g_err = "SearchForInitialization on the device supports at most 4096 octave-0 keypoints per frame";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    /* descriptors of both frames' octave-0 keypoints ride in LDS when they fit (the serial query loop then
+     * never waits for HBM); beyond ~1100 octave-0 keypoints they stay in HBM/L2 */
+    int lds_desc = 1;
+    size_t lds = vk_search_init_lds(fe->cap, max_c2, 1);
+    if (lds > 150 * 1024) {
+        lds_desc = 0;
+        lds = vk_search_init_lds(fe->cap, max_c2, 0);
+    }
     if (lds > 150 * 1024) {
         g_err = "SearchForInitialization: keypoint capacity too large for the LDS-resident matcher";
         return VSLAM_ERR_UNSUPPORTED;
@@ -201,7 +212,7 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
     float* d_p = (float*)(d_m + nm);
     int32_t* d_n = (int32_t*)(d_p + 2 * nm);
     vk_search_init(fe->stream, J, npairs, fe->cap, img_w, img_h, window, nnratio, check_orientation, d_m, d_p, d_n,
-                   max_c2);
+                   max_c2, lds_desc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(fe->h_init, fe->d_init, nm * 12 + (size_t)npairs * 4, hipMemcpyDeviceToHost, fe->stream));
     fe->init_pairs = npairs;
@@ -256,6 +267,7 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
         const char* mode = getenv("VSLAM_INIT_MATCH");
         bool fits = true;
         for (int j = 0; j < npairs; j++) fits = fits && n1[j] <= fe->cap && n2[j] <= fe->cap;
+        fits = fits && fe->tab.quota[0] + 8 <= 4096;
         if (!(mode && !strcmp(mode, "host")) && fits) {
             /* upload keypoints, counts and vbPrevMatched of every pair, run, download */
             size_t bytes = 0;
