@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Several extractor contexts (HIP streams) are kept in flight; with the runtime's default of 4 hardware
+# queues two of them end up behind each other on one queue (measured: 29k -> 38k frames/s with 8).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -110,12 +113,15 @@ def cpu_baseline(cfg, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
     ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -133,9 +139,14 @@ def main():
                   file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     cfg = WORKLOADS[args.workload]
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
@@ -160,100 +171,83 @@ def main():
     ptrs = [dev_frames[s].data_ptr() for s in range(B)]
     slot_bytes = fe.slot_bytes
     desc_off = 16 + fe.cap * 28
-    packed = torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
-    carry = torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda")
-    state = {"carry_kps": None, "matches": 0}
+    packed = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if world > 1 else 0)]
+    gathered = [torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
+                for _ in range(NCTX if world > 1 else 0)]
+    ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if world > 1 else []
+    state = {"matches": 0}
     torch.cuda.synchronize()
 
-    def slot_host_kps(view):
-        hdr = view[:16].cpu().numpy().view(np.int32)
-        n = int(hdr[0])
-        return view[16:16 + n * 28].cpu().numpy().view(V.KP_DTYPE)
+    def slot_ptrs_in(buf, r, s):
+        """(kps, desc, count) device addresses of rank r / slot s inside a gathered buffer."""
+        base = buf.data_ptr() + (r * B + s) * slot_bytes
+        return base + 16, base + desc_off, base
 
     def enqueue(t):
-        c = ctxs[t % NCTX]
+        """Enqueue step t completely -- extraction, (N>1) pack + all-gather, matcher -- without waiting for
+        anything on the host: every pointer is a fixed device address and the counts stay in HBM."""
+        c, k = ctxs[t % NCTX], t % NCTX
         if stereo:
             c.frame_stereo_async(ptrs, pitch, BF, FX)
-        else:
-            c.compute_batch_async(ptrs, pitch, lap)
-
-    def mid(t):
-        """Step t's extraction is done: results to the host; (mono) enqueue the frame-to-frame matcher for
-        every frame of the step -- on the GPU, fed with device pointers only."""
-        c = ctxs[t % NCTX]
-        if stereo:
-            feats, st = c.frame_stereo_wait()
-            state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
             return
-        t_a = time.perf_counter()
-        res = c.wait()
-        t_b = time.perf_counter()
+        nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
+        c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
+        c.compute_batch_async(ptrs, pitch, lap)
         if world > 1:
-            c.pack_slots(B, packed.data_ptr(), slot_bytes)
-            vd.exchange_slots(packed, gathered)
-            torch.cuda.synchronize()
+            c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
+            if args.dist_backend == "nccl":
+                with torch.cuda.stream(ext_streams[k]):  # the collective is ordered on c's own stream
+                    dist.all_gather_into_tensor(gathered[k], packed[k])
+            else:
+                vd.exchange_slots(packed[k], gathered[k])  # gloo rehearsal: staged through the host
+        c.event_record(0)  # step t's results (own or gathered) are complete
         jobs, n1 = [], []
+        uses_prev_step = False
         for s in range(B):
             pr, ps, prev_step = vd.predecessor(rank, s, world, B)
             if prev_step:
-                if not state.get("have_carry"):
+                if t == 0:
                     continue
-                base = carry.data_ptr()
-                prev_ptrs = (base + 16, base + desc_off, base)
-                n_prev = state["carry_n"]
+                p = slot_ptrs_in(gathered[(t - 1) % NCTX], world - 1, B - 1) if world > 1 else prv.slot_dev_ptrs(B - 1)
+                uses_prev_step = True
             elif world == 1:
-                prev_ptrs = c.slot_dev_ptrs(ps)
-                n_prev = len(res[ps][0])
+                p = c.slot_dev_ptrs(ps)
             else:
-                base = vd.slot_view(gathered, pr, ps, B, slot_bytes).data_ptr()
-                prev_ptrs = (base + 16, base + desc_off, base)
-                n_prev = fe.cap  # count lives in the packed header; deliver up to capacity
-            cur = c.slot_dev_ptrs(s)
-            jobs.append((prev_ptrs[0], prev_ptrs[1], prev_ptrs[2], cur[0], cur[1], cur[2], 0))
-            n1.append(n_prev)
+                p = slot_ptrs_in(gathered[k], pr, ps)
+            q = c.slot_dev_ptrs(s)
+            jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
+        if uses_prev_step:
+            c.event_wait(prv, 0)  # the previous step's results (not its matcher)
         if jobs:
-            if world == 1 and t > 0:
-                c.wait_for(ctxs[(t - 1) % NCTX])  # the previous step's carry copy (its stream) precedes our matcher
-            matchers[t % NCTX].search_init_dev_async(jobs, 100, (w, h))
-        state["pending_n1"] = state.get("pending_n1", {})
-        state["pending_n1"][t] = n1
-        # the last frame of this step precedes the first frame of the next one: keep it in `carry`
-        if world == 1:
-            c.pack_slots(1, carry.data_ptr(), slot_bytes, first=B - 1, sync=False)
-            state["carry_n"] = len(res[B - 1][0])
-        else:
-            carry.copy_(vd.slot_view(gathered, world - 1, B - 1, B, slot_bytes))
-            torch.cuda.synchronize()
-            state["carry_n"] = fe.cap
-        state["have_carry"] = True
-        t_c = time.perf_counter()
-        hs = state.setdefault("host_s", [0.0, 0.0, 0.0])
-        hs[0] += t_b - t_a
-        hs[1] += t_c - t_b
+            matchers[k].search_init_dev_async(jobs, 100, (w, h))
+        c.event_record(1)  # matcher(t) complete
+        state.setdefault("njobs", {})[t] = len(jobs)
 
-    def fin(t):
-        """Collect step t's matches (synchronises that context's stream, which also orders its carry copy
-        before the next step's matcher reads it)."""
-        if stereo:
-            return
+    def collect(t):
+        """One host wait per step delivers keypoints, descriptors and (mono) the matches."""
+        c = ctxs[t % NCTX]
         t_a = time.perf_counter()
-        n1 = state["pending_n1"].pop(t)
-        if n1:
-            out = matchers[t % NCTX].search_init_dev_wait(n1)
-            state["matches"] = sum(o[0] for o in out)
-        state.setdefault("host_s", [0.0, 0.0, 0.0])[2] += time.perf_counter() - t_a
+        if stereo:
+            feats, st = c.frame_stereo_wait()
+            state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
+            t_b = time.perf_counter()
+        else:
+            res = c.wait()
+            t_b = time.perf_counter()
+            nj = state["njobs"].pop(t)
+            if nj:
+                out = matchers[t % NCTX].search_init_dev_wait([fe.cap] * nj)
+                state["matches"] = sum(o[0] for o in out)
+        hs = state.setdefault("host_s", [0.0, 0.0])
+        hs[0] += t_b - t_a
+        hs[1] += time.perf_counter() - t_b
 
     def run(nsteps):
-        # enqueue(t) .. mid(t - d1) .. fin(t - d2): a context is busy from enqueue to fin, NCTX = d2 + 1 of them
-        d1, d2 = (NCTX - 1, NCTX - 1) if stereo else (2, NCTX - 1)
-        for t in range(nsteps + d2):
+        for t in range(nsteps + NCTX - 1):
             if t < nsteps:
                 enqueue(t)
-            if 0 <= t - d2 < nsteps:
-                fin(t - d2)
-            if 0 <= t - d1 < nsteps:
-                mid(t - d1)
+            if 0 <= t - (NCTX - 1) < nsteps:
+                collect(t - (NCTX - 1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -276,7 +270,7 @@ def main():
             prof[k] = prof.get(k, 0) + v
         c.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -311,12 +305,11 @@ def main():
             "config": {"workload": args.workload, "frames_per_step_per_gpu": B // 2 if stereo else B,
                        "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
                        "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100, on device",
-                       "sharding": "frames round-robin over ranks; one all-gather of result slots per step"
+                       "sharding": "frames round-robin over ranks; one all-gather of result slots per step (on the extractor stream)"
                        if not stereo else "stereo frames independent per rank, no collective",
                        "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],
                        "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in
-                                            zip(("wait_extract", "enqueue_match", "wait_match"),
-                                                state.get("host_s", [0, 0, 0]))}},
+                                            zip(("wait_step", "fetch_matches"), state.get("host_s", [0, 0]))}},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_detail": tr,

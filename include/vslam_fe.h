@@ -120,13 +120,17 @@ int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, cons
 /* GPU-side ordering between two contexts of one device: work enqueued on `waiter` after this call runs
  * after everything enqueued on `signal` so far (event record + stream wait, no host synchronisation). */
 int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal);
+/* Finer grain: four user events per context.  _record marks the current end of fe's stream; _wait makes the
+ * waiter's stream wait for the last recorded instance of the signal context's event idx (0..3). */
+int vslam_fe_event_record(vslam_fe* fe, int idx);
+int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx);
 
 /* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */
 void* vslam_fe_stream(vslam_fe* fe);
 
 /* Pack the results of slots 0..nslots-1 into caller device memory (e.g. this rank's send buffer of an
  * RCCL all-gather): per slot `slot_bytes` >= 16 + cap*60 laid out as
- *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = nfeatures + 4*nlevels + 8)
+ *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = nfeatures + 4*nlevels + 8 rounded up to a multiple of 4)
  * Returns after the copies have completed. */
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
 /* the same for slots first .. first+nslots-1 (packed from offset 0 of dev_dst) */

@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
     "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_search_init_dev_async",
-    "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for",
+    "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
+    "vslam_fe_event_wait",
 ]
 
 
@@ -102,6 +103,8 @@ def lib():
         L.vslam_fe_pack_slot_range.argtypes = [vp, i, i, vp, C.c_size_t]
         L.vslam_fe_pack_slot_range_async.argtypes = [vp, i, i, vp, C.c_size_t]
         L.vslam_fe_wait_for.argtypes = [vp, vp]
+        L.vslam_fe_event_record.argtypes = [vp, i]
+        L.vslam_fe_event_wait.argtypes = [vp, vp, i]
         L.vslam_fe_set_profiling.argtypes = [vp, i]
         L.vslam_fe_get_profile.argtypes = [vp, vp, vp, vp]
         L.vslam_fe_extract_batch_async.argtypes = [vp, i, vp, C.c_size_t, i, i, i, i]
@@ -143,7 +146,7 @@ class FExtractor:
         self.nfeatures, self.nlevels, self.width, self.height = nfeatures, nlevels, width, height
         self.scaleFactor = scaleFactor
         self.max_batch = max_batch
-        self.cap = nfeatures + 4 * nlevels + 8
+        self.cap = (nfeatures + 4 * nlevels + 8 + 3) & ~3  # vslam_fe.hip: slot capacity, multiple of 4
         self.device = device
 
     def close(self):
@@ -341,6 +344,13 @@ class FExtractor:
     def wait_for(self, other):
         """GPU-side: work enqueued on this context from now on runs after everything enqueued on `other`."""
         _check(lib().vslam_fe_wait_for(self._h, other._h))
+
+    def event_record(self, idx):
+        _check(lib().vslam_fe_event_record(self._h, idx))
+
+    def event_wait(self, other, idx):
+        """GPU-side: this context's later work waits for `other`'s last recorded event idx."""
+        _check(lib().vslam_fe_event_wait(self._h, other._h, idx))
 
     def stream(self):
         return lib().vslam_fe_stream(self._h)

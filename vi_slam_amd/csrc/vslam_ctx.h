@@ -111,6 +111,7 @@ struct vslam_fe {
     hipStream_t stream = nullptr;
     hipEvent_t ev_cand = nullptr;
     hipEvent_t ev_x = nullptr; /* cross-context ordering (vslam_fe_wait_for) */
+    hipEvent_t ev_user[4] = {};  /* vslam_fe_event_record / _wait */
 
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;

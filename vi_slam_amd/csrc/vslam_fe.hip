@@ -59,6 +59,8 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
     if (fe->ev_x) hipEventDestroy(fe->ev_x);
+    for (int i = 0; i < 4; i++)
+        if (fe->ev_user[i]) hipEventDestroy(fe->ev_user[i]);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
@@ -88,7 +90,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     (void)pp;
     vslam::build_tables(p.nfeatures, p.scale_factor, p.nlevels, fe->tab);
     fe->B = p.max_batch;
-    fe->cap = p.nfeatures + 4 * p.nlevels + 8;
+    fe->cap = (p.nfeatures + 4 * p.nlevels + 8 + 3) & ~3; /* multiple of 4: packed descriptors stay 16-B aligned */
     static const int32_t def_taps[7] = {18, 34, 48, 56, 48, 34, 18};
     bool zero = true;
     for (int i = 0; i < 7; i++) zero = zero && p.gauss_taps[i] == 0;
@@ -333,6 +335,25 @@ extern "C" int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal) {
     return VSLAM_OK;
 }
 
+/* Finer-grained form: four user events per context.  _record marks a point of fe's stream, _wait makes
+ * waiter's stream wait for the last recorded instance of signal's event idx (a never-recorded event does
+ * not block). */
+extern "C" int vslam_fe_event_record(vslam_fe* fe, int idx) {
+    if (!fe || idx < 0 || idx >= 4) return VSLAM_ERR_INVALID;
+    HIPCHK(hipSetDevice(fe->p.device));
+    if (!fe->ev_user[idx]) HIPCHK(hipEventCreateWithFlags(&fe->ev_user[idx], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(fe->ev_user[idx], fe->stream));
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx) {
+    if (!waiter || !signal || idx < 0 || idx >= 4 || waiter->p.device != signal->p.device) return VSLAM_ERR_INVALID;
+    if (!signal->ev_user[idx] || waiter == signal) return VSLAM_OK;
+    HIPCHK(hipSetDevice(waiter->p.device));
+    HIPCHK(hipStreamWaitEvent(waiter->stream, signal->ev_user[idx], 0));
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_fe_set_profiling(vslam_fe* fe, int on) {
     if (!fe) return VSLAM_ERR_INVALID;
     HIPCHK(hipSetDevice(fe->p.device));
@@ -366,27 +387,15 @@ extern "C" int vslam_fe_pack_slot_range_async(vslam_fe* fe, int first, int nslot
 
 static int pack_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes, bool sync) {
     if (!fe || first < 0 || nslots < 0 || first + nslots > fe->B || !dev_dst ||
-        slot_bytes < 16 + (size_t)fe->cap * 60) {
-        g_err = "invalid arguments";
+        slot_bytes < 16 + (size_t)fe->cap * 60 || (slot_bytes & 15) || ((uintptr_t)dev_dst & 15)) {
+        g_err = "invalid arguments (slot_bytes and dev_dst must be 16-byte aligned)";
         return VSLAM_ERR_INVALID;
     }
     HIPCHK(hipSetDevice(fe->p.device));
-    for (int k = 0; k < nslots; k++) {
-        const int s = first + k;
-        uint8_t* d = (uint8_t*)dev_dst + (size_t)k * slot_bytes;
-        int32_t* hdr = fe->pack_hdr[s];
-        hdr[0] = fe->n_out[s];
-        hdr[1] = fe->mono_out[s];
-        hdr[2] = fe->cap;
-        hdr[3] = 0;
-        HIPCHK(hipMemcpyAsync(d, hdr, 16, hipMemcpyHostToDevice, fe->stream));
-        if (fe->n_out[s]) {
-            HIPCHK(hipMemcpyAsync(d + 16, fe->d_kps + (size_t)s * fe->cap, (size_t)fe->n_out[s] * sizeof(vslam_kp),
-                                  hipMemcpyDeviceToDevice, fe->stream));
-            HIPCHK(hipMemcpyAsync(d + 16 + (size_t)fe->cap * sizeof(vslam_kp), fe->d_desc + (size_t)s * fe->cap * 32,
-                                  (size_t)fe->n_out[s] * 32, hipMemcpyDeviceToDevice, fe->stream));
-        }
-    }
+    /* one kernel; the keypoint counts are read from HBM, so this may be enqueued before the host knows them */
+    vk_pack_slots(fe->stream, fe->d_kps, fe->d_desc, fe->d_counts, fe->cap, first, nslots, (uint8_t*)dev_dst,
+                  slot_bytes);
+    HIPCHK(hipGetLastError());
     if (sync) HIPCHK(hipStreamSynchronize(fe->stream));
     return VSLAM_OK;
 }

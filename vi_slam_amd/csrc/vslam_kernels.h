@@ -63,6 +63,8 @@ int vk_search_init_set_max_lds(size_t bytes);
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
                     int max_c2, int lds_desc);
+void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
+                   int nslots, uint8_t* dst, size_t slot_bytes);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);
 
 #endif

@@ -349,3 +349,35 @@ void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int
     hipLaunchKernelGGL(k_hamming_matrix_batch, dim3((maxr + 63) / 64, (maxc + 255) / 256, njobs), dim3(256), 0, st,
                        jobs, tmp, out);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * pack result slots for an RCCL all-gather: per slot  int32 n, mono, cap, 0 | vslam_kp[cap] | desc[cap][32].
+ * Counts are read from HBM, so packing can be enqueued before the host knows them.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_pack_slots(const vslam_kp* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
+             int cap, int first, uint8_t* __restrict__ dst, size_t slot_bytes) {
+    const int slot = first + blockIdx.y;
+    const int n = min(counts[slot * 4], cap);
+    uint8_t* d = dst + (size_t)blockIdx.y * slot_bytes;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid == 0) {
+        int32_t* h = (int32_t*)d;
+        h[0] = n;
+        h[1] = counts[slot * 4 + 1];
+        h[2] = cap;
+        h[3] = 0;
+    }
+    const uint32_t* ks = (const uint32_t*)(kps + (size_t)slot * cap);
+    uint32_t* kd = (uint32_t*)(d + 16);
+    for (int i = tid; i < n * 7; i += nth) kd[i] = ks[i];
+    const uint4* ds = (const uint4*)(desc + (size_t)slot * cap * 32);
+    uint4* dd = (uint4*)(d + 16 + (size_t)cap * sizeof(vslam_kp));
+    for (int i = tid; i < n * 2; i += nth) dd[i] = ds[i];
+}
+
+void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
+                   int nslots, uint8_t* dst, size_t slot_bytes) {
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_pack_slots, dim3(8, nslots), dim3(256), 0, st, kps, desc, counts, cap, first, dst, slot_bytes);
+}

@@ -30,6 +30,12 @@ def exchange_slots(local_packed, gathered, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         gathered.copy_(local_packed)
         return gathered
+    if dist.get_backend(group) == "gloo" and local_packed.is_cuda:
+        # rehearsal path (tests / one-GPU dry runs): gloo moves host memory only
+        host = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host, local_packed.cpu(), group=group)
+        gathered.copy_(host)
+        return gathered
     dist.all_gather_into_tensor(gathered, local_packed, group=group)
     return gathered
 
