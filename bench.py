@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal: take the N>1 code path (pack + all-gather on the extractor stream) at any world size")
     args = ap.parse_args()
 
     import torch
@@ -142,12 +144,13 @@ def main():
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
 
+    multi = world > 1 or (args.force_collective and dist.is_initialized())
     cfg = WORKLOADS[args.workload]
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
     B = args.batch
@@ -171,10 +174,10 @@ def main():
     ptrs = [dev_frames[s].data_ptr() for s in range(B)]
     slot_bytes = fe.slot_bytes
     desc_off = 16 + fe.cap * 28
-    packed = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if world > 1 else 0)]
+    packed = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if multi else 0)]
     gathered = [torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
-                for _ in range(NCTX if world > 1 else 0)]
-    ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if world > 1 else []
+                for _ in range(NCTX if multi else 0)]
+    ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if multi else []
     state = {"matches": 0}
     torch.cuda.synchronize()
 
@@ -193,7 +196,7 @@ def main():
         nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
         c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
         c.compute_batch_async(ptrs, pitch, lap)
-        if world > 1:
+        if multi:
             c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
             if args.dist_backend == "nccl":
                 with torch.cuda.stream(ext_streams[k]):  # the collective is ordered on c's own stream
@@ -208,9 +211,9 @@ def main():
             if prev_step:
                 if t == 0:
                     continue
-                p = slot_ptrs_in(gathered[(t - 1) % NCTX], world - 1, B - 1) if world > 1 else prv.slot_dev_ptrs(B - 1)
+                p = slot_ptrs_in(gathered[(t - 1) % NCTX], world - 1, B - 1) if multi else prv.slot_dev_ptrs(B - 1)
                 uses_prev_step = True
-            elif world == 1:
+            elif not multi:
                 p = c.slot_dev_ptrs(ps)
             else:
                 p = slot_ptrs_in(gathered[k], pr, ps)
@@ -321,7 +324,7 @@ def main():
         print(json.dumps(out))
     for c in ctxs:
         c.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -267,3 +267,51 @@ def test_search_init_large_feature_count():
         assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp) and nm > 300
     finally:
         f.close()
+
+
+def test_pack_slots_layout_and_matcher_on_packed_buffer(fe):
+    """vslam_fe_pack_slots: the layout an RCCL all-gather moves; the device matcher must work on it."""
+    import torch
+    frames = [synth.make_frame(1241, 376, step=s) for s in range(3)]
+    res = fe.compute_batch(frames, (0, 1000))
+    sb = fe.slot_bytes
+    buf = torch.zeros(3 * sb, dtype=torch.uint8, device="cuda")
+    fe.pack_slots(3, buf.data_ptr(), sb)
+    host = buf.cpu().numpy()
+    for s in range(3):
+        k, d, mono = res[s]
+        hdr = host[s * sb:s * sb + 16].view(np.int32)
+        assert list(hdr) == [len(k), mono, fe.cap, 0]
+        pk = host[s * sb + 16:s * sb + 16 + len(k) * 28].view(V.KP_DTYPE)
+        assert all(np.array_equal(pk[f], k[f]) for f in k.dtype.names)
+        off = s * sb + 16 + fe.cap * 28
+        assert np.array_equal(host[off:off + len(k) * 32].reshape(-1, 32), d)
+    # frame 0 -> frame 1 with frame 0 read from the packed buffer (as a neighbour rank's slot would be)
+    base = buf.data_ptr()
+    cur = fe.slot_dev_ptrs(1)
+    m = V.FMatcher(fe, 0.9, True)
+    m.search_init_dev_async([(base + 16, base + 16 + fe.cap * 28, base, cur[0], cur[1], cur[2], 0)], 100)
+    out = m.search_init_dev_wait([len(res[0][0])])
+    wn, wm, _ = orbo.search_for_initialization(res[0][0], res[0][1], res[1][0], res[1][1], 1241, 376, window=100,
+                                               nnratio=0.9)
+    assert out[0][0] == wn and np.array_equal(out[0][1], wm)
+
+
+def test_odd_feature_count_keeps_buffers_aligned():
+    # nfeatures not a multiple of 4: the slot capacity is rounded so packed descriptors stay 16-byte aligned
+    a, b = synth.make_frame(640, 360, seed=2, step=0), synth.make_frame(640, 360, seed=2, step=1)
+    f = V.FExtractor(777, 1.2, 8, 20, 7, 640, 360, max_batch=2)
+    try:
+        assert f.cap % 4 == 0
+        (k1, d1, _), (k2, d2, _) = f.compute_batch([a, b], (0, 1000))
+        e = orbo.Extractor(777)
+        ko, do, _ = e.compute(a, lap=(0, 1000))
+        assert all(np.array_equal(k1[x], ko[x]) for x in ko.dtype.names) and np.array_equal(d1, do)
+        p, c = f.slot_dev_ptrs(0), f.slot_dev_ptrs(1)
+        m = V.FMatcher(f, 0.9, True)
+        m.search_init_dev_async([(p[0], p[1], p[2], c[0], c[1], c[2], 0)], 100)
+        out = m.search_init_dev_wait([len(k1)])
+        wn, wm, _ = orbo.search_for_initialization(k1, d1, k2, d2, 640, 360, window=100, nnratio=0.9)
+        assert out[0][0] == wn and np.array_equal(out[0][1], wm)
+    finally:
+        f.close()
