@@ -239,97 +239,100 @@ k_fast_cells_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     __syncthreads();
 
     const int lx = tid & 31, lyb = tid >> 5; /* 32 columns x 8 rows per sweep */
-    /* Pre-test (exact necessary condition): a nine-pixel arc always contains two compass-adjacent ring
-     * pixels (0,4,8,12), so a pixel whose score can reach minTh has two adjacent compass pixels darker than
-     * v - minTh or two brighter than v + minTh.  Everything else scores 0 -- which cannot change the NMS
-     * (a suppressing neighbour needs a score >= the candidate's >= minTh).  The test is made per polarity:
+    /* Two stages, mirroring the reference's "FAST at iniThFAST; if the cell is empty, again at minThFAST"
+     * (fextractor.cpp:800-807): stage 0 works at T = iniThFAST and is final for every cell that yields a
+     * corner (the usual case) -- only ~1/3 of the pixels that pass the minThFAST pre-test pass it at 20.
+     *
+     * Pre-test (exact necessary condition): a nine-pixel arc always contains two compass-adjacent ring
+     * pixels (0,4,8,12), so a pixel whose score can reach T has two adjacent compass pixels darker than
+     * v - T or two brighter than v + T.  Everything else scores 0 -- which cannot change the NMS at T
+     * (a suppressing neighbour needs a score >= the candidate's >= T).  The test is made per polarity:
      * a pixel that can only be a dark corner runs only the dark half of the network (and vice versa); both
      * survivor lists are compacted so the min3/max3 networks run on dense lanes. */
-    for (int xb = 0; xb < iw; xb += 32) {
-        const int x = xb + lx;
-        for (int ly0 = 0; ly0 < ih; ly0 += 8) { /* uniform trip count: the ballot below needs whole waves */
-            const int ly = ly0 + lyb;
-            bool passD = false, passB = false;
-            if (x < iw && ly < ih) {
-                const uint8_t* c = win + (ly + 3) * FP + x + 3;
-                const int v = c[0];
-                const int d0 = v - c[3 * FP], d4 = v - c[3], d8 = v - c[-3 * FP], d12 = v - c[-3];
-                const bool k0 = d0 > minTh, k4 = d4 > minTh, k8 = d8 > minTh, k12 = d12 > minTh;
-                const bool b0 = d0 < -minTh, b4 = d4 < -minTh, b8 = d8 < -minTh, b12 = d12 < -minTh;
-                passD = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
-                passB = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
-                sc[(ly + 1) * FP + x + 1] = 0;
-            }
-            const uint16_t code = (uint16_t)(ly * 64 + x);
-            unsigned long long m = __ballot(passD);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&s_npass[0], __popcll(m));
-                base = __shfl(base, leader, 64);
-                if (passD) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
-            }
-            m = __ballot(passB);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&s_npass[1], __popcll(m));
-                base = __shfl(base, leader, 64);
-                if (passB) plistB[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
-            }
-        }
-    }
-    __syncthreads();
-    /* dark half on its list, then the bright half on its own (a pixel on both lists keeps the larger) */
-    const int nD = s_npass[0], nB = s_npass[1];
-    for (int i = tid; i < nD; i += 256) {
-        const int code = plist[i], ly = code >> 6, x = code & 63;
-        const int a = fast_half_score<1>(win + (ly + 3) * FP + x + 3) - 1;
-        sc[(ly + 1) * FP + x + 1] = (uint8_t)max(a, 0);
-    }
-    __syncthreads();
-    for (int i = tid; i < nB; i += 256) {
-        const int code = plistB[i], ly = code >> 6, x = code & 63;
-        const int a = fast_half_score<-1>(win + (ly + 3) * FP + x + 3) - 1;
-        uint8_t* q = sc + (ly + 1) * FP + x + 1;
-        if (a > (int)*q) *q = (uint8_t)a;
-    }
-    __syncthreads();
-
-    /* NMS only where a score exists: walk the two survivor lists (a pixel on both is visited twice) */
-    int any_ini = 0;
-    for (int i = tid; i < nD + nB; i += 256) {
-        const int code = i < nD ? plist[i] : plistB[i - nD], ly = code >> 6, x = code & 63;
-        const uint8_t* q = sc + (ly + 1) * FP + x + 1;
-        const int s = q[0];
-        if (s >= minTh) {
-            const int m = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
-                              max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
-            if (s > m) {
-                atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
-                if (s >= iniTh) any_ini = 1;
+    int T = iniTh;
+    for (int stage = 0; stage < 2; stage++) {
+        for (int xb = 0; xb < iw; xb += 32) {
+            const int x = xb + lx;
+            for (int ly0 = 0; ly0 < ih; ly0 += 8) { /* uniform trip count: the ballots need whole waves */
+                const int ly = ly0 + lyb;
+                bool passD = false, passB = false;
+                if (x < iw && ly < ih) {
+                    const uint8_t* c = win + (ly + 3) * FP + x + 3;
+                    const int v = c[0];
+                    const int d0 = v - c[3 * FP], d4 = v - c[3], d8 = v - c[-3 * FP], d12 = v - c[-3];
+                    const bool k0 = d0 > T, k4 = d4 > T, k8 = d8 > T, k12 = d12 > T;
+                    const bool b0 = d0 < -T, b4 = d4 < -T, b8 = d8 < -T, b12 = d12 < -T;
+                    passD = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
+                    passB = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+                    sc[(ly + 1) * FP + x + 1] = 0;
+                }
+                const uint16_t code = (uint16_t)(ly * 64 + x);
+                unsigned long long m = __ballot(passD);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&s_npass[0], __popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (passD) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
+                }
+                m = __ballot(passB);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&s_npass[1], __popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (passB) plistB[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
+                }
             }
         }
+        __syncthreads();
+        /* dark half on its list, then the bright half on its own (a pixel on both lists keeps the larger) */
+        const int nD = s_npass[0], nB = s_npass[1];
+        for (int i = tid; i < nD; i += 256) {
+            const int code = plist[i], ly = code >> 6, x = code & 63;
+            const int a = fast_half_score<1>(win + (ly + 3) * FP + x + 3) - 1;
+            sc[(ly + 1) * FP + x + 1] = (uint8_t)max(a, 0);
+        }
+        __syncthreads();
+        for (int i = tid; i < nB; i += 256) {
+            const int code = plistB[i], ly = code >> 6, x = code & 63;
+            const int a = fast_half_score<-1>(win + (ly + 3) * FP + x + 3) - 1;
+            uint8_t* q = sc + (ly + 1) * FP + x + 1;
+            if (a > (int)*q) *q = (uint8_t)a;
+        }
+        __syncthreads();
+        /* NMS at T only where a score exists: walk the two survivor lists (a pixel on both is visited twice) */
+        int any = 0;
+        for (int i = tid; i < nD + nB; i += 256) {
+            const int code = i < nD ? plist[i] : plistB[i - nD], ly = code >> 6, x = code & 63;
+            const uint8_t* q = sc + (ly + 1) * FP + x + 1;
+            const int s = q[0];
+            if (s >= T) {
+                const int mx = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
+                                   max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
+                if (s > mx) {
+                    atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
+                    any = 1;
+                }
+            }
+        }
+        if (any) s_any_ini = 1; /* "this stage found a corner"; benign race, all writers store 1 */
+        __syncthreads();
+        if (s_any_ini || stage == 1 || minTh == iniTh) break; /* block-uniform */
+        /* empty at iniThFAST: the whole cell again at minThFAST */
+        T = minTh;
+        if (tid == 0) {
+            s_npass[0] = 0;
+            s_npass[1] = 0;
+        }
+        __syncthreads();
     }
-    if (any_ini) s_any_ini = 1;
-    __syncthreads();
-    const int T = s_any_ini ? iniTh : minTh;
 
-    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..) */
+    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..); every kept bit already
+     * satisfies score >= T of the stage that produced it */
     uint32_t bits = 0;
     const int kly = tid >> 1, kxb = (tid & 1) * 32;
-    if (tid < nwords) {
-        uint32_t b = keep[tid];
-        if (T != minTh) {
-            uint32_t r = b;
-            while (r) {
-                const int k = __ffs(r) - 1;
-                r &= r - 1;
-                if (sc[(kly + 1) * FP + kxb + k + 1] < T) b &= ~(1u << k);
-            }
-        }
-        bits = b;
-    }
+    if (tid < nwords) bits = keep[tid];
     const uint32_t cnt = __popc(bits);
     uint32_t incl = cnt;
 #pragma unroll
