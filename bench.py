@@ -248,7 +248,9 @@ def main():
     def run(nsteps):
         for t in range(nsteps + NCTX - 1):
             if t < nsteps:
+                t_e = time.perf_counter()
                 enqueue(t)
+                state["enq_s"] = state.get("enq_s", 0.0) + time.perf_counter() - t_e
             if 0 <= t - (NCTX - 1) < nsteps:
                 collect(t - (NCTX - 1))
 
@@ -260,6 +262,7 @@ def main():
 
     run(args.warmup)
     state.pop("host_s", None)
+    state.pop("enq_s", None)
     for c in ctxs:
         c.set_profiling(True)
     barrier()
@@ -312,7 +315,8 @@ def main():
                        if not stereo else "stereo frames independent per rank, no collective",
                        "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],
                        "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in
-                                            zip(("wait_step", "fetch_matches"), state.get("host_s", [0, 0]))}},
+                                            zip(("enqueue", "wait_step", "fetch_matches"),
+                                                [state.get("enq_s", 0.0)] + state.get("host_s", [0, 0]))}},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_detail": tr,

@@ -233,6 +233,9 @@ int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, in
 /* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
  * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */
 int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);
+/* Number of queries for which the device SearchForInitialization had to re-scan the whole window because the
+ * sorted candidate prefix (length VSLAM_INIT_TOPM, default 8) was exhausted; read-and-reset, synchronises. */
+int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count);
 
 #ifdef __cplusplus
 }

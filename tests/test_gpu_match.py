@@ -253,6 +253,38 @@ def test_search_init_device_jobs_async(fe):
         assert out[j][0] == wn and np.array_equal(out[j][1], wm), j
 
 
+@pytest.mark.parametrize("topm", ["1", "2", "8"])
+def test_search_init_sorted_prefix_and_rescan_path(monkeypatch, topm):
+    """k_si_replay works from a sorted prefix of VSLAM_INIT_TOPM candidates per query and re-scans the whole
+    window when the prefix is exhausted: a prefix of 1 or 2 forces that path, the result must not change."""
+    monkeypatch.setenv("VSLAM_INIT_TOPM", topm)
+    frames = [synth.make_frame(1241, 376, seed=11, step=s) for s in range(3)]
+    f = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=3)
+    try:
+        res = f.compute_batch(frames, (0, 1000))
+        jobs = []
+        for s in (1, 2):
+            p, c = f.slot_dev_ptrs(s - 1), f.slot_dev_ptrs(s)
+            jobs.append((p[0], p[1], p[2], c[0], c[1], c[2], 0))
+        m = V.FMatcher(f, 0.9, True)
+        m.search_init_fallbacks()
+        m.search_init_dev_async(jobs, 100)
+        out = m.search_init_dev_wait([len(res[0][0]), len(res[1][0])], want_prev=True)
+        nfb = m.search_init_fallbacks()
+        for j in range(2):
+            wn, wm, wp = orbo.search_for_initialization(res[j][0], res[j][1], res[j + 1][0], res[j + 1][1], 1241, 376,
+                                                        window=100, nnratio=0.9)
+            assert out[j][0] == wn and np.array_equal(out[j][1], wm) and np.array_equal(out[j][2], wp), j
+            assert wn > 50
+        nq = sum(int((res[j][0]["octave"] == 0).sum()) for j in range(2))
+        if topm == "8":
+            assert nfb <= nq // 10, (nfb, nq)  # the prefix almost always decides
+        else:
+            assert nfb > 0, "tiny prefix must exercise the re-scan path"
+    finally:
+        f.close()
+
+
 def test_search_init_large_feature_count():
     """The mono initialisation extractor uses 5 x nFeatures (tracking.cpp:1093): 2170 octave-0 keypoints."""
     a, b = synth.make_frame(1241, 376, seed=5, step=0), synth.make_frame(1241, 376, seed=5, step=1)

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
-    "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_search_init_dev_async",
+    "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_dbg_search_init_fallbacks", "vslam_search_init_dev_async",
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
     "vslam_fe_event_wait",
 ]
@@ -441,6 +441,12 @@ class FMatcher:
         _check(lib().vslam_search_init_dev_wait(self.fe._h, (C.c_int * n)(*n1), self._m_ptrs,
                                                 self._p_ptrs if want_prev else None, nm))
         return [(nm[j], self._m_buf[j, :n1[j]], self._p_buf[j, :n1[j]] if want_prev else None) for j in range(n)]
+
+    def search_init_fallbacks(self):
+        """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""
+        c = C.c_int()
+        _check(lib().vslam_dbg_search_init_fallbacks(self.fe._h, C.byref(c)))
+        return c.value
 
     def SearchForInitializationBatch(self, pairs, windowSize=10, img_size=None):
         """Several independent SearchForInitialization problems in one pass of the kernels.

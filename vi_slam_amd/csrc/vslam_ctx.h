@@ -169,6 +169,9 @@ struct vslam_fe {
     size_t h_init_bytes = 0;
     int init_pairs = 0;
     bool init_lds_set = false;
+    uint8_t* d_init_scratch = nullptr; /* k_si_topm -> k_si_replay: compacted octave-0 lists + sorted prefixes */
+    size_t init_scratch_bytes = 0;
+    int* d_init_fb = nullptr; /* number of full re-scans in k_si_replay (diagnostics) */
     /* stereo scratch */
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;

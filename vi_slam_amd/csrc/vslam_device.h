@@ -99,6 +99,14 @@ struct MatJobs {
     MatJob job[VSLAM_MAX_MAT_JOBS];
 };
 
+/* Up to four dword-granular ranges for k_copy_ranges (src == nullptr: zero-fill). */
+struct CopyRanges {
+    void* dst[4];
+    const void* src[4];
+    size_t bytes[4];
+    int n;
+};
+
 /* One (frame 1, frame 2) problem of k_search_init; every pointer is a device pointer. */
 struct InitJob {
     const vslam_kp* k1;

@@ -9,6 +9,12 @@
  */
 #include "vslam_ctx.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+void vslam_host_prof_report();
+
 std::string& vslam_err() {
     static thread_local std::string e;
     return e;
@@ -56,6 +62,8 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->h_counts) hipHostFree(fe->h_counts);
     if (fe->h_stereo) hipHostFree(fe->h_stereo);
     hipFree(fe->d_init);
+    hipFree(fe->d_init_scratch);
+    hipFree(fe->d_init_fb);
     if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
     if (fe->ev_x) hipEventDestroy(fe->ev_x);
@@ -69,6 +77,7 @@ static void free_ctx(vslam_fe* fe) {
 
 extern "C" void vslam_fe_destroy(vslam_fe* fe) {
     if (fe) hipSetDevice(fe->p.device);
+    vslam_host_prof_report();
     free_ctx(fe);
 }
 
@@ -476,7 +485,9 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     }
     fe->last_nimg = nimg;
     fe->cand_on_host = false;
-    HIPCHK(hipMemset2DAsync(fe->d_cand, fe->cand_stride, 0, 8, nimg, st)); /* total, overflow */
+    /* per-slot candidate header (total, overflow) and the device-quadtree error word: one tiny kernel instead
+     * of two runtime memsets */
+    vk_reset_headers(st, fe->d_cand, fe->cand_stride, nimg, fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr);
     const bool prof = fe->profiling;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
     for (int l = 1; l < L; l++)
@@ -616,7 +627,6 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     hipStream_t st = fe->stream;
     const bool prof = fe->profiling;
     int32_t* d_err = fe->d_counts + (size_t)fe->B * 4;
-    HIPCHK(hipMemsetAsync(d_err, 0, 16, st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[3], st));
     enqueue_blur(fe, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
@@ -631,30 +641,71 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
                            nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
-    HIPCHK(hipMemcpyAsync(fe->h_counts, fe->d_counts, (size_t)(fe->B * 4 + 4) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
-    return VSLAM_OK;
+    return VSLAM_OK; /* counts travel to the host with the results (vslam_enqueue_extract) */
+}
+
+/* VSLAM_HOST_PROF=1: host-side wall time per API phase, printed by vslam_fe_destroy (diagnostics only) */
+static double g_hp[6];
+static long g_hp_n;
+static const bool g_hp_on = getenv("VSLAM_HOST_PROF") != nullptr;
+static inline double hp_now() {
+    return g_hp_on ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch())
+                         .count()
+                   : 0.0;
+}
+void vslam_host_prof_report() {
+    if (!g_hp_on || !g_hp_n) return;
+    fprintf(stderr, "[vslam host prof] per call (us): front %.1f back %.1f d2h-enqueue %.1f sync %.1f deliver %.1f (n=%ld)\n",
+            g_hp[0] / g_hp_n, g_hp[1] / g_hp_n, g_hp[2] / g_hp_n, g_hp[3] / g_hp_n, g_hp[4] / g_hp_n, g_hp_n);
+    g_hp_n = 0;
+    for (double& v : g_hp) v = 0;
 }
 
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
                           int lap0, int lap1, bool want_host) {
     HIPCHK(hipSetDevice(fe->p.device));
+    const double t0 = hp_now();
     int rc = enqueue_front(fe, nimg, imgs, pitch, on_device);
     if (rc) return rc;
+    const double t1 = hp_now();
     rc = fe->dev_octree ? enqueue_back_dev(fe, nimg, lap0, lap1) : enqueue_back_host(fe, nimg, lap0, lap1);
     if (rc) return rc;
+    const double t2 = hp_now();
+    g_hp[0] += t1 - t0;
+    g_hp[1] += t2 - t1;
+    g_hp_n++;
+    struct D2hTimer {
+        double t;
+        ~D2hTimer() { g_hp[2] += hp_now() - t; }
+    } d2h_timer{t2};
     hipStream_t st = fe->stream;
-    if (want_host) { /* whole blocks: counts are not known on the host yet in the device-quadtree path */
-        HIPCHK(hipMemcpyAsync(fe->h_kps, fe->d_kps, (size_t)nimg * fe->cap * sizeof(vslam_kp),
-                              hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(fe->h_desc, fe->d_desc, (size_t)nimg * fe->cap * 32, hipMemcpyDeviceToHost, st));
+    /* results go to pinned host memory by a kernel (whole blocks: the host does not know the counts yet) */
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    if (fe->dev_octree) {
+        R.dst[R.n] = fe->h_counts;
+        R.src[R.n] = fe->d_counts;
+        R.bytes[R.n++] = (size_t)(fe->B * 4 + 4) * 4;
     }
+    if (want_host) {
+        R.dst[R.n] = fe->h_kps;
+        R.src[R.n] = fe->d_kps;
+        R.bytes[R.n++] = (size_t)nimg * fe->cap * sizeof(vslam_kp);
+        R.dst[R.n] = fe->h_desc;
+        R.src[R.n] = fe->d_desc;
+        R.bytes[R.n++] = (size_t)nimg * fe->cap * 32;
+    }
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
     return VSLAM_OK;
 }
 
 int vslam_finish_extract(vslam_fe* fe, int nimg) {
     hipStream_t st = fe->stream;
+    const double t_sync = hp_now();
     HIPCHK(hipStreamSynchronize(st));
+    g_hp[3] += hp_now() - t_sync;
     if (fe->dev_octree) {
         const int32_t* err = fe->h_counts + (size_t)fe->B * 4;
         if (err[0] & 1) {
@@ -685,6 +736,10 @@ int vslam_finish_extract(vslam_fe* fe, int nimg) {
 
 int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
                   int* mono_index) {
+    struct DeliverTimer {
+        double t;
+        ~DeliverTimer() { g_hp[4] += hp_now() - t; }
+    } deliver_timer{hp_now()};
     for (int s = 0; s < nimg; s++) {
         if (kps && desc) {
             if (fe->n_out[s] > cap) {

@@ -1,17 +1,26 @@
 /* vslam_init_kernel.hip -- FMatcher::SearchForInitialization (fmatcher.cpp:983-1098) entirely on the GPU.
  *
  * The reference loop is sequential over the octave-0 keypoints of frame 1 (a later query may steal an
- * earlier query's match, and a candidate whose current owner is at least as close is skipped), so ONE WAVE
- * owns a frame pair and walks the queries in index order.  Everything inside one query is order-free once
- * each candidate carries the position it would have in Frame::GetFeaturesInArea's output (grid cell
- * column-major, ascending index inside a cell; frame.cpp:712-741): with key = dist << 28 | cell << 16 | slot
- *   bestDist/bestIdx2 = min key over the non-skipped window candidates ("first wins" on equal distance),
- *   bestDist2         = smallest distance among the remaining ones (multiset second minimum),
- * both wave min-reductions.  Acceptance (TH_LOW, ratio test in float), stealing, the 30-bin rotation
- * histogram and ComputeThreeMaxima follow the reference literally.
+ * earlier query's match, and a candidate whose current owner is at least as close is skipped).  Only that
+ * skip/steal bookkeeping is order-dependent; the expensive part -- which frame-2 keypoints lie in a query's
+ * window and how far their descriptors are -- is not.  Two kernels:
  *
- * Frame 2's octave-0 keypoints (position, grid cell, owner, owner distance) live in LDS; descriptors are
- * read from HBM (L2) only for candidates inside the window.
+ *   k_si_topm   (parallel, one wave per query, all pairs at once): every window candidate gets
+ *               key = min(dist,255) << 24 | gridcell << 12 | slot, i.e. (distance, position in
+ *               Frame::GetFeaturesInArea's output: grid cell column-major, ascending index inside a cell,
+ *               frame.cpp:712-741).  The M smallest keys of each query are written in ascending order.
+ *   k_si_replay (one wave per pair, queries in index order): the first two list entries that are not skipped
+ *               (vMatchedDistance[i2] <= dist, fmatcher.cpp:1022) are bestDist/bestIdx2 and bestDist2 --
+ *               "first wins" on equal distance is the key order, bestDist2 is the multiset second minimum.
+ *               A list is a sorted prefix of all candidates, so this is exact whenever two survivors are found
+ *               (or the list is not full, or the last list entry already decides the ratio test); otherwise
+ *               the wave re-scans that query's window in full (rare; forced in tests with a tiny M).
+ *               Acceptance (TH_LOW, ratio test in float), stealing, the 30-bin rotation histogram and
+ *               ComputeThreeMaxima follow the reference literally.
+ *
+ * Distances are clamped to 255 inside the key (the only other value is 256): an accepted best and every
+ * owner's distance are <= TH_LOW = 50, so the clamp can only matter through the ratio test against a second
+ * of exactly 256, and nnratio * 255 > 50 for every nnratio >= 0.2 -- the host wrapper refuses smaller ratios.
  */
 #include "vslam_kernels.h"
 
@@ -19,6 +28,8 @@
 #define SI_HISTO 30
 #define SI_GRID_COLS 64 /* FRAME_GRID_COLS, frame.h:42 */
 #define SI_GRID_ROWS 48 /* FRAME_GRID_ROWS, frame.h:43 */
+#define SI_QPB 32       /* queries per k_si_topm workgroup (4 waves x 8) */
+#define SI_MAX_M 16
 
 /* wave64 min-reduction on DPP (no LDS traffic, a few cycles per step instead of a ds_bpermute round trip):
  * quad swaps, row rotations, then row_bcast:15 / row_bcast:31; the result sits in lane 63 and is returned
@@ -47,36 +58,65 @@ struct SiQuery { /* one octave-0 keypoint of frame 1 */
     uint32_t idx;
 };
 
-__global__ void __launch_bounds__(64)
-k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
-              int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
-              int32_t* nmatch_out /* [pair] */, int max_c2, int lds_desc) {
-    extern __shared__ __align__(16) uint8_t sism[];
-    const InitJob jb = jobs.job[blockIdx.x];
-    const int lane = threadIdx.x;
-    const int n1 = min(*jb.cnt1, cap), n2 = min(*jb.cnt2, cap);
-    /* LDS: [desc2 | desc1] (only if lds_desc) | cand | query | owner | ownerDist | m12 | rotBin */
-    uint4* ldesc2 = (uint4*)sism;                                      /* max_c2 x 32 B */
-    uint4* ldesc1 = ldesc2 + (lds_desc ? 2 * max_c2 : 0);              /* max_c2 x 32 B */
-    SiCand* cand = (SiCand*)(ldesc1 + (lds_desc ? 2 * max_c2 : 0));    /* max_c2 */
-    SiQuery* qry = (SiQuery*)(cand + max_c2);                          /* max_c2 (frame 1 has the same quota) */
-    int32_t* owner = (int32_t*)(qry + max_c2);                         /* vnMatches21 (query index) */
-    int32_t* ownerDist = owner + max_c2;                               /* vMatchedDistance */
-    int32_t* m12 = ownerDist + max_c2;                                 /* vnMatches12, cap */
-    uint8_t* rotBin = (uint8_t*)(m12 + cap);                           /* bin of an accepted query, 255 = none */
-    __shared__ int s_hist[SI_HISTO];
+/* per-pair scratch in HBM: [c1, c2, pad, pad] | SiCand[max_c2] | SiQuery[max_c2] | topm[max_c2][M] */
+__host__ __device__ inline size_t si_pair_bytes(int max_c2, int M) {
+    return 16 + (size_t)max_c2 * (sizeof(SiCand) + sizeof(SiQuery) + 4 * (size_t)M);
+}
 
-    int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
-    float* po = prev_out + (size_t)blockIdx.x * cap * 2;
+struct SiWindow {
+    int minX, maxX, minY, maxY;
+    bool empty;
+};
+/* GetFeaturesInArea(x, y, r, 0, 0): cell range (frame.cpp:686-708) */
+__device__ __forceinline__ SiWindow si_window(float px, float py, float r, float invW, float invH) {
+    SiWindow w;
+    w.minX = max(0, (int)floorf(__fmul_rn(__fsub_rn(px, r), invW)));
+    w.maxX = min(SI_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(px, r), invW)));
+    w.minY = max(0, (int)floorf(__fmul_rn(__fsub_rn(py, r), invH)));
+    w.maxY = min(SI_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(py, r), invH)));
+    w.empty = w.minX >= SI_GRID_COLS || w.maxX < 0 || w.minY >= SI_GRID_ROWS || w.maxY < 0;
+    return w;
+}
+__device__ __forceinline__ bool si_in_window(const SiCand& cd, const SiWindow& w, float px, float py, float r) {
+    const int gx = cd.cell >> 6, gy = cd.cell & 63;
+    if (gx < w.minX || gx > w.maxX || gy < w.minY || gy > w.maxY) return false;
+    const float distx = __fsub_rn(cd.x, px), disty = __fsub_rn(cd.y, py);
+    return fabsf(distx) < r && fabsf(disty) < r;
+}
+__device__ __forceinline__ uint32_t si_hamming(const uint4& da, const uint4& db, const uint4& ta, const uint4& tb) {
+    return __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
+           __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * phase A: grid (chunks of SI_QPB queries, pairs), 256 threads.  Every workgroup compacts the octave-0
+ * keypoints of both frames in index order (block scan per 256), keeps frame 2's in LDS, and ranks the window
+ * candidates of its own queries.  Chunk 0 also publishes the compacted candidate list and the counts.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, int M, uint8_t* scratch) {
+    extern __shared__ __align__(16) uint8_t sism[];
+    SiCand* cand = (SiCand*)sism;                    /* max_c2 */
+    uint32_t* wkeys = (uint32_t*)(cand + max_c2);    /* 4 waves x max_c2: window keys of the current query */
+    __shared__ SiQuery s_q[SI_QPB];
+    __shared__ int s_wcnt[4];
+    const InitJob jb = jobs.job[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = min(*jb.cnt1, cap), n2 = min(*jb.cnt2, cap);
+    uint8_t* sp = scratch + (size_t)blockIdx.y * si_pair_bytes(max_c2, M);
+    int32_t* hdr = (int32_t*)sp;
+    SiCand* gcand = (SiCand*)(sp + 16);
+    SiQuery* gqry = (SiQuery*)(gcand + max_c2);
+    uint32_t* topm = (uint32_t*)(gqry + max_c2);
+    const int q0 = blockIdx.x * SI_QPB;
 
     /* Frame grid of frame 2 (frame.cpp:322-323, 746-756): mnMinX = 0, mnMaxX = cols (no distortion) */
     const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)imgW);
     const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)imgH);
 
-    /* ---- compaction of the octave-0 keypoints of both frames, order preserved (wave scan per 64) */
     int c2 = 0;
-    for (int b = 0; b < n2; b += 64) {
-        const int i = b + lane;
+    for (int b = 0; b < n2; b += 256) {
+        const int i = b + tid;
         bool take = false;
         vslam_kp k;
         int gx = 0, gy = 0;
@@ -89,28 +129,27 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
             }
         }
         const unsigned long long m = __ballot(take);
-        if (take) {
-            const int pos = c2 + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < max_c2) {
-                cand[pos].x = k.x;
-                cand[pos].y = k.y;
-                cand[pos].angle = k.angle;
-                cand[pos].cell = (uint16_t)(gx * 64 + gy);
-                cand[pos].idx = (uint16_t)i;
-                owner[pos] = -1;
-                ownerDist[pos] = 0x7FFFFFFF;
-                if (lds_desc) {
-                    ldesc2[2 * pos] = ((const uint4*)jb.d2)[(size_t)i * 2];
-                    ldesc2[2 * pos + 1] = ((const uint4*)jb.d2)[(size_t)i * 2 + 1];
-                }
-            }
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int pos = c2 + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) pos += s_wcnt[w];
+        if (take && pos < max_c2) {
+            SiCand cd;
+            cd.x = k.x;
+            cd.y = k.y;
+            cd.angle = k.angle;
+            cd.cell = (uint16_t)(gx * 64 + gy);
+            cd.idx = (uint16_t)i;
+            cand[pos] = cd;
+            if (blockIdx.x == 0) gcand[pos] = cd;
         }
-        c2 += __popcll(m);
+        c2 += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
     }
     c2 = min(c2, max_c2);
     int c1 = 0;
-    for (int b = 0; b < n1; b += 64) {
-        const int i = b + lane;
+    for (int b = 0; b < n1; b += 256) {
+        const int i = b + tid;
         vslam_kp k;
         bool take = false;
         if (i < n1) {
@@ -118,22 +157,146 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
             take = k.octave == 0; /* level1 > 0 -> continue, fmatcher.cpp:999-1001 */
         }
         const unsigned long long m = __ballot(take);
-        if (take) {
-            const int pos = c1 + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < max_c2) {
-                qry[pos].px = jb.prev ? jb.prev[2 * i] : k.x;
-                qry[pos].py = jb.prev ? jb.prev[2 * i + 1] : k.y;
-                qry[pos].angle = k.angle;
-                qry[pos].idx = (uint32_t)i;
-                if (lds_desc) {
-                    ldesc1[2 * pos] = ((const uint4*)jb.d1)[(size_t)i * 2];
-                    ldesc1[2 * pos + 1] = ((const uint4*)jb.d1)[(size_t)i * 2 + 1];
-                }
-            }
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int pos = c1 + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) pos += s_wcnt[w];
+        if (take && pos >= q0 && pos < q0 + SI_QPB && pos < max_c2) {
+            SiQuery q;
+            q.px = jb.prev ? jb.prev[2 * i] : k.x;
+            q.py = jb.prev ? jb.prev[2 * i + 1] : k.y;
+            q.angle = k.angle;
+            q.idx = (uint32_t)i;
+            s_q[pos - q0] = q;
+            gqry[pos] = q;
         }
-        c1 += __popcll(m);
+        c1 += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
     }
     c1 = min(c1, max_c2);
+    if (blockIdx.x == 0 && tid == 0) {
+        hdr[0] = c1;
+        hdr[1] = c2;
+    }
+
+    const float r = (float)window;
+    uint32_t* wk = wkeys + (size_t)wave * max_c2;
+    for (int t = q0 + wave; t < min(c1, q0 + SI_QPB); t += 4) {
+        const SiQuery qq = s_q[t - q0];
+        const SiWindow win = si_window(qq.px, qq.py, r, invW, invH);
+        uint32_t mine = 0xFFFFFFFFu; /* lane j < M ends up with the j-th smallest key */
+        if (!win.empty) {
+            const uint4 da = ((const uint4*)jb.d1)[(size_t)qq.idx * 2];
+            const uint4 db = ((const uint4*)jb.d1)[(size_t)qq.idx * 2 + 1];
+            int nk = 0; /* window candidates, compacted (their order is irrelevant: keys are unique) */
+            for (int cb = 0; cb < c2; cb += 64) {
+                const int c = cb + lane;
+                bool in = false;
+                uint32_t key = 0;
+                if (c < c2) {
+                    const SiCand cd = cand[c];
+                    if (si_in_window(cd, win, qq.px, qq.py, r)) {
+                        const uint4 ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
+                        const uint4 tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
+                        const uint32_t dist = si_hamming(da, db, ta, tb);
+                        key = (min(dist, 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+                        in = true;
+                    }
+                }
+                const unsigned long long m = __ballot(in);
+                if (in) wk[nk + __popcll(m & ((1ull << lane) - 1ull))] = key;
+                nk += __popcll(m);
+            }
+            /* M rounds of "smallest key not yet taken" (keys are unique; same wave, LDS is in order) */
+            uint32_t lower = 0;
+            for (int j = 0; j < M; j++) {
+                uint32_t lm = 0xFFFFFFFFu;
+                for (int e = lane; e < nk; e += 64) {
+                    const uint32_t kv = wk[e];
+                    if (kv >= lower) lm = min(lm, kv);
+                }
+                const uint32_t g = wave_min_u32(lm);
+                if (g == 0xFFFFFFFFu) break;
+                if (lane == j) mine = g;
+                lower = g + 1u;
+            }
+        }
+        if (lane < M) topm[(size_t)t * M + lane] = mine;
+    }
+}
+
+/* Full re-scan of one query's window (the reference loop body, fmatcher.cpp:1003-1035): used by the replay wave
+ * when its sorted prefix ran out.  Returns the best key; *second_out = bestDist2 (0x7FFFFFFF if none). */
+__device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const int32_t* ownerDist, int c2, int lane,
+                                 const SiQuery& qq, float r, float invW, float invH, uint32_t* second_out) {
+    const SiWindow win = si_window(qq.px, qq.py, r, invW, invH);
+    uint32_t bestKey = 0xFFFFFFFFu, second = 0x7FFFFFFFu; /* per lane: best key, smallest other distance */
+    if (!win.empty) {
+        const uint4 da = ((const uint4*)jb.d1)[(size_t)qq.idx * 2];
+        const uint4 db = ((const uint4*)jb.d1)[(size_t)qq.idx * 2 + 1];
+        for (int c = lane; c < c2; c += 64) {
+            const SiCand cd = gcand[c];
+            if (!si_in_window(cd, win, qq.px, qq.py, r)) continue;
+            const uint4 ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
+            const uint4 tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
+            const uint32_t dist = min(si_hamming(da, db, ta, tb), 255u);
+            if ((uint32_t)ownerDist[c] <= dist) continue; /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
+            const uint32_t key = (dist << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+            if (key < bestKey) {
+                if (bestKey != 0xFFFFFFFFu) second = min(second, bestKey >> 24);
+                bestKey = key;
+            } else {
+                second = min(second, dist);
+            }
+        }
+    }
+    const uint32_t gBest = wave_min_u32(bestKey);
+    /* second minimum over the multiset: lanes that do not hold the winner contribute their own best */
+    uint32_t contrib = second;
+    if (bestKey != gBest && bestKey != 0xFFFFFFFFu) contrib = min(contrib, bestKey >> 24);
+    *second_out = wave_min_u32(contrib);
+    return gBest;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * phase B: one wave per pair, queries in index order.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64)
+k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
+            int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
+            int32_t* nmatch_out /* [pair] */, int max_c2, int M, const uint8_t* scratch, int* fallbacks) {
+    extern __shared__ __align__(16) uint8_t sism[];
+    const InitJob jb = jobs.job[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n1 = min(*jb.cnt1, cap);
+    const uint8_t* sp = scratch + (size_t)blockIdx.x * si_pair_bytes(max_c2, M);
+    const int32_t* hdr = (const int32_t*)sp;
+    const SiCand* gcand = (const SiCand*)(sp + 16);
+    const SiQuery* gqry = (const SiQuery*)(gcand + max_c2);
+    const uint32_t* topm = (const uint32_t*)(gqry + max_c2);
+    const int c1 = hdr[0], c2 = hdr[1];
+    /* LDS: owner | ownerDist | candIdx | candAngle | m12 | kbuf | rotBin */
+    int32_t* owner = (int32_t*)sism;             /* vnMatches21 (query index), max_c2 */
+    int32_t* ownerDist = owner + max_c2;         /* vMatchedDistance */
+    int32_t* candIdx = ownerDist + max_c2;
+    float* candAngle = (float*)(candIdx + max_c2);
+    int32_t* m12 = (int32_t*)(candAngle + max_c2); /* vnMatches12, cap */
+    uint32_t* kbuf = (uint32_t*)(m12 + cap);     /* 64 queries x M keys */
+    SiQuery* qbuf = (SiQuery*)(kbuf + 64 * SI_MAX_M); /* 64 queries */
+    uint8_t* rotBin = (uint8_t*)(qbuf + 64);     /* bin of an accepted query, 255 = none */
+    __shared__ int s_hist[SI_HISTO];
+
+    int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
+    float* po = prev_out + (size_t)blockIdx.x * cap * 2;
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)imgH);
+
+    for (int c = lane; c < c2; c += 64) {
+        owner[c] = -1;
+        ownerDist[c] = 0x7FFFFFFF;
+        candIdx[c] = gcand[c].idx;
+        candAngle[c] = gcand[c].angle;
+    }
     for (int i = lane; i < n1; i += 64) {
         m12[i] = -1;
         rotBin[i] = 255;
@@ -143,87 +306,75 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
 
     const float r = (float)window;
     const float factor = 1.0f / SI_HISTO;
-    for (int t = 0; t < c1; t++) {
-        const SiQuery qq = qry[t];
-        const int i1 = (int)qq.idx;
-        const float px = qq.px, py = qq.py;
-        /* GetFeaturesInArea(x, y, r, 0, 0): cell range (frame.cpp:686-708) */
-        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(px, r), invW)));
-        const int nMaxCellX = min(SI_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(px, r), invW)));
-        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(py, r), invH)));
-        const int nMaxCellY = min(SI_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(py, r), invH)));
-        if (nMinCellX >= SI_GRID_COLS || nMaxCellX < 0 || nMinCellY >= SI_GRID_ROWS || nMaxCellY < 0) continue;
-        uint4 da, db;
-        if (lds_desc) {
-            da = ldesc1[2 * t];
-            db = ldesc1[2 * t + 1];
-        } else {
-            da = ((const uint4*)jb.d1)[(size_t)i1 * 2];
-            db = ((const uint4*)jb.d1)[(size_t)i1 * 2 + 1];
-        }
-
-        /* key = min(dist,63) << 24 | cell << 12 | slot: distances above TH_LOW are rejected anyway, so the
-         * clamp cannot change an accepted match; true distances are tracked beside the key */
-        uint32_t bestKey = 0xFFFFFFFFu, bestD = 0x7FFFFFFFu;
-        uint32_t second = 0x7FFFFFFFu; /* smallest distance among this lane's other candidates */
-        for (int c = lane; c < c2; c += 64) {
-            const SiCand cd = cand[c];
-            const int gx = cd.cell >> 6, gy = cd.cell & 63;
-            if (gx < nMinCellX || gx > nMaxCellX || gy < nMinCellY || gy > nMaxCellY) continue;
-            const float distx = __fsub_rn(cd.x, px), disty = __fsub_rn(cd.y, py);
-            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            uint4 ta, tb;
-            if (lds_desc) {
-                ta = ldesc2[2 * c];
-                tb = ldesc2[2 * c + 1];
+    int nfb = 0;
+    for (int qb = 0; qb < c1; qb += 64) {
+        const int nq = min(64, c1 - qb);
+        __syncthreads();
+        for (int i = lane; i < nq * M; i += 64) kbuf[i] = topm[(size_t)qb * M + i];
+        if (lane < nq) qbuf[lane] = gqry[qb + lane];
+        __syncthreads();
+        for (int tq = 0; tq < nq; tq++) {
+            const uint32_t key = lane < M ? kbuf[tq * M + lane] : 0xFFFFFFFFu;
+            const bool valid = key != 0xFFFFFFFFu;
+            const uint32_t kd = key >> 24;
+            bool ok = false;
+            if (valid) ok = !((uint32_t)ownerDist[key & 0xFFF] <= kd); /* fmatcher.cpp:1022 */
+            const unsigned long long mv = __ballot(valid), mk = __ballot(ok);
+            const bool full = __popcll(mv) == M;
+            uint32_t gBest = 0xFFFFFFFFu, bestDist2 = 0x7FFFFFFFu;
+            bool need_scan = false;
+            if (mk == 0) {
+                if (!full) continue; /* vIndices2 empty or everything skipped: bestDist stays INT_MAX */
+                need_scan = true;
             } else {
-                ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
-                tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
-            }
-            const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) +
-                                  __popc(da.w ^ ta.w) + __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) +
-                                  __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
-            if ((uint32_t)ownerDist[c] <= dist) continue; /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
-            const uint32_t key = (min(dist, 63u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
-            /* compare on (true distance, grid order): identical to the key order whenever dist < 63 */
-            if (dist < bestD || (dist == bestD && key < bestKey)) {
-                second = min(second, bestD);
-                bestKey = key;
-                bestD = dist;
-            } else {
-                second = min(second, dist);
-            }
-        }
-        const uint32_t gBest = wave_min_u32(bestKey);
-        if (gBest == 0xFFFFFFFFu) continue; /* vIndices2 empty or everything skipped: bestDist = INT_MAX */
-        if ((gBest >> 24) > SI_TH_LOW) continue; /* bestDist > TH_LOW (clamped distances are all > 50) */
-        /* second minimum over the multiset: lanes that do not hold the winner contribute their own best */
-        uint32_t contrib = second;
-        if (bestKey != gBest) contrib = min(contrib, bestD);
-        const uint32_t bestDist2 = wave_min_u32(contrib); /* 0x7FFFFFFF == INT_MAX when there is none */
-        const int bestDist = (int)(gBest >> 24);
-        const int slot2 = (int)(gBest & 0xFFF);
-        if (bestDist <= SI_TH_LOW && (float)bestDist < __fmul_rn((float)(int)bestDist2, nnratio)) {
-            /* wave-uniform branch; lane 0 updates the shared state */
-            if (lane == 0) {
-                const int prevOwner = owner[slot2];
-                if (prevOwner >= 0) m12[prevOwner] = -1;
-                m12[i1] = cand[slot2].idx;
-                owner[slot2] = i1;
-                ownerDist[slot2] = bestDist;
-                if (checkOri) {
-                    float rot = __fsub_rn(qq.angle, cand[slot2].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == SI_HISTO) bin = 0;
-                    rotBin[i1] = (uint8_t)bin;
-                    s_hist[bin]++; /* rotHist[bin].push_back(i1): never removed, even if stolen later */
+                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+                gBest = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+                if ((gBest >> 24) > SI_TH_LOW) continue; /* bestDist > TH_LOW */
+                const unsigned long long rest = mk & (mk - 1ull);
+                if (rest) {
+                    const int sec = __builtin_amdgcn_readfirstlane(__ffsll((long long)rest) - 1);
+                    bestDist2 = (uint32_t)__builtin_amdgcn_readlane((int)key, sec) >> 24;
+                } else if (full) {
+                    /* the second survivor lies beyond the list: it is at least as far as the last entry */
+                    const uint32_t dlast = (uint32_t)__builtin_amdgcn_readlane((int)key, M - 1) >> 24;
+                    if ((float)(int)(gBest >> 24) < __fmul_rn((float)(int)dlast, nnratio))
+                        bestDist2 = dlast; /* accepted whatever the true second is */
+                    else
+                        need_scan = true;
                 }
             }
-            __syncthreads(); /* one wave: orders lane 0's LDS updates before the next query's reads */
+            if (need_scan) {
+                nfb++;
+                gBest = si_full_scan(jb, gcand, ownerDist, c2, lane, qbuf[tq], r, invW, invH, &bestDist2);
+                if (gBest == 0xFFFFFFFFu) continue;
+                if ((gBest >> 24) > SI_TH_LOW) continue;
+            }
+            const int bestDist = (int)(gBest >> 24);
+            const int slot2 = (int)(gBest & 0xFFF);
+            if (bestDist <= SI_TH_LOW && (float)bestDist < __fmul_rn((float)(int)bestDist2, nnratio)) {
+                /* wave-uniform branch; lane 0 updates the shared state */
+                if (lane == 0) {
+                    const int i1 = (int)qbuf[tq].idx;
+                    const int prevOwner = owner[slot2];
+                    if (prevOwner >= 0) m12[prevOwner] = -1;
+                    m12[i1] = candIdx[slot2];
+                    owner[slot2] = i1;
+                    ownerDist[slot2] = bestDist;
+                    if (checkOri) {
+                        float rot = __fsub_rn(qbuf[tq].angle, candAngle[slot2]);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, factor));
+                        if (bin == SI_HISTO) bin = 0;
+                        rotBin[i1] = (uint8_t)bin;
+                        s_hist[bin]++; /* rotHist[bin].push_back(i1): never removed, even if stolen later */
+                    }
+                }
+                __syncthreads(); /* one wave: orders lane 0's LDS updates before the next query's reads */
+            }
         }
     }
     __syncthreads();
+    if (fallbacks && lane == 0 && nfb) atomicAdd(fallbacks, nfb);
     /* nmatches is counted from vnMatches12 at the end: the reference's running count equals it */
     if (checkOri) {
         /* ComputeThreeMaxima (fmatcher.cpp:2813-2854) */
@@ -268,18 +419,28 @@ k_search_init(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnra
     if (lane == 0) nmatch_out[blockIdx.x] = cnt;
 }
 
-size_t vk_search_init_lds(int cap, int max_c2, int lds_desc) {
-    return (size_t)max_c2 * (sizeof(SiCand) + sizeof(SiQuery) + 8 + (lds_desc ? 64 : 0)) + (size_t)cap * (4 + 1) + 64;
+size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M) { return (size_t)npairs * si_pair_bytes(max_c2, M); }
+
+static size_t si_topm_lds(int max_c2) { return (size_t)max_c2 * (sizeof(SiCand) + 4 * 4); }
+static size_t si_replay_lds(int cap, int max_c2) {
+    return (size_t)max_c2 * 16 + (size_t)cap * 5 + 64 * SI_MAX_M * 4 + 64 * sizeof(SiQuery) + 64;
 }
 
+size_t vk_search_init_lds(int cap, int max_c2) { return std::max(si_topm_lds(max_c2), si_replay_lds(cap, max_c2)); }
+
 int vk_search_init_set_max_lds(size_t bytes) {
-    return (int)hipFuncSetAttribute((const void*)k_search_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    int rc = (int)hipFuncSetAttribute((const void*)k_si_topm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_si_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2, int lds_desc) {
+                    int max_c2, int M, uint8_t* scratch, int* fallbacks) {
     if (npairs <= 0) return;
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), vk_search_init_lds(cap, max_c2, lds_desc), st, jobs, cap,
-                       imgW, imgH, window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, lds_desc);
+    const int chunks = (max_c2 + SI_QPB - 1) / SI_QPB;
+    hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
+                       window, max_c2, M, scratch);
+    hipLaunchKernelGGL(k_si_replay, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
+                       window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
 }

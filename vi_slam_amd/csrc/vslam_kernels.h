@@ -58,11 +58,16 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
                int32_t* sad, int cap);
 void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
                              uint8_t* tmp, uint8_t* out);
-size_t vk_search_init_lds(int cap, int max_c2, int lds_desc);
+size_t vk_search_init_lds(int cap, int max_c2);
+size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M);
 int vk_search_init_set_max_lds(size_t bytes);
+/* k_si_topm + k_si_replay; scratch = vk_search_init_scratch_bytes(); fallbacks (nullable) counts full re-scans */
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2, int lds_desc);
+                    int max_c2, int M, uint8_t* scratch, int* fallbacks);
+void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
+/* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
+void vk_copy_ranges(hipStream_t st, const CopyRanges& R);
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
                    int nslots, uint8_t* dst, size_t slot_bytes);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);

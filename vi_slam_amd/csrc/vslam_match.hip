@@ -67,7 +67,14 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
               feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap);
     HIPCHK(hipGetLastError());
     const size_t n = (size_t)npairs * feL->cap;
-    HIPCHK(hipMemcpyAsync(feL->h_stereo, sc.uRight, n * 8, hipMemcpyDeviceToHost, st)); /* uRight | depth */
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = feL->h_stereo;
+    R.src[0] = sc.uRight; /* uRight | depth */
+    R.bytes[0] = n * 8;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
     feL->stereo_pairs = npairs;
     for (int j = 0; j < npairs; j++) feL->stereo_slotL[j] = slotsL[j];
     return VSLAM_OK;
@@ -162,6 +169,10 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
+    if (!(nnratio >= 0.2f)) { /* see the distance clamp in vslam_init_kernel.hip */
+        g_err = "SearchForInitialization on the device needs nnratio >= 0.2";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
     HIPCHK(hipSetDevice(fe->p.device));
     InitJobs J;
     memset(&J, 0, sizeof(J));
@@ -188,33 +199,43 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
         g_err = "SearchForInitialization on the device supports at most 4096 octave-0 keypoints per frame";
         return VSLAM_ERR_UNSUPPORTED;
     }
-    /* descriptors of both frames' octave-0 keypoints ride in LDS when they fit (the serial query loop then
-     * never waits for HBM); beyond ~1100 octave-0 keypoints they stay in HBM/L2 */
-    int lds_desc = 1;
-    size_t lds = vk_search_init_lds(fe->cap, max_c2, 1);
-    if (lds > 150 * 1024) {
-        lds_desc = 0;
-        lds = vk_search_init_lds(fe->cap, max_c2, 0);
-    }
+    const size_t lds = vk_search_init_lds(fe->cap, max_c2);
     if (lds > 150 * 1024) {
         g_err = "SearchForInitialization: keypoint capacity too large for the LDS-resident matcher";
         return VSLAM_ERR_UNSUPPORTED;
     }
     if (!fe->init_lds_set) {
-        if (vk_search_init_set_max_lds(lds) != 0) {
-            g_err = "hipFuncSetAttribute(k_search_init) failed";
+        if (vk_search_init_set_max_lds(150 * 1024) != 0) {
+            g_err = "hipFuncSetAttribute(k_si_*) failed";
             return VSLAM_ERR_HIP;
         }
         fe->init_lds_set = true;
+    }
+    /* sorted candidate prefix per query; VSLAM_INIT_TOPM=<1..16> (tests force the re-scan path with 2) */
+    int M = 8;
+    if (const char* e = getenv("VSLAM_INIT_TOPM")) M = std::min(16, std::max(1, atoi(e)));
+    rc = vslam_ensure((void**)&fe->d_init_scratch, &fe->init_scratch_bytes,
+                      vk_search_init_scratch_bytes(npairs, max_c2, M) + 16);
+    if (rc) return rc;
+    if (!fe->d_init_fb) {
+        HIPCHK(hipMalloc((void**)&fe->d_init_fb, 16));
+        HIPCHK(hipMemset(fe->d_init_fb, 0, 16));
     }
     const size_t nm = (size_t)npairs * fe->cap;
     int32_t* d_m = (int32_t*)fe->d_init;
     float* d_p = (float*)(d_m + nm);
     int32_t* d_n = (int32_t*)(d_p + 2 * nm);
     vk_search_init(fe->stream, J, npairs, fe->cap, img_w, img_h, window, nnratio, check_orientation, d_m, d_p, d_n,
-                   max_c2, lds_desc);
+                   max_c2, M, fe->d_init_scratch, fe->d_init_fb);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(fe->h_init, fe->d_init, nm * 12 + (size_t)npairs * 4, hipMemcpyDeviceToHost, fe->stream));
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = fe->h_init;
+    R.src[0] = fe->d_init;
+    R.bytes[0] = nm * 12 + (size_t)npairs * 4;
+    R.n = 1;
+    vk_copy_ranges(fe->stream, R); /* device -> pinned host by a kernel (cheaper to enqueue than hipMemcpyAsync) */
+    HIPCHK(hipGetLastError());
     fe->init_pairs = npairs;
     return VSLAM_OK;
 }
@@ -262,12 +283,12 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
         }
     HIPCHK(hipSetDevice(fe->p.device));
     {
-        /* default: the whole matcher on the GPU (k_search_init).  VSLAM_INIT_MATCH=host keeps the distance
+        /* default: the whole matcher on the GPU (k_si_topm + k_si_replay).  VSLAM_INIT_MATCH=host keeps the distance
          * matrices on the GPU and replays the order-dependent part on the host (cross-check path). */
         const char* mode = getenv("VSLAM_INIT_MATCH");
         bool fits = true;
         for (int j = 0; j < npairs; j++) fits = fits && n1[j] <= fe->cap && n2[j] <= fe->cap;
-        fits = fits && fe->tab.quota[0] + 8 <= 4096;
+        fits = fits && fe->tab.quota[0] + 8 <= 4096 && nnratio >= 0.2f;
         if (!(mode && !strcmp(mode, "host")) && fits) {
             /* upload keypoints, counts and vbPrevMatched of every pair, run, download */
             size_t bytes = 0;
@@ -416,5 +437,16 @@ extern "C" int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x
     vk_dbg_atan2(fe->stream, dy, dx, n, fma, da);
     HIPCHK(hipMemcpyAsync(deg, da, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
     HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count) {
+    if (!fe || !count) return VSLAM_ERR_INVALID;
+    *count = 0;
+    if (!fe->d_init_fb) return VSLAM_OK;
+    HIPCHK(hipSetDevice(fe->p.device));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(hipMemcpy(count, fe->d_init_fb, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(fe->d_init_fb, 0, 4));
     return VSLAM_OK;
 }

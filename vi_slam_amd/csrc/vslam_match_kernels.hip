@@ -381,3 +381,51 @@ void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, con
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_pack_slots, dim3(8, nslots), dim3(256), 0, st, kps, desc, counts, cap, first, dst, slot_bytes);
 }
+
+/* --------------------------------------------------------------------------------------------------
+ * Result delivery without the runtime's copy path: a kernel stores up to four device ranges straight into
+ * pinned, device-visible host memory (hipHostMalloc).  One ~4 us launch replaces several hipMemcpyAsync
+ * calls, each of which costs ~60 us of host time on this stack -- the host thread, not the GPU, was the
+ * limit of the batched pipeline.  Ranges are dword-granular; uint4 when both ends are 16-byte aligned.
+ * Also used with src == nullptr to zero device ranges (replaces hipMemsetAsync).
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256) k_copy_ranges(CopyRanges R) {
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (int r = 0; r < R.n; r++) {
+        const size_t bytes = R.bytes[r];
+        uint8_t* dst = (uint8_t*)R.dst[r];
+        const uint8_t* src = (const uint8_t*)R.src[r];
+        if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+            const size_t n16 = bytes >> 4;
+            if (src)
+                for (size_t i = tid; i < n16; i += nth) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+            else
+                for (size_t i = tid; i < n16; i += nth) ((uint4*)dst)[i] = make_uint4(0, 0, 0, 0);
+            const size_t done = n16 << 4, tail = (bytes - done) >> 2;
+            for (size_t i = tid; i < tail; i += nth)
+                ((uint32_t*)(dst + done))[i] = src ? ((const uint32_t*)(src + done))[i] : 0u;
+        } else {
+            const size_t n4 = bytes >> 2;
+            for (size_t i = tid; i < n4; i += nth) ((uint32_t*)dst)[i] = src ? ((const uint32_t*)src)[i] : 0u;
+        }
+    }
+}
+
+void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
+    size_t total = 0;
+    for (int r = 0; r < R.n; r++) total += R.bytes[r];
+    if (!total) return;
+    const int blocks = (int)std::min<size_t>(256, (total / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
+}
+
+/* zero the (total, overflow) header of every slot's candidate buffer and the quadtree's 16-byte error word */
+__global__ void k_reset_headers(uint8_t* d_cand, size_t stride, int nimg, int32_t* d_err) {
+    const int t = threadIdx.x;
+    if (t < nimg) *(uint2*)(d_cand + (size_t)t * stride) = make_uint2(0u, 0u);
+    if (d_err && t < 4) d_err[t] = 0;
+}
+
+void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err) {
+    hipLaunchKernelGGL(k_reset_headers, dim3(1), dim3(64), 0, st, d_cand, cand_stride_bytes, nimg, d_err);
+}
