@@ -117,6 +117,12 @@ int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int ca
 int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** dev_kps, const uint8_t** dev_desc,
                           int* n);
 
+/* Host-side views of the same results: the context's pinned staging that the result kernel fills
+ * (vslam_kp[cap] / cap*32 bytes per slot).  After vslam_fe_extract_wait / vslam_frame_stereo_wait with
+ * kps == desc == NULL (n != NULL) the first n[slot] entries are valid until the next enqueue on this context --
+ * a consumer that reads them in place saves the copy into its own arrays. */
+int vslam_fe_slot_host_views(vslam_fe* fe, int slot, const vslam_kp** host_kps, const uint8_t** host_desc);
+
 /* GPU-side ordering between two contexts of one device: work enqueued on `waiter` after this call runs
  * after everything enqueued on `signal` so far (event record + stream wait, no host synchronisation). */
 int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal);

@@ -30,7 +30,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 ABI_SYMBOLS = [
     "vslam_fe_create", "vslam_fe_destroy", "vslam_last_error", "vslam_fe_tables", "vslam_fe_extract",
     "vslam_fe_extract_batch", "vslam_fe_level_size", "vslam_fe_level_copy", "vslam_fe_candidates",
-    "vslam_fe_slot_buffers", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
+    "vslam_fe_slot_buffers", "vslam_fe_slot_host_views", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
     "vslam_stereo_match", "vslam_stereo_match_batch", "vslam_search_for_initialization",
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
@@ -89,6 +89,7 @@ def lib():
         L.vslam_fe_level_copy.argtypes = [vp, i, i, i, vp, C.c_size_t]
         L.vslam_fe_candidates.argtypes = [vp, i, i, vp, i]
         L.vslam_fe_slot_buffers.argtypes = [vp, i, vp, vp, vp]
+        L.vslam_fe_slot_host_views.argtypes = [vp, i, vp, vp]
         L.vslam_fe_stream.argtypes = [vp]
         L.vslam_fe_stream.restype = vp
         L.vslam_hamming_top2.argtypes = [vp, vp, i, vp, i, vp, vp]
@@ -239,7 +240,7 @@ class FExtractor:
         """Enqueue one batched pass on HBM-resident images and return immediately (see
         vslam_fe_extract_batch_async); collect with wait()."""
         nimg = len(device_ptrs)
-        ptrs = (C.c_void_p * nimg)(*device_ptrs)
+        ptrs = device_ptrs if isinstance(device_ptrs, C.Array) else (C.c_void_p * nimg)(*device_ptrs)
         self._pending = (nimg, to_host)
         _check(lib().vslam_fe_extract_batch_async(self._h, nimg, ptrs, pitch, 1, vLappingArea[0], vLappingArea[1],
                                                   int(to_host)))
@@ -253,24 +254,30 @@ class FExtractor:
         if not to_host:
             _check(lib().vslam_fe_extract_wait(self._h, None, None, 0, n, mono))
             return [(n[i], mono[i]) for i in range(nimg)]
-        if getattr(self, "_out_kps", None) is None or self._out_kps.shape[0] < nimg:
-            self._out_kps = np.zeros((self.max_batch, self.cap), KP_DTYPE)
-            self._out_desc = np.zeros((self.max_batch, self.cap, 32), np.uint8)
-            self._out_kp_ptrs = (C.c_void_p * self.max_batch)(*[self._out_kps[i].ctypes.data
-                                                                for i in range(self.max_batch)])
-            self._out_d_ptrs = (C.c_void_p * self.max_batch)(*[self._out_desc[i].ctypes.data
-                                                               for i in range(self.max_batch)])
-        _check(lib().vslam_fe_extract_wait(self._h, self._out_kp_ptrs, self._out_d_ptrs, self.cap, n, mono))
+        self._host_views()
+        _check(lib().vslam_fe_extract_wait(self._h, None, None, 0, n, mono))
         if copy:
             return [(self._out_kps[i, :n[i]].copy(), self._out_desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
         return [(self._out_kps[i, :n[i]], self._out_desc[i, :n[i]], mono[i]) for i in range(nimg)]
+
+    def _host_views(self):
+        """numpy views of the context's pinned result staging (vslam_fe_slot_host_views): the result kernel
+        writes there, so reading in place needs no further copy."""
+        if getattr(self, "_out_kps", None) is None:
+            hk, hd = C.c_void_p(), C.c_void_p()
+            _check(lib().vslam_fe_slot_host_views(self._h, 0, C.byref(hk), C.byref(hd)))
+            nk = self.max_batch * self.cap
+            self._out_kps = np.ctypeslib.as_array((C.c_uint8 * (nk * 28)).from_address(hk.value)).view(KP_DTYPE) \
+                .reshape(self.max_batch, self.cap)
+            self._out_desc = np.ctypeslib.as_array((C.c_uint8 * (nk * 32)).from_address(hd.value)) \
+                .reshape(self.max_batch, self.cap, 32)
 
     # ---- Frame::Frame(stereo) hot section (frame.cpp:102-132), several frames per enqueue
     def frame_stereo_async(self, device_ptrs, pitch, bf, fx, to_host=True):
         """device_ptrs = [L0, R0, L1, R1, ...] HBM-resident images.  Enqueues extraction of all images and
         ComputeStereoMatches of every (L,R) pair; returns immediately.  Collect with frame_stereo_wait()."""
         nimg = len(device_ptrs)
-        ptrs = (C.c_void_p * nimg)(*device_ptrs)
+        ptrs = device_ptrs if isinstance(device_ptrs, C.Array) else (C.c_void_p * nimg)(*device_ptrs)
         self._pending = (nimg, to_host)
         _check(lib().vslam_frame_stereo_batch_async(self._h, nimg // 2, ptrs, pitch, 1, bf, fx, int(to_host)))
 
@@ -280,13 +287,7 @@ class FExtractor:
         nimg, to_host = self._pending
         npairs = nimg // 2
         n = (C.c_int * nimg)()
-        if getattr(self, "_out_kps", None) is None:
-            self._out_kps = np.zeros((self.max_batch, self.cap), KP_DTYPE)
-            self._out_desc = np.zeros((self.max_batch, self.cap, 32), np.uint8)
-            self._out_kp_ptrs = (C.c_void_p * self.max_batch)(*[self._out_kps[i].ctypes.data
-                                                                for i in range(self.max_batch)])
-            self._out_d_ptrs = (C.c_void_p * self.max_batch)(*[self._out_desc[i].ctypes.data
-                                                               for i in range(self.max_batch)])
+        self._host_views()
         if getattr(self, "_out_u", None) is None:
             self._out_u = np.zeros((self.max_batch, self.cap), np.float32)
             self._out_dep = np.zeros((self.max_batch, self.cap), np.float32)
@@ -294,8 +295,7 @@ class FExtractor:
                                                                for i in range(self.max_batch)])
             self._out_dep_ptrs = (C.c_void_p * self.max_batch)(*[self._out_dep[i].ctypes.data
                                                                  for i in range(self.max_batch)])
-        kp, dp = (self._out_kp_ptrs, self._out_d_ptrs) if to_host else (None, None)
-        _check(lib().vslam_frame_stereo_wait(self._h, kp, dp, self.cap, n, self._out_u_ptrs, self._out_dep_ptrs))
+        _check(lib().vslam_frame_stereo_wait(self._h, None, None, self.cap, n, self._out_u_ptrs, self._out_dep_ptrs))
         feats = [(self._out_kps[i, :n[i]], self._out_desc[i, :n[i]]) for i in range(nimg)] if to_host else \
             [(n[i], None) for i in range(nimg)]
         stereo = [(self._out_u[j, :n[2 * j]], self._out_dep[j, :n[2 * j]]) for j in range(npairs)]
@@ -420,13 +420,19 @@ class FMatcher:
         """jobs: list of (dev_kps1, dev_desc1, dev_n1, dev_kps2, dev_desc2, dev_n2, dev_prev_or_0) device
         addresses.  Enqueues the whole matcher for all pairs on the extractor's stream and returns."""
         n = len(jobs)
-        arr = (_InitJob * n)()
-        for j, t in enumerate(jobs):
-            arr[j] = _InitJob(*[C.c_void_p(v or None) for v in t])
+        arr = jobs if isinstance(jobs, C.Array) else self.make_init_jobs(jobs)
         w, h = img_size or (self.fe.width, self.fe.height)
         self._init_n = n
         _check(lib().vslam_search_init_dev_async(self.fe._h, n, arr, w, h, windowSize, self.mfNNratio,
                                                  int(self.mbCheckOrientation)))
+
+    @staticmethod
+    def make_init_jobs(jobs):
+        """ctypes job array for search_init_dev_async (build once when the device addresses are fixed)."""
+        arr = (_InitJob * len(jobs))()
+        for j, t in enumerate(jobs):
+            arr[j] = _InitJob(*[C.c_void_p(v or None) for v in t])
+        return arr
 
     def search_init_dev_wait(self, n1, want_prev=False):
         """-> list of (nmatches, vnMatches12[n1[j]], vbPrevMatched or None)."""

@@ -847,6 +847,14 @@ extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** de
     return VSLAM_OK;
 }
 
+extern "C" int vslam_fe_slot_host_views(vslam_fe* fe, int slot, const vslam_kp** host_kps,
+                                        const uint8_t** host_desc) {
+    if (!fe || slot < 0 || slot >= fe->B) return VSLAM_ERR_INVALID;
+    if (host_kps) *host_kps = fe->h_kps + (size_t)slot * fe->cap;
+    if (host_desc) *host_desc = fe->h_desc + (size_t)slot * fe->cap * 32;
+    return VSLAM_OK;
+}
+
 /* ------------------------------------------------------------------ matcher */
 int vslam_ensure(void** p, size_t* have, size_t want) {
     if (*have >= want) return VSLAM_OK;

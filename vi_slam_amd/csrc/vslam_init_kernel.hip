@@ -28,7 +28,7 @@
 #define SI_HISTO 30
 #define SI_GRID_COLS 64 /* FRAME_GRID_COLS, frame.h:42 */
 #define SI_GRID_ROWS 48 /* FRAME_GRID_ROWS, frame.h:43 */
-#define SI_QPB 32       /* queries per k_si_topm workgroup (4 waves x 8) */
+#define SI_QPB 8        /* queries per k_si_topm workgroup (4 waves x 2) */
 #define SI_MAX_M 16
 
 /* wave64 min-reduction on DPP (no LDS traffic, a few cycles per step instead of a ds_bpermute round trip):
@@ -275,15 +275,13 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     const SiQuery* gqry = (const SiQuery*)(gcand + max_c2);
     const uint32_t* topm = (const uint32_t*)(gqry + max_c2);
     const int c1 = hdr[0], c2 = hdr[1];
-    /* LDS: owner | ownerDist | candIdx | candAngle | m12 | kbuf | rotBin */
-    int32_t* owner = (int32_t*)sism;             /* vnMatches21 (query index), max_c2 */
-    int32_t* ownerDist = owner + max_c2;         /* vMatchedDistance */
-    int32_t* candIdx = ownerDist + max_c2;
-    float* candAngle = (float*)(candIdx + max_c2);
-    int32_t* m12 = (int32_t*)(candAngle + max_c2); /* vnMatches12, cap */
-    uint32_t* kbuf = (uint32_t*)(m12 + cap);     /* 64 queries x M keys */
-    SiQuery* qbuf = (SiQuery*)(kbuf + 64 * SI_MAX_M); /* 64 queries */
-    uint8_t* rotBin = (uint8_t*)(qbuf + 64);     /* bin of an accepted query, 255 = none */
+    /* LDS: ownerDist | ownerEntry | log | m12 | kbuf | rotBin */
+    int32_t* ownerDist = (int32_t*)sism;            /* vMatchedDistance, max_c2 */
+    int32_t* ownerEntry = ownerDist + max_c2;       /* log entry of the last query that took the slot */
+    uint32_t* alog = (uint32_t*)(ownerEntry + max_c2); /* accepted (query position << 12 | slot), in order */
+    int32_t* m12 = (int32_t*)(alog + max_c2);       /* vnMatches12, cap */
+    uint32_t* kbuf = (uint32_t*)(m12 + cap);        /* 64 queries x M keys */
+    uint8_t* rotBin = (uint8_t*)(kbuf + 64 * SI_MAX_M); /* bin of an accepted query, 255 = none */
     __shared__ int s_hist[SI_HISTO];
 
     int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
@@ -292,10 +290,8 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)imgH);
 
     for (int c = lane; c < c2; c += 64) {
-        owner[c] = -1;
         ownerDist[c] = 0x7FFFFFFF;
-        candIdx[c] = gcand[c].idx;
-        candAngle[c] = gcand[c].angle;
+        ownerEntry[c] = -1;
     }
     for (int i = lane; i < n1; i += 64) {
         m12[i] = -1;
@@ -304,21 +300,29 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     if (lane < SI_HISTO) s_hist[lane] = 0;
     __syncthreads();
 
+    /* The sequential part carries ONE piece of state, vMatchedDistance (ownerDist): a query's decision needs
+     * nothing else.  Accepted (query, slot) pairs are appended to a log; ownership ("last acceptor wins", which
+     * is what the reference's steal/undo amounts to), vnMatches12 and the rotation histogram are rebuilt from
+     * the log in parallel afterwards.  The next query's keys and owner distances are fetched one iteration
+     * ahead (patched in registers when the current query takes one of those slots), so the loop never waits
+     * for LDS. */
     const float r = (float)window;
-    const float factor = 1.0f / SI_HISTO;
-    int nfb = 0;
+    int nlog = 0, nfb = 0;
     for (int qb = 0; qb < c1; qb += 64) {
         const int nq = min(64, c1 - qb);
         __syncthreads();
         for (int i = lane; i < nq * M; i += 64) kbuf[i] = topm[(size_t)qb * M + i];
-        if (lane < nq) qbuf[lane] = gqry[qb + lane];
         __syncthreads();
+        uint32_t keyN = lane < M ? kbuf[lane] : 0xFFFFFFFFu;
+        uint32_t odN = keyN != 0xFFFFFFFFu ? (uint32_t)ownerDist[keyN & 0xFFF] : 0u;
         for (int tq = 0; tq < nq; tq++) {
-            const uint32_t key = lane < M ? kbuf[tq * M + lane] : 0xFFFFFFFFu;
+            const uint32_t key = keyN, od = odN;
+            if (tq + 1 < nq) {
+                keyN = lane < M ? kbuf[(tq + 1) * M + lane] : 0xFFFFFFFFu;
+                odN = keyN != 0xFFFFFFFFu ? (uint32_t)ownerDist[keyN & 0xFFF] : 0u;
+            }
             const bool valid = key != 0xFFFFFFFFu;
-            const uint32_t kd = key >> 24;
-            bool ok = false;
-            if (valid) ok = !((uint32_t)ownerDist[key & 0xFFF] <= kd); /* fmatcher.cpp:1022 */
+            const bool ok = valid && !(od <= (key >> 24)); /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
             const unsigned long long mv = __ballot(valid), mk = __ballot(ok);
             const bool full = __popcll(mv) == M;
             uint32_t gBest = 0xFFFFFFFFu, bestDist2 = 0x7FFFFFFFu;
@@ -345,36 +349,43 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
             }
             if (need_scan) {
                 nfb++;
-                gBest = si_full_scan(jb, gcand, ownerDist, c2, lane, qbuf[tq], r, invW, invH, &bestDist2);
+                gBest = si_full_scan(jb, gcand, ownerDist, c2, lane, gqry[qb + tq], r, invW, invH, &bestDist2);
                 if (gBest == 0xFFFFFFFFu) continue;
                 if ((gBest >> 24) > SI_TH_LOW) continue;
             }
             const int bestDist = (int)(gBest >> 24);
-            const int slot2 = (int)(gBest & 0xFFF);
+            const uint32_t slot2 = gBest & 0xFFF;
             if (bestDist <= SI_TH_LOW && (float)bestDist < __fmul_rn((float)(int)bestDist2, nnratio)) {
-                /* wave-uniform branch; lane 0 updates the shared state */
                 if (lane == 0) {
-                    const int i1 = (int)qbuf[tq].idx;
-                    const int prevOwner = owner[slot2];
-                    if (prevOwner >= 0) m12[prevOwner] = -1;
-                    m12[i1] = candIdx[slot2];
-                    owner[slot2] = i1;
                     ownerDist[slot2] = bestDist;
-                    if (checkOri) {
-                        float rot = __fsub_rn(qbuf[tq].angle, candAngle[slot2]);
-                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                        int bin = (int)roundf(__fmul_rn(rot, factor));
-                        if (bin == SI_HISTO) bin = 0;
-                        rotBin[i1] = (uint8_t)bin;
-                        s_hist[bin]++; /* rotHist[bin].push_back(i1): never removed, even if stolen later */
-                    }
+                    alog[nlog] = ((uint32_t)(qb + tq) << 12) | slot2;
                 }
-                __syncthreads(); /* one wave: orders lane 0's LDS updates before the next query's reads */
+                nlog++;
+                if (keyN != 0xFFFFFFFFu && (keyN & 0xFFF) == slot2) odN = (uint32_t)bestDist;
             }
         }
     }
     __syncthreads();
     if (fallbacks && lane == 0 && nfb) atomicAdd(fallbacks, nfb);
+    /* ownership: the last acceptor of a slot keeps it (fmatcher.cpp:1041-1049 undoes the previous owner) */
+    for (int e = lane; e < nlog; e += 64) atomicMax(&ownerEntry[alog[e] & 0xFFF], e);
+    __syncthreads();
+    const float factor = 1.0f / SI_HISTO;
+    for (int e = lane; e < nlog; e += 64) {
+        const uint32_t le = alog[e];
+        const SiQuery q = gqry[le >> 12];
+        const SiCand cd = gcand[le & 0xFFF];
+        if (ownerEntry[le & 0xFFF] == e) m12[q.idx] = cd.idx;
+        if (checkOri) {
+            float rot = __fsub_rn(q.angle, cd.angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            rotBin[q.idx] = (uint8_t)bin;
+            atomicAdd(&s_hist[bin], 1); /* rotHist[bin].push_back(i1): never removed, even if stolen later */
+        }
+    }
+    __syncthreads();
     /* nmatches is counted from vnMatches12 at the end: the reference's running count equals it */
     if (checkOri) {
         /* ComputeThreeMaxima (fmatcher.cpp:2813-2854) */
@@ -423,7 +434,7 @@ size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M) { return (siz
 
 static size_t si_topm_lds(int max_c2) { return (size_t)max_c2 * (sizeof(SiCand) + 4 * 4); }
 static size_t si_replay_lds(int cap, int max_c2) {
-    return (size_t)max_c2 * 16 + (size_t)cap * 5 + 64 * SI_MAX_M * 4 + 64 * sizeof(SiQuery) + 64;
+    return (size_t)max_c2 * 12 + (size_t)cap * 5 + 64 * SI_MAX_M * 4 + 64;
 }
 
 size_t vk_search_init_lds(int cap, int max_c2) { return std::max(si_topm_lds(max_c2), si_replay_lds(cap, max_c2)); }

@@ -93,7 +93,9 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
     __shared__ int s_size, s_M, s_nexp, s_cut;
 
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, slot = blockIdx.y;
+    /* grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
+     * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
+    const int level = blockIdx.y, slot = blockIdx.x;
 #ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
                            of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
     int dbgn = 0;
@@ -531,7 +533,7 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots) {
-    hipLaunchKernelGGL(k_octree, dim3(nlevels, nslots), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
+    hipLaunchKernelGGL(k_octree, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
                        cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag);
 }
 
