@@ -120,6 +120,8 @@ struct vslam_fe {
     int16_t* d_xa[VSLAM_MAX_LEVELS] = {};
     uint16_t* d_ytab[VSLAM_MAX_LEVELS] = {};
     int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
+    uint16_t* d_qbase[VSLAM_MAX_LEVELS] = {};    /* k_resize_level_v2 quad tables (nullptr: level uses v1) */
+    ResizeQuad* d_quads[VSLAM_MAX_LEVELS] = {};
     /* FAST cells */
     std::vector<vslam::HostCell> cells;
     int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};

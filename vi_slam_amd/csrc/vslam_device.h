@@ -99,6 +99,15 @@ struct MatJobs {
     MatJob job[VSLAM_MAX_MAT_JOBS];
 };
 
+/* k_resize_level_v2: four consecutive output pixels of a row.  base[] (separate u16 array) is the first source
+ * column of an 8-byte window that holds all eight taps; sel[j] is the v_perm_b32 selector that pulls output
+ * j's two taps out of that window as packed u16 (tap0 | tap1 << 16); coef[j] = a0 | a1 << 16 (11-bit fixed
+ * point, cv::resize INTER_LINEAR 8u). */
+struct ResizeQuad {
+    uint32_t sel[4];
+    uint32_t coef[4];
+};
+
 /* Up to four dword-granular ranges for k_copy_ranges (src == nullptr: zero-fill). */
 struct CopyRanges {
     void* dst[4];

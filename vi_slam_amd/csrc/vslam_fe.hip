@@ -32,6 +32,8 @@ static void free_ctx(vslam_fe* fe) {
         hipFree(fe->d_xa[l]);
         hipFree(fe->d_ytab[l]);
         hipFree(fe->d_yb[l]);
+        hipFree(fe->d_qbase[l]);
+        hipFree(fe->d_quads[l]);
     }
     hipFree(fe->d_cells);
     hipFree(fe->d_cand);
@@ -145,6 +147,13 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if ((rc = upload(&fe->d_xa[l], r.xa.data(), r.xa.size() * 2))) return rc;
         if ((rc = upload(&fe->d_ytab[l], r.ytab.data(), r.ytab.size() * 2))) return rc;
         if ((rc = upload(&fe->d_yb[l], r.yb.data(), r.yb.size() * 2))) return rc;
+        std::vector<uint16_t> qbase;
+        std::vector<uint32_t> quads;
+        const char* gen = getenv("VSLAM_KERNELS");
+        if (!(gen && !strcmp(gen, "v1")) && vslam::build_resize_quads(r, s.w, d.w, qbase, quads)) {
+            if ((rc = upload(&fe->d_qbase[l], qbase.data(), qbase.size() * 2))) return rc;
+            if ((rc = upload(&fe->d_quads[l], quads.data(), quads.size() * 4))) return rc;
+        }
     }
 
     /* FAST cells */
@@ -490,9 +499,14 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     vk_reset_headers(st, fe->d_cand, fe->cand_stride, nimg, fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr);
     const bool prof = fe->profiling;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
-    for (int l = 1; l < L; l++)
-        vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
-                        fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
+    for (int l = 1; l < L; l++) {
+        if (fe->d_quads[l])
+            vk_resize_level_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
+                               fe->d_qbase[l], fe->d_quads[l], fe->d_ytab[l], fe->d_yb[l], nimg);
+        else
+            vk_resize_level(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
+                            fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
+    }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
     if (fe->use_v2_fast)
         vk_fast_cells_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),

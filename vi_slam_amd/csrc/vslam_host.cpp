@@ -111,6 +111,32 @@ void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables& r) {
     }
 }
 
+bool build_resize_quads(const ResizeTables& r, int sw, int dw, std::vector<uint16_t>& qbase,
+                        std::vector<uint32_t>& quads) {
+    if (sw < 8) return false;
+    const int nq = (dw + 3) / 4;
+    qbase.assign(nq, 0);
+    quads.assign((size_t)nq * 8, 0);
+    for (int q = 0; q < nq; q++) {
+        int lo = 1 << 30, hi = -1;
+        for (int j = 0; j < 4; j++) {
+            const int dx = std::min(4 * q + j, dw - 1); /* outputs past the row end repeat the last column */
+            lo = std::min(lo, (int)r.xtab[2 * dx]);
+            hi = std::max(hi, (int)r.xtab[2 * dx + 1]);
+        }
+        const int base = std::min(lo, sw - 8); /* the 8-byte window must stay inside the source row */
+        if (hi - base > 7) return false;
+        qbase[q] = (uint16_t)base;
+        for (int j = 0; j < 4; j++) {
+            const int dx = std::min(4 * q + j, dw - 1);
+            const uint32_t o0 = r.xtab[2 * dx] - base, o1 = r.xtab[2 * dx + 1] - base;
+            quads[(size_t)q * 8 + j] = o0 | (0x0cu << 8) | (o1 << 16) | (0x0cu << 24);
+            quads[(size_t)q * 8 + 4 + j] = (uint32_t)(uint16_t)r.xa[2 * dx] | ((uint32_t)(uint16_t)r.xa[2 * dx + 1] << 16);
+        }
+    }
+    return true;
+}
+
 void build_cells(int level, int lw, int lh, std::vector<HostCell>& out) {
     /* fextractor.cpp:764-797 */
     const float W = 30;

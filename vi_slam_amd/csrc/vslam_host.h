@@ -37,6 +37,11 @@ struct ResizeTables {
     std::vector<int16_t> xa, yb;
 };
 void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables& r);
+/* Quad form of the column table for k_resize_level_v2 (see ResizeQuad in vslam_device.h): qbase[q], and per
+ * quad 4 selectors + 4 packed coefficient pairs (8 uint32).  Returns false when some quad's taps do not fit an
+ * 8-byte window (scale factor > 2) or the source is narrower than 8 px -- the caller keeps the v1 kernel. */
+bool build_resize_quads(const ResizeTables& r, int sw, int dw, std::vector<uint16_t>& qbase,
+                        std::vector<uint32_t>& quads);
 
 /* FAST cell grid of one level (fextractor.cpp:764-797).  Cells are listed in the reference's visiting
  * order (row-major, skipped cells omitted). */

@@ -380,3 +380,58 @@ void vk_fast_cells_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
 
 int vk_fast_v2_max_window() { return 66; } /* widest window the fixed LDS pitch supports (needs x+3 < FP-3) */
 int vk_fast_v2_max_rows() { return 128 + 6; } /* keep mask: 2 words per interior row, <= 256 threads */
+
+/* ------------------------------------------------------------------------------------------------
+ * pyramid level, second generation: one thread = four consecutive output pixels of a row (same arithmetic as
+ * k_resize_level, cv::resize INTER_LINEAR 8u).  All eight taps of a row lie in one 8-byte window of the source
+ * row (host table: window start per quad), so a thread issues two 8-byte loads instead of sixteen byte loads;
+ * a v_perm_b32 per output picks its two taps as packed u16 and v_dot2_i32_i16 does the horizontal pass.
+ * ---------------------------------------------------------------------------------------------- */
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int hdot2(uint32_t taps, uint32_t coef) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, taps), __builtin_bit_cast(short2v, coef), 0, false);
+}
+
+__global__ void __launch_bounds__(256)
+k_resize_level_v2(uint8_t* pyr, size_t slot_stride, BatchSrc src, LevelGeom sg, LevelGeom dg, int src_level,
+                  const uint16_t* __restrict__ qbase, const ResizeQuad* __restrict__ quads,
+                  const uint16_t* __restrict__ ytab, const int16_t* __restrict__ yb, int nq) {
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int slot = blockIdx.z;
+    if (q >= nq || dy >= dg.h) return;
+    int spitch;
+    const uint8_t* S = level_base_v2(pyr, slot_stride, src, sg, src_level, slot, &spitch);
+    const int sy0 = ytab[2 * dy], sy1 = ytab[2 * dy + 1];
+    const int b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+    const int base = qbase[q];
+    const uint4 sel = *(const uint4*)quads[q].sel;
+    const uint4 cf = *(const uint4*)quads[q].coef;
+    const uint32_t* r0 = (const uint32_t*)(S + (size_t)sy0 * spitch + base); /* unaligned dwords, in-row */
+    const uint32_t* r1 = (const uint32_t*)(S + (size_t)sy1 * spitch + base);
+    const uint32_t lo0 = r0[0], hi0 = r0[1], lo1 = r1[0], hi1 = r1[1];
+    uint32_t out = 0;
+#define RZ_ONE(j, SEL, CF)                                                                                 \
+    {                                                                                                      \
+        const int h0 = hdot2(__builtin_amdgcn_perm(hi0, lo0, SEL), CF);                                    \
+        const int h1 = hdot2(__builtin_amdgcn_perm(hi1, lo1, SEL), CF);                                    \
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;                     \
+        out |= (uint32_t)(v & 0xFF) << (8 * (j));                                                          \
+    }
+    RZ_ONE(0, sel.x, cf.x)
+    RZ_ONE(1, sel.y, cf.y)
+    RZ_ONE(2, sel.z, cf.z)
+    RZ_ONE(3, sel.w, cf.w)
+#undef RZ_ONE
+    /* rows are padded to a multiple of 128 bytes, so the last quad may spill into the padding */
+    *(uint32_t*)(pyr + (size_t)slot * slot_stride + dg.off + (size_t)dy * dg.pitch + 4 * q) = out;
+}
+
+void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
+                        const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,
+                        const uint16_t* ytab, const int16_t* yb, int nslots) {
+    const int nq = (dg.w + 3) / 4;
+    dim3 grid((nq + 63) / 64, (dg.h + 3) / 4, nslots);
+    hipLaunchKernelGGL(k_resize_level_v2, grid, dim3(256), 0, st, pyr, slot_stride, src, sg, dg, src_level, qbase,
+                       quads, ytab, yb, nq);
+}
