@@ -137,7 +137,7 @@ struct vslam_fe {
     int n_blur_tiles = 0;
     int32_t taps[7];
     /* v2 kernels (vslam_kernels_v2.hip); VSLAM_KERNELS=v1 in the environment selects the first generation */
-    bool use_v2_fast = false, use_v2_blur = false;
+    bool use_v2_fast = false, use_v2_blur = false, use_v3_fast = false;
     uint32_t* d_blur_tasks = nullptr;
     int n_blur_tasks = 0;
     /* selection + outputs */

@@ -222,6 +222,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         const bool v1 = gen && !strcmp(gen, "v1");
         fe->use_v2_blur = !v1;
         fe->use_v2_fast = !v1 && maxw <= vk_fast_v2_max_window() && maxh <= vk_fast_v2_max_rows();
+        fe->use_v3_fast = !(gen && !strcmp(gen, "v2")); /* same limits as v2 (LDS pitch, keep mask) */
     }
 
     const size_t nk = (size_t)fe->B * fe->cap;
@@ -508,7 +509,10 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    if (fe->use_v2_fast)
+    if (fe->use_v2_fast && fe->use_v3_fast)
+        vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
+                         fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, nimg);
+    else if (fe->use_v2_fast)
         vk_fast_cells_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
                          fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_rows, nimg);
     else

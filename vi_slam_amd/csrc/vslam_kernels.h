@@ -30,6 +30,9 @@ void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t,
 
 void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                  uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int nslots);
+void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int nslots);
 void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
                         const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,
                         const uint16_t* ytab, const int16_t* yb, int nslots);

@@ -435,3 +435,257 @@ void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const 
     hipLaunchKernelGGL(k_resize_level_v2, grid, dim3(256), 0, st, pyr, slot_stride, src, sg, dg, src_level, qbase,
                        quads, ytab, yb, nq);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * FAST cells, third generation.  Same results as k_fast_cells / k_fast_cells_v2; the differences are all in
+ * how many instructions the pre-test and the survivor bookkeeping cost:
+ *   - the window is staged one column to the left (LDS column = window column + 1), so the four interior
+ *     pixels x = 4q..4q+3 of a row and their up/down compass pixels are aligned dwords and the left/right ones
+ *     come out of two v_alignbyte_b32;
+ *   - the compass pre-test runs on FOUR pixels per thread in packed u16 arithmetic: "ring pixel darker than
+ *     v - T" is v_pk_sub_u16 clamp(v - T, c) != 0, "brighter than v + T" is v_pk_sub_u16 clamp(c, v + T) != 0,
+ *     and the four adjacent-pair terms fold into (down|up) & (right|left) = two v_or + one v_pk_min_u16;
+ *   - survivors are counted per thread, placed by ONE wave scan (DPP) and ONE LDS atomic per wave for all
+ *     three lists, instead of two ballots + two atomics per pixel column;
+ *   - the lists are disjoint (dark-only, bright-only, both), so a single pass of the min3/max3 networks
+ *     covers them without a barrier in between.
+ * ---------------------------------------------------------------------------------------------- */
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { /* per u16 half: max(a - b, 0) */
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t v) { /* lanes without a source read 0 */
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += dpp_or0<0x111, 0xf>(v); /* row_shr:1 */
+    v += dpp_or0<0x112, 0xf>(v); /* row_shr:2 */
+    v += dpp_or0<0x114, 0xf>(v); /* row_shr:4 */
+    v += dpp_or0<0x118, 0xf>(v); /* row_shr:8 */
+    v += dpp_or0<0x142, 0xa>(v); /* row_bcast:15 -> rows 1,3 */
+    v += dpp_or0<0x143, 0xc>(v); /* row_bcast:31 -> rows 2,3 */
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
+                const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
+                int iniTh, int minTh, int tile_rows) {
+    extern __shared__ __align__(16) uint8_t smem3[];
+    uint8_t* win = smem3;                        /* tile_rows x FP; window column c at LDS column c + 1 */
+    uint8_t* sc = win + tile_rows * FP;          /* (tile_rows-4) x FP, interior at (1..ih, 1..iw) */
+    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * FP); /* 2 words per interior row */
+    const int lcap = (tile_rows - 6) * 64;
+    uint16_t* listD = (uint16_t*)(keep + (tile_rows - 6) * 2); /* dark-only up from 0, "both" down from lcap-1 */
+    uint16_t* listB = listD + lcap;                             /* bright-only */
+    __shared__ unsigned long long s_cnt; /* nD | nB << 21 | nX << 42 */
+    __shared__ uint32_t s_wave_tot[4];
+    __shared__ int s_any;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = blockIdx.y;
+    const int per_xcd = (ncells + 7) >> 3; /* XCD-aware cell order, see k_fast_cells_v2 */
+    const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (cell >= ncells) return;
+    const CellDesc cd = cells[cell];
+    const int level = cd.level;
+    const LevelGeom lg = g.lv[level];
+    int pitch;
+    const uint8_t* img = level_base_v2(pyr, slot_stride, src, lg, level, slot, &pitch);
+    const int ww = cd.x1 - cd.x0, wh = cd.y1 - cd.y0;
+    const int iw = ww - 6, ih = wh - 6;
+    const int nwords = ih * 2;
+
+    /* stage columns x0-1 .. x1+2 (x0 >= 16; windows end >= 13 px before the row end) as dwords */
+    {
+        const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
+        const int srow = tid >> 4, scol = (tid & 15) * 4;
+        for (int y = srow; y < wh; y += 16) {
+            if (scol < ww + 1) *(uint32_t*)(win + y * FP + scol) = *(const uint32_t*)(gsrc + (size_t)y * pitch + scol);
+            if (scol == 0 && ww + 1 > 64) *(uint32_t*)(win + y * FP + 64) = *(const uint32_t*)(gsrc + (size_t)y * pitch + 64);
+        }
+    }
+    for (int i = tid; i < (ih + 2) * (FP / 4); i += 256) ((uint32_t*)sc)[i] = 0;
+    if (tid < nwords) keep[tid] = 0;
+    if (tid == 0) {
+        s_any = 0;
+        s_cnt = 0ull;
+    }
+    __syncthreads();
+
+    const int QW = (iw + 3) >> 2;               /* quads per interior row */
+    const int qsh = QW > 8 ? 4 : 3;             /* 16 or 8 quad columns per sweep */
+    const int qx = tid & ((1 << qsh) - 1), qly = tid >> qsh;
+    const uint32_t* W32 = (const uint32_t*)win;
+    int T = iniTh;
+    for (int stage = 0; stage < 2; stage++) {
+        const uint32_t TT = (uint32_t)T | ((uint32_t)T << 16);
+        for (int ly0 = 0; ly0 < ih; ly0 += (256 >> qsh)) { /* block-uniform trip count */
+            const int ly = ly0 + qly;
+            uint32_t mD = 0, mB = 0;
+            if (qx < QW && ly < ih) {
+                const uint32_t* rowc = W32 + (ly + 3) * (FP / 4) + qx;
+                const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
+                const uint32_t U = W32[ly * (FP / 4) + qx + 1], Dn = W32[(ly + 6) * (FP / 4) + qx + 1];
+                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, A0, 1); /* columns x-3 */
+                const uint32_t Rt = __builtin_amdgcn_alignbyte(E, C, 3);  /* columns x+3 */
+#define EVN(x) __builtin_amdgcn_perm(0u, (x), 0x0c020c00u) /* pixels 0,2 as u16 halves */
+#define ODD(x) __builtin_amdgcn_perm(0u, (x), 0x0c030c01u) /* pixels 1,3 */
+                uint32_t passD[2], passB[2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const uint32_t v = par ? ODD(C) : EVN(C);
+                    const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
+                    const uint32_t u = par ? ODD(U) : EVN(U), d = par ? ODD(Dn) : EVN(Dn);
+                    const uint32_t l = par ? ODD(Lf) : EVN(Lf), r = par ? ODD(Rt) : EVN(Rt);
+                    /* dark: ring < v - T; bright: ring > v + T; (down|up) & (right|left) */
+                    passD[par] = pk_min(pk_sub_sat(vm, d) | pk_sub_sat(vm, u), pk_sub_sat(vm, r) | pk_sub_sat(vm, l));
+                    passB[par] = pk_min(pk_sub_sat(d, vp) | pk_sub_sat(u, vp), pk_sub_sat(r, vp) | pk_sub_sat(l, vp));
+                }
+#undef EVN
+#undef ODD
+                /* halves -> bit per pixel: bit0 px0, bit1 px1, bit2 px2, bit3 px3 */
+                const uint32_t one = 0x00010001u;
+                uint32_t t = pk_min(passD[0], one) | (pk_min(passD[1], one) << 1);
+                mD = (t & 3u) | ((t >> 14) & 0xCu);
+                t = pk_min(passB[0], one) | (pk_min(passB[1], one) << 1);
+                mB = (t & 3u) | ((t >> 14) & 0xCu);
+                const int rem = iw - 4 * qx; /* >= 1 */
+                const uint32_t vmask = rem >= 4 ? 0xFu : ((1u << rem) - 1u);
+                mD &= vmask;
+                mB &= vmask;
+            }
+            const uint32_t mX = mD & mB;
+            mD &= ~mX;
+            mB &= ~mX;
+            const uint32_t cntp = __popc(mD) | (__popc(mB) << 10) | (__popc(mX) << 20);
+            const uint32_t incl = wave_incl_scan(cntp);
+            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (wtot) { /* wave-uniform */
+                unsigned long long base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&s_cnt, (unsigned long long)(wtot & 0x3FFu) |
+                                                 ((unsigned long long)((wtot >> 10) & 0x3FFu) << 21) |
+                                                 ((unsigned long long)(wtot >> 20) << 42));
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+                const unsigned long long b64 = ((unsigned long long)bhi << 32) | blo;
+                const uint32_t excl = incl - cntp;
+                uint32_t oD = (uint32_t)(b64 & 0x1FFFFFu) + (excl & 0x3FFu);
+                uint32_t oB = (uint32_t)((b64 >> 21) & 0x1FFFFFu) + ((excl >> 10) & 0x3FFu);
+                uint32_t oX = (uint32_t)(b64 >> 42) + (excl >> 20);
+                const uint32_t code = (uint32_t)(ly * 64 + 4 * qx);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (mD & (1u << k)) listD[oD++] = (uint16_t)(code + k);
+                    if (mB & (1u << k)) listB[oB++] = (uint16_t)(code + k);
+                }
+                uint32_t mx = mX; /* rare */
+                while (mx) {
+                    const int k = __ffs(mx) - 1;
+                    mx &= mx - 1;
+                    listD[lcap - 1 - (int)(oX++)] = (uint16_t)(code + k);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned long long tot = s_cnt;
+        const int nD = (int)(tot & 0x1FFFFFu), nB = (int)((tot >> 21) & 0x1FFFFFu), nX = (int)(tot >> 42);
+        const int ntot = nD + nB + nX;
+        /* one pass of the networks over three disjoint lists: no two threads touch the same score byte */
+        for (int i = tid; i < ntot; i += 256) {
+            int code, a;
+            if (i < nD) {
+                code = listD[i];
+                a = fast_half_score<1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
+            } else if (i < nD + nB) {
+                code = listB[i - nD];
+                a = fast_half_score<-1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
+            } else {
+                code = listD[lcap - 1 - (i - nD - nB)];
+                const uint8_t* c = win + ((code >> 6) + 3) * FP + (code & 63) + 4;
+                a = max(fast_half_score<1>(c), fast_half_score<-1>(c));
+            }
+            sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+        }
+        __syncthreads();
+        /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
+        int any = 0;
+        for (int i = tid; i < ntot; i += 256) {
+            const int code = i < nD ? listD[i] : i < nD + nB ? listB[i - nD] : listD[lcap - 1 - (i - nD - nB)];
+            const int ly = code >> 6, x = code & 63;
+            const uint8_t* q = sc + (ly + 1) * FP + x + 1;
+            const int s = q[0];
+            if (s >= T) {
+                const int mx = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
+                                   max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
+                if (s > mx) {
+                    atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
+                    any = 1;
+                }
+            }
+        }
+        if (any) s_any = 1; /* benign race, all writers store 1 */
+        __syncthreads();
+        if (s_any || stage == 1 || minTh == iniTh) break; /* block-uniform */
+        /* empty at iniThFAST: the whole cell again at minThFAST (fextractor.cpp:800-807).  Scores already in
+         * the tile belong to pixels that are listed again (the pre-test is monotone in T) and get rewritten. */
+        T = minTh;
+        if (tid == 0) s_cnt = 0ull;
+        __syncthreads();
+    }
+
+    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..) */
+    uint32_t bits = 0;
+    const int kly = tid >> 1, kxb = (tid & 1) * 32;
+    if (tid < nwords) bits = keep[tid];
+    const uint32_t cnt = __popc(bits);
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (lane == 63) s_wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < wv) wave_off += s_wave_tot[k];
+        total += s_wave_tot[k];
+    }
+    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    CellOut* cout = (CellOut*)(hdr + 2);
+    uint32_t* cand = (uint32_t*)(cout + ncells);
+    if (tid == 0) {
+        cout[cell].base = cd.base;
+        cout[cell].count = total;
+    }
+    if (bits == 0) return;
+    uint32_t o = cd.base + wave_off + incl - cnt;
+    const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
+    while (bits) {
+        const int k = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
+        cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+    }
+}
+
+void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
+                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int nslots) {
+    const size_t shm = (size_t)tile_rows * FP + (size_t)(tile_rows - 4) * FP + (size_t)(tile_rows - 6) * 8 +
+                       (size_t)(tile_rows - 6) * 64 * 2 * 2 + 16;
+    hipLaunchKernelGGL(k_fast_cells_v3, dim3(((ncells + 7) / 8) * 8, nslots), dim3(256), shm, st, pyr, slot_stride,
+                       src, g, cells, cand_region, cand_stride, ncells, std::min(iniTh, 256), std::min(minTh, 256),
+                       tile_rows);
+}
