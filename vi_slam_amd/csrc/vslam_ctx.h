@@ -140,6 +140,7 @@ struct vslam_fe {
     bool use_v2_fast = false, use_v2_blur = false, use_v3_fast = false;
     uint32_t* d_blur_tasks = nullptr;
     int n_blur_tasks = 0;
+    int blur_rows = 32; /* output rows per wave task of k_blur7_v2 (VSLAM_BLUR_ROWS) */
     /* selection + outputs */
     SelKp* d_sel = nullptr;
     SelKp* h_sel = nullptr; /* pinned, B*cap */

@@ -208,10 +208,12 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
     vk_upload_disc(fe->tab.disc_u.data(), fe->tab.disc_v.data(), (int)fe->tab.disc_u.size());
     {
-        /* marching-rows blur: one wave task per (level, 32-row chunk, 248-column strip) */
+        /* marching-rows blur: one wave task per (level, row chunk, 248-column strip) */
+        if (const char* e = getenv("VSLAM_BLUR_ROWS")) fe->blur_rows = std::min(512, std::max(8, atoi(e)));
         std::vector<uint32_t> tasks;
         for (int l = 0; l < p.nlevels; l++) {
-            const int ns = std::max(1, (fe->geom.lv[l].w + 247) / 248), nc = (fe->geom.lv[l].h + 31) / 32;
+            const int br = fe->blur_rows;
+            const int ns = std::max(1, (fe->geom.lv[l].w + 247) / 248), nc = (fe->geom.lv[l].h + br - 1) / br;
             for (int c = 0; c < nc; c++)
                 for (int s = 0; s < ns; s++) tasks.push_back(((uint32_t)l << 24) | ((uint32_t)c << 12) | (uint32_t)s);
         }
@@ -220,7 +222,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if ((rc = upload(&fe->d_blur_tasks, tasks.data(), tasks.size() * 4))) return rc;
         const char* gen = getenv("VSLAM_KERNELS");
         const bool v1 = gen && !strcmp(gen, "v1");
-        fe->use_v2_blur = !v1;
+        fe->use_v2_blur = !v1 && fe->geom.lv[p.nlevels - 1].w >= 8; /* its row fetch reads 8-byte windows */
         fe->use_v2_fast = !v1 && maxw <= vk_fast_v2_max_window() && maxh <= vk_fast_v2_max_rows();
         fe->use_v3_fast = !(gen && !strcmp(gen, "v2")); /* same limits as v2 (LDS pitch, keep mask) */
     }
@@ -553,7 +555,7 @@ static int wait_candidates(vslam_fe* fe, int nimg) {
 static void enqueue_blur(vslam_fe* fe, int nimg) {
     if (fe->use_v2_blur)
         vk_blur7_v2(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks,
-                    fe->n_blur_tasks, fe->taps, nimg);
+                    fe->n_blur_tasks, fe->taps, fe->blur_rows, nimg);
     else
         vk_blur7(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles,
                  fe->n_blur_tiles, fe->taps, nimg);

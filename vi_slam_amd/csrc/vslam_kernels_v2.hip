@@ -31,7 +31,6 @@ __device__ __forceinline__ int refl101_v2(int p, int len) {
 /* ------------------------------------------------------------------------------------------------
  * blur
  * ---------------------------------------------------------------------------------------------- */
-#define BV_ROWS 32   /* output rows per wave task */
 #define BV_OUTW 248  /* output columns per strip: lanes 1..62 of 64, 4 px each */
 
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
@@ -47,7 +46,7 @@ struct BlurTapsV2 {
 
 __global__ void __launch_bounds__(256)
 k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
-           const uint32_t* __restrict__ tasks, int ntasks, int nslots, BlurTapsV2 T) {
+           const uint32_t* __restrict__ tasks, int ntasks, int nslots, int rows_per_task, BlurTapsV2 T) {
     const int lane = threadIdx.x & 63;
     /* XCD-aware order (workgroups b, b+8 share an L2): the (slot, task) list is cut into 8 contiguous parts */
     const int tpb = (ntasks + 3) >> 2, nwork = tpb * nslots, per_xcd = (nwork + 7) >> 3;
@@ -56,7 +55,9 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
     const int slot = wk / tpb;
     const int task = (wk - slot * tpb) * 4 + (threadIdx.x >> 6);
     if (task >= ntasks) return; /* wave-uniform */
-    const uint32_t td = tasks[task]; /* level << 24 | rowchunk << 12 | strip */
+    /* level << 24 | rowchunk << 12 | strip; wave-uniform by construction -- say so, or every loop bound and
+     * branch below is treated as divergent */
+    const uint32_t td = (uint32_t)__builtin_amdgcn_readfirstlane((int)tasks[task]);
     const int level = td >> 24, rc = (td >> 12) & 0xFFF, strip = td & 0xFFF;
     const LevelGeom lg = g.lv[level];
     int pitch;
@@ -66,23 +67,29 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
     /* the last strip is shifted left so that it ends at the image edge (overlap is rewritten identically) */
     const int ox0 = min(strip * BV_OUTW, max(w - BV_OUTW, 0)); /* first output column of the strip */
     const int x = ox0 - 4 + lane * 4;                          /* first of this lane's 4 columns */
-    const int y0 = rc * BV_ROWS;
-    const int nrows = min(BV_ROWS, h - y0);
-    const bool fast_x = x >= 0 && x + 3 < w;
-    /* columns of a border lane, reflected once */
+    const int y0 = rc * rows_per_task;
+    const int nrows = min(rows_per_task, h - y0);
+    /* Branch-free row fetch: every lane reads the 8-byte window [bc, bc+8) of the row (inside the row for any
+     * w >= 8) and picks its four columns -- reflected once at the image border -- with one v_perm_b32.  (A
+     * divergent "interior dword / border bytes" choice made the compiler wait for each load where it was
+     * issued, i.e. one full memory latency per row.) */
     int bx[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) bx[k] = refl101_v2(x + k, w);
+    const int bc = min(min(min(bx[0], bx[1]), min(bx[2], bx[3])), w - 8);
+    const uint32_t sel = (uint32_t)(bx[0] - bc) | ((uint32_t)(bx[1] - bc) << 8) | ((uint32_t)(bx[2] - bc) << 16) |
+                         ((uint32_t)(bx[3] - bc) << 24);
 
     uint32_t hq[7][4]; /* ring of row-pass results, hq[r % 7] */
-    auto load_row = [&](int yy) -> uint32_t {
-        const uint8_t* row = img + (size_t)refl101_v2(yy, h) * pitch;
-        if (fast_x) return *(const uint32_t*)(row + x);
-        return (uint32_t)row[bx[0]] | ((uint32_t)row[bx[1]] << 8) | ((uint32_t)row[bx[2]] << 16) |
-               ((uint32_t)row[bx[3]] << 24);
+    auto load_row = [&](int yy) -> uint2 { /* raw window; the v_perm happens where the row is consumed */
+        const uint32_t* row = (const uint32_t*)(img + (size_t)refl101_v2(yy, h) * pitch + bc);
+        return make_uint2(row[0], row[1]);
     };
-    auto hpass = [&](uint32_t Cw, uint32_t* o) {
-        const uint32_t Lw = __shfl_up(Cw, 1, 64), Rw = __shfl_down(Cw, 1, 64);
+    auto hpass = [&](uint2 raw, uint32_t* o) {
+        const uint32_t Cw = __builtin_amdgcn_perm(raw.y, raw.x, sel);
+        /* neighbours' dwords by DPP wave shifts (lanes 0 / 63 are halo lanes whose outputs are never stored) */
+        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp((int)Cw, (int)Cw, 0x138, 0xf, 0xf, false); /* wave_shr:1 */
+        const uint32_t Rw = (uint32_t)__builtin_amdgcn_update_dpp((int)Cw, (int)Cw, 0x130, 0xf, 0xf, false); /* wave_shl:1 */
         o[0] = udot4(Lw, T.l0, udot4(Cw, T.c0, 0));
         o[1] = udot4(Lw, T.l1, udot4(Cw, T.c1, udot4(Rw, T.r1, 0)));
         o[2] = udot4(Lw, T.l2, udot4(Cw, T.c2, udot4(Rw, T.r2, 0)));
@@ -92,14 +99,18 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
 #pragma unroll
     for (int r = 0; r < 6; r++) hpass(load_row(y0 - 3 + r), hq[r]);
     const bool writer = lane >= 1 && lane <= 62 && x < w; /* halo lanes and lanes past the image do not store */
-    uint32_t nextw = load_row(y0 + 3);
+    /* input rows are fetched seven iterations ahead (a ring of 7 dwords): with only a few waves per SIMD one
+     * row of look-ahead left the wave waiting on HBM every iteration */
+    uint2 nw[7];
+#pragma unroll
+    for (int u = 0; u < 7; u++) nw[u] = load_row(y0 + 3 + u);
     for (int rb = 0; rb < nrows; rb += 7) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int r = rb + u;
             if (r < nrows) { /* wave-uniform */
-                hpass(nextw, hq[(u + 6) % 7]);
-                nextw = load_row(y0 + r + 4);
+                hpass(nw[u], hq[(u + 6) % 7]);
+                if (r + 7 < nrows) nw[u] = load_row(y0 + r + 10);
                 uint32_t px[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -123,7 +134,8 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
 }
 
 void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
-                 uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int nslots) {
+                 uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int rows_per_task,
+                 int nslots) {
     BlurTapsV2 T;
     const uint32_t k0 = taps[0], k1 = taps[1], k2 = taps[2], k3 = taps[3], k4 = taps[4], k5 = taps[5], k6 = taps[6];
     auto pk = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); };
@@ -135,7 +147,7 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
     for (int i = 0; i < 7; i++) T.k[i] = taps[i];
     const int nwork = ((ntasks + 3) / 4) * nslots;
     hipLaunchKernelGGL(k_blur7_v2, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
-                       ntasks, nslots, T);
+                       ntasks, nslots, rows_per_task, T);
 }
 
 /* ------------------------------------------------------------------------------------------------
