@@ -52,17 +52,18 @@ def algorithmic_bytes(fe, nf):
 def pmc_traffic(kernel, cfg, batch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/collect_pmc.sh,
     separate FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of
-    a coalesced stream (MI355X_MICROARCH.md 'HBM'): calibrated here on k_fast_cells_v2, whose unique input is
-    the 23.1 MB of pyramid pixels and whose raw FETCH_SIZE reads 11.1 MB -> the factor 2 is applied.
+    a coalesced stream (MI355X_MICROARCH.md 'HBM'): calibrated here on the FAST kernel, whose unique input is
+    the pyramid pixels (1.44 MB per image) and whose raw FETCH_SIZE reads half of that -> the factor 2 is applied.
     Only valid for the geometry/batch the profile was taken with; otherwise None."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_kitti_n2000_b16.json")
-    if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376 and batch == 16):
+    name = "r01e_pmc_traffic_kitti_b%d.json" % batch
+    path = os.path.join(ROOT, "profiles", name)
+    if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376):
         return None
     k = json.load(open(path))["kernels"].get(kernel.split("(")[0])
     if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
         return None
     return {"bytes": 2 * k["fetch_bytes_raw"] + k["write_bytes"], "fetch_size_raw_bytes": k["fetch_bytes_raw"],
-            "write_size_bytes": k["write_bytes"], "source": "profiles/r01c_pmc_traffic_kitti_n2000_b16.json"}
+            "write_size_bytes": k["write_bytes"], "source": "profiles/" + name}
 
 
 def cpu_baseline(cfg, seconds=12.0):
@@ -116,7 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=16, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
     ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -297,13 +298,14 @@ def main():
         nb = max(prof["batches"], 1)
         stage_ms = {"pyramid": prof["pyramid_ms"] / nb, "fast": prof["fast_ms"] / nb, "blur": prof["blur_ms"] / nb,
                     "describe": prof["describe_ms"] / nb, "octree": prof["octree_ms"] / nb}
-        streaming = {k: v for k, v in stage_ms.items() if k != "octree"}  # the quadtree moves no image bytes
-        dom = max(streaming, key=streaming.get)
-        kernel = {"pyramid": "k_resize_level(x7)", "fast": "k_fast_cells_v2", "blur": "k_blur7_v2",
+        # dominant streaming KERNEL: per launch (the pyramid stage is 7 launches; the quadtree moves no image bytes)
+        per_launch = {k: (v / 7.0 if k == "pyramid" else v) for k, v in stage_ms.items() if k != "octree"}
+        dom = max(per_launch, key=per_launch.get)
+        kernel = {"pyramid": "k_resize_level_v2(x7)", "fast": "k_fast_cells_v3", "blur": "k_blur7_v2",
                   "describe": "k_orient_describe_dev"}[dom]
         tr = pmc_traffic(kernel, cfg, B)
-        bytes_per_launch = ab[dom] * B
-        achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        bytes_per_launch = ab[dom] * B / (7.0 if dom == "pyramid" else 1.0)
+        achieved = bytes_per_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
         out = {
             "metric": "frames/sec ORB extract+match",
             "value": value,
@@ -330,7 +332,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_detail": tr,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": stage_ms[dom], "stage_ms_per_batch": stage_ms},
+                         "avg_launch_ms": per_launch[dom], "stage_ms_per_batch": stage_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -4,10 +4,12 @@
 set -e
 OUT=${1:-/root/repo/gpurun_out/pmc_traffic}
 WL=${2:-mono}
+B=${3:-16}
+NF=${4:-2000}
 mkdir -p $OUT/fetch $OUT/write $OUT/sq
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 /root/repo/tools/run_extract_loop.py $WL 5 > $OUT/fetch/log.txt 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 /root/repo/tools/run_extract_loop.py $WL 5 > $OUT/write/log.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 /root/repo/tools/run_extract_loop.py $WL 5 $B $NF > $OUT/fetch/log.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 /root/repo/tools/run_extract_loop.py $WL 5 $B $NF > $OUT/write/log.txt 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-    --output-format csv -d $OUT/sq -- python3 /root/repo/tools/run_extract_loop.py $WL 5 > $OUT/sq/log.txt 2>&1
-python3 /root/repo/tools/summarize_pmc.py $OUT
+    --output-format csv -d $OUT/sq -- python3 /root/repo/tools/run_extract_loop.py $WL 5 $B $NF > $OUT/sq/log.txt 2>&1
+python3 /root/repo/tools/summarize_pmc.py $OUT $B $NF

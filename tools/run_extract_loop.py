@@ -6,9 +6,11 @@ import torch
 import vi_slam_amd as V
 from vi_slam_amd import synth
 
-W, H, NF, B = 1241, 376, 2000, 16
 stereo = len(sys.argv) > 1 and sys.argv[1] == "stereo"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+NF = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+W, H = 1241, 376
 fe = V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=B)
 pitch = 1280
 dev = torch.zeros((B, H, pitch), dtype=torch.uint8, device="cuda")

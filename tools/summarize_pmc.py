@@ -23,7 +23,10 @@ for sub in ("fetch", "write", "sq"):
     for (k, c), v in acc.items():
         out[k][c] = sum(v) / len(v)
         out[k]["launches_" + sub] = len(v)
-res = {"workload": "run_extract_loop.py: 1241x376, 2000 features, 16 images per launch, 5 launches", "kernels": {}}
+B = sys.argv[2] if len(sys.argv) > 2 else "16"
+NF = sys.argv[3] if len(sys.argv) > 3 else "2000"
+res = {"workload": "run_extract_loop.py: 1241x376, %s features, %s images per launch, 5 launches" % (NF, B),
+       "kernels": {}}
 for k, d in sorted(out.items()):
     e = dict(d)
     if "FETCH_SIZE" in d:
