@@ -1,0 +1,90 @@
+/* Exercises include/vslam_shim.hpp the way frame.cpp / tracking.cpp use the reference classes:
+ *   two mono frames  -> FExtractor::compute x2 + FMatcher::SearchForInitialization
+ *   one stereo pair  -> two extractors + ComputeStereoMatches
+ * Input: raw u8 images written by the pytest driver; output: one line of JSON with counts and FNV-1a checksums
+ * that the driver compares with the ctypes path (and through it with the oracle).
+ *   shim_demo W H a.raw b.raw left.raw right.raw nfeatures
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "vslam_shim.hpp"
+
+using namespace vi_slam_amd::geometry;
+
+static Mat8u load(const char* path, int w, int h) {
+    Mat8u m;
+    m.create(h, w);
+    FILE* f = std::fopen(path, "rb");
+    if (!f || std::fread(m.data, 1, (size_t)w * h, f) != (size_t)w * h) {
+        std::fprintf(stderr, "cannot read %s\n", path);
+        std::exit(2);
+    }
+    std::fclose(f);
+    return m;
+}
+
+static unsigned long long fnv(const void* p, size_t n, unsigned long long h = 1469598103934665603ull) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 8) return 2;
+    const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), nf = std::atoi(argv[7]);
+    try {
+        /* ---- mono initialisation: tracking.cpp:2290-2330 */
+        FExtractor ini1(nf, 1.2f, 8, 20, 7), ini2(nf, 1.2f, 8, 20, 7);
+        Mat8u a = load(argv[3], w, h), b = load(argv[4], w, h), mask;
+        std::vector<KeyPoint> k1, k2;
+        Mat8u d1, d2;
+        std::vector<int> lap = {0, 1000};
+        const int mono1 = ini1.compute(a, mask, k1, d1, lap);
+        const int mono2 = ini2.compute(b, mask, k2, d2, lap);
+        Mat8u empty;
+        std::vector<KeyPoint> kx;
+        Mat8u dx;
+        const int rc_empty = ini1.compute(empty, mask, kx, dx, lap); /* -1, and must not disturb ini1's frame */
+        std::vector<Point2f> prev(k1.size());
+        for (size_t i = 0; i < k1.size(); i++) prev[i] = k1[i].pt;
+        std::vector<int> m12;
+        FrameView F1, F2;
+        F1.ukeypoints = &k1; F1.extractor = &ini1; F1.mnMaxX = w; F1.mnMaxY = h;
+        F2.ukeypoints = &k2; F2.extractor = &ini2; F2.mnMaxX = w; F2.mnMaxY = h;
+        FMatcher matcher(0.9f, true);
+        const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+        const int dd = k1.size() > 1 ? FMatcher::DescriptorDistance(d1.ptr(0), d1.ptr(1)) : -1;
+
+        /* ---- stereo: frame.cpp:102-132 */
+        FExtractor left(nf, 1.2f, 8, 20, 7), right(nf, 1.2f, 8, 20, 7);
+        Mat8u L = load(argv[5], w, h), R = load(argv[6], w, h);
+        std::vector<KeyPoint> kL, kR;
+        Mat8u dL, dR;
+        std::vector<int> nolap = {0, 0};
+        left.compute(L, mask, kL, dL, nolap);
+        right.compute(R, mask, kR, dR, nolap);
+        std::vector<float> uR, depth;
+        ComputeStereoMatches(left, right, 386.1448f, 718.856f, (int)kL.size(), uR, depth);
+        int nst = 0;
+        for (float u : uR) nst += u >= 0.f;
+        int lw = 0, lh = 0;
+        std::vector<uint8_t> lvl3 = left.ImagePyramidLevel(3, &lw, &lh);
+
+        std::printf("{\"n1\": %zu, \"n2\": %zu, \"mono1\": %d, \"mono2\": %d, \"rc_empty\": %d, \"nmatches\": %d, "
+                    "\"dd01\": %d, \"kp1\": %llu, \"desc1\": %llu, \"kp2\": %llu, \"desc2\": %llu, \"m12\": %llu, "
+                    "\"prev\": %llu, \"nL\": %zu, \"nR\": %zu, \"nstereo\": %d, \"uR\": %llu, \"depth\": %llu, "
+                    "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g}\n",
+                    k1.size(), k2.size(), mono1, mono2, rc_empty, nm, dd, fnv(k1.data(), k1.size() * sizeof(KeyPoint)),
+                    fnv(d1.data, (size_t)d1.rows * 32), fnv(k2.data(), k2.size() * sizeof(KeyPoint)),
+                    fnv(d2.data, (size_t)d2.rows * 32), fnv(m12.data(), m12.size() * 4),
+                    fnv(prev.data(), prev.size() * 8), kL.size(), kR.size(), nst, fnv(uR.data(), uR.size() * 4),
+                    fnv(depth.data(), depth.size() * 4), lw, lh, fnv(lvl3.data(), lvl3.size()), left.GetLevels(),
+                    (double)left.GetScaleFactors()[7]);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
