@@ -232,6 +232,36 @@ int vslam_fe_slot_count_ptr(vslam_fe* fe, int slot, const int32_t** dev_n);
 
 /* ---------------------------------------------------------------- diagnostics */
 
+/* FMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (fmatcher.h, fmatcher.cpp:2471-2687; pinhole frames, Nleft == -1) -- the tracking matcher of
+ * TrackWithMotionModel (tracking.cpp:2728).  What the function reads of the two frames is passed explicitly:
+ *   p            pose of CurrentFrame as rows [Rcw | tcw] (the reference's T_w_c_ member is used that way),
+ *                pinhole intrinsics, mbf, th, bForward/bBackward (vslam_projection_direction), image bounds of
+ *                CurrentFrame's grid (mnMinX = mnMinY = 0, mnMaxX = img_w, mnMaxY = img_h)
+ *   last frame   host arrays of n_last entries: keypoints (octave from keypoints_, angle from ukeypoints_),
+ *                flags (bit0: mvpMapPoints[i] != NULL && !mvbOutlier[i]; bit1: that MapPoint has
+ *                Observations() > 0), world positions (3 floats), MapPoint descriptors (32 bytes)
+ *   current      DEVICE keypoints/descriptors (vslam_fe_slot_buffers), n_cur <= 4096; host mvuRight (NULL =
+ *                monocular, all -1) and the initial "mvpMapPoints[i2] with Observations() > 0" mask (NULL = none:
+ *                tracking.cpp fills mvpMapPoints with NULL before the call)
+ * Output: match_cur[i2] = index i of the last-frame keypoint whose MapPoint ends up in mvpMapPoints[i2], or -1;
+ * *nmatches as the reference counts it. */
+typedef struct vslam_proj_params {
+    float Tcw[12];
+    float fx, fy, cx, cy, mbf, th;
+    int32_t forward, backward;
+    int32_t check_orientation;
+    int32_t img_w, img_h;
+    int32_t gemm_float; /* 0: Rcw*x+tcw as cv::gemm evaluates it (double accumulation); 1: float arithmetic */
+} vslam_proj_params;
+int vslam_projection_direction(const float* Tcw, const float* Tlw, float mb, int mono, int gemm_float,
+                               int* forward, int* backward);
+int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p, const vslam_kp* last_kps_host,
+                                     int n_last, const uint8_t* last_flags, const float* last_x3dw,
+                                     const uint8_t* mp_desc_host, const vslam_kp* dev_cur_kps,
+                                     const uint8_t* dev_cur_desc, int n_cur, const float* cur_u_right_host,
+                                     const uint8_t* cur_occupied_host, int32_t* match_cur, int* nmatches);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

@@ -911,4 +911,119 @@ int search_for_initialization(const std::vector<KeyPoint>& kps1, const std::vect
     return nmatches;
 }
 
+
+/* ---- cv::Mat float algebra as the reference's expressions evaluate it.  `A*x + t` is ONE cv::gemm call
+ * (MatExpr folds the addition in as beta*C); for CV_32F OpenCV's GEMMSingleMul<float,double> accumulates in
+ * double and rounds once: d = float(sum_k double(a_k)*double(b_k) + double(c)).  OpenCV is not in this image, so
+ * this is restated from its published source and kept behind a knob (gemmDouble = 0: plain float arithmetic). */
+static inline float gemm_row(const float* r, const float* x, float t, int dbl) {
+    if (dbl) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)r[k] * (double)x[k];
+        return (float)(s + (double)t);
+    }
+    float s = 0;
+    for (int k = 0; k < 3; k++) s += r[k] * x[k];
+    return s + t;
+}
+
+void projection_direction(const ProjFrameArgs& a, bool& bForward, bool& bBackward) {
+    /* twc = -Rcw.t()*tcw (gemm with alpha = -1, no C); tlc = Rlw*twc + tlw; fmatcher.cpp:2482-2495 */
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) {
+        const float col[3] = {a.Tcw[0 * 4 + r], a.Tcw[1 * 4 + r], a.Tcw[2 * 4 + r]};
+        const float t[3] = {a.Tcw[3], a.Tcw[7], a.Tcw[11]};
+        if (a.gemmDouble) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)col[k] * (double)t[k];
+            twc[r] = (float)(s * -1.0);
+        } else {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += col[k] * t[k];
+            twc[r] = -s;
+        }
+    }
+    for (int r = 0; r < 3; r++) tlc[r] = gemm_row(a.Tlw + 4 * r, twc, a.Tlw[4 * r + 3], a.gemmDouble);
+    bForward = tlc[2] > a.mb && !a.bMono;
+    bBackward = -tlc[2] > a.mb && !a.bMono;
+}
+
+int search_by_projection_frame(const ProjFrameArgs& a, const std::vector<KeyPoint>& lastKps,
+                               const std::vector<uint8_t>& flags, const std::vector<float>& x3Dw,
+                               const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& curKps,
+                               const std::vector<uint8_t>& curDesc, const std::vector<float>& mvuRight,
+                               const std::vector<uint8_t>& occupied0, const std::vector<float>& scaleFactors,
+                               std::vector<int>& matchCur) { /* fmatcher.cpp:2471-2687, Nleft == -1 */
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    bool bForward, bBackward;
+    projection_direction(a, bForward, bBackward);
+    const int N = (int)lastKps.size(), N2 = (int)curKps.size();
+    matchCur.assign(N2, -1);
+    std::vector<uint8_t> occ(N2, 0); /* mvpMapPoints[i2] != NULL && Observations() > 0 */
+    for (int i = 0; i < N2 && i < (int)occupied0.size(); i++) occ[i] = occupied0[i];
+    FrameGrid grid(curKps, a.imgW, a.imgH);
+    const float mnMinX = 0.f, mnMinY = 0.f, mnMaxX = (float)a.imgW, mnMaxY = (float)a.imgH;
+    for (int i = 0; i < N; i++) {
+        if (!(flags[i] & 1)) continue; /* pMP && !mvbOutlier[i] */
+        const float* Xw = &x3Dw[3 * (size_t)i];
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) x3Dc[r] = gemm_row(a.Tcw + 4 * r, Xw, a.Tcw[4 * r + 3], a.gemmDouble);
+        const float invzc = (float)(1.0 / (double)x3Dc[2]); /* const float invzc = 1.0/x3Dc.at<float>(2) */
+        if (invzc < 0) continue;
+        /* Pinhole::project(cv::Point3f), pinhole.cpp:13-16 */
+        const float u = a.fx * x3Dc[0] / x3Dc[2] + a.cx;
+        const float v = a.fy * x3Dc[1] / x3Dc[2] + a.cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const int nLastOctave = lastKps[i].octave;
+        const float radius = a.th * scaleFactors[nLastOctave];
+        std::vector<int> vIndices2;
+        if (bForward) vIndices2 = grid.GetFeaturesInArea(u, v, radius, nLastOctave, -1);
+        else if (bBackward) vIndices2 = grid.GetFeaturesInArea(u, v, radius, 0, nLastOctave);
+        else vIndices2 = grid.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = &mpDesc[32 * (size_t)i];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (occ[i2]) continue;
+            if (mvuRight[i2] > 0) {
+                const float ur = u - a.mbf * invzc;
+                const float er = std::fabs(ur - mvuRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptor_distance(dMP, &curDesc[32 * (size_t)i2]);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            matchCur[bestIdx2] = i;
+            if (flags[i] & 2) occ[bestIdx2] = 1;
+            nmatches++;
+            if (a.checkOri) {
+                float rot = lastKps[i].angle - curKps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (int idx : rotHist[b]) {
+                    matchCur[idx] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
 } // namespace orbo

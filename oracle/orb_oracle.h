@@ -113,6 +113,32 @@ int search_for_initialization(const std::vector<KeyPoint>& kps1, const std::vect
                               int imgW, int imgH, std::vector<float>& prevMatchedXY /* 2*N1, in/out */,
                               std::vector<int>& matches12, int windowSize, float nnratio, bool checkOri);
 
+/* FMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (fmatcher.cpp:2471-2687)
+ * for pinhole frames (Nleft == -1).  What it reads of the two frames is passed explicitly. */
+struct ProjFrameArgs {
+    float Tcw[12];   /* CurrentFrame pose rows [Rcw | tcw] (the reference's T_w_c_ member, used as Rcw/tcw) */
+    float Tlw[12];   /* LastFrame pose, only for bForward / bBackward */
+    float fx, fy, cx, cy, mbf, mb;
+    float th;
+    int bMono, checkOri;
+    int imgW, imgH;  /* mnMinX = mnMinY = 0, mnMaxX = imgW, mnMaxY = imgH (no distortion) */
+    int gemmDouble;  /* knob: cv::gemm accumulates CV_32F products in double (OpenCV GEMMSingleMul<float,double>) */
+};
+/* last frame: per keypoint i -- flags bit0 = has a MapPoint that is not an outlier, bit1 = that MapPoint has
+ * Observations() > 0; x3Dw = its world position; mpDesc = its descriptor; lastKps = keypoints_ (octave) /
+ * ukeypoints_ (angle).  current frame: ukeypoints_, descriptors_, mvuRight (-1 = none), occupied = initial
+ * "mvpMapPoints[i2] with Observations() > 0" (normally all 0: tracking.cpp fills NULL before the call).
+ * Output: matchCur[i2] = index i of the last-frame keypoint whose MapPoint was assigned, -1 = none.  Returns
+ * nmatches exactly as the reference counts it. */
+int search_by_projection_frame(const ProjFrameArgs& a, const std::vector<KeyPoint>& lastKps,
+                               const std::vector<uint8_t>& flags, const std::vector<float>& x3Dw,
+                               const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& curKps,
+                               const std::vector<uint8_t>& curDesc, const std::vector<float>& mvuRight,
+                               const std::vector<uint8_t>& occupied, const std::vector<float>& scaleFactors,
+                               std::vector<int>& matchCur);
+/* bForward / bBackward of the same function (fmatcher.cpp:2482-2495) */
+void projection_direction(const ProjFrameArgs& a, bool& bForward, bool& bBackward);
+
 } // namespace orbo
 
 #endif

@@ -163,4 +163,33 @@ int orbo_grid_query(const KeyPoint* kps, int n, int imgW, int imgH, float x, flo
     return (int)v.size();
 }
 
+/* args: 12 Tcw, 12 Tlw, fx, fy, cx, cy, mbf, mb, th (31 floats); iargs: bMono, checkOri, imgW, imgH, gemmDouble */
+int orbo_search_by_projection_frame(const float* fargs, const int* iargs, const KeyPoint* lastKps, int n,
+                                    const uint8_t* flags, const float* x3Dw, const uint8_t* mpDesc,
+                                    const KeyPoint* curKps, int n2, const uint8_t* curDesc, const float* mvuRight,
+                                    const uint8_t* occupied, const float* scaleFactors, int nlevels, int* matchCur,
+                                    int* dir_out) {
+    ProjFrameArgs a;
+    memcpy(a.Tcw, fargs, 48);
+    memcpy(a.Tlw, fargs + 12, 48);
+    a.fx = fargs[24]; a.fy = fargs[25]; a.cx = fargs[26]; a.cy = fargs[27]; a.mbf = fargs[28]; a.mb = fargs[29];
+    a.th = fargs[30];
+    a.bMono = iargs[0]; a.checkOri = iargs[1]; a.imgW = iargs[2]; a.imgH = iargs[3]; a.gemmDouble = iargs[4];
+    std::vector<KeyPoint> lk(lastKps, lastKps + n), ck(curKps, curKps + n2);
+    std::vector<uint8_t> fl(flags, flags + n), md(mpDesc, mpDesc + (size_t)n * 32), cd(curDesc, curDesc + (size_t)n2 * 32);
+    std::vector<float> xw(x3Dw, x3Dw + (size_t)n * 3), ur(mvuRight, mvuRight + n2), sf(scaleFactors, scaleFactors + nlevels);
+    std::vector<uint8_t> occ;
+    if (occupied) occ.assign(occupied, occupied + n2);
+    std::vector<int> m;
+    const int nm = search_by_projection_frame(a, lk, fl, xw, md, ck, cd, ur, occ, sf, m);
+    if (n2) memcpy(matchCur, m.data(), (size_t)n2 * sizeof(int));
+    if (dir_out) {
+        bool f, b;
+        projection_direction(a, f, b);
+        dir_out[0] = f;
+        dir_out[1] = b;
+    }
+    return nm;
+}
+
 } /* extern "C" */

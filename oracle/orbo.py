@@ -64,6 +64,9 @@ def lib():
                                        C.c_int]
         L.orbo_grid_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        vp = C.c_void_p
+        L.orbo_search_by_projection_frame.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp,
+                                                      C.c_int, vp, vp]
         _lib = L
     return _lib
 
@@ -247,3 +250,28 @@ def grid_query(kps, W, H, x, y, r, min_level, max_level):
     out = np.zeros(len(kps) + 1, np.int32)
     n = lib().orbo_grid_query(_p(kps), len(kps), W, H, x, y, r, min_level, max_level, _p(out), len(out))
     return out[:n]
+
+
+def search_by_projection_frame(Tcw, Tlw, cam, th, last_kps, flags, x3dw, mp_desc, cur_kps, cur_desc, mvu_right,
+                               scale_factors, W, H, mono=False, check_ori=True, occupied=None, gemm_double=True):
+    """FMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), fmatcher.cpp:2471-2687 (pinhole frames).
+    cam = (fx, fy, cx, cy, mbf, mb).  -> (nmatches, matchCur[n2] (index into the last frame or -1),
+    (bForward, bBackward))."""
+    last_kps = np.ascontiguousarray(last_kps, KP_DTYPE)
+    cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    fargs = np.concatenate([np.asarray(Tcw, np.float32).reshape(-1)[:12], np.asarray(Tlw, np.float32).reshape(-1)[:12],
+                            np.asarray(cam, np.float32), np.asarray([th], np.float32)]).astype(np.float32)
+    iargs = np.asarray([int(mono), int(check_ori), W, H, int(gemm_double)], np.int32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    x3dw = np.ascontiguousarray(x3dw, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    mvu = np.ascontiguousarray(mvu_right, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    m = np.full(max(len(cur_kps), 1), -1, np.int32)
+    d = np.zeros(2, np.int32)
+    nm = lib().orbo_search_by_projection_frame(_p(fargs), _p(iargs), _p(last_kps), len(last_kps), _p(flags), _p(x3dw),
+                                               _p(mp_desc), _p(cur_kps), len(cur_kps), _p(cur_desc), _p(mvu),
+                                               _p(occ) if occ is not None else None, _p(sf), len(sf), _p(m), _p(d))
+    return nm, m[:len(cur_kps)], (bool(d[0]), bool(d[1]))

@@ -234,3 +234,26 @@ def test_search_for_initialization_properties():
     dy = k2["y"][matched] - k1["y"][m12 >= 0]
     assert np.mean((np.abs(dx - 3) <= 1) & (np.abs(dy - 1) <= 1)) > 0.8
     assert np.array_equal(pm[m12 >= 0], np.stack([k2["x"][matched], k2["y"][matched]], 1))
+
+
+def test_search_by_projection_oracle_identity_pose():
+    """fmatcher.cpp:2471-2687 restated: with the identity motion and the frame's own descriptors as MapPoint
+    descriptors every keypoint with a MapPoint finds itself (distance 0 wins, first in grid order on ties)."""
+    from vi_slam_amd import synth
+    W, H = 640, 360
+    e = orbo.Extractor(800)
+    k, d, _ = e.compute(synth.make_frame(W, H))
+    fx = fy = 500.0
+    z = np.full(len(k), 8.0, np.float32)
+    X = np.stack([(k["x"] - W / 2) / fx * z, (k["y"] - H / 2) / fy * z, z], 1).astype(np.float32)
+    T = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    flags = np.full(len(k), 3, np.uint8)
+    flags[::5] = 0
+    nm, m, dirs = orbo.search_by_projection_frame(T, T, (fx, fy, W / 2, H / 2, 40.0, 0.08), 7, k, flags, X, d, k, d,
+                                                  np.full(len(k), -1, np.float32), e.tables()["scale"], W, H,
+                                                  check_ori=False)
+    assert dirs == (False, False)
+    sel = np.nonzero(flags)[0]
+    # identical keypoints may exist at several octaves with equal descriptors only by accident: allow a handful
+    assert nm >= len(sel) - 5 and (m[sel] == sel).sum() >= len(sel) - 5
+    assert np.all(m[flags == 0][m[flags == 0] >= 0] != np.nonzero(flags == 0)[0][m[flags == 0] >= 0])

@@ -37,8 +37,15 @@ ABI_SYMBOLS = [
     "vslam_search_for_initialization_batch", "vslam_frame_stereo_batch_async", "vslam_frame_stereo_wait",
     "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_dbg_search_init_fallbacks", "vslam_search_init_dev_async",
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
-    "vslam_fe_event_wait",
+    "vslam_fe_event_wait", "vslam_projection_direction", "vslam_search_by_projection_frame",
 ]
+
+
+class _ProjParams(C.Structure):  # vslam_proj_params
+    _fields_ = [("Tcw", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mbf", C.c_float), ("th", C.c_float), ("forward", C.c_int32), ("backward", C.c_int32),
+                ("check_orientation", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
+                ("gemm_float", C.c_int32)]
 
 
 class VslamError(RuntimeError):
@@ -90,6 +97,8 @@ def lib():
         L.vslam_fe_candidates.argtypes = [vp, i, i, vp, i]
         L.vslam_fe_slot_buffers.argtypes = [vp, i, vp, vp, vp]
         L.vslam_fe_slot_host_views.argtypes = [vp, i, vp, vp]
+        L.vslam_projection_direction.argtypes = [vp, vp, C.c_float, i, i, vp, vp]
+        L.vslam_search_by_projection_frame.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
         L.vslam_fe_stream.argtypes = [vp]
         L.vslam_fe_stream.restype = vp
         L.vslam_hamming_top2.argtypes = [vp, vp, i, vp, i, vp, vp]
@@ -447,6 +456,42 @@ class FMatcher:
         _check(lib().vslam_search_init_dev_wait(self.fe._h, (C.c_int * n)(*n1), self._m_ptrs,
                                                 self._p_ptrs if want_prev else None, nm))
         return [(nm[j], self._m_buf[j, :n1[j]], self._p_buf[j, :n1[j]] if want_prev else None) for j in range(n)]
+
+    # ---- tracking matcher of TrackWithMotionModel (tracking.cpp:2728)
+    def SearchByProjection(self, Tcw, Tlw, cam, th, last_kps, last_flags, last_x3dw, mp_desc, dev_cur_kps,
+                           dev_cur_desc, n_cur, cur_u_right=None, bMono=False, img_size=None, occupied=None,
+                           gemm_float=False):
+        """FMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (fmatcher.cpp:2471-2687, pinhole).
+        Tcw/Tlw: 3x4 poses [R|t] of the current / last frame; cam = (fx, fy, cx, cy, mbf, mb).
+        last_flags: bit0 = has a non-outlier MapPoint, bit1 = that MapPoint has observations.
+        -> (nmatches, match_cur[n_cur]) with match_cur[i2] = last-frame index or -1."""
+        Tcw = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(-1)[:12])
+        Tlw = np.ascontiguousarray(np.asarray(Tlw, np.float32).reshape(-1)[:12])
+        fx, fy, cx, cy, mbf, mb = [float(v) for v in cam]
+        fwd, bwd = C.c_int(), C.c_int()
+        _check(lib().vslam_projection_direction(_p(Tcw), _p(Tlw), C.c_float(mb), int(bMono), int(gemm_float),
+                                                C.byref(fwd), C.byref(bwd)))
+        w, h = img_size or (self.fe.width, self.fe.height)
+        P = _ProjParams()
+        for i in range(12):
+            P.Tcw[i] = float(Tcw[i])
+        P.fx, P.fy, P.cx, P.cy, P.mbf, P.th = fx, fy, cx, cy, mbf, float(th)
+        P.forward, P.backward = fwd.value, bwd.value
+        P.check_orientation = int(self.mbCheckOrientation)
+        P.img_w, P.img_h, P.gemm_float = w, h, int(gemm_float)
+        last_kps = np.ascontiguousarray(last_kps, KP_DTYPE)
+        fl = np.ascontiguousarray(last_flags, np.uint8)
+        xw = np.ascontiguousarray(last_x3dw, np.float32)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        ur = None if cur_u_right is None else np.ascontiguousarray(cur_u_right, np.float32)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        m = np.full(max(n_cur, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_projection_frame(
+            self.fe._h, C.byref(P), _p(last_kps), len(last_kps), _p(fl), _p(xw), _p(md), C.c_void_p(dev_cur_kps),
+            C.c_void_p(dev_cur_desc), n_cur, _p(ur) if ur is not None else None, _p(oc) if oc is not None else None,
+            _p(m), C.byref(nm)))
+        return nm.value, m[:n_cur], (bool(fwd.value), bool(bwd.value))
 
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""

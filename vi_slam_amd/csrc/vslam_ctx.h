@@ -174,7 +174,12 @@ struct vslam_fe {
     bool init_lds_set = false;
     uint8_t* d_init_scratch = nullptr; /* k_si_topm -> k_si_replay: compacted octave-0 lists + sorted prefixes */
     size_t init_scratch_bytes = 0;
-    int* d_init_fb = nullptr; /* number of full re-scans in k_si_replay (diagnostics) */
+    int* d_init_fb = nullptr; /* number of full re-scans in k_si_replay / k_sbp_replay (diagnostics) */
+    uint8_t* d_proj = nullptr;  /* SearchByProjection: uploaded last-frame arrays | scratch | results */
+    size_t proj_bytes = 0;
+    uint8_t* h_proj = nullptr;  /* pinned mirror (inputs, then results) */
+    size_t h_proj_bytes = 0;
+    bool proj_lds_set = false;
     /* stereo scratch */
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;

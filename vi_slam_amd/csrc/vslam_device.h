@@ -108,6 +108,14 @@ struct ResizeQuad {
     uint32_t coef[4];
 };
 
+/* host-side argument block of vk_search_by_projection (SearchByProjection(CurrentFrame, LastFrame)) */
+struct SbpHostArgs {
+    float Tcw[12];
+    float fx, fy, cx, cy, mbf, th;
+    float scale[VSLAM_MAX_LEVELS];
+    int forward, backward, checkOri, imgW, imgH, gemmFloat, nlevels;
+};
+
 /* Up to four dword-granular ranges for k_copy_ranges (src == nullptr: zero-fill). */
 struct CopyRanges {
     void* dst[4];

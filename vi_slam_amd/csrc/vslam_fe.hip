@@ -65,6 +65,8 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->h_stereo) hipHostFree(fe->h_stereo);
     hipFree(fe->d_init);
     hipFree(fe->d_init_scratch);
+    hipFree(fe->d_proj);
+    if (fe->h_proj) hipHostFree(fe->h_proj);
     hipFree(fe->d_init_fb);
     if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);

@@ -455,3 +455,335 @@ void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, i
     hipLaunchKernelGGL(k_si_replay, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
                        window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
 }
+
+/* ==================================================================================================
+ * FMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (fmatcher.cpp:2471-2687, pinhole frames: Nleft == -1) -- the per-frame tracking matcher of
+ * TrackWithMotionModel (tracking.cpp:2728).  Same decomposition as SearchForInitialization above:
+ *
+ *   k_sbp_rank   (parallel, one wave per last-frame keypoint): project its MapPoint into the current frame
+ *                (Rcw*x3Dw+tcw as ONE cv::gemm: products accumulated in double, rounded once; 1.0/z in
+ *                double; Pinhole::project in float), query the window (Frame::GetFeaturesInArea with the
+ *                forward / backward / +-1 octave rule), apply the order-free mvuRight gate, and write the M
+ *                smallest keys = dist << 24 | gridcell << 12 | i2 in ascending order ("first wins" on equal
+ *                distance is the key order).
+ *   k_sbp_replay (one wave, last-frame keypoints in index order): the only sequential state is "current
+ *                keypoint i2 already carries a MapPoint with observations" (the skip at fmatcher.cpp:2545-
+ *                2547); the first list entry that is not occupied is bestIdx2.  An exhausted full list falls
+ *                back to a full re-scan of that query.  Assignments go to a log; mvpMapPoints ("last writer
+ *                wins"), the rotation histogram, ComputeThreeMaxima and nmatches are rebuilt from it.
+ * ================================================================================================== */
+#define SBP_TH_HIGH 100
+#define SBP_QPB 16 /* queries per k_sbp_rank workgroup (4 waves x 4) */
+
+struct SbpCand { /* one keypoint of the current frame */
+    float x, y, uRight;
+    uint16_t cell;
+    uint16_t octave;
+};
+struct SbpProj { /* projection record of one last-frame keypoint (k_sbp_rank -> k_sbp_replay's re-scan) */
+    float u, v, radius, ur;
+    int32_t minLevel, maxLevel, valid, pad;
+};
+
+struct SbpArgs {
+    float Tcw[12];
+    float fx, fy, cx, cy, mbf, th;
+    float scale[VSLAM_MAX_LEVELS];
+    int forward, backward, checkOri, imgW, imgH, gemmFloat, nlevels;
+};
+
+__device__ __forceinline__ float sbp_gemm_row(const float* r, float x0, float x1, float x2, float t, int flt) {
+    if (!flt) { /* GEMMSingleMul<float,double>: s += double(a)*double(b), then float(s + double(c)) */
+        double s = __dmul_rn((double)r[0], (double)x0);
+        s = __dadd_rn(s, __dmul_rn((double)r[1], (double)x1));
+        s = __dadd_rn(s, __dmul_rn((double)r[2], (double)x2));
+        return (float)__dadd_rn(s, (double)t);
+    }
+    float s = __fmul_rn(r[0], x0);
+    s = __fadd_rn(s, __fmul_rn(r[1], x1));
+    s = __fadd_rn(s, __fmul_rn(r[2], x2));
+    return __fadd_rn(s, t);
+}
+
+__device__ __forceinline__ bool sbp_level_ok(int octave, int minLevel, int maxLevel) { /* frame.cpp:712-728 */
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    if (!bCheckLevels) return true;
+    if (octave < minLevel) return false;
+    if (maxLevel >= 0 && octave > maxLevel) return false;
+    return true;
+}
+
+/* the order-free part of the candidate loop body (fmatcher.cpp:2541-2556): window, level, mvuRight gate */
+__device__ __forceinline__ bool sbp_candidate_ok(const SbpCand& cd, const SiWindow& w, const SbpProj& pr) {
+    const int gx = cd.cell >> 6, gy = cd.cell & 63;
+    if (gx < w.minX || gx > w.maxX || gy < w.minY || gy > w.maxY) return false;
+    if (!sbp_level_ok(cd.octave, pr.minLevel, pr.maxLevel)) return false;
+    const float distx = __fsub_rn(cd.x, pr.u), disty = __fsub_rn(cd.y, pr.v);
+    if (!(fabsf(distx) < pr.radius && fabsf(disty) < pr.radius)) return false;
+    if (cd.uRight > 0.f) { /* CurrentFrame.mvuRight[i2] > 0 */
+        const float er = fabsf(__fsub_rn(pr.ur, cd.uRight));
+        if (er > pr.radius) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ SbpCand sbp_make_cand(const vslam_kp& k, float uRight, float invW, float invH, bool* in_grid) {
+    SbpCand c;
+    c.x = k.x;
+    c.y = k.y;
+    c.uRight = uRight;
+    const int gx = (int)roundf(__fmul_rn(k.x, invW)), gy = (int)roundf(__fmul_rn(k.y, invH));
+    *in_grid = !(gx < 0 || gx >= SI_GRID_COLS || gy < 0 || gy >= SI_GRID_ROWS); /* PosInGrid, frame.cpp:746-756 */
+    c.cell = (uint16_t)(*in_grid ? gx * 64 + gy : 0xFFFF);
+    c.octave = (uint16_t)k.octave;
+    return c;
+}
+
+__global__ void __launch_bounds__(256)
+k_sbp_rank(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uint8_t* __restrict__ flags,
+           const float* __restrict__ x3Dw, const uint8_t* __restrict__ mpDesc, const vslam_kp* __restrict__ curKps,
+           const uint8_t* __restrict__ curDesc, const float* __restrict__ uRight /* may be null */, int nCur, int M,
+           SbpProj* __restrict__ proj, uint32_t* __restrict__ topm) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    SbpCand* cand = (SbpCand*)sbsm; /* nCur */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)A.imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)A.imgH);
+    for (int i = tid; i < nCur; i += 256) {
+        bool ing;
+        cand[i] = sbp_make_cand(curKps[i], uRight ? uRight[i] : -1.f, invW, invH, &ing);
+    }
+    __syncthreads();
+    for (int q = blockIdx.x * SBP_QPB + wave; q < min(nLast, (int)(blockIdx.x + 1) * SBP_QPB); q += 4) {
+        SbpProj pr;
+        pr.valid = 0;
+        pr.u = pr.v = pr.radius = pr.ur = 0.f;
+        pr.minLevel = pr.maxLevel = 0;
+        pr.pad = 0;
+        if (flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
+            const float X = x3Dw[3 * q], Y = x3Dw[3 * q + 1], Z = x3Dw[3 * q + 2];
+            const float xc = sbp_gemm_row(A.Tcw + 0, X, Y, Z, A.Tcw[3], A.gemmFloat);
+            const float yc = sbp_gemm_row(A.Tcw + 4, X, Y, Z, A.Tcw[7], A.gemmFloat);
+            const float zc = sbp_gemm_row(A.Tcw + 8, X, Y, Z, A.Tcw[11], A.gemmFloat);
+            const float invzc = (float)__ddiv_rn(1.0, (double)zc);
+            if (!(invzc < 0.f)) {
+                const float u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx); /* pinhole.cpp:13-16 */
+                const float v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
+                if (!(u < 0.f || u > (float)A.imgW) && !(v < 0.f || v > (float)A.imgH)) {
+                    const int oct = lastKps[q].octave;
+                    pr.u = u;
+                    pr.v = v;
+                    pr.radius = __fmul_rn(A.th, A.scale[min(max(oct, 0), A.nlevels - 1)]);
+                    pr.ur = __fsub_rn(u, __fmul_rn(A.mbf, invzc));
+                    if (A.forward) { pr.minLevel = oct; pr.maxLevel = -1; }
+                    else if (A.backward) { pr.minLevel = 0; pr.maxLevel = oct; }
+                    else { pr.minLevel = oct - 1; pr.maxLevel = oct + 1; }
+                    pr.valid = 1;
+                }
+            }
+        }
+        /* per-lane sorted prefix (ascending), then an M-way merge across the wave */
+        uint32_t best[SI_MAX_M];
+#pragma unroll
+        for (int j = 0; j < SI_MAX_M; j++) best[j] = 0xFFFFFFFFu;
+        if (pr.valid) { /* wave-uniform */
+            const SiWindow win = si_window(pr.u, pr.v, pr.radius, invW, invH);
+            if (!win.empty) {
+                const uint4 da = ((const uint4*)mpDesc)[(size_t)q * 2], db = ((const uint4*)mpDesc)[(size_t)q * 2 + 1];
+                for (int c = lane; c < nCur; c += 64) {
+                    const SbpCand cd = cand[c];
+                    if (cd.cell == 0xFFFF || !sbp_candidate_ok(cd, win, pr)) continue;
+                    const uint4 ta = ((const uint4*)curDesc)[(size_t)c * 2], tb = ((const uint4*)curDesc)[(size_t)c * 2 + 1];
+                    uint32_t key = (min(si_hamming(da, db, ta, tb), 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+#pragma unroll
+                    for (int j = 0; j < SI_MAX_M; j++) { /* insertion: keeps best[] ascending, drops the largest */
+                        const uint32_t lo = min(key, best[j]);
+                        key = max(key, best[j]);
+                        best[j] = lo;
+                    }
+                }
+            }
+        }
+        uint32_t mine = 0xFFFFFFFFu;
+        for (int j = 0; j < M; j++) {
+            const uint32_t g = wave_min_u32(best[0]);
+            if (g == 0xFFFFFFFFu) break;
+            if (lane == j) mine = g;
+            if (best[0] == g) { /* pop (keys are unique: they contain i2) */
+#pragma unroll
+                for (int t = 0; t + 1 < SI_MAX_M; t++) best[t] = best[t + 1];
+                best[SI_MAX_M - 1] = 0xFFFFFFFFu;
+            }
+        }
+        if (lane < M) topm[(size_t)q * M + lane] = mine;
+        if (lane == 0) proj[q] = pr;
+    }
+}
+
+/* full re-scan of one query's window in candidate order (the reference loop body) -> best key or ~0 */
+__device__ uint32_t sbp_full_scan(const SbpProj& pr, const vslam_kp* curKps, const float* uRight, int nCur,
+                                  const uint8_t* mpDescQ, const uint8_t* curDesc, const uint32_t* occupied, float invW,
+                                  float invH, int lane) {
+    uint32_t bestKey = 0xFFFFFFFFu;
+    const SiWindow win = si_window(pr.u, pr.v, pr.radius, invW, invH);
+    if (!win.empty) {
+        const uint4 da = ((const uint4*)mpDescQ)[0], db = ((const uint4*)mpDescQ)[1];
+        for (int c = lane; c < nCur; c += 64) {
+            bool ing;
+            const SbpCand cd = sbp_make_cand(curKps[c], uRight ? uRight[c] : -1.f, invW, invH, &ing);
+            if (!ing || occupied[c] || !sbp_candidate_ok(cd, win, pr)) continue;
+            const uint4 ta = ((const uint4*)curDesc)[(size_t)c * 2], tb = ((const uint4*)curDesc)[(size_t)c * 2 + 1];
+            bestKey = min(bestKey, (min(si_hamming(da, db, ta, tb), 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c);
+        }
+    }
+    return wave_min_u32(bestKey);
+}
+
+__global__ void __launch_bounds__(64)
+k_sbp_replay(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uint8_t* __restrict__ flags,
+             const uint8_t* __restrict__ mpDesc, const vslam_kp* __restrict__ curKps,
+             const uint8_t* __restrict__ curDesc, const float* __restrict__ uRight,
+             const uint8_t* __restrict__ occupied0 /* may be null */, int nCur, int M,
+             const SbpProj* __restrict__ proj, const uint32_t* __restrict__ topm, int32_t* __restrict__ matchCur,
+             int32_t* __restrict__ nmatches_out, int* fallbacks) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    uint32_t* occupied = (uint32_t*)sbsm;              /* nCur: mvpMapPoints[i2] with Observations() > 0 */
+    int32_t* ownerEntry = (int32_t*)(occupied + nCur); /* nCur: last log entry that wrote mvpMapPoints[i2] */
+    uint32_t* alog = (uint32_t*)(ownerEntry + nCur);   /* nLast: (query << 12 | i2), in order */
+    uint8_t* logBin = (uint8_t*)(alog + nLast);        /* nLast: rotation bin of a log entry */
+    uint32_t* kbuf = (uint32_t*)(sbsm + (((size_t)nCur * 8 + (size_t)nLast * 5 + 15) & ~(size_t)15)); /* 64 x M */
+    __shared__ int s_hist[SI_HISTO];
+    const int lane = threadIdx.x;
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)A.imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)A.imgH);
+    for (int c = lane; c < nCur; c += 64) {
+        occupied[c] = occupied0 ? occupied0[c] : 0u;
+        ownerEntry[c] = -1;
+        matchCur[c] = -1;
+    }
+    if (lane < SI_HISTO) s_hist[lane] = 0;
+    __syncthreads();
+
+    int nlog = 0, nfb = 0;
+    for (int qb = 0; qb < nLast; qb += 64) {
+        const int nq = min(64, nLast - qb);
+        __syncthreads();
+        for (int i = lane; i < nq * M; i += 64) kbuf[i] = topm[(size_t)qb * M + i];
+        const uint32_t myflags = lane < nq ? flags[qb + lane] : 0u; /* lane tq holds query qb+tq's flags */
+        __syncthreads();
+        uint32_t keyN = lane < M ? kbuf[lane] : 0xFFFFFFFFu;
+        uint32_t occN = keyN != 0xFFFFFFFFu ? occupied[keyN & 0xFFF] : 0u;
+        for (int tq = 0; tq < nq; tq++) {
+            const uint32_t key = keyN, occ = occN;
+            if (tq + 1 < nq) {
+                keyN = lane < M ? kbuf[(tq + 1) * M + lane] : 0xFFFFFFFFu;
+                occN = keyN != 0xFFFFFFFFu ? occupied[keyN & 0xFFF] : 0u;
+            }
+            const bool valid = key != 0xFFFFFFFFu;
+            const unsigned long long mv = __ballot(valid), mk = __ballot(valid && !occ);
+            if (mv == 0) continue; /* vIndices2 empty, or every candidate failed an order-free gate */
+            uint32_t gBest;
+            if (mk) {
+                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+                gBest = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+            } else if (__popcll(mv) < M) {
+                continue; /* the list is complete and every entry is occupied: bestDist stays 256 */
+            } else {
+                nfb++;
+                gBest = sbp_full_scan(proj[qb + tq], curKps, uRight, nCur, mpDesc + (size_t)(qb + tq) * 32, curDesc,
+                                      occupied, invW, invH, lane);
+                if (gBest == 0xFFFFFFFFu) continue;
+            }
+            if ((gBest >> 24) > SBP_TH_HIGH) continue; /* bestDist <= TH_HIGH */
+            const uint32_t i2 = gBest & 0xFFF;
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)myflags, tq);
+            if (lane == 0) {
+                alog[nlog] = ((uint32_t)(qb + tq) << 12) | i2;
+                if (fl & 2) occupied[i2] = 1u; /* pMP->Observations() > 0: later queries skip i2 */
+            }
+            nlog++;
+            if ((fl & 2) && keyN != 0xFFFFFFFFu && (keyN & 0xFFF) == i2) occN = 1u;
+        }
+    }
+    __syncthreads();
+    if (fallbacks && lane == 0 && nfb) atomicAdd(fallbacks, nfb);
+    /* mvpMapPoints[bestIdx2] = pMP: the last writer stays */
+    for (int e = lane; e < nlog; e += 64) atomicMax(&ownerEntry[alog[e] & 0xFFF], e);
+    __syncthreads();
+    const float factor = 1.0f / SI_HISTO;
+    for (int e = lane; e < nlog; e += 64) {
+        const uint32_t le = alog[e];
+        const int q = (int)(le >> 12), i2 = (int)(le & 0xFFF);
+        if (ownerEntry[i2] == e) matchCur[i2] = q;
+        if (A.checkOri) {
+            float rot = __fsub_rn(lastKps[q].angle, curKps[i2].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == SI_HISTO) bin = 0;
+            logBin[e] = (uint8_t)bin;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    int removed = 0;
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0; /* ComputeThreeMaxima, fmatcher.cpp:2813-2854 */
+        for (int i = 0; i < SI_HISTO; i++) {
+            const int s = s_hist[i];
+            if (s > max1) {
+                max3 = max2; max2 = max1; max1 = s;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (s > max2) {
+                max3 = max2; max2 = s;
+                ind3 = ind2; ind2 = i;
+            } else if (s > max3) {
+                max3 = s;
+                ind3 = i;
+            }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        /* every entry of a rejected bin clears mvpMapPoints[idx] and decrements nmatches (fmatcher.cpp:2668-2681) */
+        for (int e = lane; e < nlog; e += 64) {
+            const int b = logBin[e];
+            if (b != ind1 && b != ind2 && b != ind3) {
+                matchCur[alog[e] & 0xFFF] = -1;
+                removed++;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o, 64);
+    if (lane == 0) nmatches_out[0] = nlog - removed;
+}
+
+size_t vk_sbp_rank_lds(int nCur) { return (size_t)nCur * sizeof(SbpCand); }
+size_t vk_sbp_replay_lds(int nCur, int nLast) {
+    return (((size_t)nCur * 8 + (size_t)nLast * 5 + 15) & ~(size_t)15) + 64 * SI_MAX_M * 4;
+}
+size_t vk_sbp_scratch_bytes(int nLast, int M) { return (size_t)nLast * (sizeof(SbpProj) + 4 * (size_t)M); }
+int vk_sbp_set_max_lds(size_t bytes) {
+    int rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_sbp_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+void vk_search_by_projection(hipStream_t st, const SbpHostArgs& H, const vslam_kp* lastKps, int nLast,
+                             const uint8_t* flags, const float* x3Dw, const uint8_t* mpDesc, const vslam_kp* curKps,
+                             const uint8_t* curDesc, const float* uRight, const uint8_t* occupied0, int nCur, int M,
+                             uint8_t* scratch, int32_t* matchCur, int32_t* nmatches, int* fallbacks) {
+    SbpArgs A;
+    for (int i = 0; i < 12; i++) A.Tcw[i] = H.Tcw[i];
+    A.fx = H.fx; A.fy = H.fy; A.cx = H.cx; A.cy = H.cy; A.mbf = H.mbf; A.th = H.th;
+    for (int l = 0; l < VSLAM_MAX_LEVELS; l++) A.scale[l] = H.scale[l];
+    A.forward = H.forward; A.backward = H.backward; A.checkOri = H.checkOri; A.imgW = H.imgW; A.imgH = H.imgH;
+    A.gemmFloat = H.gemmFloat; A.nlevels = H.nlevels;
+    SbpProj* proj = (SbpProj*)scratch;
+    uint32_t* topm = (uint32_t*)(proj + nLast);
+    if (nLast > 0)
+        hipLaunchKernelGGL(k_sbp_rank, dim3((nLast + SBP_QPB - 1) / SBP_QPB), dim3(256), vk_sbp_rank_lds(nCur), st, A,
+                           lastKps, nLast, flags, x3Dw, mpDesc, curKps, curDesc, uRight, nCur, M, proj, topm);
+    hipLaunchKernelGGL(k_sbp_replay, dim3(1), dim3(64), vk_sbp_replay_lds(nCur, nLast), st, A, lastKps, nLast, flags,
+                       mpDesc, curKps, curDesc, uRight, occupied0, nCur, M, proj, topm, matchCur, nmatches, fallbacks);
+}

@@ -450,3 +450,126 @@ extern "C" int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count) {
     HIPCHK(hipMemset(fe->d_init_fb, 0, 4));
     return VSLAM_OK;
 }
+
+/* ------------------------------------------------------------------ SearchByProjection(CurrentFrame, LastFrame) */
+extern "C" int vslam_projection_direction(const float* Tcw, const float* Tlw, float mb, int mono, int gemm_float,
+                                          int* forward, int* backward) {
+    if (!Tcw || !Tlw || !forward || !backward) return VSLAM_ERR_INVALID;
+    /* twc = -Rcw.t()*tcw ; tlc = Rlw*twc + tlw (fmatcher.cpp:2482-2492), each ONE cv::gemm */
+    float twc[3], tlc2;
+    for (int r = 0; r < 3; r++) {
+        if (!gemm_float) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + r] * (double)Tcw[k * 4 + 3];
+            twc[r] = (float)(s * -1.0);
+        } else {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += Tcw[k * 4 + r] * Tcw[k * 4 + 3];
+            twc[r] = -s;
+        }
+    }
+    if (!gemm_float) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tlw[8 + k] * (double)twc[k];
+        tlc2 = (float)(s + (double)Tlw[11]);
+    } else {
+        float s = 0;
+        for (int k = 0; k < 3; k++) s += Tlw[8 + k] * twc[k];
+        tlc2 = s + Tlw[11];
+    }
+    *forward = (tlc2 > mb && !mono) ? 1 : 0;
+    *backward = (-tlc2 > mb && !mono) ? 1 : 0;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p,
+                                                const vslam_kp* last_kps_host, int n_last, const uint8_t* last_flags,
+                                                const float* last_x3dw, const uint8_t* mp_desc_host,
+                                                const vslam_kp* dev_cur_kps, const uint8_t* dev_cur_desc, int n_cur,
+                                                const float* cur_u_right_host, const uint8_t* cur_occupied_host,
+                                                int32_t* match_cur, int* nmatches) {
+    if (!fe || !p || n_last < 0 || n_cur < 0 || !nmatches || (n_cur && (!dev_cur_kps || !dev_cur_desc || !match_cur)) ||
+        (n_last && (!last_kps_host || !last_flags || !last_x3dw || !mp_desc_host)) || p->img_w < 1 || p->img_h < 1) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    *nmatches = 0;
+    if (n_cur == 0 || n_last == 0) {
+        for (int i = 0; i < n_cur; i++) match_cur[i] = -1;
+        return VSLAM_OK;
+    }
+    if (n_cur > 4096) { /* i2 is a 12-bit field of the ordering key */
+        g_err = "SearchByProjection on the device supports at most 4096 current-frame keypoints";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    int M = 8;
+    if (const char* e = getenv("VSLAM_SBP_TOPM")) M = std::min(16, std::max(1, atoi(e)));
+    const size_t lds = std::max(vk_sbp_rank_lds(n_cur), vk_sbp_replay_lds(n_cur, n_last));
+    if (lds > 150 * 1024) {
+        g_err = "SearchByProjection: frame too large for the LDS-resident matcher";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    if (!fe->proj_lds_set) {
+        if (vk_sbp_set_max_lds(150 * 1024) != 0) {
+            g_err = "hipFuncSetAttribute(k_sbp_*) failed";
+            return VSLAM_ERR_HIP;
+        }
+        fe->proj_lds_set = true;
+    }
+    /* one pinned block -> one upload: kps | x3Dw | mpDesc | flags | uRight | occupied, 16-byte aligned parts */
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_kps = 0, o_x = al(o_kps + (size_t)n_last * sizeof(vslam_kp)), o_d = al(o_x + (size_t)n_last * 12),
+                 o_f = al(o_d + (size_t)n_last * 32), o_u = al(o_f + (size_t)n_last), o_o = al(o_u + (size_t)n_cur * 4),
+                 in_bytes = al(o_o + (size_t)n_cur);
+    const size_t o_scr = in_bytes, o_m = al(o_scr + vk_sbp_scratch_bytes(n_last, M)), o_n = al(o_m + (size_t)n_cur * 4),
+                 total = o_n + 16;
+    int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < total) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
+        fe->h_proj_bytes = total;
+    }
+    if (!fe->d_init_fb) {
+        HIPCHK(hipMalloc((void**)&fe->d_init_fb, 16));
+        HIPCHK(hipMemset(fe->d_init_fb, 0, 16));
+    }
+    uint8_t* h = fe->h_proj;
+    memcpy(h + o_kps, last_kps_host, (size_t)n_last * sizeof(vslam_kp));
+    memcpy(h + o_x, last_x3dw, (size_t)n_last * 12);
+    memcpy(h + o_d, mp_desc_host, (size_t)n_last * 32);
+    memcpy(h + o_f, last_flags, (size_t)n_last);
+    if (cur_u_right_host) memcpy(h + o_u, cur_u_right_host, (size_t)n_cur * 4);
+    if (cur_occupied_host) memcpy(h + o_o, cur_occupied_host, (size_t)n_cur);
+    hipStream_t st = fe->stream;
+    HIPCHK(hipMemcpyAsync(fe->d_proj, h, in_bytes, hipMemcpyHostToDevice, st));
+    SbpHostArgs H;
+    memset(&H, 0, sizeof(H));
+    memcpy(H.Tcw, p->Tcw, sizeof(H.Tcw));
+    H.fx = p->fx; H.fy = p->fy; H.cx = p->cx; H.cy = p->cy; H.mbf = p->mbf; H.th = p->th;
+    for (int l = 0; l < fe->p.nlevels; l++) H.scale[l] = fe->tab.scale[l];
+    H.nlevels = fe->p.nlevels;
+    H.forward = p->forward; H.backward = p->backward; H.checkOri = p->check_orientation;
+    H.imgW = p->img_w; H.imgH = p->img_h; H.gemmFloat = p->gemm_float;
+    uint8_t* d = fe->d_proj;
+    vk_search_by_projection(st, H, (const vslam_kp*)(d + o_kps), n_last, d + o_f, (const float*)(d + o_x), d + o_d,
+                            dev_cur_kps, dev_cur_desc, cur_u_right_host ? (const float*)(d + o_u) : nullptr,
+                            cur_occupied_host ? d + o_o : nullptr, n_cur, M, d + o_scr, (int32_t*)(d + o_m),
+                            (int32_t*)(d + o_n), fe->d_init_fb);
+    HIPCHK(hipGetLastError());
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = h + o_m;
+    R.src[0] = d + o_m;
+    R.bytes[0] = (o_n + 16) - o_m;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
+    *nmatches = *(const int32_t*)(h + o_n);
+    return VSLAM_OK;
+}
