@@ -146,6 +146,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_collective:
+        if world == 1:  # --force-collective without a launcher: a one-rank group
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
