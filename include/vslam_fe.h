@@ -262,6 +262,36 @@ int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p, c
                                      const uint8_t* dev_cur_desc, int n_cur, const float* cur_u_right_host,
                                      const uint8_t* cur_occupied_host, int32_t* match_cur, int* nmatches);
 
+/* Device-resident, batched form of the same matcher: every pointer of a job is a DEVICE pointer; counts are
+ * int32 in HBM (vslam_fe_slot_count_ptr); keypoint arrays hold up to the context's capacity (<= 4096).  Up to 16
+ * jobs per call run in one pass of the two kernels on fe's stream.  _async returns without waiting; _wait
+ * delivers n_cur[j] entries of match_cur[j] and nmatches[j]. */
+typedef struct vslam_sbp_job {
+    vslam_proj_params p;
+    const vslam_kp* dev_last_kps;
+    const int32_t* dev_n_last;
+    const uint8_t* dev_last_flags;
+    const float* dev_last_x3dw;
+    const uint8_t* dev_mp_desc;
+    const vslam_kp* dev_cur_kps;
+    const uint8_t* dev_cur_desc;
+    const int32_t* dev_n_cur;
+    const float* dev_cur_u_right;    /* may be NULL */
+    const uint8_t* dev_cur_occupied; /* may be NULL */
+} vslam_sbp_job;
+int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, const vslam_sbp_job* jobs);
+int vslam_search_by_projection_dev_wait(vslam_fe* fe, const int* n_cur, int32_t* const* match_cur, int* nmatches);
+
+/* Frame::UnprojectStereo (frame.cpp:1023-1037) on the device for all left keypoints of the stereo pairs of fe's
+ * last vslam_frame_stereo_batch_async / vslam_stereo_match_batch: the stereo points that UpdateLastFrame
+ * (tracking.cpp) turns into MapPoints for the next frame's SearchByProjection.  Twc: npairs x 12 floats, rows
+ * [mRwc | mOw] per pair.  flags[i] = 0 (no depth) or 1 | (observations ? 2 : 0).  Enqueued on fe's stream;
+ * vslam_stereo_points_buffers returns the per-pair device arrays (stable for the life of the context). */
+int vslam_stereo_points_dev_async(vslam_fe* fe, int npairs, const float* Twc, float cx, float cy, float invfx,
+                                  float invfy, int observations, int gemm_float);
+int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float** dev_x3dw, const uint8_t** dev_flags,
+                                const float** dev_u_right, const float** dev_depth);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

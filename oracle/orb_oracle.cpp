@@ -927,6 +927,17 @@ static inline float gemm_row(const float* r, const float* x, float t, int dbl) {
     return s + t;
 }
 
+bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
+                      int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
+    if (!(z > 0)) return false;
+    const float u = kpUn.x, v = kpUn.y;
+    const float x = (u - cx) * z * invfx;
+    const float y = (v - cy) * z * invfy;
+    const float x3Dc[3] = {x, y, z};
+    for (int r = 0; r < 3; r++) out[r] = gemm_row(Twc + 4 * r, x3Dc, Twc[4 * r + 3], gemmDouble); /* mRwc*x3Dc+mOw */
+    return true;
+}
+
 void projection_direction(const ProjFrameArgs& a, bool& bForward, bool& bBackward) {
     /* twc = -Rcw.t()*tcw (gemm with alpha = -1, no C); tlc = Rlw*twc + tlw; fmatcher.cpp:2482-2495 */
     float twc[3], tlc[3];

@@ -136,6 +136,9 @@ int search_by_projection_frame(const ProjFrameArgs& a, const std::vector<KeyPoin
                                const std::vector<uint8_t>& curDesc, const std::vector<float>& mvuRight,
                                const std::vector<uint8_t>& occupied, const std::vector<float>& scaleFactors,
                                std::vector<int>& matchCur);
+/* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
+bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
+                      int gemmDouble, float out[3]);
 /* bForward / bBackward of the same function (fmatcher.cpp:2482-2495) */
 void projection_direction(const ProjFrameArgs& a, bool& bForward, bool& bBackward);
 

@@ -192,4 +192,14 @@ int orbo_search_by_projection_frame(const float* fargs, const int* iargs, const 
     return nm;
 }
 
+/* x3dw: n x 3 out, flags: n out (0 / 1) */
+void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
+                           float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {
+    for (int i = 0; i < n; i++) {
+        float o[3] = {0, 0, 0};
+        flags[i] = unproject_stereo(kps[i], depth[i], Twc, cx, cy, invfx, invfy, gemmDouble, o) ? 1 : 0;
+        memcpy(x3dw + 3 * i, o, 12);
+    }
+}
+
 } /* extern "C" */

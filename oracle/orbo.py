@@ -65,6 +65,9 @@ def lib():
         L.orbo_grid_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
         vp = C.c_void_p
+        L.orbo_unproject_stereo.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                            vp, vp]
+        L.orbo_unproject_stereo.restype = None
         L.orbo_search_by_projection_frame.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp,
                                                       C.c_int, vp, vp]
         _lib = L
@@ -275,3 +278,14 @@ def search_by_projection_frame(Tcw, Tlw, cam, th, last_kps, flags, x3dw, mp_desc
                                                _p(mp_desc), _p(cur_kps), len(cur_kps), _p(cur_desc), _p(mvu),
                                                _p(occ) if occ is not None else None, _p(sf), len(sf), _p(m), _p(d))
     return nm, m[:len(cur_kps)], (bool(d[0]), bool(d[1]))
+
+
+def unproject_stereo(kps, depth, Twc, cx, cy, invfx, invfy, gemm_double=True):
+    """Frame::UnprojectStereo (frame.cpp:1023-1037) for every keypoint -> (x3Dw [n,3], has_point [n] u8)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    depth = np.ascontiguousarray(depth, np.float32)
+    T = np.ascontiguousarray(np.asarray(Twc, np.float32).reshape(-1)[:12])
+    x = np.zeros((len(kps), 3), np.float32)
+    f = np.zeros(len(kps), np.uint8)
+    lib().orbo_unproject_stereo(_p(kps), len(kps), _p(depth), _p(T), cx, cy, invfx, invfy, int(gemm_double), _p(x), _p(f))
+    return x, f

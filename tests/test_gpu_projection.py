@@ -116,3 +116,76 @@ def test_degenerate_inputs(scene):
     flags = np.full(len(scene["k0"]), 3, np.uint8)
     nm, mc, _ = _run(scene, _pose(tz=-1000.0), 15, flags)
     assert nm == 0
+
+
+def _dev_read(ptr, nbytes):
+    """Copy raw device memory to a numpy byte array (tests only)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.zeros(nbytes, np.uint8)
+    assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    return out
+
+
+def test_device_resident_tracking_chain_equals_oracle():
+    """Frame::Frame(stereo) x 4 -> UnprojectStereo of every frame -> SearchByProjection(frame s, frame s-1) for
+    s = 1..3, all enqueued without touching the host: one extraction+stereo enqueue, one unprojection kernel, one
+    pass of the two matcher kernels.  Compared with the oracle chain."""
+    import torch
+    nst = 4
+    fe = V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=2 * nst)
+    try:
+        frames = [synth.make_stereo_pair(W, H, step=s) for s in range(nst)]
+        pitch = 1280
+        dev = torch.zeros((2 * nst, H, pitch), dtype=torch.uint8, device="cuda")
+        for s in range(nst):
+            dev[2 * s, :, :W] = torch.from_numpy(frames[s][0]).cuda()
+            dev[2 * s + 1, :, :W] = torch.from_numpy(frames[s][1]).cuda()
+        torch.cuda.synchronize()
+        fe.frame_stereo_async([dev[i].data_ptr() for i in range(2 * nst)], pitch, BF, FX)
+        # world = camera of each frame's own pose; poses: frame s sits at s * (dx, dy, 0)
+        zmed = 12.0
+        dx, dy = 3.0 / FX * zmed, 1.0 / FY * zmed
+        Twc = [np.hstack([np.eye(3), np.array([[-s * dx], [-s * dy], [0.0]])]).astype(np.float32) for s in range(nst)]
+        Tcw = [np.hstack([np.eye(3), np.array([[s * dx], [s * dy], [0.0]])]).astype(np.float32) for s in range(nst)]
+        invfx, invfy = np.float32(1.0) / np.float32(FX), np.float32(1.0) / np.float32(FY)
+        fe.stereo_points_async(Twc, (CX, CY, float(invfx), float(invfy)), observations=True)
+        m = V.FMatcher(fe, 0.9, True)
+        jobs = []
+        for s in range(1, nst):
+            lk, ld, ln = fe.slot_dev_ptrs(2 * (s - 1))
+            ck, cd, cn = fe.slot_dev_ptrs(2 * s)
+            x, f, _, _ = fe.stereo_points_buffers(s - 1)
+            _, _, ur, _ = fe.stereo_points_buffers(s)
+            fwd, bwd = orbo.search_by_projection_frame(Tcw[s], Tcw[s - 1], (FX, FY, CX, CY, BF, MB), 15,
+                                                       np.zeros(0, V.KP_DTYPE), np.zeros(0, np.uint8),
+                                                       np.zeros((0, 3), np.float32), np.zeros((0, 32), np.uint8),
+                                                       np.zeros(0, V.KP_DTYPE), np.zeros((0, 32), np.uint8),
+                                                       np.zeros(0, np.float32), fe.GetScaleFactors(), W, H)[2]
+            jobs.append(dict(Tcw=Tcw[s], cam=(FX, FY, CX, CY, BF), th=15, forward=fwd, backward=bwd, img=(W, H),
+                             last_kps=lk, n_last=ln, last_flags=f, last_x3dw=x, mp_desc=ld, cur_kps=ck, cur_desc=cd,
+                             n_cur=cn, cur_u_right=ur))
+        m.search_by_projection_dev_async(jobs)
+        feats, st = fe.frame_stereo_wait()
+        feats = [(k.copy(), d.copy()) for k, d in feats]
+        st = [(u.copy(), d.copy()) for u, d in st]
+        out = m.search_by_projection_dev_wait([len(feats[2 * s][0]) for s in range(1, nst)])
+        cap = fe.cap
+        for s in range(nst):
+            kL = feats[2 * s][0]
+            wx, wf = orbo.unproject_stereo(kL, st[s][1], Twc[s], CX, CY, float(invfx), float(invfy))
+            x, f, _, _ = fe.stereo_points_buffers(s)
+            gx = _dev_read(x, cap * 12).view(np.float32).reshape(cap, 3)[:len(kL)]
+            gf = _dev_read(f, cap)[:len(kL)]
+            assert np.array_equal(gf, wf * 3) and np.array_equal(gx[wf > 0], wx[wf > 0]), s
+        for j, s in enumerate(range(1, nst)):
+            k0, d0 = feats[2 * (s - 1)]
+            k1, d1 = feats[2 * s]
+            wx, wf = orbo.unproject_stereo(k0, st[s - 1][1], Twc[s - 1], CX, CY, float(invfx), float(invfy))
+            wn, wm, _ = orbo.search_by_projection_frame(Tcw[s], Tcw[s - 1], (FX, FY, CX, CY, BF, MB), 15, k0, wf * 3, wx,
+                                                        d0, k1, d1, st[s][0], fe.GetScaleFactors(), W, H)
+            assert out[j][0] == wn and np.array_equal(out[j][1], wm), s
+            assert wn > 100
+    finally:
+        fe.close()

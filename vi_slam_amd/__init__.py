@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "vslam_fe_pack_slot_range", "vslam_dbg_octree_stamps", "vslam_dbg_search_init_fallbacks", "vslam_search_init_dev_async",
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
     "vslam_fe_event_wait", "vslam_projection_direction", "vslam_search_by_projection_frame",
+    "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
+    "vslam_stereo_points_buffers",
 ]
 
 
@@ -46,6 +48,12 @@ class _ProjParams(C.Structure):  # vslam_proj_params
                 ("mbf", C.c_float), ("th", C.c_float), ("forward", C.c_int32), ("backward", C.c_int32),
                 ("check_orientation", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
                 ("gemm_float", C.c_int32)]
+
+
+class _SbpJob(C.Structure):  # vslam_sbp_job
+    _fields_ = [("p", _ProjParams)] + [(n, C.c_void_p) for n in (
+        "dev_last_kps", "dev_n_last", "dev_last_flags", "dev_last_x3dw", "dev_mp_desc", "dev_cur_kps", "dev_cur_desc",
+        "dev_n_cur", "dev_cur_u_right", "dev_cur_occupied")]
 
 
 class VslamError(RuntimeError):
@@ -98,6 +106,10 @@ def lib():
         L.vslam_fe_slot_buffers.argtypes = [vp, i, vp, vp, vp]
         L.vslam_fe_slot_host_views.argtypes = [vp, i, vp, vp]
         L.vslam_projection_direction.argtypes = [vp, vp, C.c_float, i, i, vp, vp]
+        L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
+        L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
+        L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
+        L.vslam_stereo_points_buffers.argtypes = [vp, i, vp, vp, vp, vp]
         L.vslam_search_by_projection_frame.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
         L.vslam_fe_stream.argtypes = [vp]
         L.vslam_fe_stream.restype = vp
@@ -373,6 +385,23 @@ class FExtractor:
         fn = lib().vslam_fe_pack_slot_range if sync else lib().vslam_fe_pack_slot_range_async
         _check(fn(self._h, first, nslots, dev_dst, slot_bytes or self.slot_bytes))
 
+    # ---- stereo points of the last stereo enqueue (Frame::UnprojectStereo, frame.cpp:1023-1037)
+    def stereo_points_async(self, Twc, cam, observations=True, gemm_float=False):
+        """Twc: list of 3x4 [mRwc | mOw], one per stereo pair of the last stereo enqueue; cam = (cx, cy, invfx,
+        invfy).  Fills the per-pair device arrays returned by stereo_points_buffers()."""
+        T = np.ascontiguousarray(np.asarray(Twc, np.float32).reshape(len(Twc), -1)[:, :12])
+        _check(lib().vslam_stereo_points_dev_async(self._h, len(Twc), _p(T), C.c_float(cam[0]), C.c_float(cam[1]),
+                                                   C.c_float(cam[2]), C.c_float(cam[3]), int(observations),
+                                                   int(gemm_float)))
+
+    def stereo_points_buffers(self, pair, with_stereo=True):
+        """-> device addresses (x3Dw [cap x 3 f32], flags [cap u8], mvuRight [cap f32], mvDepth [cap f32])."""
+        x, f, u, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().vslam_stereo_points_buffers(self._h, pair, C.byref(x), C.byref(f),
+                                                 C.byref(u) if with_stereo else None,
+                                                 C.byref(d) if with_stereo else None))
+        return x.value, f.value, u.value, d.value
+
     def set_profiling(self, on=True):
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))
 
@@ -492,6 +521,44 @@ class FMatcher:
             C.c_void_p(dev_cur_desc), n_cur, _p(ur) if ur is not None else None, _p(oc) if oc is not None else None,
             _p(m), C.byref(nm)))
         return nm.value, m[:n_cur], (bool(fwd.value), bool(bwd.value))
+
+    @staticmethod
+    def make_sbp_jobs(jobs, check_orientation=True):
+        """jobs: list of dicts with keys Tcw, cam=(fx,fy,cx,cy,mbf), th, forward, backward, img=(w,h) and the device
+        addresses last_kps, n_last, last_flags, last_x3dw, mp_desc, cur_kps, cur_desc, n_cur, cur_u_right (or 0),
+        cur_occupied (or 0).  -> ctypes array for search_by_projection_dev_async."""
+        arr = (_SbpJob * len(jobs))()
+        for j, d in enumerate(jobs):
+            P = arr[j].p
+            T = np.asarray(d["Tcw"], np.float32).reshape(-1)
+            for i in range(12):
+                P.Tcw[i] = float(T[i])
+            P.fx, P.fy, P.cx, P.cy, P.mbf = [float(v) for v in d["cam"][:5]]
+            P.th = float(d["th"])
+            P.forward, P.backward = int(d.get("forward", 0)), int(d.get("backward", 0))
+            P.check_orientation = int(check_orientation)
+            P.img_w, P.img_h = d["img"]
+            P.gemm_float = int(d.get("gemm_float", 0))
+            for k in ("last_kps", "n_last", "last_flags", "last_x3dw", "mp_desc", "cur_kps", "cur_desc", "n_cur",
+                      "cur_u_right", "cur_occupied"):
+                setattr(arr[j], "dev_" + k, d.get(k) or None)
+        return arr
+
+    def search_by_projection_dev_async(self, jobs):
+        arr = jobs if isinstance(jobs, C.Array) else self.make_sbp_jobs(jobs, self.mbCheckOrientation)
+        self._sbp_n = len(arr)
+        _check(lib().vslam_search_by_projection_dev_async(self.fe._h, len(arr), arr))
+
+    def search_by_projection_dev_wait(self, n_cur):
+        """-> list of (nmatches, match_cur[n_cur[j]])."""
+        n = self._sbp_n
+        cap = self.fe.cap
+        if getattr(self, "_sbp_buf", None) is None:
+            self._sbp_buf = np.zeros((16, cap), np.int32)
+            self._sbp_ptrs = (C.c_void_p * 16)(*[self._sbp_buf[i].ctypes.data for i in range(16)])
+        nm = (C.c_int * n)()
+        _check(lib().vslam_search_by_projection_dev_wait(self.fe._h, (C.c_int * n)(*n_cur), self._sbp_ptrs, nm))
+        return [(nm[j], self._sbp_buf[j, :n_cur[j]]) for j in range(n)]
 
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""

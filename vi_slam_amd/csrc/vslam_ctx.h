@@ -180,6 +180,13 @@ struct vslam_fe {
     uint8_t* h_proj = nullptr;  /* pinned mirror (inputs, then results) */
     size_t h_proj_bytes = 0;
     bool proj_lds_set = false;
+    uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */
+    size_t sbp_bytes = 0;
+    uint8_t* h_sbp = nullptr;   /* pinned results */
+    size_t h_sbp_bytes = 0;
+    int sbp_jobs = 0, sbp_M = 8;
+    float* d_x3dw = nullptr;    /* stereo points per pair: B x cap x 3 */
+    uint8_t* d_mpflags = nullptr; /* B x cap */
     /* stereo scratch */
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;

@@ -108,12 +108,49 @@ struct ResizeQuad {
     uint32_t coef[4];
 };
 
-/* host-side argument block of vk_search_by_projection (SearchByProjection(CurrentFrame, LastFrame)) */
-struct SbpHostArgs {
+/* One SearchByProjection(CurrentFrame, LastFrame) problem; every pointer is a DEVICE pointer.  nLast / nCur are
+ * the counts, or -- when nLastPtr / nCurPtr are set -- capacities with the real counts read from HBM. */
+struct SbpProj;
+struct SbpJobDev {
     float Tcw[12];
     float fx, fy, cx, cy, mbf, th;
+    int32_t forward, backward, checkOri, imgW, imgH, gemmFloat;
+    int32_t nLast, nCur;
+    const vslam_kp* lastKps;
+    const int32_t* nLastPtr;
+    const uint8_t* flags;
+    const float* x3Dw;
+    const uint8_t* mpDesc;
+    const vslam_kp* curKps;
+    const uint8_t* curDesc;
+    const int32_t* nCurPtr;
+    const float* uRight;      /* may be null */
+    const uint8_t* occupied0; /* may be null */
+    SbpProj* proj;            /* scratch: nLast projection records */
+    uint32_t* topm;           /* scratch: nLast x M keys */
+    int32_t* matchCur;        /* out: nCur */
+    int32_t* nmatches;        /* out: 1 */
+};
+#define VSLAM_MAX_SBP_JOBS 16
+struct SbpJobs { /* by-value kernel argument (< 4 KB) */
+    SbpJobDev job[VSLAM_MAX_SBP_JOBS];
     float scale[VSLAM_MAX_LEVELS];
-    int forward, backward, checkOri, imgW, imgH, gemmFloat, nlevels;
+    int32_t nlevels, M;
+};
+
+/* k_unproject_stereo: one stereo pair's left keypoints -> world points (Frame::UnprojectStereo) */
+struct UnprojJob {
+    float Twc[12]; /* rows [mRwc | mOw] */
+    const vslam_kp* kps;
+    const int32_t* nPtr;
+    const float* depth;
+    float* x3Dw;
+    uint8_t* flags;
+};
+struct UnprojJobs {
+    UnprojJob job[VSLAM_MAX_SBP_JOBS];
+    float cx, cy, invfx, invfy;
+    int32_t cap, observations, gemmFloat;
 };
 
 /* Up to four dword-granular ranges for k_copy_ranges (src == nullptr: zero-fill). */

@@ -66,6 +66,10 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_init);
     hipFree(fe->d_init_scratch);
     hipFree(fe->d_proj);
+    hipFree(fe->d_sbp);
+    if (fe->h_sbp) hipHostFree(fe->h_sbp);
+    hipFree(fe->d_x3dw);
+    hipFree(fe->d_mpflags);
     if (fe->h_proj) hipHostFree(fe->h_proj);
     hipFree(fe->d_init_fb);
     if (fe->h_init) hipHostFree(fe->h_init);

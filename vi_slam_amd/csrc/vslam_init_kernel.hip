@@ -486,13 +486,6 @@ struct SbpProj { /* projection record of one last-frame keypoint (k_sbp_rank -> 
     int32_t minLevel, maxLevel, valid, pad;
 };
 
-struct SbpArgs {
-    float Tcw[12];
-    float fx, fy, cx, cy, mbf, th;
-    float scale[VSLAM_MAX_LEVELS];
-    int forward, backward, checkOri, imgW, imgH, gemmFloat, nlevels;
-};
-
 __device__ __forceinline__ float sbp_gemm_row(const float* r, float x0, float x1, float x2, float t, int flt) {
     if (!flt) { /* GEMMSingleMul<float,double>: s += double(a)*double(b), then float(s + double(c)) */
         double s = __dmul_rn((double)r[0], (double)x0);
@@ -541,15 +534,22 @@ __device__ __forceinline__ SbpCand sbp_make_cand(const vslam_kp& k, float uRight
 }
 
 __global__ void __launch_bounds__(256)
-k_sbp_rank(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uint8_t* __restrict__ flags,
-           const float* __restrict__ x3Dw, const uint8_t* __restrict__ mpDesc, const vslam_kp* __restrict__ curKps,
-           const uint8_t* __restrict__ curDesc, const float* __restrict__ uRight /* may be null */, int nCur, int M,
-           SbpProj* __restrict__ proj, uint32_t* __restrict__ topm) {
+k_sbp_rank(SbpJobs JS) {
     extern __shared__ __align__(16) uint8_t sbsm[];
     SbpCand* cand = (SbpCand*)sbsm; /* nCur */
+    const SbpJobDev& J = JS.job[blockIdx.y];
+    const int M = JS.M;
+    const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
+    const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
+    if ((int)blockIdx.x * SBP_QPB >= nLast) return; /* grid is sized for the capacity */
+    const vslam_kp* __restrict__ lastKps = J.lastKps;
+    const vslam_kp* __restrict__ curKps = J.curKps;
+    const uint8_t* __restrict__ curDesc = J.curDesc;
+    const uint8_t* __restrict__ mpDesc = J.mpDesc;
+    const float* __restrict__ uRight = J.uRight;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)A.imgW);
-    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)A.imgH);
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)J.imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)J.imgH);
     for (int i = tid; i < nCur; i += 256) {
         bool ing;
         cand[i] = sbp_make_cand(curKps[i], uRight ? uRight[i] : -1.f, invW, invH, &ing);
@@ -561,23 +561,23 @@ k_sbp_rank(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uin
         pr.u = pr.v = pr.radius = pr.ur = 0.f;
         pr.minLevel = pr.maxLevel = 0;
         pr.pad = 0;
-        if (flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
-            const float X = x3Dw[3 * q], Y = x3Dw[3 * q + 1], Z = x3Dw[3 * q + 2];
-            const float xc = sbp_gemm_row(A.Tcw + 0, X, Y, Z, A.Tcw[3], A.gemmFloat);
-            const float yc = sbp_gemm_row(A.Tcw + 4, X, Y, Z, A.Tcw[7], A.gemmFloat);
-            const float zc = sbp_gemm_row(A.Tcw + 8, X, Y, Z, A.Tcw[11], A.gemmFloat);
+        if (J.flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
+            const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
+            const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
+            const float yc = sbp_gemm_row(J.Tcw + 4, X, Y, Z, J.Tcw[7], J.gemmFloat);
+            const float zc = sbp_gemm_row(J.Tcw + 8, X, Y, Z, J.Tcw[11], J.gemmFloat);
             const float invzc = (float)__ddiv_rn(1.0, (double)zc);
             if (!(invzc < 0.f)) {
-                const float u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx); /* pinhole.cpp:13-16 */
-                const float v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
-                if (!(u < 0.f || u > (float)A.imgW) && !(v < 0.f || v > (float)A.imgH)) {
+                const float u = __fadd_rn(__fdiv_rn(__fmul_rn(J.fx, xc), zc), J.cx); /* pinhole.cpp:13-16 */
+                const float v = __fadd_rn(__fdiv_rn(__fmul_rn(J.fy, yc), zc), J.cy);
+                if (!(u < 0.f || u > (float)J.imgW) && !(v < 0.f || v > (float)J.imgH)) {
                     const int oct = lastKps[q].octave;
                     pr.u = u;
                     pr.v = v;
-                    pr.radius = __fmul_rn(A.th, A.scale[min(max(oct, 0), A.nlevels - 1)]);
-                    pr.ur = __fsub_rn(u, __fmul_rn(A.mbf, invzc));
-                    if (A.forward) { pr.minLevel = oct; pr.maxLevel = -1; }
-                    else if (A.backward) { pr.minLevel = 0; pr.maxLevel = oct; }
+                    pr.radius = __fmul_rn(J.th, JS.scale[min(max(oct, 0), JS.nlevels - 1)]);
+                    pr.ur = __fsub_rn(u, __fmul_rn(J.mbf, invzc));
+                    if (J.forward) { pr.minLevel = oct; pr.maxLevel = -1; }
+                    else if (J.backward) { pr.minLevel = 0; pr.maxLevel = oct; }
                     else { pr.minLevel = oct - 1; pr.maxLevel = oct + 1; }
                     pr.valid = 1;
                 }
@@ -616,8 +616,8 @@ k_sbp_rank(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uin
                 best[SI_MAX_M - 1] = 0xFFFFFFFFu;
             }
         }
-        if (lane < M) topm[(size_t)q * M + lane] = mine;
-        if (lane == 0) proj[q] = pr;
+        if (lane < M) J.topm[(size_t)q * M + lane] = mine;
+        if (lane == 0) J.proj[q] = pr;
     }
 }
 
@@ -641,13 +641,24 @@ __device__ uint32_t sbp_full_scan(const SbpProj& pr, const vslam_kp* curKps, con
 }
 
 __global__ void __launch_bounds__(64)
-k_sbp_replay(SbpArgs A, const vslam_kp* __restrict__ lastKps, int nLast, const uint8_t* __restrict__ flags,
-             const uint8_t* __restrict__ mpDesc, const vslam_kp* __restrict__ curKps,
-             const uint8_t* __restrict__ curDesc, const float* __restrict__ uRight,
-             const uint8_t* __restrict__ occupied0 /* may be null */, int nCur, int M,
-             const SbpProj* __restrict__ proj, const uint32_t* __restrict__ topm, int32_t* __restrict__ matchCur,
-             int32_t* __restrict__ nmatches_out, int* fallbacks) {
+k_sbp_replay(SbpJobs JS, int* fallbacks) {
     extern __shared__ __align__(16) uint8_t sbsm[];
+    const SbpJobDev& J = JS.job[blockIdx.x];
+    const int M = JS.M;
+    const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
+    const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
+    const vslam_kp* __restrict__ lastKps = J.lastKps;
+    const vslam_kp* __restrict__ curKps = J.curKps;
+    const uint8_t* __restrict__ curDesc = J.curDesc;
+    const uint8_t* __restrict__ mpDesc = J.mpDesc;
+    const uint8_t* __restrict__ flags = J.flags;
+    const float* __restrict__ uRight = J.uRight;
+    const uint8_t* __restrict__ occupied0 = J.occupied0;
+    const SbpProj* __restrict__ proj = J.proj;
+    const uint32_t* __restrict__ topm = J.topm;
+    int32_t* __restrict__ matchCur = J.matchCur;
+    int32_t* __restrict__ nmatches_out = J.nmatches;
+    struct { int checkOri, imgW, imgH; } A = {J.checkOri, J.imgW, J.imgH};
     uint32_t* occupied = (uint32_t*)sbsm;              /* nCur: mvpMapPoints[i2] with Observations() > 0 */
     int32_t* ownerEntry = (int32_t*)(occupied + nCur); /* nCur: last log entry that wrote mvpMapPoints[i2] */
     uint32_t* alog = (uint32_t*)(ownerEntry + nCur);   /* nLast: (query << 12 | i2), in order */
@@ -763,27 +774,54 @@ size_t vk_sbp_replay_lds(int nCur, int nLast) {
     return (((size_t)nCur * 8 + (size_t)nLast * 5 + 15) & ~(size_t)15) + 64 * SI_MAX_M * 4;
 }
 size_t vk_sbp_scratch_bytes(int nLast, int M) { return (size_t)nLast * (sizeof(SbpProj) + 4 * (size_t)M); }
+size_t vk_sbp_proj_bytes(int nLast) { return (size_t)nLast * sizeof(SbpProj); }
 int vk_sbp_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     return (int)hipFuncSetAttribute((const void*)k_sbp_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void vk_search_by_projection(hipStream_t st, const SbpHostArgs& H, const vslam_kp* lastKps, int nLast,
-                             const uint8_t* flags, const float* x3Dw, const uint8_t* mpDesc, const vslam_kp* curKps,
-                             const uint8_t* curDesc, const float* uRight, const uint8_t* occupied0, int nCur, int M,
-                             uint8_t* scratch, int32_t* matchCur, int32_t* nmatches, int* fallbacks) {
-    SbpArgs A;
-    for (int i = 0; i < 12; i++) A.Tcw[i] = H.Tcw[i];
-    A.fx = H.fx; A.fy = H.fy; A.cx = H.cx; A.cy = H.cy; A.mbf = H.mbf; A.th = H.th;
-    for (int l = 0; l < VSLAM_MAX_LEVELS; l++) A.scale[l] = H.scale[l];
-    A.forward = H.forward; A.backward = H.backward; A.checkOri = H.checkOri; A.imgW = H.imgW; A.imgH = H.imgH;
-    A.gemmFloat = H.gemmFloat; A.nlevels = H.nlevels;
-    SbpProj* proj = (SbpProj*)scratch;
-    uint32_t* topm = (uint32_t*)(proj + nLast);
-    if (nLast > 0)
-        hipLaunchKernelGGL(k_sbp_rank, dim3((nLast + SBP_QPB - 1) / SBP_QPB), dim3(256), vk_sbp_rank_lds(nCur), st, A,
-                           lastKps, nLast, flags, x3Dw, mpDesc, curKps, curDesc, uRight, nCur, M, proj, topm);
-    hipLaunchKernelGGL(k_sbp_replay, dim3(1), dim3(64), vk_sbp_replay_lds(nCur, nLast), st, A, lastKps, nLast, flags,
-                       mpDesc, curKps, curDesc, uRight, occupied0, nCur, M, proj, topm, matchCur, nmatches, fallbacks);
+void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int maxLast, int maxCur, int* fallbacks) {
+    if (njobs <= 0) return;
+    if (maxLast > 0)
+        hipLaunchKernelGGL(k_sbp_rank, dim3((maxLast + SBP_QPB - 1) / SBP_QPB, njobs), dim3(256),
+                           vk_sbp_rank_lds(maxCur), st, JS);
+    hipLaunchKernelGGL(k_sbp_replay, dim3(njobs), dim3(64), vk_sbp_replay_lds(maxCur, maxLast), st, JS, fallbacks);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame::UnprojectStereo (frame.cpp:1023-1037) for every left keypoint of up to VSLAM_MAX_SBP_JOBS stereo
+ * pairs: z = mvDepth[i] > 0  ->  x3Dc = ((u-cx)*z*invfx, (v-cy)*z*invfy, z), x3Dw = mRwc*x3Dc + mOw (one
+ * cv::gemm, see sbp_gemm_row).  These are the points UpdateLastFrame turns into (temporal) MapPoints for
+ * TrackWithMotionModel, i.e. the last-frame side of SearchByProjection; flags = has-a-point | observations.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_unproject_stereo(UnprojJobs U) {
+    const UnprojJob& J = U.job[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(*J.nPtr, U.cap);
+    if (i >= U.cap) return;
+    float X = 0.f, Y = 0.f, Z = 0.f;
+    uint8_t fl = 0;
+    if (i < n) {
+        const float z = J.depth[i];
+        if (z > 0.f) {
+            const vslam_kp k = J.kps[i];
+            const float x = __fmul_rn(__fmul_rn(__fsub_rn(k.x, U.cx), z), U.invfx);
+            const float y = __fmul_rn(__fmul_rn(__fsub_rn(k.y, U.cy), z), U.invfy);
+            X = sbp_gemm_row(J.Twc + 0, x, y, z, J.Twc[3], U.gemmFloat);
+            Y = sbp_gemm_row(J.Twc + 4, x, y, z, J.Twc[7], U.gemmFloat);
+            Z = sbp_gemm_row(J.Twc + 8, x, y, z, J.Twc[11], U.gemmFloat);
+            fl = (uint8_t)(1 | (U.observations ? 2 : 0));
+        }
+    }
+    J.x3Dw[3 * i] = X;
+    J.x3Dw[3 * i + 1] = Y;
+    J.x3Dw[3 * i + 2] = Z;
+    J.flags[i] = fl;
+}
+
+void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs) {
+    if (njobs <= 0) return;
+    hipLaunchKernelGGL(k_unproject_stereo, dim3((U.cap + 255) / 256, njobs), dim3(256), 0, st, U);
 }

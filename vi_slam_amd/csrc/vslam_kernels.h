@@ -72,16 +72,15 @@ int vk_search_init_set_max_lds(size_t bytes);
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
                     int max_c2, int M, uint8_t* scratch, int* fallbacks);
-/* FMatcher::SearchByProjection(CurrentFrame, LastFrame): k_sbp_rank + k_sbp_replay; every pointer is a device
- * pointer; scratch = vk_sbp_scratch_bytes(nLast, M) */
+/* FMatcher::SearchByProjection(CurrentFrame, LastFrame): k_sbp_rank + k_sbp_replay over up to
+ * VSLAM_MAX_SBP_JOBS problems; maxLast / maxCur size the grid and the LDS (capacities) */
 size_t vk_sbp_rank_lds(int nCur);
 size_t vk_sbp_replay_lds(int nCur, int nLast);
 size_t vk_sbp_scratch_bytes(int nLast, int M);
+size_t vk_sbp_proj_bytes(int nLast);
 int vk_sbp_set_max_lds(size_t bytes);
-void vk_search_by_projection(hipStream_t st, const SbpHostArgs& H, const vslam_kp* lastKps, int nLast,
-                             const uint8_t* flags, const float* x3Dw, const uint8_t* mpDesc, const vslam_kp* curKps,
-                             const uint8_t* curDesc, const float* uRight, const uint8_t* occupied0, int nCur, int M,
-                             uint8_t* scratch, int32_t* matchCur, int32_t* nmatches, int* fallbacks);
+void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int maxLast, int maxCur, int* fallbacks);
+void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
 void vk_copy_ranges(hipStream_t st, const CopyRanges& R);

@@ -546,19 +546,32 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     if (cur_occupied_host) memcpy(h + o_o, cur_occupied_host, (size_t)n_cur);
     hipStream_t st = fe->stream;
     HIPCHK(hipMemcpyAsync(fe->d_proj, h, in_bytes, hipMemcpyHostToDevice, st));
-    SbpHostArgs H;
-    memset(&H, 0, sizeof(H));
-    memcpy(H.Tcw, p->Tcw, sizeof(H.Tcw));
-    H.fx = p->fx; H.fy = p->fy; H.cx = p->cx; H.cy = p->cy; H.mbf = p->mbf; H.th = p->th;
-    for (int l = 0; l < fe->p.nlevels; l++) H.scale[l] = fe->tab.scale[l];
-    H.nlevels = fe->p.nlevels;
-    H.forward = p->forward; H.backward = p->backward; H.checkOri = p->check_orientation;
-    H.imgW = p->img_w; H.imgH = p->img_h; H.gemmFloat = p->gemm_float;
+    static_assert(sizeof(SbpJobs) <= 4000, "SbpJobs travels as a kernel argument");
+    SbpJobs JS;
+    memset(&JS, 0, sizeof(JS));
+    for (int l = 0; l < fe->p.nlevels; l++) JS.scale[l] = fe->tab.scale[l];
+    JS.nlevels = fe->p.nlevels;
+    JS.M = M;
     uint8_t* d = fe->d_proj;
-    vk_search_by_projection(st, H, (const vslam_kp*)(d + o_kps), n_last, d + o_f, (const float*)(d + o_x), d + o_d,
-                            dev_cur_kps, dev_cur_desc, cur_u_right_host ? (const float*)(d + o_u) : nullptr,
-                            cur_occupied_host ? d + o_o : nullptr, n_cur, M, d + o_scr, (int32_t*)(d + o_m),
-                            (int32_t*)(d + o_n), fe->d_init_fb);
+    SbpJobDev& J = JS.job[0];
+    memcpy(J.Tcw, p->Tcw, sizeof(J.Tcw));
+    J.fx = p->fx; J.fy = p->fy; J.cx = p->cx; J.cy = p->cy; J.mbf = p->mbf; J.th = p->th;
+    J.forward = p->forward; J.backward = p->backward; J.checkOri = p->check_orientation;
+    J.imgW = p->img_w; J.imgH = p->img_h; J.gemmFloat = p->gemm_float;
+    J.nLast = n_last; J.nCur = n_cur;
+    J.lastKps = (const vslam_kp*)(d + o_kps);
+    J.flags = d + o_f;
+    J.x3Dw = (const float*)(d + o_x);
+    J.mpDesc = d + o_d;
+    J.curKps = dev_cur_kps;
+    J.curDesc = dev_cur_desc;
+    J.uRight = cur_u_right_host ? (const float*)(d + o_u) : nullptr;
+    J.occupied0 = cur_occupied_host ? d + o_o : nullptr;
+    J.proj = (SbpProj*)(d + o_scr);
+    J.topm = (uint32_t*)(d + o_scr + vk_sbp_proj_bytes(n_last));
+    J.matchCur = (int32_t*)(d + o_m);
+    J.nmatches = (int32_t*)(d + o_n);
+    vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb);
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -571,5 +584,172 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     HIPCHK(hipStreamSynchronize(st));
     memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
     *nmatches = *(const int32_t*)(h + o_n);
+    return VSLAM_OK;
+}
+
+static int sbp_prepare(vslam_fe* fe, int* M_out) {
+    int M = 8;
+    if (const char* e = getenv("VSLAM_SBP_TOPM")) M = std::min(16, std::max(1, atoi(e)));
+    *M_out = M;
+    if (!fe->proj_lds_set) {
+        if (vk_sbp_set_max_lds(150 * 1024) != 0) {
+            g_err = "hipFuncSetAttribute(k_sbp_*) failed";
+            return VSLAM_ERR_HIP;
+        }
+        fe->proj_lds_set = true;
+    }
+    if (!fe->d_init_fb) {
+        HIPCHK(hipMalloc((void**)&fe->d_init_fb, 16));
+        HIPCHK(hipMemset(fe->d_init_fb, 0, 16));
+    }
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, const vslam_sbp_job* jobs) {
+    if (!fe || njobs < 1 || njobs > VSLAM_MAX_SBP_JOBS || !jobs) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    const int cap = fe->cap;
+    if (cap > 4096) {
+        g_err = "SearchByProjection on the device supports at most 4096 keypoints per frame";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    if (std::max(vk_sbp_rank_lds(cap), vk_sbp_replay_lds(cap, cap)) > 150 * 1024) {
+        g_err = "SearchByProjection: frame too large for the LDS-resident matcher";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    int M;
+    int rc = sbp_prepare(fe, &M);
+    if (rc) return rc;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    /* per job: proj | topm ; then all match tables and counts together (one result copy) */
+    const size_t per_scr = al(vk_sbp_scratch_bytes(cap, M));
+    const size_t o_res = per_scr * njobs, res_bytes = al((size_t)njobs * cap * 4 + (size_t)njobs * 4);
+    rc = vslam_ensure((void**)&fe->d_sbp, &fe->sbp_bytes, o_res + res_bytes);
+    if (rc) return rc;
+    if (fe->h_sbp_bytes < res_bytes) {
+        if (fe->h_sbp) HIPCHK(hipHostFree(fe->h_sbp));
+        fe->h_sbp = nullptr;
+        fe->h_sbp_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_sbp, res_bytes, hipHostMallocDefault));
+        fe->h_sbp_bytes = res_bytes;
+    }
+    SbpJobs JS;
+    memset(&JS, 0, sizeof(JS));
+    for (int l = 0; l < fe->p.nlevels; l++) JS.scale[l] = fe->tab.scale[l];
+    JS.nlevels = fe->p.nlevels;
+    JS.M = M;
+    int32_t* d_match = (int32_t*)(fe->d_sbp + o_res);
+    int32_t* d_nm = d_match + (size_t)njobs * cap;
+    for (int j = 0; j < njobs; j++) {
+        const vslam_sbp_job& s = jobs[j];
+        if (!s.dev_last_kps || !s.dev_n_last || !s.dev_last_flags || !s.dev_last_x3dw || !s.dev_mp_desc ||
+            !s.dev_cur_kps || !s.dev_cur_desc || !s.dev_n_cur || s.p.img_w < 1 || s.p.img_h < 1) {
+            g_err = "null device pointer in job";
+            return VSLAM_ERR_INVALID;
+        }
+        SbpJobDev& J = JS.job[j];
+        memcpy(J.Tcw, s.p.Tcw, sizeof(J.Tcw));
+        J.fx = s.p.fx; J.fy = s.p.fy; J.cx = s.p.cx; J.cy = s.p.cy; J.mbf = s.p.mbf; J.th = s.p.th;
+        J.forward = s.p.forward; J.backward = s.p.backward; J.checkOri = s.p.check_orientation;
+        J.imgW = s.p.img_w; J.imgH = s.p.img_h; J.gemmFloat = s.p.gemm_float;
+        J.nLast = cap; J.nCur = cap;
+        J.lastKps = s.dev_last_kps; J.nLastPtr = s.dev_n_last; J.flags = s.dev_last_flags; J.x3Dw = s.dev_last_x3dw;
+        J.mpDesc = s.dev_mp_desc; J.curKps = s.dev_cur_kps; J.curDesc = s.dev_cur_desc; J.nCurPtr = s.dev_n_cur;
+        J.uRight = s.dev_cur_u_right; J.occupied0 = s.dev_cur_occupied;
+        uint8_t* scr = fe->d_sbp + per_scr * j;
+        J.proj = (SbpProj*)scr;
+        J.topm = (uint32_t*)(scr + vk_sbp_proj_bytes(cap));
+        J.matchCur = d_match + (size_t)j * cap;
+        J.nmatches = d_nm + j;
+    }
+    vk_search_by_projection(fe->stream, JS, njobs, cap, cap, fe->d_init_fb);
+    HIPCHK(hipGetLastError());
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = fe->h_sbp;
+    R.src[0] = d_match;
+    R.bytes[0] = (size_t)njobs * cap * 4 + (size_t)njobs * 4;
+    R.n = 1;
+    vk_copy_ranges(fe->stream, R);
+    HIPCHK(hipGetLastError());
+    fe->sbp_jobs = njobs;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_search_by_projection_dev_wait(vslam_fe* fe, const int* n_cur, int32_t* const* match_cur,
+                                                   int* nmatches) {
+    if (!fe || fe->sbp_jobs < 1) {
+        g_err = "nothing enqueued";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    const int njobs = fe->sbp_jobs, cap = fe->cap;
+    const int32_t* h_m = (const int32_t*)fe->h_sbp;
+    const int32_t* h_n = h_m + (size_t)njobs * cap;
+    for (int j = 0; j < njobs; j++) {
+        if (match_cur && match_cur[j] && n_cur) memcpy(match_cur[j], h_m + (size_t)j * cap, (size_t)std::min(n_cur[j], cap) * 4);
+        if (nmatches) nmatches[j] = h_n[j];
+    }
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_stereo_points_dev_async(vslam_fe* fe, int npairs, const float* Twc, float cx, float cy,
+                                             float invfx, float invfy, int observations, int gemm_float) {
+    if (!fe || npairs < 1 || npairs > VSLAM_MAX_SBP_JOBS || npairs > fe->stereo_pairs || !Twc) {
+        g_err = "invalid arguments (npairs must not exceed the pairs of the last stereo enqueue, <= 16)";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    if (!fe->d_x3dw) {
+        HIPCHK(hipMalloc((void**)&fe->d_x3dw, (size_t)fe->B * fe->cap * 12));
+        HIPCHK(hipMalloc((void**)&fe->d_mpflags, (size_t)fe->B * fe->cap));
+    }
+    StereoScratch sc;
+    int rc = stereo_scratch(fe, fe->stereo_pairs, &sc); /* same carving as the enqueue that filled it */
+    if (rc) return rc;
+    UnprojJobs U;
+    memset(&U, 0, sizeof(U));
+    U.cx = cx; U.cy = cy; U.invfx = invfx; U.invfy = invfy;
+    U.cap = fe->cap; U.observations = observations; U.gemmFloat = gemm_float;
+    for (int j = 0; j < npairs; j++) {
+        UnprojJob& J = U.job[j];
+        memcpy(J.Twc, Twc + 12 * j, sizeof(J.Twc));
+        const int sl = fe->stereo_slotL[j];
+        J.kps = fe->d_kps + (size_t)sl * fe->cap;
+        J.nPtr = fe->d_counts + sl * 4;
+        J.depth = sc.depth + (size_t)j * fe->cap;
+        J.x3Dw = fe->d_x3dw + (size_t)j * fe->cap * 3;
+        J.flags = fe->d_mpflags + (size_t)j * fe->cap;
+    }
+    vk_unproject_stereo(fe->stream, U, npairs);
+    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float** dev_x3dw, const uint8_t** dev_flags,
+                                           const float** dev_u_right, const float** dev_depth) {
+    if (!fe || pair < 0 || pair >= fe->B || pair >= VSLAM_MAX_SBP_JOBS) return VSLAM_ERR_INVALID;
+    HIPCHK(hipSetDevice(fe->p.device));
+    if (!fe->d_x3dw) {
+        HIPCHK(hipMalloc((void**)&fe->d_x3dw, (size_t)fe->B * fe->cap * 12));
+        HIPCHK(hipMalloc((void**)&fe->d_mpflags, (size_t)fe->B * fe->cap));
+    }
+    if (dev_x3dw) *dev_x3dw = fe->d_x3dw + (size_t)pair * fe->cap * 3;
+    if (dev_flags) *dev_flags = fe->d_mpflags + (size_t)pair * fe->cap;
+    if (dev_u_right || dev_depth) {
+        if (fe->stereo_pairs < 1 || pair >= fe->stereo_pairs) {
+            g_err = "no stereo result for this pair yet";
+            return VSLAM_ERR_INVALID;
+        }
+        StereoScratch sc;
+        int rc = stereo_scratch(fe, fe->stereo_pairs, &sc);
+        if (rc) return rc;
+        if (dev_u_right) *dev_u_right = sc.uRight + (size_t)pair * fe->cap;
+        if (dev_depth) *dev_depth = sc.depth + (size_t)pair * fe->cap;
+    }
     return VSLAM_OK;
 }
