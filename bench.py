@@ -34,8 +34,13 @@ WORKLOADS = {
     "kitti00_stereo_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True),
     # configs[4]: synthetic 1920x1080 stream, 4000 features/frame
     "synthetic_stereo_1920x1080_n4000": dict(w=1920, h=1080, nf=4000, stereo=True),
+    # SURVEY.md 8(f) rank 1, the per-frame tracking front-end of TrackWithMotionModel: stereo frame construction +
+    # UnprojectStereo + SearchByProjection(frame, previous frame); every rank follows its own sequence
+    "kitti00_stereo_track_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True, track=True),
 }
 BF, FX = 386.1448, 718.856  # config/KITTI00-Stereo.yaml Camera.bf, Camera.fx
+FY, CX, CY = 718.856, 607.1928, 185.2157
+TRACK_Z = 12.0  # the synthetic scene moves (+3,+1) px per frame; as a camera translation at this depth
 
 
 def level_pixels(fe):
@@ -59,6 +64,8 @@ def pmc_traffic(kernel, cfg, batch):
     path = os.path.join(ROOT, "profiles", name)
     if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376):
         return None
+    if kernel.startswith("k_orient_describe") and cfg["nf"] != 1000:
+        return None  # the profile was taken with 1000 features; only this kernel's traffic depends on that
     k = json.load(open(path))["kernels"].get(kernel.split("(")[0])
     if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
         return None
@@ -82,17 +89,27 @@ def cpu_baseline(cfg, seconds=12.0):
         pairs = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
         eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
         pool = ThreadPoolExecutor(2)
+        prev_track = None
         t0 = time.time()
         while time.time() < t_end:
             L, R = pairs[frames % nsample]
             fl = pool.submit(eL.compute, L)
             fr = pool.submit(eR.compute, R)
             (kL, dL, _), (kR, dR, _) = fl.result(), fr.result()
-            orbo.stereo(eL, eR, kL, dL, kR, dR, BF, FX)
+            uR, depth = orbo.stereo(eL, eR, kL, dL, kR, dR, BF, FX)[:2]
+            if cfg.get("track"):
+                T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+                x3, has = orbo.unproject_stereo(kL, depth, T0, CX, CY, 1.0 / FX, 1.0 / FY)
+                if prev_track is not None:
+                    pk, pd, px, pf = prev_track
+                    Tcw = np.hstack([np.eye(3), np.array([[3.0 / FX * TRACK_Z], [1.0 / FY * TRACK_Z], [0.0]])])
+                    orbo.search_by_projection_frame(Tcw, T0, (FX, FY, CX, CY, BF, BF / FX), 15, pk, pf * 3, px, pd, kL, dL,
+                                                    uR, eL.tables()["scale"], w, h)
+                prev_track = (kL.copy(), dL.copy(), x3, has)
             frames += 1
         cores = 2
-        sample = "%d synthetic stereo frames %dx%d, %d features: 2 threads extract L/R + ComputeStereoMatches" % (
-            frames, w, h, nf)
+        sample = "%d synthetic stereo frames %dx%d, %d features: 2 threads extract L/R + ComputeStereoMatches%s" % (
+            frames, w, h, nf, " + UnprojectStereo + SearchByProjection(prev frame)" if cfg.get("track") else "")
     else:
         imgs = [synth.make_frame(w, h, step=s) for s in range(nsample)]
         e = orbo.Extractor(nf)
@@ -159,6 +176,7 @@ def main():
     multi = world > 1 or (args.force_collective and dist.is_initialized())
     cfg = WORKLOADS[args.workload]
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    track = bool(cfg.get("track"))
     B = args.batch
     if stereo and B % 2:
         B += 1
@@ -172,7 +190,9 @@ def main():
     pitch = (w + 127) & ~127
     dev_frames = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
     for s in range(B):
-        if stereo:
+        if track:  # one contiguous sequence per rank
+            fr = synth.make_frame(w, h, seed=20250215 + rank, step=s // 2, right=bool(s & 1))
+        elif stereo:
             fr = synth.make_frame(w, h, step=(s // 2) * world + rank, right=bool(s & 1))
         else:
             fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world))
@@ -194,15 +214,46 @@ def main():
         return base + 16, base + desc_off, base
 
     job_cache = {}
+    track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
+    track_cam = (CX, CY, float(np.float32(1.0) / np.float32(FX)), float(np.float32(1.0) / np.float32(FY)))
+    track_Tcw = np.hstack([np.eye(3), np.array([[3.0 / FX * TRACK_Z], [1.0 / FY * TRACK_Z], [0.0]])]).astype(np.float32)
 
     def enqueue(t):
         """Enqueue step t completely -- extraction, (N>1) pack + all-gather, matcher -- without waiting for
         anything on the host: every pointer is a fixed device address and the counts stay in HBM."""
         c, k = ctxs[t % NCTX], t % NCTX
+        nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
+        if track:
+            npairs = B // 2
+            c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last frame: it must finish first
+            c.frame_stereo_async(ptrs, pitch, BF, FX)
+            c.stereo_points_async(track_Twc, track_cam)  # UnprojectStereo of every left keypoint, own camera = world
+            c.event_record(0)
+            ck = (k, t == 0)
+            if ck not in job_cache:
+                jobs = []
+                for j in range(npairs):
+                    if j == 0 and t == 0:
+                        continue
+                    lc, lj = (c, j - 1) if j else (prv, npairs - 1)
+                    lk, ld, ln = lc.slot_dev_ptrs(2 * lj)
+                    x3, fl, _, _ = lc.stereo_points_buffers(lj, with_stereo=False)
+                    ckp, cd, cn = c.slot_dev_ptrs(2 * j)
+                    ur = c.stereo_points_buffers(j)[2]
+                    jobs.append(dict(Tcw=track_Tcw, cam=(FX, FY, CX, CY, BF), th=15, forward=0, backward=0, img=(w, h),
+                                     last_kps=lk, n_last=ln, last_flags=fl, last_x3dw=x3, mp_desc=ld, cur_kps=ckp,
+                                     cur_desc=cd, n_cur=cn, cur_u_right=ur))
+                job_cache[ck] = (V.FMatcher.make_sbp_jobs(jobs, True), len(jobs))
+            arr, njobs = job_cache[ck]
+            if t > 0:
+                c.event_wait(prv, 0)
+            matchers[k].search_by_projection_dev_async(arr)
+            c.event_record(1)
+            state.setdefault("njobs", {})[t] = njobs
+            return
         if stereo:
             c.frame_stereo_async(ptrs, pitch, BF, FX)
             return
-        nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
         c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
         c.compute_batch_async(ptrs, pitch, lap)
         if multi:
@@ -249,6 +300,11 @@ def main():
             feats, st = c.frame_stereo_wait()
             state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
             t_b = time.perf_counter()
+            if track:
+                nj = state["njobs"].pop(t)
+                ncur = [len(feats[2 * j][0]) for j in range(B // 2 - nj, B // 2)]
+                out = matchers[t % NCTX].search_by_projection_dev_wait(ncur)
+                state["track_matches"] = sum(o[0] for o in out)
         else:
             res = c.wait()
             t_b = time.perf_counter()
@@ -326,10 +382,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "frames_per_step_per_gpu": B // 2 if stereo else B,
                        "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
-                       "match": "ComputeStereoMatches L<->R" if stereo else "SearchForInitialization(prev frame), window 100, on device",
+                       "match": ("ComputeStereoMatches L<->R + UnprojectStereo + SearchByProjection(frame, previous frame), th 15, on device"
+                                 if track else "ComputeStereoMatches L<->R") if stereo else "SearchForInitialization(prev frame), window 100, on device",
                        "sharding": "frames round-robin over ranks; one all-gather of result slots per step (on the extractor stream)"
-                       if not stereo else "stereo frames independent per rank, no collective",
+                       if not stereo else ("one independent stereo sequence per rank, no collective" if track else
+                                           "stereo frames independent per rank, no collective"),
                        "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],
+                       "track_matches_last_step_rank0": state.get("track_matches"),
                        "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in
                                             zip(("enqueue", "wait_step", "fetch_matches"),
                                                 [state.get("enq_s", 0.0)] + state.get("host_s", [0, 0]))}},

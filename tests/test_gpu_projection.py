@@ -68,6 +68,16 @@ def test_projection_matches_with_stereo_gate(scene):
     _run(scene, Tcw, 15, flags, gemm_float=True)
 
 
+def test_sequential_replay_path_agrees(scene, monkeypatch):
+    """VSLAM_SBP_MODE=seq skips the parallel (deferred-acceptance) resolution: one wave walks the queries in order."""
+    monkeypatch.setenv("VSLAM_SBP_MODE", "seq")
+    rng = np.random.default_rng(3)
+    flags = rng.integers(0, 4, len(scene["k0"])).astype(np.uint8)
+    zmed = float(np.median(scene["z"][scene["has_depth"]]))
+    _run(scene, _pose(tx=3.0 / FX * zmed, ty=1.0 / FY * zmed), 30, flags)
+    _run(scene, _pose(tz=-1.0), 15, np.full(len(scene["k0"]), 3, np.uint8))
+
+
 def test_forward_backward_level_rules_and_mono(scene):
     flags = np.full(len(scene["k0"]), 3, np.uint8)
     nm_f, _, d_f = _run(scene, _pose(tz=-1.0), 15, flags)   # camera moved forward: tlc.z > mb

@@ -130,6 +130,7 @@ struct SbpJobDev {
     uint32_t* topm;           /* scratch: nLast x M keys */
     int32_t* matchCur;        /* out: nCur */
     int32_t* nmatches;        /* out: 1 */
+    int32_t* needSeq;         /* scratch: k_sbp_resolve -> k_sbp_replay hand-over flag */
 };
 #define VSLAM_MAX_SBP_JOBS 16
 struct SbpJobs { /* by-value kernel argument (< 4 KB) */

@@ -640,6 +640,134 @@ __device__ uint32_t sbp_full_scan(const SbpProj& pr, const vslam_kp* curKps, con
     return wave_min_u32(bestKey);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The sequential rule "query q takes the first candidate of its sorted list that no earlier query with
+ * observations has taken" is a serial dictatorship, and a serial dictatorship is the fixpoint of deferred
+ * acceptance with one common priority order: every query points at a candidate; a candidate is held by the
+ * lowest-index blocking query pointing at it; whoever sees a lower-index holder moves on to its next candidate.
+ * Holders' indices only decrease, so a rejection is final and the fixpoint is the sequential result.  One
+ * 1024-thread workgroup per job iterates this in parallel (a handful of rounds) instead of one wave walking
+ * 2000 queries in order.  Only when some query runs off a FULL sorted prefix (it would need candidates that
+ * k_sbp_rank did not keep) the job is handed to k_sbp_replay, which walks it sequentially with full re-scans.
+ * ---------------------------------------------------------------------------------------------- */
+#define SBP_RT 1024
+#define SBP_QPT 4 /* queries per thread: capacity 4096 */
+__global__ void __launch_bounds__(SBP_RT)
+k_sbp_resolve(SbpJobs JS, int forceSeq) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    const SbpJobDev& J = JS.job[blockIdx.x];
+    const int M = JS.M;
+    const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
+    const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
+    int32_t* holder = (int32_t*)sbsm; /* nCur: lowest-index blocking query pointing here; -1 = occupied from the start */
+    int32_t* owner = holder + nCur;   /* nCur: highest-index query assigned here (mvpMapPoints: last writer wins) */
+    __shared__ int s_changed, s_seq, s_nlog, s_removed;
+    __shared__ int s_hist[SI_HISTO];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_seq = forceSeq;
+        s_nlog = 0;
+        s_removed = 0;
+    }
+    if (tid < SI_HISTO) s_hist[tid] = 0;
+    for (int c = tid; c < nCur; c += SBP_RT) {
+        holder[c] = (J.occupied0 && J.occupied0[c]) ? -1 : 0x7FFFFFFF;
+        owner[c] = -1;
+    }
+    uint32_t key[SBP_QPT];
+    int ptr[SBP_QPT];
+    bool blocking[SBP_QPT];
+#pragma unroll
+    for (int k = 0; k < SBP_QPT; k++) {
+        const int q = tid + k * SBP_RT;
+        ptr[k] = 0;
+        key[k] = q < nLast ? J.topm[(size_t)q * M] : 0xFFFFFFFFu;
+        blocking[k] = q < nLast && (J.flags[q] & 2);
+    }
+    __syncthreads();
+    for (int round = 0; round < 4096 && !s_seq; round++) { /* s_seq / s_changed are block-uniform at the barriers */
+        if (tid == 0) s_changed = 0;
+#pragma unroll
+        for (int k = 0; k < SBP_QPT; k++)
+            if (key[k] != 0xFFFFFFFFu && blocking[k] && (key[k] >> 24) <= SBP_TH_HIGH)
+                atomicMin(&holder[key[k] & 0xFFF], tid + k * SBP_RT);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SBP_QPT; k++) {
+            const int q = tid + k * SBP_RT;
+            if (key[k] != 0xFFFFFFFFu && holder[key[k] & 0xFFF] < q) { /* taken by an earlier query: next candidate */
+                ptr[k]++;
+                if (ptr[k] >= M) {
+                    s_seq = 1; /* ran off a full prefix */
+                    key[k] = 0xFFFFFFFFu;
+                } else {
+                    key[k] = J.topm[(size_t)q * M + ptr[k]]; /* ~0: the list is complete and exhausted */
+                }
+                s_changed = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) *J.needSeq = s_seq;
+    if (s_seq) return;
+    /* assignments */
+    uint32_t bin[SBP_QPT];
+    const float factor = 1.0f / SI_HISTO;
+#pragma unroll
+    for (int k = 0; k < SBP_QPT; k++) {
+        const int q = tid + k * SBP_RT;
+        bin[k] = 255;
+        if (key[k] != 0xFFFFFFFFu && (key[k] >> 24) <= SBP_TH_HIGH) {
+            const int i2 = (int)(key[k] & 0xFFF);
+            atomicMax(&owner[i2], q);
+            atomicAdd(&s_nlog, 1);
+            bin[k] = 254;
+            if (J.checkOri) {
+                float rot = __fsub_rn(J.lastKps[q].angle, J.curKps[i2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int b = (int)roundf(__fmul_rn(rot, factor));
+                if (b == SI_HISTO) b = 0;
+                bin[k] = (uint32_t)b;
+                atomicAdd(&s_hist[b], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < nCur; c += SBP_RT) J.matchCur[c] = owner[c];
+    __syncthreads();
+    if (J.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0; /* ComputeThreeMaxima, fmatcher.cpp:2813-2854 */
+        for (int i = 0; i < SI_HISTO; i++) {
+            const int sv = s_hist[i];
+            if (sv > max1) {
+                max3 = max2; max2 = max1; max1 = sv;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (sv > max2) {
+                max3 = max2; max2 = sv;
+                ind3 = ind2; ind2 = i;
+            } else if (sv > max3) {
+                max3 = sv;
+                ind3 = i;
+            }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+#pragma unroll
+        for (int k = 0; k < SBP_QPT; k++) {
+            const int b = (int)bin[k];
+            if (b < SI_HISTO && b != ind1 && b != ind2 && b != ind3) { /* fmatcher.cpp:2668-2681 */
+                J.matchCur[key[k] & 0xFFF] = -1;
+                atomicAdd(&s_removed, 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) J.nmatches[0] = s_nlog - s_removed;
+}
+
 __global__ void __launch_bounds__(64)
 k_sbp_replay(SbpJobs JS, int* fallbacks) {
     extern __shared__ __align__(16) uint8_t sbsm[];
@@ -666,6 +794,7 @@ k_sbp_replay(SbpJobs JS, int* fallbacks) {
     uint32_t* kbuf = (uint32_t*)(sbsm + (((size_t)nCur * 8 + (size_t)nLast * 5 + 15) & ~(size_t)15)); /* 64 x M */
     __shared__ int s_hist[SI_HISTO];
     const int lane = threadIdx.x;
+    if (*J.needSeq == 0) return; /* k_sbp_resolve finished this job */
     const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)A.imgW);
     const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)A.imgH);
     for (int c = lane; c < nCur; c += 64) {
@@ -776,16 +905,22 @@ size_t vk_sbp_replay_lds(int nCur, int nLast) {
 size_t vk_sbp_scratch_bytes(int nLast, int M) { return (size_t)nLast * (sizeof(SbpProj) + 4 * (size_t)M); }
 size_t vk_sbp_proj_bytes(int nLast) { return (size_t)nLast * sizeof(SbpProj); }
 int vk_sbp_set_max_lds(size_t bytes) {
-    int rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    int rc = (int)hipFuncSetAttribute((const void*)k_sbp_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     return (int)hipFuncSetAttribute((const void*)k_sbp_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int maxLast, int maxCur, int* fallbacks) {
+size_t vk_sbp_resolve_lds(int nCur) { return (size_t)nCur * 8; }
+
+void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int maxLast, int maxCur, int* fallbacks,
+                             int forceSeq) {
     if (njobs <= 0) return;
     if (maxLast > 0)
         hipLaunchKernelGGL(k_sbp_rank, dim3((maxLast + SBP_QPB - 1) / SBP_QPB, njobs), dim3(256),
                            vk_sbp_rank_lds(maxCur), st, JS);
+    hipLaunchKernelGGL(k_sbp_resolve, dim3(njobs), dim3(SBP_RT), vk_sbp_resolve_lds(maxCur), st, JS, forceSeq);
     hipLaunchKernelGGL(k_sbp_replay, dim3(njobs), dim3(64), vk_sbp_replay_lds(maxCur, maxLast), st, JS, fallbacks);
 }
 

@@ -571,7 +571,9 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     J.topm = (uint32_t*)(d + o_scr + vk_sbp_proj_bytes(n_last));
     J.matchCur = (int32_t*)(d + o_m);
     J.nmatches = (int32_t*)(d + o_n);
-    vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb);
+    J.needSeq = (int32_t*)(d + o_n) + 1;
+    const char* mode = getenv("VSLAM_SBP_MODE"); /* "seq": skip the parallel resolution (cross-check path) */
+    vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb, mode && !strcmp(mode, "seq"));
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -626,7 +628,7 @@ extern "C" int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, con
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     /* per job: proj | topm ; then all match tables and counts together (one result copy) */
     const size_t per_scr = al(vk_sbp_scratch_bytes(cap, M));
-    const size_t o_res = per_scr * njobs, res_bytes = al((size_t)njobs * cap * 4 + (size_t)njobs * 4);
+    const size_t o_res = per_scr * njobs, res_bytes = al((size_t)njobs * cap * 4 + (size_t)njobs * 8);
     rc = vslam_ensure((void**)&fe->d_sbp, &fe->sbp_bytes, o_res + res_bytes);
     if (rc) return rc;
     if (fe->h_sbp_bytes < res_bytes) {
@@ -664,8 +666,10 @@ extern "C" int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, con
         J.topm = (uint32_t*)(scr + vk_sbp_proj_bytes(cap));
         J.matchCur = d_match + (size_t)j * cap;
         J.nmatches = d_nm + j;
+        J.needSeq = d_nm + njobs + j;
     }
-    vk_search_by_projection(fe->stream, JS, njobs, cap, cap, fe->d_init_fb);
+    const char* mode = getenv("VSLAM_SBP_MODE");
+    vk_search_by_projection(fe->stream, JS, njobs, cap, cap, fe->d_init_fb, mode && !strcmp(mode, "seq"));
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
