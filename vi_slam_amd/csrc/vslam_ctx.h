@@ -138,6 +138,7 @@ struct vslam_fe {
     int32_t taps[7];
     /* v2 kernels (vslam_kernels_v2.hip); VSLAM_KERNELS=v1 in the environment selects the first generation */
     bool use_v2_fast = false, use_v2_blur = false, use_v3_fast = false;
+    int octree_gen = 2; /* k_octree_v2 (keys never move); VSLAM_OCTREE=v1 selects the first generation */
     uint32_t* d_blur_tasks = nullptr;
     int n_blur_tasks = 0;
     int blur_rows = 32; /* output rows per wave task of k_blur7_v2 (VSLAM_BLUR_ROWS) */

@@ -232,6 +232,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         fe->use_v2_blur = !v1 && fe->geom.lv[p.nlevels - 1].w >= 8; /* its row fetch reads 8-byte windows */
         fe->use_v2_fast = !v1 && maxw <= vk_fast_v2_max_window() && maxh <= vk_fast_v2_max_rows();
         fe->use_v3_fast = !(gen && !strcmp(gen, "v2")); /* same limits as v2 (LDS pitch, keep mask) */
+        const char* og = getenv("VSLAM_OCTREE"); /* "v1": scan-based stable partition (first generation) */
+        fe->octree_gen = (og && !strcmp(og, "v1")) ? 1 : 2;
     }
 
     const size_t nk = (size_t)fe->B * fe->cap;
@@ -262,6 +264,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             const int cap_l = std::max(O.N[l] + 3, 4 * nIni) + 1;
             selOff += cap_l;
             maxNodes = std::max(maxNodes, cap_l);
+            /* k_octree_v2 parks a level's cell offsets (one u32 per cell) in the second node array (4 u32 per node) */
+            maxNodes = std::max(maxNodes, (fe->level_cell_first[l + 1] - fe->level_cell_first[l] + 3) / 4);
             if (nIni > 64) ok = false;
         }
         O.cellFirst[p.nlevels] = fe->level_cell_first[p.nlevels];
@@ -672,7 +676,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
-              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg);
+              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg, fe->octree_gen);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
                   d_err, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));

@@ -459,6 +459,345 @@ k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Second generation: the same node logic, but the keys never move.  What a pass needs from the keys is only
+ * the per-child COUNT of every expandable node (which children exist, which can still be split, the sort key of
+ * phase 2) -- a histogram (64-bit LDS atomics on the packed counters) -- and afterwards the keys' new node
+ * labels.  The final "best response, first wins" is a segmented arg-max on (response, ~position).  All key
+ * walks are strided by the workgroup size, i.e. coalesced; v1 gave each thread a contiguous chunk (needed by
+ * its scan-based stable partition), which made every load of a wave hit 64 different cache lines -- 5.6 ms per
+ * launch at 1080p / 100 k candidates.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(OT)
+k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
+         uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
+         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag) {
+    extern __shared__ __align__(16) uint8_t osm[];
+    const int MAXN = P.maxNodes;
+    ONode* cur = (ONode*)osm;
+    ONode* nxt = cur + MAXN;
+    u64* Sbeg = (u64*)(nxt + MAXN);
+    u64* Cnt = Sbeg + MAXN;               /* Send during a pass, then quadrant counts */
+    uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
+    uint16_t* newIdx = cb + MAXN;             /* list index of a survivor after the pass */
+    uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
+    uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
+    __shared__ u64 s_w64[OT / 64];
+    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ int s_size, s_M, s_nexp, s_cut;
+
+    const int tid = threadIdx.x;
+    /* grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
+     * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
+    const int level = blockIdx.y, slot = blockIdx.x;
+#ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
+                           of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
+    int dbgn = 0;
+    unsigned long long* DBG = (unsigned long long*)P.dbg;
+#define STAMP() do { if (DBG && tid == 0 && level == 0 && slot == 0 && dbgn < 60) DBG[dbgn++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
+    const int N = P.N[level];
+    const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    const CellOut* cout = (const CellOut*)(hdr + 2);
+    const uint32_t* cand = (const uint32_t*)(cout + ncells);
+    uint32_t* pa = pts_a + (size_t)slot * pts_stride;
+    (void)pts_b;
+    (void)nid_b;
+    uint16_t* na = nid_a + (size_t)slot * pts_stride;
+    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
+    int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
+
+    /* ---- 0. gather this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817):
+     * a wave per cell, coalesced.  A key's position in this array IS its rank in the reference's key order. */
+    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
+    uint32_t before = 0;
+    for (int c = tid; c < c0; c += OT) before += cout[c].count;
+    uint32_t off0;
+    {
+        uint32_t tot;
+        block_excl_scan<uint32_t>(before, s_w32, &tot);
+        off0 = tot;
+    }
+    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
+    uint32_t mine = 0;
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) mine += cout[c].count;
+    }
+    uint32_t ntot;
+    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
+    const int n = (int)ntot;
+    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
+        if (tid == 0) {
+            atomicOr(err_flag, 1);
+            *ocnt = 0;
+        }
+        return;
+    }
+    pa += off0; na += off0;
+    uint32_t* coff = (uint32_t*)nxt; /* cell offsets, borrowed from the second node array (ncl <= 4 * MAXN) */
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) {
+            coff[c - c0] = woff;
+            woff += cout[c].count;
+        }
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int c = c0 + wv; c < c1; c += OT / 64) {
+            const uint32_t* q = cand + cout[c].base;
+            const uint32_t cnt = cout[c].count, o = coff[c - c0];
+            for (uint32_t e = lane; e < cnt; e += 64) pa[o + e] = q[e];
+        }
+    }
+    if (n == 0) {
+        if (tid == 0) *ocnt = 0;
+        return;
+    }
+    __syncthreads();
+
+    STAMP();
+
+    /* ---- 1. initial nodes: stable bucketing by (int)(x / hX) (fextractor.cpp:534-576) */
+    const int nIni = P.nIni[level];
+    const float hX = P.hX[level];
+    const int Hh = P.H[level];
+    __shared__ uint32_t s_bcnt[64], s_bidx[64];
+    if (tid < 64) s_bcnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += OT) {
+        int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+        b = min(b, nIni - 1);
+        atomicAdd(&s_bcnt[b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int li = 0;
+        for (int b = 0; b < nIni; b++) {
+            const uint32_t cb0 = s_bcnt[b];
+            s_bidx[b] = (uint32_t)li;
+            if (cb0) { /* empty initial nodes are erased (fextractor.cpp:572-573) */
+                ONode nd;
+                nd.x0 = (int16_t)(int)__fmul_rn(hX, (float)b);
+                nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
+                nd.y0 = 0;
+                nd.y1 = (int16_t)Hh;
+                nd.begin = 0;
+                nd.cf = (cb0 << 1) | (cb0 == 1 ? 1u : 0u);
+                cur[li++] = nd;
+            }
+        }
+        s_size = li;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += OT) { /* keys never move: every key carries the list index of its node */
+        int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+        b = min(b, nIni - 1);
+        na[i] = (uint16_t)s_bidx[b];
+    }
+    __syncthreads();
+
+    STAMP();
+    /* ---- 2. split passes */
+    int phase = 1;
+    const int KN = (MAXN + OT - 1) / OT;
+    for (int iter = 0; iter < P.maxIter; iter++) {
+        const int size0 = s_size;
+        /* A. children's key counts of every expandable node: a histogram, no key moves */
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0) Cnt[v] = 0ull;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = tid; i < n; i += OT) {
+            const int v = na[i];
+            const ONode nd = cur[v];
+            if (!ND_NOMORE(nd)) {
+                const int q = quadrant(pa[i], nd);
+                if (q < 3) atomicAdd(&Cnt[v], 1ull << (FB * q));
+            }
+        }
+        __syncthreads();
+        STAMP();
+        /* D. node level */
+        /* D1. processing rank of every expandable node */
+        uint32_t nexp_mine = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
+        }
+        uint32_t nexp;
+        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
+        if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
+        if (phase == 1) {
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !ND_NOMORE(cur[v])) {
+                    prank[v] = (uint16_t)rbase;
+                    ordv[rbase] = (uint16_t)v;
+                    rbase++;
+                }
+            }
+        } else {
+            /* descending (count, "created later" == smaller list index) */
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !ND_NOMORE(cur[v])) {
+                    const uint32_t cv = ND_COUNT(cur[v]);
+                    uint32_t r = 0;
+#pragma unroll 8
+                    for (int u = 0; u < size0; u++) {
+                        const uint32_t cfu = cur[u].cf; /* count << 1 | noMore */
+                        r += (!(cfu & 1u) && ((cfu >> 1) > cv || ((cfu >> 1) == cv && u < v))) ? 1u : 0u;
+                    }
+                    prank[v] = (uint16_t)r;
+                    ordv[r] = (uint16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        STAMP();
+        /* D2. in processing order: children created before me, running list size -> cut */
+        const int KE = ((int)nexp + OT - 1) / OT;
+        uint32_t chl = 0;
+        for (int k = 0; k < KE; k++) {
+            const int r = tid * KE + k;
+            if (r < (int)nexp) {
+                const int v = ordv[r];
+                chl += nchildren(Cnt[v], ND_COUNT(cur[v]));
+            }
+        }
+        uint32_t chtot;
+        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
+        if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
+        __syncthreads();
+        {
+            /* parent r is processed iff size0 + sum_{r'<r}(nch-1) < N (phase 2); phase 1: all */
+            uint32_t cb_run = chbase;
+            for (int k = 0; k < KE; k++) {
+                const int r = tid * KE + k;
+                if (r < (int)nexp) {
+                    const int v = ordv[r];
+                    const uint32_t nch = nchildren(Cnt[v], ND_COUNT(cur[v]));
+                    if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
+                    cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
+                    cb_run += nch;
+                }
+            }
+        }
+        __syncthreads();
+        const int ncut = s_cut;
+        /* M = children of processed parents; new size */
+        if (tid == 0) {
+            int M;
+            if (ncut >= (int)nexp) M = (int)chtot;
+            else M = cb[ordv[ncut]];
+            s_M = M;
+            s_size = size0 + M - ncut;
+            s_nexp = 0;
+        }
+        __syncthreads();
+        const int M = s_M;
+        STAMP();
+        /* D3. survivors: list index after the pass */
+        uint32_t sv = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0) {
+                const bool processed = !ND_NOMORE(cur[v]) && prank[v] < ncut;
+                if (!processed) sv++;
+            }
+        }
+        uint32_t svtot;
+        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
+        int nexp_children = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v >= size0) continue;
+            const ONode nd = cur[v];
+            const bool processed = !ND_NOMORE(nd) && prank[v] < ncut;
+            if (!processed) {
+                newIdx[v] = (uint16_t)(M + svbase);
+                nxt[M + svbase] = nd;
+                svbase++;
+            } else {
+                const u64 c = Cnt[v];
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                int kq = 0;
+                const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
+                const uint32_t c3 = ND_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cq = q < 3 ? fld(c, q) : c3;
+                    if (!cq) continue;
+                    ONode ch;
+                    ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
+                    ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
+                    ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
+                    ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
+                    ch.begin = 0;
+                    ch.cf = (cq << 1) | (cq == 1 ? 1u : 0u);
+                    nxt[first - kq] = ch;
+                    if (cq > 1) nexp_children++;
+                    kq++;
+                }
+                cb[v] = (uint16_t)first;
+            }
+        }
+        if (nexp_children) atomicAdd(&s_nexp, nexp_children);
+        __syncthreads();
+        STAMP();
+        /* E. relabel every key with the list index of the node that holds it after the pass */
+#pragma unroll 4
+        for (int i = tid; i < n; i += OT) {
+            const int v = na[i];
+            const ONode nd = cur[v];
+            if (ND_NOMORE(nd) || prank[v] >= ncut) {
+                na[i] = newIdx[v];
+            } else {
+                const int q = quadrant(pa[i], nd);
+                const u64 c = Cnt[v];
+                int kq = 0;
+                for (int q2 = 0; q2 < q; q2++) kq += fld(c, q2) != 0;
+                na[i] = (uint16_t)(cb[v] - kq);
+            }
+        }
+        __syncthreads();
+        { ONode* t = cur; cur = nxt; nxt = t; }
+        STAMP();
+        /* F. loop control (fextractor.cpp:658-729) */
+        const int size = s_size, nToExpand = s_nexp;
+        __syncthreads();
+        if (size >= N || size == size0) break;
+        if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
+    }
+
+    STAMP();
+    /* ---- 3. best response per node, first in key order wins (fextractor.cpp:732-751): a segmented arg-max,
+     * key = response << 32 | ~position; output in list order */
+    const int size = s_size;
+    u64* best = Sbeg;
+    for (int v = tid; v < size; v += OT) best[v] = 0ull;
+    __syncthreads();
+#pragma unroll 4
+    for (int i = tid; i < n; i += OT)
+        atomicMax(&best[na[i]], ((u64)(pa[i] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+    __syncthreads();
+    for (int v = tid; v < size; v += OT) /* every listed node holds at least one key */
+        out[v] = best[v] ? pa[0xFFFFFFFFu - (uint32_t)(best[v] & 0xFFFFFFFFull)] : 0u;
+#ifdef VSLAM_OCT_STAMPS
+    __syncthreads();
+    STAMP();
+    if (DBG && tid == 0 && level == 0 && slot == 0) DBG[63] = dbgn;
+#endif
+    if (tid == 0) *ocnt = size;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * output order of a slot (fextractor.cpp:1071-1129): level-major; a keypoint whose scaled x lies in
  * [lap0, lap1] takes the next free index from the tail, the others from the head.  One workgroup per
  * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
@@ -532,9 +871,14 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots) {
-    hipLaunchKernelGGL(k_octree, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
-                       cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag);
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int generation) {
+    if (generation >= 2)
+        hipLaunchKernelGGL(k_octree_v2, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st,
+                           cand_region, cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt,
+                           err_flag);
+    else
+        hipLaunchKernelGGL(k_octree, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
+                           cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag);
 }
 
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
@@ -545,5 +889,7 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, con
 }
 
 int vk_octree_set_max_lds(size_t bytes) {
+    int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
     return (int)hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
