@@ -76,7 +76,7 @@ int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scale, float* s
 
 /* FExtractor::compute (fextractor.h:38-40, fextractor.cpp:1034-1133) for one host image, synchronous.
  *   img/pitch : CV_8UC1 rows.   lap0/lap1 : vLappingArea (frame.cpp:107-108 passes {0,0}, :289 {0,1000}).
- *   kps/desc  : caller storage for cap keypoints / cap*32 descriptor bytes; cap >= nfeatures + 4*nlevels.
+ *   kps/desc  : caller storage for cap keypoints / cap*32 descriptor bytes; cap >= vslam_fe_capacity(fe).
  *   *n        : keypoints written;  *mono_index : the reference's return value.
  * Uses image slot 0. */
 int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, int lap1, vslam_kp* kps,
@@ -105,6 +105,11 @@ int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* de
  * borderless level image of a slot into dst (dst_pitch >= level width).  blurred != 0 returns the
  * GaussianBlur'ed clone used for the descriptors (fextractor.cpp:1085-1086). */
 int vslam_fe_level_size(const vslam_fe* fe, int level, int* w, int* h);
+
+/* Keypoint capacity of one image slot = the most keypoints one extraction can return: nfeatures + 4*nlevels + 8
+ * rounded up to a multiple of 4, or -- for very small nfeatures -- the exact bound of the quadtree
+ * (sum over levels of max(quota + 3, 4 * initial nodes)) if that is larger.  Size caller arrays with it. */
+int vslam_fe_capacity(const vslam_fe* fe);
 int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurred, uint8_t* dst, size_t dst_pitch);
 
 /* Stage taps for parity tests and profilers: per-level FAST candidates of the last extract of a slot in
@@ -136,7 +141,7 @@ void* vslam_fe_stream(vslam_fe* fe);
 
 /* Pack the results of slots 0..nslots-1 into caller device memory (e.g. this rank's send buffer of an
  * RCCL all-gather): per slot `slot_bytes` >= 16 + cap*60 laid out as
- *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = nfeatures + 4*nlevels + 8 rounded up to a multiple of 4)
+ *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = vslam_fe_capacity(fe))
  * Returns after the copies have completed. */
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
 /* the same for slots first .. first+nslots-1 (packed from offset 0 of dev_dst) */

@@ -187,7 +187,7 @@ protected:
             w_ = cols;
             h_ = rows;
         }
-        const int cap = (nfeatures + 4 * nlevels + 8 + 3) & ~3; /* quota + the quadtree's overshoot, see vslam_fe.h */
+        const int cap = vslam_fe_capacity(fe_); /* quota + the quadtree's overshoot, see vslam_fe.h */
         keypoints.resize(cap);
         desc.resize((size_t)cap * 32);
         int n = 0, mono = 0;

@@ -96,6 +96,8 @@ def test_device_resident_input_zero_copy(kitti):
     (752, 480, 500, 20, 7),      # hut_stereo size
     (640, 480, 10000, 20, 7),    # 5 x nFeatures initialisation extractor (tracking.cpp:1093)
     (321, 203, 300, 35, 12),     # odd size, other thresholds
+    (1920, 1080, 120, 20, 7),    # far more FAST cells per level than quadtree nodes (cell-offset scratch)
+    (1241, 376, 60, 20, 7),
 ])
 def test_other_geometries(cfg):
     w, h, nf, ini, mn = cfg

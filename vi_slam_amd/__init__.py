@@ -30,7 +30,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 ABI_SYMBOLS = [
     "vslam_fe_create", "vslam_fe_destroy", "vslam_last_error", "vslam_fe_tables", "vslam_fe_extract",
     "vslam_fe_extract_batch", "vslam_fe_level_size", "vslam_fe_level_copy", "vslam_fe_candidates",
-    "vslam_fe_slot_buffers", "vslam_fe_slot_host_views", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
+    "vslam_fe_slot_buffers", "vslam_fe_slot_host_views", "vslam_fe_capacity", "vslam_fe_stream", "vslam_hamming_top2", "vslam_hamming_matrix",
     "vslam_stereo_match", "vslam_stereo_match_batch", "vslam_search_for_initialization",
     "vslam_dbg_sincos", "vslam_dbg_fast_atan2", "vslam_fe_pack_slots", "vslam_fe_set_profiling",
     "vslam_fe_get_profile", "vslam_fe_extract_batch_async", "vslam_fe_extract_wait",
@@ -105,6 +105,7 @@ def lib():
         L.vslam_fe_candidates.argtypes = [vp, i, i, vp, i]
         L.vslam_fe_slot_buffers.argtypes = [vp, i, vp, vp, vp]
         L.vslam_fe_slot_host_views.argtypes = [vp, i, vp, vp]
+        L.vslam_fe_capacity.argtypes = [vp]
         L.vslam_projection_direction.argtypes = [vp, vp, C.c_float, i, i, vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
@@ -168,7 +169,7 @@ class FExtractor:
         self.nfeatures, self.nlevels, self.width, self.height = nfeatures, nlevels, width, height
         self.scaleFactor = scaleFactor
         self.max_batch = max_batch
-        self.cap = (nfeatures + 4 * nlevels + 8 + 3) & ~3  # vslam_fe.hip: slot capacity, multiple of 4
+        self.cap = L.vslam_fe_capacity(h)  # slot capacity: nfeatures + 4*nlevels + 8 (multiple of 4) or the exact bound
         self.device = device
 
     def close(self):

@@ -140,6 +140,18 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         }
     }
     fe->slot_stride = off;
+    {
+        /* exact bound of what DistributeOctTree can return: a level ends with at most N_l + 2 nodes, except that
+         * the first pass splits all nIni initial nodes unconditionally (up to 4*nIni).  Only matters for very
+         * small nfeatures; the documented formula stays the floor so common configurations keep their layout. */
+        int bound = 0;
+        for (int l = 0; l < p.nlevels; l++) {
+            const int W = fe->geom.lv[l].w - 2 * VSLAM_FAST_BORDER, H = fe->geom.lv[l].h - 2 * VSLAM_FAST_BORDER;
+            const int nIni = (int)std::round((float)W / (float)H);
+            bound += std::max(fe->tab.quota[l] + 3, 4 * nIni);
+        }
+        fe->cap = std::max(fe->cap, (bound + 3) & ~3);
+    }
     HIPCHK(hipMalloc((void**)&fe->d_pyr, fe->slot_stride * fe->B));
     HIPCHK(hipMalloc((void**)&fe->d_blur, fe->slot_stride * fe->B));
     HIPCHK(hipMemset(fe->d_pyr, 0, fe->slot_stride * fe->B));
@@ -890,6 +902,8 @@ extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** de
     if (n) *n = fe->n_out[slot];
     return VSLAM_OK;
 }
+
+extern "C" int vslam_fe_capacity(const vslam_fe* fe) { return fe ? fe->cap : VSLAM_ERR_INVALID; }
 
 extern "C" int vslam_fe_slot_host_views(vslam_fe* fe, int slot, const vslam_kp** host_kps,
                                         const uint8_t** host_desc) {
