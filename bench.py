@@ -125,7 +125,50 @@ def cpu_baseline(cfg, seconds=12.0):
         sample = "%d synthetic mono frames %dx%d, %d features: extract + SearchForInitialization(prev)" % (
             frames, w, h, nf)
     dt = time.time() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+    out = {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+    out["all_cores"] = cpu_baseline_all_cores(cfg)
+    return out
+
+
+def cpu_baseline_all_cores(cfg, seconds=8.0):
+    """SURVEY.md 8(d) variant (ii): every host core of the box, frame-parallel (one oracle extractor per thread,
+    each thread following its own frame sequence; ctypes releases the GIL).  Reported beside the
+    reference-faithful figure, never as the headline."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orbo
+    from vi_slam_amd import synth
+    w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    ncores = max(1, min(os.cpu_count() or 1, 64))
+    nsample = 3
+    if stereo:
+        data = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
+    else:
+        data = [synth.make_frame(w, h, step=s) for s in range(nsample)]
+    t_end = time.time() + seconds
+
+    def worker(_):
+        e, e2 = orbo.Extractor(nf), orbo.Extractor(nf)
+        prev, n = None, 0
+        while time.time() < t_end:
+            if stereo:
+                L, R = data[n % nsample]
+                kL, dL, _ = e.compute(L)
+                kR, dR, _ = e2.compute(R)
+                orbo.stereo(e, e2, kL, dL, kR, dR, BF, FX)
+            else:
+                k, d, _ = e.compute(data[n % nsample], lap=(0, 1000))
+                if prev is not None:
+                    orbo.search_for_initialization(prev[0], prev[1], k, d, w, h, window=100, nnratio=0.9)
+                prev = (k, d)
+            n += 1
+        return n
+
+    t0 = time.time()
+    with ThreadPoolExecutor(ncores) as pool:
+        total = sum(pool.map(worker, range(ncores)))
+    dt = time.time() - t0
+    return {"value": total / dt, "unit": "frames/s", "cores": ncores,
+            "sample": "%d frames on %d threads, one sequence per thread" % (total, ncores)}
 
 
 def main():
