@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t nchildren(unsigned long long c, uint32_t cou
     return (c0 != 0) + (c1 != 0) + (c2 != 0) + (count - c0 - c1 - c2 != 0);
 }
 
-template <typename T>
+template <typename T, int NT = OT>
 __device__ __forceinline__ T block_excl_scan(T v, T* s_wave, T* total) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     T inc = v;
@@ -57,7 +57,7 @@ __device__ __forceinline__ T block_excl_scan(T v, T* s_wave, T* total) {
     __syncthreads();
     T woff = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < OT / 64; k++) {
+    for (int k = 0; k < NT / 64; k++) {
         const T x = s_wave[k];
         if (k < wv) woff += x;
         tot += x;
@@ -802,11 +802,12 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
  * [lap0, lap1] takes the next free index from the tail, the others from the head.  One workgroup per
  * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
  * ---------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(OT)
+#define AO_T 256 /* a small workgroup finds a free CU slot quickly next to the other streams' kernels */
+__global__ void __launch_bounds__(AO_T)
 k_assign_out(OctParams P, PyramidGeom g, const uint32_t* __restrict__ sel_xyr, const int32_t* __restrict__ sel_cnt,
              int lap0, int lap1, SelKp* sel, int32_t* slot_counts /* [slot][4]: n, mono, 0, 0 */, int cap,
              int32_t* err_flag) {
-    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ uint32_t s_w32[AO_T / 64];
     __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
     const int tid = threadIdx.x, slot = blockIdx.x;
     const int L = g.nlevels;
@@ -828,7 +829,7 @@ k_assign_out(OctParams P, PyramidGeom g, const uint32_t* __restrict__ sel_xyr, c
         }
         return;
     }
-    const int Cc = (nk + OT - 1) / OT;
+    const int Cc = (nk + AO_T - 1) / AO_T;
     const int i0 = min(tid * Cc, nk), i1 = min(i0 + Cc, nk);
     const uint32_t* base = sel_xyr + (size_t)slot * P.selStride;
     uint32_t lapc = 0;
@@ -841,7 +842,7 @@ k_assign_out(OctParams P, PyramidGeom g, const uint32_t* __restrict__ sel_xyr, c
         lapc += (px >= (float)lap0 && px <= (float)lap1) ? 1u : 0u;
     }
     uint32_t laptot;
-    uint32_t lapbefore = block_excl_scan<uint32_t>(lapc, s_w32, &laptot);
+    uint32_t lapbefore = block_excl_scan<uint32_t, AO_T>(lapc, s_w32, &laptot);
     l = 0;
     for (int i = i0; i < i1; i++) {
         while (i >= s_lvl_off[l + 1]) l++;
@@ -884,7 +885,7 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
                    const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
                    int32_t* err_flag, int nslots) {
-    hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(OT), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
+    hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(AO_T), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
                        slot_counts, cap, err_flag);
 }
 
