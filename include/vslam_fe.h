@@ -267,6 +267,24 @@ int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p, c
                                      const uint8_t* dev_cur_desc, int n_cur, const float* cur_u_right_host,
                                      const uint8_t* cur_occupied_host, int32_t* match_cur, int* nmatches);
 
+/* FMatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * (fmatcher.cpp:321-411; pinhole frames) -- the local-map matcher of Tracking::SearchLocalPoints.  Each MapPoint
+ * arrives with what Frame::isInFrustum left in it (mappoint.h:73-81):
+ *   flags bit0 = mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints), bit1 = Observations() > 0.
+ * cur_occupied_host marks keypoints whose mvpMapPoints entry already holds a MapPoint with observations (the
+ * matches of TrackWithMotionModel).  match_cur[idx] = index of the MapPoint written to F.mvpMapPoints[idx], or -1.
+ * nnratio is FMatcher::mfNNratio (>= 0.4 on the device). */
+typedef struct vslam_mp_track {
+    float proj_x, proj_y, proj_xr, view_cos; /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos */
+    int32_t level;                           /* mnTrackScaleLevel */
+    uint32_t flags;
+} vslam_mp_track;
+int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp_track* mps_host, const uint8_t* mp_desc_host,
+                                         int n_mp, const vslam_kp* dev_cur_kps, const uint8_t* dev_cur_desc,
+                                         int n_cur, const float* cur_u_right_host, const uint8_t* cur_occupied_host,
+                                         int img_w, int img_h, float th, float nnratio, int32_t* match_cur,
+                                         int* nmatches);
+
 /* Device-resident, batched form of the same matcher: every pointer of a job is a DEVICE pointer; counts are
  * int32 in HBM (vslam_fe_slot_count_ptr); keypoint arrays hold up to the context's capacity (<= 4096).  Up to 16
  * jobs per call run in one pass of the two kernels on fe's stream.  _async returns without waiting; _wait

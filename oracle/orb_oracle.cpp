@@ -927,6 +927,60 @@ static inline float gemm_row(const float* r, const float* x, float t, int dbl) {
     return s + t;
 }
 
+int search_by_projection_mappoints(const std::vector<MapPointTrack>& mps, const std::vector<uint8_t>& mpDesc,
+                                   const std::vector<KeyPoint>& curKps, const std::vector<uint8_t>& curDesc,
+                                   const std::vector<float>& mvuRight, const std::vector<uint8_t>& occupied0,
+                                   const std::vector<float>& scaleFactors, int imgW, int imgH, float th, float nnratio,
+                                   std::vector<int>& matchCur) { /* fmatcher.cpp:321-411, Nleft == -1 */
+    const int TH_HIGH = 100;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    const int N2 = (int)curKps.size();
+    matchCur.assign(N2, -1);
+    std::vector<uint8_t> occ(N2, 0); /* F.mvpMapPoints[idx] && Observations() > 0 */
+    for (int i = 0; i < N2 && i < (int)occupied0.size(); i++) occ[i] = occupied0[i];
+    FrameGrid grid(curKps, imgW, imgH);
+    for (size_t iMP = 0; iMP < mps.size(); iMP++) {
+        const MapPointTrack& mp = mps[iMP];
+        if (!(mp.flags & 1)) continue; /* !mbTrackInView / far point / isBad() */
+        const int nPredictedLevel = mp.level;
+        float r = mp.viewCos > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos, fmatcher.cpp:493-499 */
+        if (bFactor) r *= th;
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(mp.projX, mp.projY, r * scaleFactors[nPredictedLevel],
+                                                                 nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = &mpDesc[32 * iMP];
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (occ[idx]) continue;
+            if (mvuRight[idx] > 0) {
+                const float er = std::fabs(mp.projXR - mvuRight[idx]);
+                if (er > r * scaleFactors[nPredictedLevel]) continue;
+            }
+            const int dist = descriptor_distance(MPdescriptor, &curDesc[32 * (size_t)idx]);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = curKps[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = curKps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                matchCur[bestIdx] = (int)iMP;
+                if (mp.flags & 2) occ[bestIdx] = 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -136,6 +136,20 @@ int search_by_projection_frame(const ProjFrameArgs& a, const std::vector<KeyPoin
                                const std::vector<uint8_t>& curDesc, const std::vector<float>& mvuRight,
                                const std::vector<uint8_t>& occupied, const std::vector<float>& scaleFactors,
                                std::vector<int>& matchCur);
+/* FMatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * (fmatcher.cpp:321-411, pinhole frames: Nleft == -1) -- the local-map matcher of SearchLocalPoints.
+ * Per MapPoint what Frame::isInFrustum left in it: */
+struct MapPointTrack {
+    float projX, projY, projXR, viewCos; /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos */
+    int level;                           /* mnTrackScaleLevel */
+    unsigned flags; /* bit0: mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints); bit1: Observations() > 0 */
+};
+int search_by_projection_mappoints(const std::vector<MapPointTrack>& mps, const std::vector<uint8_t>& mpDesc,
+                                   const std::vector<KeyPoint>& curKps, const std::vector<uint8_t>& curDesc,
+                                   const std::vector<float>& mvuRight, const std::vector<uint8_t>& occupied,
+                                   const std::vector<float>& scaleFactors, int imgW, int imgH, float th, float nnratio,
+                                   std::vector<int>& matchCur);
+
 /* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]);

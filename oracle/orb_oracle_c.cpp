@@ -192,6 +192,21 @@ int orbo_search_by_projection_frame(const float* fargs, const int* iargs, const 
     return nm;
 }
 
+int orbo_search_by_projection_mappoints(const MapPointTrack* mps, int n, const uint8_t* mpDesc, const KeyPoint* curKps,
+                                        int n2, const uint8_t* curDesc, const float* mvuRight, const uint8_t* occupied,
+                                        const float* scaleFactors, int nlevels, int imgW, int imgH, float th,
+                                        float nnratio, int* matchCur) {
+    std::vector<MapPointTrack> m(mps, mps + n);
+    std::vector<KeyPoint> ck(curKps, curKps + n2);
+    std::vector<uint8_t> md(mpDesc, mpDesc + (size_t)n * 32), cd(curDesc, curDesc + (size_t)n2 * 32), occ;
+    std::vector<float> ur(mvuRight, mvuRight + n2), sf(scaleFactors, scaleFactors + nlevels);
+    if (occupied) occ.assign(occupied, occupied + n2);
+    std::vector<int> out;
+    const int nm = search_by_projection_mappoints(m, md, ck, cd, ur, occ, sf, imgW, imgH, th, nnratio, out);
+    if (n2) memcpy(matchCur, out.data(), (size_t)n2 * sizeof(int));
+    return nm;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

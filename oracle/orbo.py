@@ -65,6 +65,8 @@ def lib():
         L.orbo_grid_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
         vp = C.c_void_p
+        L.orbo_search_by_projection_mappoints.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
+                                                          C.c_int, C.c_float, C.c_float, vp]
         L.orbo_unproject_stereo.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                             vp, vp]
         L.orbo_unproject_stereo.restype = None
@@ -289,3 +291,26 @@ def unproject_stereo(kps, depth, Twc, cx, cy, invfx, invfy, gemm_double=True):
     f = np.zeros(len(kps), np.uint8)
     lib().orbo_unproject_stereo(_p(kps), len(kps), _p(depth), _p(T), cx, cy, invfx, invfy, int(gemm_double), _p(x), _p(f))
     return x, f
+
+
+#: per-MapPoint tracking record (orbo::MapPointTrack == vslam_mp_track): what Frame::isInFrustum left in the MapPoint
+MP_TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"),
+                           ("level", "<i4"), ("flags", "<u4")])
+
+
+def search_by_projection_mappoints(mps, mp_desc, cur_kps, cur_desc, mvu_right, scale_factors, W, H, th=1.0,
+                                   nnratio=0.8, occupied=None):
+    """FMatcher::SearchByProjection(F, vpMapPoints, th, ...) (fmatcher.cpp:321-411, pinhole) -> (nmatches,
+    matchCur[n2] = MapPoint index or -1)."""
+    mps = np.ascontiguousarray(mps, MP_TRACK_DTYPE)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    mvu = np.ascontiguousarray(mvu_right, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    m = np.full(max(len(cur_kps), 1), -1, np.int32)
+    nm = lib().orbo_search_by_projection_mappoints(_p(mps), len(mps), _p(mp_desc), _p(cur_kps), len(cur_kps),
+                                                   _p(cur_desc), _p(mvu), _p(occ) if occ is not None else None, _p(sf),
+                                                   len(sf), W, H, th, nnratio, _p(m))
+    return nm, m[:len(cur_kps)]

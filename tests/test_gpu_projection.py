@@ -199,3 +199,64 @@ def test_device_resident_tracking_chain_equals_oracle():
             assert wn > 100
     finally:
         fe.close()
+
+
+# ---------------------------------------------------------------- SearchByProjection(F, vpMapPoints) (local map)
+def _local_map(scene, seed, jitter=2.0, frac_in_view=0.85):
+    """MapPoints as Tracking::SearchLocalPoints hands them over: the last frame's stereo points seen from the
+    current pose, with what Frame::isInFrustum would have stored (projection, predicted level, viewing cosine)."""
+    rng = np.random.default_rng(seed)
+    k0 = scene["k0"]
+    n = len(k0)
+    zmed = float(np.median(scene["z"][scene["has_depth"]]))
+    mps = np.zeros(n, V.MP_TRACK_DTYPE)
+    mps["proj_x"] = (k0["x"] + 3.0 + rng.normal(0, jitter, n)).astype(np.float32)
+    mps["proj_y"] = (k0["y"] + 1.0 + rng.normal(0, jitter, n)).astype(np.float32)
+    mps["proj_xr"] = (mps["proj_x"] - BF / np.maximum(scene["z"], 1.0)).astype(np.float32)
+    mps["view_cos"] = rng.choice(np.array([0.9, 0.9985, 1.0], np.float32), n)
+    mps["level"] = np.clip(k0["octave"] + rng.integers(-1, 2, n), 0, 7)
+    inview = rng.random(n) < frac_in_view
+    obs = rng.random(n) < 0.9
+    mps["flags"] = (inview.astype(np.uint32)) | (obs.astype(np.uint32) << 1)
+    return mps
+
+
+@pytest.mark.parametrize("th,nnratio,seed", [(1.0, 0.8, 1), (3.0, 0.8, 2), (5.0, 0.6, 3)])
+def test_local_map_matcher_equals_oracle(scene, th, nnratio, seed):
+    mps = _local_map(scene, seed)
+    rng = np.random.default_rng(100 + seed)
+    occ = (rng.random(len(scene["k1"])) < 0.3).astype(np.uint8)   # matches TrackWithMotionModel already made
+    m = V.FMatcher(scene["fe"], nnratio, True)
+    m.search_init_fallbacks()
+    for occupied in (None, occ):
+        nm, mc = m.SearchByProjectionMapPoints(mps, scene["de0"], scene["cur"][0], scene["cur"][1], len(scene["k1"]),
+                                               scene["u1"], th, occupied, (W, H))
+        wn, wm = orbo.search_by_projection_mappoints(mps, scene["de0"], scene["k1"], scene["de1"], scene["u1"],
+                                                     scene["sf"], W, H, th, nnratio, occupied)
+        assert nm == wn and np.array_equal(mc, wm), (th, nnratio, occupied is not None)
+        assert nm > 100
+        if occupied is not None:
+            assert not np.any((mc >= 0) & (occ == 1))
+    if th == 1.0:
+        assert m.search_init_fallbacks() == 0  # tracking's usual window: resolved by the parallel fixpoint alone
+
+
+@pytest.mark.parametrize("env", [{"VSLAM_SBP_MODE": "seq"}, {"VSLAM_SBP_TOPM": "2"}, {"VSLAM_SBP_TOPM": "1"}])
+def test_local_map_matcher_sequential_and_short_prefix(scene, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    mps = _local_map(scene, 9, jitter=4.0)
+    mps["flags"] |= np.uint32(1)
+    m = V.FMatcher(scene["fe"], 0.8, True)
+    nm, mc = m.SearchByProjectionMapPoints(mps, scene["de0"], scene["cur"][0], scene["cur"][1], len(scene["k1"]),
+                                           None, 5.0, None, (W, H))
+    wn, wm = orbo.search_by_projection_mappoints(mps, scene["de0"], scene["k1"], scene["de1"],
+                                                 np.full(len(scene["k1"]), -1, np.float32), scene["sf"], W, H, 5.0, 0.8)
+    assert nm == wn and np.array_equal(mc, wm)
+
+
+def test_local_map_matcher_rejects_small_ratio(scene):
+    m = V.FMatcher(scene["fe"], 0.3, True)
+    with pytest.raises(V.VslamError):
+        m.SearchByProjectionMapPoints(_local_map(scene, 1), scene["de0"], scene["cur"][0], scene["cur"][1],
+                                      len(scene["k1"]), None, 1.0, None, (W, H))

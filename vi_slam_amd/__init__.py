@@ -39,8 +39,13 @@ ABI_SYMBOLS = [
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
     "vslam_fe_event_wait", "vslam_projection_direction", "vslam_search_by_projection_frame",
     "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
-    "vslam_stereo_points_buffers",
+    "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints",
 ]
+
+
+#: vslam_mp_track: per-MapPoint tracking record (mappoint.h:73-81 after Frame::isInFrustum)
+MP_TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"),
+                           ("level", "<i4"), ("flags", "<u4")])
 
 
 class _ProjParams(C.Structure):  # vslam_proj_params
@@ -107,6 +112,8 @@ def lib():
         L.vslam_fe_slot_host_views.argtypes = [vp, i, vp, vp]
         L.vslam_fe_capacity.argtypes = [vp]
         L.vslam_projection_direction.argtypes = [vp, vp, C.c_float, i, i, vp, vp]
+        L.vslam_search_by_projection_mappoints.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, C.c_float, C.c_float,
+                                                           vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
         L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
@@ -522,6 +529,23 @@ class FMatcher:
             C.c_void_p(dev_cur_desc), n_cur, _p(ur) if ur is not None else None, _p(oc) if oc is not None else None,
             _p(m), C.byref(nm)))
         return nm.value, m[:n_cur], (bool(fwd.value), bool(bwd.value))
+
+    def SearchByProjectionMapPoints(self, mps, mp_desc, dev_cur_kps, dev_cur_desc, n_cur, cur_u_right=None, th=1.0,
+                                    occupied=None, img_size=None):
+        """FMatcher::SearchByProjection(F, vpMapPoints, th, ...) (fmatcher.cpp:321-411, pinhole): mps is a
+        MP_TRACK_DTYPE array (what Frame::isInFrustum left in each MapPoint).  -> (nmatches, match_cur[n_cur])."""
+        mps = np.ascontiguousarray(mps, MP_TRACK_DTYPE)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        ur = None if cur_u_right is None else np.ascontiguousarray(cur_u_right, np.float32)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        w, h = img_size or (self.fe.width, self.fe.height)
+        m = np.full(max(n_cur, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_projection_mappoints(
+            self.fe._h, _p(mps), _p(md), len(mps), C.c_void_p(dev_cur_kps), C.c_void_p(dev_cur_desc), n_cur,
+            _p(ur) if ur is not None else None, _p(oc) if oc is not None else None, w, h, C.c_float(th),
+            C.c_float(self.mfNNratio), _p(m), C.byref(nm)))
+        return nm.value, m[:n_cur]
 
     @staticmethod
     def make_sbp_jobs(jobs, check_orientation=True):

@@ -108,6 +108,13 @@ struct ResizeQuad {
     uint32_t coef[4];
 };
 
+/* vslam_mp_track: per MapPoint, what Frame::isInFrustum left in it */
+struct MpTrack {
+    float projX, projY, projXR, viewCos;
+    int32_t level;
+    uint32_t flags;
+};
+
 /* One SearchByProjection(CurrentFrame, LastFrame) problem; every pointer is a DEVICE pointer.  nLast / nCur are
  * the counts, or -- when nLastPtr / nCurPtr are set -- capacities with the real counts read from HBM. */
 struct SbpProj;
@@ -131,6 +138,10 @@ struct SbpJobDev {
     int32_t* matchCur;        /* out: nCur */
     int32_t* nmatches;        /* out: 1 */
     int32_t* needSeq;         /* scratch: k_sbp_resolve -> k_sbp_replay hand-over flag */
+    /* mode 1 = SearchByProjection(F, vpMapPoints): queries come pre-projected (Frame::isInFrustum) */
+    const MpTrack* mps;
+    float nnratio;
+    int32_t mode;
 };
 #define VSLAM_MAX_SBP_JOBS 16
 struct SbpJobs { /* by-value kernel argument (< 4 KB) */

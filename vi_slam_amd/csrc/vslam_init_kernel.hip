@@ -561,7 +561,20 @@ k_sbp_rank(SbpJobs JS) {
         pr.u = pr.v = pr.radius = pr.ur = 0.f;
         pr.minLevel = pr.maxLevel = 0;
         pr.pad = 0;
-        if (J.flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
+        if (J.mode == 1) { /* pre-projected MapPoints (fmatcher.cpp:327-350) */
+            const MpTrack mp = J.mps[q];
+            if (mp.flags & 1) {
+                float r = (double)mp.viewCos > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos, fmatcher.cpp:493-499 */
+                if (J.th != 1.0f) r = __fmul_rn(r, J.th);
+                pr.u = mp.projX;
+                pr.v = mp.projY;
+                pr.radius = __fmul_rn(r, JS.scale[min(max(mp.level, 0), JS.nlevels - 1)]);
+                pr.ur = mp.projXR;
+                pr.minLevel = mp.level - 1;
+                pr.maxLevel = mp.level;
+                pr.valid = 1;
+            }
+        } else if (J.flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
             const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
             const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
             const float yc = sbp_gemm_row(J.Tcw + 4, X, Y, Z, J.Tcw[7], J.gemmFloat);
@@ -904,13 +917,199 @@ size_t vk_sbp_replay_lds(int nCur, int nLast) {
 }
 size_t vk_sbp_scratch_bytes(int nLast, int M) { return (size_t)nLast * (sizeof(SbpProj) + 4 * (size_t)M); }
 size_t vk_sbp_proj_bytes(int nLast) { return (size_t)nLast * sizeof(SbpProj); }
+__global__ void k_sbpm_resolve(SbpJobs JS, int forceSeq); /* defined below */
 int vk_sbp_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_sbp_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    rc = (int)hipFuncSetAttribute((const void*)k_sbpm_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     return (int)hipFuncSetAttribute((const void*)k_sbp_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SearchByProjection(Frame& F, const vector<MapPoint*>&, th, ...) (fmatcher.cpp:321-411): same ranking, but a
+ * query now looks at its first TWO free candidates (best / second with their octaves, ratio test only when both
+ * lie on the same level).  A query's proposal can therefore appear or vanish while the occupancy around it
+ * changes, so the resolution is a plain fixpoint: every round rebuilds "lowest-index blocking query that chose
+ * this keypoint" from the current choices and lets every query choose again; by induction on the query index the
+ * unique fixpoint is the sequential result.  Same hand-over to a sequential wave when a list prefix runs out.
+ * ---------------------------------------------------------------------------------------------- */
+#define SBPM_M 8
+__global__ void __launch_bounds__(SBP_RT)
+k_sbpm_resolve(SbpJobs JS, int forceSeq) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    const SbpJobDev& J = JS.job[blockIdx.x];
+    const int M = min(JS.M, SBPM_M);
+    const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
+    const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
+    int32_t* holder = (int32_t*)sbsm;
+    int32_t* owner = holder + nCur;
+    uint8_t* oct = (uint8_t*)(owner + nCur);
+    __shared__ int s_changed, s_seq, s_nlog;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_seq = forceSeq;
+        s_nlog = 0;
+        s_changed = 0;
+    }
+    for (int c = tid; c < nCur; c += SBP_RT) {
+        oct[c] = (uint8_t)J.curKps[c].octave;
+        owner[c] = -1;
+    }
+    uint32_t keys[SBP_QPT][SBPM_M];
+    int choice[SBP_QPT];
+    bool blocking[SBP_QPT], full[SBP_QPT];
+#pragma unroll
+    for (int k = 0; k < SBP_QPT; k++) {
+        const int q = tid + k * SBP_RT;
+        choice[k] = -1;
+        blocking[k] = q < nLast && (J.flags[q] & 2);
+        full[k] = true;
+#pragma unroll
+        for (int j = 0; j < SBPM_M; j++) {
+            keys[k][j] = (q < nLast && j < M) ? J.topm[(size_t)q * JS.M + j] : 0xFFFFFFFFu;
+            if (j < M && keys[k][j] == 0xFFFFFFFFu) full[k] = false;
+        }
+    }
+    __syncthreads();
+    for (int round = 0; round < 1024 && !s_seq; round++) {
+        for (int c = tid; c < nCur; c += SBP_RT) holder[c] = (J.occupied0 && J.occupied0[c]) ? -1 : 0x7FFFFFFF;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SBP_QPT; k++)
+            if (choice[k] >= 0 && blocking[k]) atomicMin(&holder[choice[k]], tid + k * SBP_RT);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SBP_QPT; k++) {
+            const int q = tid + k * SBP_RT;
+            if (keys[k][0] == 0xFFFFFFFFu) continue; /* no candidates at all */
+            int found = 0, best = -1, bd = 256, bl = -1, sd = 256, sl = -1;
+#pragma unroll
+            for (int j = 0; j < SBPM_M; j++) {
+                const uint32_t key = keys[k][j];
+                if (key == 0xFFFFFFFFu || found == 2) continue;
+                const int c = (int)(key & 0xFFF);
+                if (holder[c] < q) continue; /* held by an earlier query (or occupied from the start) */
+                if (found == 0) {
+                    best = c;
+                    bd = (int)(key >> 24);
+                    bl = oct[c];
+                } else {
+                    sd = (int)(key >> 24);
+                    sl = oct[c];
+                }
+                found++;
+            }
+            int nc = -1;
+            if (found == 0) {
+                if (full[k]) s_seq = 1; /* free candidates may exist beyond the prefix */
+            } else if (bd <= SBP_TH_HIGH) {
+                if (found == 2) {
+                    if (!(bl == sl && (float)bd > __fmul_rn(J.nnratio, (float)sd))) nc = best;
+                } else if (!full[k]) {
+                    nc = best; /* bestLevel2 stays -1 */
+                } else {
+                    uint32_t klast = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < SBPM_M; j++)
+                        if (j == M - 1) klast = keys[k][j];
+                    const int dlast = (int)(klast >> 24);
+                    if ((float)bd <= __fmul_rn(J.nnratio, (float)dlast)) nc = best; /* whatever the second is */
+                    else s_seq = 1;
+                }
+            }
+            if (nc != choice[k]) {
+                choice[k] = nc;
+                s_changed = 1;
+            }
+        }
+        __syncthreads();
+        const int ch = s_changed;
+        __syncthreads();
+        if (tid == 0) s_changed = 0;
+        if (!ch) break;
+        if (round == 1023 && tid == 0) s_seq = 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) *J.needSeq = s_seq;
+    if (s_seq) return;
+#pragma unroll
+    for (int k = 0; k < SBP_QPT; k++)
+        if (choice[k] >= 0) {
+            atomicMax(&owner[choice[k]], tid + k * SBP_RT); /* F.mvpMapPoints[bestIdx] = pMP: last writer */
+            atomicAdd(&s_nlog, 1);
+        }
+    __syncthreads();
+    for (int c = tid; c < nCur; c += SBP_RT) J.matchCur[c] = owner[c];
+    if (tid == 0) J.nmatches[0] = s_nlog;
+}
+
+/* sequential cross-check / fallback of the same function: one wave, MapPoints in index order, every window
+ * scanned in full (two smallest free keys by two wave reductions) */
+__global__ void __launch_bounds__(64)
+k_sbpm_replay(SbpJobs JS, int* fallbacks) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    const SbpJobDev& J = JS.job[blockIdx.x];
+    if (*J.needSeq == 0) return;
+    const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
+    const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
+    uint32_t* occupied = (uint32_t*)sbsm;
+    const int lane = threadIdx.x;
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)J.imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)J.imgH);
+    for (int c = lane; c < nCur; c += 64) {
+        occupied[c] = J.occupied0 ? J.occupied0[c] : 0u;
+        J.matchCur[c] = -1;
+    }
+    __syncthreads();
+    int nm = 0, nscan = 0;
+    for (int q = 0; q < nLast; q++) {
+        const SbpProj pr = J.proj[q];
+        if (!pr.valid) continue;
+        nscan++;
+        const SiWindow win = si_window(pr.u, pr.v, pr.radius, invW, invH);
+        if (win.empty) continue;
+        const uint4 da = ((const uint4*)J.mpDesc)[(size_t)q * 2], db = ((const uint4*)J.mpDesc)[(size_t)q * 2 + 1];
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu; /* this lane's two smallest free keys */
+        for (int c = lane; c < nCur; c += 64) {
+            bool ing;
+            const SbpCand cd = sbp_make_cand(J.curKps[c], J.uRight ? J.uRight[c] : -1.f, invW, invH, &ing);
+            if (!ing || occupied[c] || !sbp_candidate_ok(cd, win, pr)) continue;
+            const uint4 ta = ((const uint4*)J.curDesc)[(size_t)c * 2], tb = ((const uint4*)J.curDesc)[(size_t)c * 2 + 1];
+            const uint32_t key = (min(si_hamming(da, db, ta, tb), 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+            if (key < k1) { k2 = k1; k1 = key; }
+            else if (key < k2) k2 = key;
+        }
+        const uint32_t g1 = wave_min_u32(k1);
+        if (g1 == 0xFFFFFFFFu) continue;
+        const uint32_t g2 = wave_min_u32(k1 == g1 ? k2 : k1);
+        const int bd = (int)(g1 >> 24), best = (int)(g1 & 0xFFF);
+        if (bd > SBP_TH_HIGH) continue;
+        const int bl = J.curKps[best].octave;
+        bool accept = true;
+        if (g2 != 0xFFFFFFFFu) {
+            const int sd = (int)(g2 >> 24), sl = J.curKps[g2 & 0xFFF].octave;
+            if (bl == sl && (float)bd > __fmul_rn(J.nnratio, (float)sd)) accept = false;
+        }
+        if (!accept) continue;
+        if (lane == 0) {
+            J.matchCur[best] = q;
+            if (J.flags[q] & 2) occupied[best] = 1u;
+        }
+        nm++;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane == 0) {
+        J.nmatches[0] = nm;
+        if (fallbacks && nscan) atomicAdd(fallbacks, nscan);
+    }
+}
+
+size_t vk_sbpm_resolve_lds(int nCur) { return (size_t)nCur * 9 + 16; }
 
 size_t vk_sbp_resolve_lds(int nCur) { return (size_t)nCur * 8; }
 
@@ -920,6 +1119,11 @@ void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int m
     if (maxLast > 0)
         hipLaunchKernelGGL(k_sbp_rank, dim3((maxLast + SBP_QPB - 1) / SBP_QPB, njobs), dim3(256),
                            vk_sbp_rank_lds(maxCur), st, JS);
+    if (JS.job[0].mode == 1) {
+        hipLaunchKernelGGL(k_sbpm_resolve, dim3(njobs), dim3(SBP_RT), vk_sbpm_resolve_lds(maxCur), st, JS, forceSeq);
+        hipLaunchKernelGGL(k_sbpm_replay, dim3(njobs), dim3(64), (size_t)maxCur * 4, st, JS, fallbacks);
+        return;
+    }
     hipLaunchKernelGGL(k_sbp_resolve, dim3(njobs), dim3(SBP_RT), vk_sbp_resolve_lds(maxCur), st, JS, forceSeq);
     hipLaunchKernelGGL(k_sbp_replay, dim3(njobs), dim3(64), vk_sbp_replay_lds(maxCur, maxLast), st, JS, fallbacks);
 }

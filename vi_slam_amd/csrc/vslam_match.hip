@@ -757,3 +757,106 @@ extern "C" int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float**
     }
     return VSLAM_OK;
 }
+
+/* ------------------------------------------------------------------ SearchByProjection(F, vpMapPoints) */
+extern "C" int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp_track* mps_host,
+                                                    const uint8_t* mp_desc_host, int n_mp, const vslam_kp* dev_cur_kps,
+                                                    const uint8_t* dev_cur_desc, int n_cur,
+                                                    const float* cur_u_right_host, const uint8_t* cur_occupied_host,
+                                                    int img_w, int img_h, float th, float nnratio, int32_t* match_cur,
+                                                    int* nmatches) {
+    static_assert(sizeof(vslam_mp_track) == sizeof(MpTrack), "vslam_mp_track layout");
+    if (!fe || n_mp < 0 || n_cur < 0 || !nmatches || (n_cur && (!dev_cur_kps || !dev_cur_desc || !match_cur)) ||
+        (n_mp && (!mps_host || !mp_desc_host)) || img_w < 1 || img_h < 1) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    *nmatches = 0;
+    if (n_cur == 0 || n_mp == 0) {
+        for (int i = 0; i < n_cur; i++) match_cur[i] = -1;
+        return VSLAM_OK;
+    }
+    if (n_cur > 4096 || n_mp > 4096) {
+        g_err = "SearchByProjection on the device supports at most 4096 keypoints / MapPoints per call";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    if (!(nnratio >= 0.4f)) { /* keys clamp distances to 255; exact for bestDist <= 100 when 0.4 * 255 > 100 */
+        g_err = "SearchByProjection on the device needs nnratio >= 0.4";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    int M;
+    int rc = sbp_prepare(fe, &M);
+    if (rc) return rc;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_mp = 0, o_d = al(o_mp + (size_t)n_mp * sizeof(MpTrack)), o_f = al(o_d + (size_t)n_mp * 32),
+                 o_u = al(o_f + (size_t)n_mp), o_o = al(o_u + (size_t)n_cur * 4), in_bytes = al(o_o + (size_t)n_cur);
+    const size_t o_scr = in_bytes, o_m = al(o_scr + vk_sbp_scratch_bytes(n_mp, M)), o_n = al(o_m + (size_t)n_cur * 4),
+                 total = o_n + 16;
+    rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < total) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
+        fe->h_proj_bytes = total;
+    }
+    uint8_t* h = fe->h_proj;
+    memcpy(h + o_mp, mps_host, (size_t)n_mp * sizeof(MpTrack));
+    memcpy(h + o_d, mp_desc_host, (size_t)n_mp * 32);
+    for (int i = 0; i < n_mp; i++) h[o_f + i] = (uint8_t)(mps_host[i].flags & 3u);
+    if (cur_u_right_host) memcpy(h + o_u, cur_u_right_host, (size_t)n_cur * 4);
+    if (cur_occupied_host) memcpy(h + o_o, cur_occupied_host, (size_t)n_cur);
+    hipStream_t st = fe->stream;
+    uint8_t* d = fe->d_proj;
+    {
+        CopyRanges R;
+        memset(&R, 0, sizeof(R));
+        R.dst[0] = d;
+        R.src[0] = h;
+        R.bytes[0] = in_bytes;
+        R.n = 1;
+        vk_copy_ranges(st, R); /* pinned -> HBM by a kernel (cheaper to enqueue than hipMemcpyAsync) */
+    }
+    SbpJobs JS;
+    memset(&JS, 0, sizeof(JS));
+    for (int l = 0; l < fe->p.nlevels; l++) JS.scale[l] = fe->tab.scale[l];
+    JS.nlevels = fe->p.nlevels;
+    JS.M = M;
+    SbpJobDev& J = JS.job[0];
+    J.mode = 1;
+    J.th = th;
+    J.nnratio = nnratio;
+    J.imgW = img_w;
+    J.imgH = img_h;
+    J.nLast = n_mp;
+    J.nCur = n_cur;
+    J.mps = (const MpTrack*)(d + o_mp);
+    J.mpDesc = d + o_d;
+    J.flags = d + o_f;
+    J.curKps = dev_cur_kps;
+    J.curDesc = dev_cur_desc;
+    J.uRight = cur_u_right_host ? (const float*)(d + o_u) : nullptr;
+    J.occupied0 = cur_occupied_host ? d + o_o : nullptr;
+    J.proj = (SbpProj*)(d + o_scr);
+    J.topm = (uint32_t*)(d + o_scr + vk_sbp_proj_bytes(n_mp));
+    J.matchCur = (int32_t*)(d + o_m);
+    J.nmatches = (int32_t*)(d + o_n);
+    J.needSeq = (int32_t*)(d + o_n) + 1;
+    const char* mode = getenv("VSLAM_SBP_MODE");
+    vk_search_by_projection(st, JS, 1, n_mp, n_cur, fe->d_init_fb, mode && !strcmp(mode, "seq"));
+    HIPCHK(hipGetLastError());
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = h + o_m;
+    R.src[0] = d + o_m;
+    R.bytes[0] = (o_n + 16) - o_m;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
+    *nmatches = *(const int32_t*)(h + o_n);
+    return VSLAM_OK;
+}
