@@ -315,6 +315,13 @@ int vslam_stereo_points_dev_async(vslam_fe* fe, int npairs, const float* Twc, fl
 int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float** dev_x3dw, const uint8_t** dev_flags,
                                 const float** dev_u_right, const float** dev_depth);
 
+/* MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390) for nsets MapPoints in one pass: set s owns the
+ * descriptors desc_host[offsets[s] .. offsets[s+1]) (32 bytes each, its observations in the reference's iteration
+ * order); best[s] = index inside the set of the descriptor with the least median distance to the others
+ * (median = sorted[int(0.5*(N-1))], first wins), -1 for an empty set.  At most 2048 descriptors per set. */
+int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_host, const int32_t* offsets, int nsets,
+                                  int32_t* best);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

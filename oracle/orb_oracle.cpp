@@ -981,6 +981,31 @@ int search_by_projection_mappoints(const std::vector<MapPointTrack>& mps, const 
     return nmatches;
 }
 
+int distinctive_descriptor(const uint8_t* desc, int n) { /* mappoint.cpp:358-385 */
+    if (n <= 0) return -1;
+    const size_t N = (size_t)n;
+    std::vector<float> Distances(N * N);
+    for (size_t i = 0; i < N; i++) {
+        Distances[i * N + i] = 0;
+        for (size_t j = i + 1; j < N; j++) {
+            const int distij = descriptor_distance(desc + 32 * i, desc + 32 * j);
+            Distances[i * N + j] = (float)distij;
+            Distances[j * N + i] = (float)distij;
+        }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (size_t i = 0; i < N; i++) {
+        std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+        std::sort(vDists.begin(), vDists.end());
+        const int median = vDists[(size_t)(0.5 * (N - 1))];
+        if (median < BestMedian) {
+            BestMedian = median;
+            BestIdx = (int)i;
+        }
+    }
+    return BestIdx;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -150,6 +150,10 @@ int search_by_projection_mappoints(const std::vector<MapPointTrack>& mps, const 
                                    const std::vector<float>& scaleFactors, int imgW, int imgH, float th, float nnratio,
                                    std::vector<int>& matchCur);
 
+/* MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390): index of the descriptor with the least median
+ * Hamming distance to the others (median = sorted[int(0.5*(N-1))], first wins); -1 for an empty set. */
+int distinctive_descriptor(const uint8_t* desc, int n);
+
 /* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]);

@@ -207,6 +207,10 @@ int orbo_search_by_projection_mappoints(const MapPointTrack* mps, int n, const u
     return nm;
 }
 
+void orbo_distinctive_descriptors(const uint8_t* desc, const int* offsets, int nsets, int* best) {
+    for (int s = 0; s < nsets; s++) best[s] = distinctive_descriptor(desc + 32 * (size_t)offsets[s], offsets[s + 1] - offsets[s]);
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

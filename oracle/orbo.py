@@ -67,6 +67,8 @@ def lib():
         vp = C.c_void_p
         L.orbo_search_by_projection_mappoints.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                                           C.c_int, C.c_float, C.c_float, vp]
+        L.orbo_distinctive_descriptors.argtypes = [vp, vp, C.c_int, vp]
+        L.orbo_distinctive_descriptors.restype = None
         L.orbo_unproject_stereo.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                             vp, vp]
         L.orbo_unproject_stereo.restype = None
@@ -314,3 +316,13 @@ def search_by_projection_mappoints(mps, mp_desc, cur_kps, cur_desc, mvu_right, s
                                                    _p(cur_desc), _p(mvu), _p(occ) if occ is not None else None, _p(sf),
                                                    len(sf), W, H, th, nnratio, _p(m))
     return nm, m[:len(cur_kps)]
+
+
+def distinctive_descriptors(desc, offsets):
+    """MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390) for many MapPoints: set s owns descriptors
+    desc[offsets[s]:offsets[s+1]] -> index (within the set) of its representative descriptor, -1 if empty."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    off = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(len(off) - 1, np.int32)
+    lib().orbo_distinctive_descriptors(_p(desc), _p(off), len(off) - 1, _p(best))
+    return best

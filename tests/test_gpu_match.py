@@ -347,3 +347,25 @@ def test_odd_feature_count_keeps_buffers_aligned():
         assert out[0][0] == wn and np.array_equal(out[0][1], wm)
     finally:
         f.close()
+
+
+def test_compute_distinctive_descriptors_batched(fe):
+    """MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390): sets of 0..300 observations; real descriptors
+    with a few bits flipped per observation (ties in the medians are common: 'first wins' must hold)."""
+    res = fe.compute_batch([synth.make_frame(1241, 376, step=0)])
+    base = res[0][1]
+    rng = np.random.default_rng(21)
+    sizes = [0, 1, 2, 3, 4, 5, 8, 17, 64, 65, 100, 256, 300] + list(rng.integers(1, 40, 200))
+    descs, off = [], [0]
+    for n in sizes:
+        d = np.repeat(base[rng.integers(0, len(base))][None, :], n, 0).copy()
+        for i in range(n):
+            for f in rng.integers(0, 256, rng.integers(0, 40)):
+                d[i, f // 8] ^= np.uint8(1 << (f % 8))
+        descs.append(d)
+        off.append(off[-1] + n)
+    desc = np.concatenate(descs, 0)
+    got = V.ComputeDistinctiveDescriptors(fe, desc, off)
+    want = orbo.distinctive_descriptors(desc, off)
+    assert np.array_equal(got, want)
+    assert got[0] == -1 and got[1] == 0

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
     "vslam_fe_event_wait", "vslam_projection_direction", "vslam_search_by_projection_frame",
     "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
-    "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints",
+    "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors",
 ]
 
 
@@ -114,6 +114,7 @@ def lib():
         L.vslam_projection_direction.argtypes = [vp, vp, C.c_float, i, i, vp, vp]
         L.vslam_search_by_projection_mappoints.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, C.c_float, C.c_float,
                                                            vp, vp]
+        L.vslam_distinctive_descriptors.argtypes = [vp, vp, vp, i, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
         L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
@@ -616,6 +617,16 @@ class FMatcher:
             vpa(*[a.ctypes.data for a in pm]), vpa(*[a.ctypes.data for a in m]), windowSize, self.mfNNratio,
             int(self.mbCheckOrientation), nm))
         return [(nm[j], m[j][:len(k1[j])], pm[j][:len(k1[j])]) for j in range(npairs)]
+
+
+def ComputeDistinctiveDescriptors(fe, desc, offsets):
+    """MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390) for many MapPoints: set s owns
+    desc[offsets[s]:offsets[s+1]] -> index inside the set of its representative descriptor (-1 if empty)."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(offsets, np.int32)
+    best = np.full(max(len(off) - 1, 1), -1, np.int32)
+    _check(lib().vslam_distinctive_descriptors(fe._h, _p(desc) if len(desc) else None, _p(off), len(off) - 1, _p(best)))
+    return best[:len(off) - 1]
 
 
 def ComputeStereoMatches(feL, slotL, feR, slotR, bf, fx):

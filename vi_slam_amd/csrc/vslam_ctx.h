@@ -180,7 +180,7 @@ struct vslam_fe {
     size_t proj_bytes = 0;
     uint8_t* h_proj = nullptr;  /* pinned mirror (inputs, then results) */
     size_t h_proj_bytes = 0;
-    bool proj_lds_set = false;
+    bool proj_lds_set = false, dist_lds_set = false;
     uint8_t* h_img = nullptr;   /* pinned staging for host images: B x height x level-0 pitch */
     uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */
     size_t sbp_bytes = 0;

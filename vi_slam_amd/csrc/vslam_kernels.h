@@ -81,6 +81,8 @@ size_t vk_sbp_proj_bytes(int nLast);
 int vk_sbp_set_max_lds(size_t bytes);
 void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int maxLast, int maxCur, int* fallbacks,
                              int forceSeq);
+int vk_distinctive_set_max_lds(size_t bytes);
+void vk_distinctive(hipStream_t st, const uint8_t* desc, const int32_t* offsets, int nsets, int maxN, int32_t* best);
 void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */

@@ -860,3 +860,69 @@ extern "C" int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp
     *nmatches = *(const int32_t*)(h + o_n);
     return VSLAM_OK;
 }
+
+/* ------------------------------------------------------------------ MapPoint::ComputeDistinctiveDescriptors */
+extern "C" int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_host, const int32_t* offsets, int nsets,
+                                             int32_t* best) {
+    if (!fe || nsets < 0 || (nsets && (!offsets || !best))) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    if (nsets == 0) return VSLAM_OK;
+    int maxN = 0;
+    for (int s = 0; s < nsets; s++) {
+        const int n = offsets[s + 1] - offsets[s];
+        if (n < 0 || offsets[s] < 0) {
+            g_err = "offsets must be non-negative and ascending";
+            return VSLAM_ERR_INVALID;
+        }
+        maxN = std::max(maxN, n);
+    }
+    if (maxN > 2048) {
+        g_err = "ComputeDistinctiveDescriptors on the device supports at most 2048 observations per MapPoint";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    const int total = offsets[nsets];
+    if (total > 0 && !desc_host) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_d = 0, o_o = al((size_t)total * 32), o_b = al(o_o + (size_t)(nsets + 1) * 4),
+                 bytes = al(o_b + (size_t)nsets * 4);
+    int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, bytes);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < bytes) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, bytes, hipHostMallocDefault));
+        fe->h_proj_bytes = bytes;
+    }
+    uint8_t *h = fe->h_proj, *d = fe->d_proj;
+    if (total) memcpy(h + o_d, desc_host, (size_t)total * 32);
+    memcpy(h + o_o, offsets, (size_t)(nsets + 1) * 4);
+    if (!fe->dist_lds_set && vk_distinctive_set_max_lds(2048 * 32) != 0) {
+        g_err = "hipFuncSetAttribute(k_distinctive) failed";
+        return VSLAM_ERR_HIP;
+    }
+    fe->dist_lds_set = true;
+    hipStream_t st = fe->stream;
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = d;
+    R.src[0] = h;
+    R.bytes[0] = o_b;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    vk_distinctive(st, d + o_d, (const int32_t*)(d + o_o), nsets, maxN, (int32_t*)(d + o_b));
+    R.dst[0] = h + o_b;
+    R.src[0] = d + o_b;
+    R.bytes[0] = (size_t)nsets * 4;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(best, h + o_b, (size_t)nsets * 4);
+    return VSLAM_OK;
+}

@@ -429,3 +429,54 @@ __global__ void k_reset_headers(uint8_t* d_cand, size_t stride, int nimg, int32_
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err) {
     hipLaunchKernelGGL(k_reset_headers, dim3(1), dim3(64), 0, st, d_cand, cand_stride_bytes, nimg, d_err);
 }
+
+/* --------------------------------------------------------------------------------------------------
+ * MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390) for many MapPoints at once: one workgroup per
+ * MapPoint, its N observed descriptors in LDS, one thread per row of the (never materialised) N x N distance
+ * matrix.  The row median sorted[int(0.5*(N-1))] is found by bisection on the value (count of entries <= v),
+ * the winner by an LDS atomicMin on median << 16 | row ("first wins").
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ offsets, int32_t* __restrict__ best) {
+    extern __shared__ __align__(16) uint8_t dsm[];
+    uint4* sd = (uint4*)dsm;
+    __shared__ uint32_t s_best;
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const int o = offsets[set], N = offsets[set + 1] - o;
+    if (N <= 0) {
+        if (tid == 0) best[set] = -1;
+        return;
+    }
+    for (int i = tid; i < 2 * N; i += 256) sd[i] = ((const uint4*)desc)[(size_t)o * 2 + i];
+    if (tid == 0) s_best = 0xFFFFFFFFu;
+    __syncthreads();
+    const int m = (int)(0.5 * (double)(N - 1)); /* vDists[0.5*(N-1)] */
+    for (int i = tid; i < N; i += 256) {
+        const uint4 a = sd[2 * i], b = sd[2 * i + 1];
+        int lo = 0, hi = 256; /* smallest v with #(d <= v) >= m + 1 */
+        while (lo < hi) {
+            const int v = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; j++) {
+                const uint4 c = sd[2 * j], d = sd[2 * j + 1];
+                const int dist = __popc(a.x ^ c.x) + __popc(a.y ^ c.y) + __popc(a.z ^ c.z) + __popc(a.w ^ c.w) +
+                                 __popc(b.x ^ d.x) + __popc(b.y ^ d.y) + __popc(b.z ^ d.z) + __popc(b.w ^ d.w);
+                cnt += dist <= v ? 1 : 0;
+            }
+            if (cnt >= m + 1) hi = v;
+            else lo = v + 1;
+        }
+        atomicMin(&s_best, ((uint32_t)lo << 16) | (uint32_t)i);
+    }
+    __syncthreads();
+    if (tid == 0) best[set] = (int32_t)(s_best & 0xFFFF);
+}
+
+void vk_distinctive(hipStream_t st, const uint8_t* desc, const int32_t* offsets, int nsets, int maxN, int32_t* best) {
+    if (nsets <= 0) return;
+    hipLaunchKernelGGL(k_distinctive, dim3(nsets), dim3(256), (size_t)std::max(maxN, 1) * 32, st, desc, offsets, best);
+}
+
+int vk_distinctive_set_max_lds(size_t bytes) {
+    return (int)hipFuncSetAttribute((const void*)k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
