@@ -8,7 +8,7 @@ A "step" = one pass of the hot path over one batch of synthetic frames per rank:
 through extraction (pyramid, FAST+NMS per cell, quadtree, orientation, blur, rBRIEF) and each frame is
 matched against its predecessor in video order (mono: FMatcher::SearchForInitialization, window 100;
 stereo: Frame::ComputeStereoMatches L<->R).  Frames are dealt round-robin over ranks; the only collective
-is one all-gather of packed result slots per step (mono workload, N>1).  Input frames are resident in
+is one ring shift of packed result slots per step (mono workload, N>1; every predecessor lives on rank-1).  Input frames are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -184,7 +184,7 @@ def main():
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--force-collective", action="store_true",
-                    help="rehearsal: take the N>1 code path (pack + all-gather on the extractor stream) at any world size")
+                    help="rehearsal: take the N>1 code path (pack + ring shift on the extractor stream) at any world size")
     args = ap.parse_args()
 
     import torch
@@ -245,15 +245,18 @@ def main():
     slot_bytes = fe.slot_bytes
     desc_off = 16 + fe.cap * 28
     packed = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if multi else 0)]
-    gathered = [torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda")
-                for _ in range(NCTX if multi else 0)]
+    # packed slots of the LEFT neighbour (every predecessor lives there, vi_slam_amd/dist.py), one buffer per context
+    from_left = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if multi else 0)]
+    ring_in, ring_out = [0] * world, [0] * world
+    ring_in[(rank + 1) % world] = B * slot_bytes
+    ring_out[(rank - 1) % world] = B * slot_bytes
     ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if multi else []
     state = {"matches": 0}
     torch.cuda.synchronize()
 
-    def slot_ptrs_in(buf, r, s):
-        """(kps, desc, count) device addresses of rank r / slot s inside a gathered buffer."""
-        base = buf.data_ptr() + (r * B + s) * slot_bytes
+    def slot_ptrs_in(buf, s):
+        """(kps, desc, count) device addresses of slot s inside a packed buffer."""
+        base = buf.data_ptr() + s * slot_bytes
         return base + 16, base + desc_off, base
 
     job_cache = {}
@@ -262,7 +265,7 @@ def main():
     track_Tcw = np.hstack([np.eye(3), np.array([[3.0 / FX * TRACK_Z], [1.0 / FY * TRACK_Z], [0.0]])]).astype(np.float32)
 
     def enqueue(t):
-        """Enqueue step t completely -- extraction, (N>1) pack + all-gather, matcher -- without waiting for
+        """Enqueue step t completely -- extraction, (N>1) pack + ring shift, matcher -- without waiting for
         anything on the host: every pointer is a fixed device address and the counts stay in HBM."""
         c, k = ctxs[t % NCTX], t % NCTX
         nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
@@ -300,13 +303,16 @@ def main():
         c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
         c.compute_batch_async(ptrs, pitch, lap)
         if multi:
-            c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
             if args.dist_backend == "nccl":
-                with torch.cuda.stream(ext_streams[k]):  # the collective is ordered on c's own stream
-                    dist.all_gather_into_tensor(gathered[k], packed[k])
-            else:
-                vd.exchange_slots(packed[k], gathered[k])  # gloo rehearsal: staged through the host
-        c.event_record(0)  # step t's results (own or gathered) are complete
+                c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
+                with torch.cuda.stream(ext_streams[k]):  # the ring shift is ordered on c's own stream
+                    dist.all_to_all_single(from_left[k], packed[k], output_split_sizes=ring_out,
+                                           input_split_sizes=ring_in)
+            else:  # gloo rehearsal: staged through the host, fully synchronous
+                c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=True)
+                vd.shift_slots(packed[k], from_left[k])
+                torch.cuda.synchronize()
+        c.event_record(0)  # step t's results (own, and the left neighbour's) are complete
         # the device addresses are fixed per context, so the job array is built once (t == 0 has no predecessor
         # for slot 0 and is built separately)
         ck = (k, t == 0)
@@ -318,12 +324,12 @@ def main():
                 if prev_step:
                     if t == 0:
                         continue
-                    p = slot_ptrs_in(gathered[(t - 1) % NCTX], world - 1, B - 1) if multi else prv.slot_dev_ptrs(B - 1)
+                    p = slot_ptrs_in(from_left[(t - 1) % NCTX], B - 1) if multi else prv.slot_dev_ptrs(B - 1)
                     uses_prev_step = True
                 elif not multi:
                     p = c.slot_dev_ptrs(ps)
                 else:
-                    p = slot_ptrs_in(gathered[k], pr, ps)
+                    p = slot_ptrs_in(from_left[k], ps)  # pr == (rank - 1) % world always
                 q = c.slot_dev_ptrs(s)
                 jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
             job_cache[ck] = (V.FMatcher.make_init_jobs(jobs) if jobs else None, len(jobs), uses_prev_step)
@@ -427,7 +433,7 @@ def main():
                        "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
                        "match": ("ComputeStereoMatches L<->R + UnprojectStereo + SearchByProjection(frame, previous frame), th 15, on device"
                                  if track else "ComputeStereoMatches L<->R") if stereo else "SearchForInitialization(prev frame), window 100, on device",
-                       "sharding": "frames round-robin over ranks; one all-gather of result slots per step (on the extractor stream)"
+                       "sharding": "frames round-robin over ranks; one ring shift of result slots per step (all_to_all_single, on the extractor stream)"
                        if not stereo else ("one independent stereo sequence per rank, no collective" if track else
                                            "stereo frames independent per rank, no collective"),
                        "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],

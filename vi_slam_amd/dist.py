@@ -1,10 +1,13 @@
-"""Frame sharding across GPUs and the one collective of the path.
+"""Frame sharding across GPUs and the one exchange step of the path.
 
 Extraction and stereo matching are independent per frame, so frames are dealt round-robin: global frame
 g of a step lives on rank g % world, slot g // world.  Cross-frame matching (mono initialisation,
-frame.cpp:289 + fmatcher.cpp:983) needs the predecessor frame's keypoints and descriptors, which sit on
-the neighbouring rank: ONE all-gather of fixed-size packed result slots per step (RCCL over xGMI when the
-tensors are on GPUs; gloo in the CPU tests).  No other collective exists on this path.
+frame.cpp:289 + fmatcher.cpp:983) needs the predecessor frame's keypoints and descriptors.  With this dealing
+every predecessor lives on the LEFT neighbour (rank - 1 mod world: same slot, or for rank 0 the slot before),
+so the exchange is a ring shift of the fixed-size packed result slots: every rank sends its slots to
+rank + 1 and receives rank - 1's -- ONE torch.distributed.all_to_all_single per step whose split lists
+have a single non-empty entry (RCCL over xGMI executes it as one send/recv pair; gloo in the CPU tests).  An
+all-gather would move world times as much for nothing.  No other collective exists on this path.
 """
 import torch
 import torch.distributed as dist
@@ -24,22 +27,27 @@ def predecessor(rank, slot, world, batch):
     return g % world, g // world, False
 
 
-def exchange_slots(local_packed, gathered, group=None):
-    """All-gather every rank's packed slots.  local_packed: uint8 [batch*slot_bytes]; gathered: uint8
-    [world*batch*slot_bytes] (rank-major).  World 1: a plain copy, no collective."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        gathered.copy_(local_packed)
-        return gathered
+def shift_slots(local_packed, from_left, group=None):
+    """Ring shift: send this rank's packed slots to rank+1, receive rank-1's into from_left (both uint8
+    [batch*slot_bytes]).  World 1 without a process group: a plain copy (the only frame's predecessor is local)."""
+    if not dist.is_initialized():
+        from_left.copy_(local_packed)
+        return from_left
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = local_packed.numel()
+    ins, outs = [0] * world, [0] * world
+    ins[(rank + 1) % world] = n   # everything goes to the right neighbour
+    outs[(rank - 1) % world] = n  # everything comes from the left neighbour
     if dist.get_backend(group) == "gloo" and local_packed.is_cuda:
         # rehearsal path (tests / one-GPU dry runs): gloo moves host memory only
-        host = torch.empty(gathered.shape, dtype=gathered.dtype)
-        dist.all_gather_into_tensor(host, local_packed.cpu(), group=group)
-        gathered.copy_(host)
-        return gathered
-    dist.all_gather_into_tensor(gathered, local_packed, group=group)
-    return gathered
+        host = torch.empty(n, dtype=from_left.dtype)
+        dist.all_to_all_single(host, local_packed.cpu(), output_split_sizes=outs, input_split_sizes=ins, group=group)
+        from_left.copy_(host)
+        return from_left
+    dist.all_to_all_single(from_left, local_packed, output_split_sizes=outs, input_split_sizes=ins, group=group)
+    return from_left
 
 
-def slot_view(gathered, rank, slot, batch, slot_bytes):
-    off = (rank * batch + slot) * slot_bytes
-    return gathered[off:off + slot_bytes]
+def slot_view(buf, slot, slot_bytes):
+    """Slot `slot` of a packed buffer (own slots or the left neighbour's)."""
+    return buf[slot * slot_bytes:(slot + 1) * slot_bytes]
