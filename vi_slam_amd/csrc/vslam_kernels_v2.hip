@@ -521,14 +521,14 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int iw = ww - 6, ih = wh - 6;
     const int nwords = ih * 2;
 
-    /* stage columns x0-1 .. x1+2 (x0 >= 16; windows end >= 13 px before the row end) as dwords */
+    /* stage columns x0-1 .. (x0 >= 16; windows end >= 13 px before the row end): 9 lanes x 8 bytes per row
+     * (= the LDS pitch), 28 rows per sweep */
     {
         const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
-        const int srow = tid >> 4, scol = (tid & 15) * 4;
-        for (int y = srow; y < wh; y += 16) {
-            if (scol < ww + 1) *(uint32_t*)(win + y * FP + scol) = *(const uint32_t*)(gsrc + (size_t)y * pitch + scol);
-            if (scol == 0 && ww + 1 > 64) *(uint32_t*)(win + y * FP + 64) = *(const uint32_t*)(gsrc + (size_t)y * pitch + 64);
-        }
+        const int srow = tid / 9, scol = (tid - srow * 9) * 8;
+        if (tid < 252 && scol < ww + 1)
+            for (int y = srow; y < wh; y += 28)
+                *(uint2*)(win + y * FP + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
     }
     for (int i = tid; i < (ih + 2) * (FP / 4); i += 256) ((uint32_t*)sc)[i] = 0;
     if (tid < nwords) keep[tid] = 0;
@@ -617,20 +617,26 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         const unsigned long long tot = s_cnt;
         const int nD = (int)(tot & 0x1FFFFFu), nB = (int)((tot >> 21) & 0x1FFFFFu), nX = (int)(tot >> 42);
         const int ntot = nD + nB + nX;
-        /* one pass of the networks over three disjoint lists: no two threads touch the same score byte */
-        for (int i = tid; i < ntot; i += 256) {
-            int code, a;
-            if (i < nD) {
-                code = listD[i];
-                a = fast_half_score<1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
-            } else if (i < nD + nB) {
-                code = listB[i - nD];
-                a = fast_half_score<-1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
-            } else {
-                code = listD[lcap - 1 - (i - nD - nB)];
-                const uint8_t* c = win + ((code >> 6) + 3) * FP + (code & 63) + 4;
-                a = max(fast_half_score<1>(c), fast_half_score<-1>(c));
+        /* one pass of the networks over three disjoint lists (no two threads touch the same score byte).  Dark
+         * entries are handed out from thread 0 upwards, bright ones from thread 255 downwards, so with the usual
+         * ~110 + ~110 entries no wave has to run both networks */
+        for (int base = 0; base < max(nD, nB); base += 256) {
+            const int iD = base + tid, iB = base + 255 - tid;
+            if (iD < nD) {
+                const int code = listD[iD];
+                const int a = fast_half_score<1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
+                sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
+            if (iB < nB) {
+                const int code = listB[iB];
+                const int a = fast_half_score<-1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
+                sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+            }
+        }
+        for (int i = tid; i < nX; i += 256) { /* rare: both polarities possible */
+            const int code = listD[lcap - 1 - i];
+            const uint8_t* c = win + ((code >> 6) + 3) * FP + (code & 63) + 4;
+            const int a = max(fast_half_score<1>(c), fast_half_score<-1>(c));
             sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
         }
         __syncthreads();
