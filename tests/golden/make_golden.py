@@ -55,6 +55,38 @@ def main():
     eM = orbo.Extractor(500)
     kM, dM, mM = eM.compute(L, lap=(0, 1000))
     nm, m12, pm = orbo.search_for_initialization(kL, dL, kR, dR, 320, 240, window=100)
+    # ---- tracking matchers on the same real-image pair (frame 1 = left image, frame 2 = the third image of the
+    # hut_stereo set cropped the same way): stereo points of frame 1 as MapPoints, a small sideways motion
+    hut3 = gray(os.path.join(IMG, "scenery/hut_stereo/03.png"))
+    C = hut3[100:340, 160:480].copy()
+    eC = orbo.Extractor(500)
+    kC, dC, _ = eC.compute(C)
+    T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    cam = (400.0, 400.0, 160.0, 120.0, 40.0, 0.1)
+    z = np.where(dep > 0, dep, 5.0).astype(np.float32)
+    x3, has = orbo.unproject_stereo(kL, z, T0, cam[2], cam[3], 1.0 / cam[0], 1.0 / cam[1])
+    Tcw = np.hstack([np.eye(3), np.array([[0.02], [0.0], [0.0]])]).astype(np.float32)
+    flags = (has * 3).astype(np.uint8)
+    flags[::7] = 1  # some temporal points without observations
+    sbp_n, sbp_m, sbp_dir = orbo.search_by_projection_frame(Tcw, T0, cam, 15, kL, flags, x3, dL, kC, dC,
+                                                            np.full(len(kC), -1, np.float32), eL.tables()["scale"],
+                                                            320, 240)
+    mps = np.zeros(len(kL), orbo.MP_TRACK_DTYPE)
+    mps["proj_x"], mps["proj_y"] = kL["x"] + 2.0, kL["y"] + 0.5
+    mps["proj_xr"] = mps["proj_x"] - 40.0 / z
+    mps["view_cos"] = np.where(np.arange(len(kL)) % 3 == 0, 0.9, 0.999).astype(np.float32)
+    mps["level"] = kL["octave"]
+    mps["flags"] = 3
+    occ = (sbp_m >= 0).astype(np.uint8)
+    mp_n, mp_m = orbo.search_by_projection_mappoints(mps, dL, kC, dC, np.full(len(kC), -1, np.float32),
+                                                     eL.tables()["scale"], 320, 240, 3.0, 0.8, occ)
+    sizes = [1, 2, 3, 5, 9, 20]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dd = dL[:off[-1]]
+    np.savez_compressed(os.path.join(OUT, "tracking_hut_320x240.npz"), C=C, kC=kC, dC=dC, x3=x3, flags=flags, Tcw=Tcw,
+                        cam=np.asarray(cam, np.float32), sbp_nmatches=np.int32(sbp_n), sbp_match=sbp_m, mps=mps, occ=occ,
+                        mp_nmatches=np.int32(mp_n), mp_match=mp_m, dist_off=off, dist_desc=dd,
+                        dist_best=orbo.distinctive_descriptors(dd, off))
     np.savez_compressed(os.path.join(OUT, "pipeline_hut_320x240.npz"), L=L, R=R, kL=kL, dL=dL, kR=kR, dR=dR,
                         uRight=u, depth=dep, kM=kM, dM=dM, monoIndex=np.int32(mM), init_matches=m12,
                         init_nmatches=np.int32(nm), lvl3=eL.level(3), lvl3_blur=eL.level(3, blurred=True))

@@ -260,3 +260,25 @@ def test_local_map_matcher_rejects_small_ratio(scene):
     with pytest.raises(V.VslamError):
         m.SearchByProjectionMapPoints(_local_map(scene, 1), scene["de0"], scene["cur"][0], scene["cur"][1],
                                       len(scene["k1"]), None, 1.0, None, (W, H))
+
+
+def test_tracking_matchers_against_golden_fixture(golden_dir):
+    """Device results vs the committed real-image fixture (tests/golden/tracking_hut_320x240.npz), no oracle call."""
+    import os
+    p = np.load(os.path.join(golden_dir, "pipeline_hut_320x240.npz"))
+    g = np.load(os.path.join(golden_dir, "tracking_hut_320x240.npz"))
+    fe = V.FExtractor(500, 1.2, 8, 20, 7, 320, 240, max_batch=1)
+    try:
+        kC, dC, _ = fe.compute(g["C"])
+        assert all(np.array_equal(kC[f], g["kC"][f]) for f in kC.dtype.names) and np.array_equal(dC, g["dC"])
+        ck, cd, _ = fe.slot_dev_ptrs(0)
+        m = V.FMatcher(fe, 0.8, True)
+        T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+        n, mc, _ = m.SearchByProjection(g["Tcw"], T0, tuple(float(v) for v in g["cam"]), 15, p["kL"], g["flags"], g["x3"],
+                                        p["dL"], ck, cd, len(kC), None, False, (320, 240))
+        assert n == int(g["sbp_nmatches"]) and np.array_equal(mc, g["sbp_match"])
+        n, mc = m.SearchByProjectionMapPoints(g["mps"], p["dL"], ck, cd, len(kC), None, 3.0, g["occ"], (320, 240))
+        assert n == int(g["mp_nmatches"]) and np.array_equal(mc, g["mp_match"])
+        assert np.array_equal(V.ComputeDistinctiveDescriptors(fe, g["dist_desc"], g["dist_off"]), g["dist_best"])
+    finally:
+        fe.close()

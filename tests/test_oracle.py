@@ -257,3 +257,22 @@ def test_search_by_projection_oracle_identity_pose():
     # identical keypoints may exist at several octaves with equal descriptors only by accident: allow a handful
     assert nm >= len(sel) - 5 and (m[sel] == sel).sum() >= len(sel) - 5
     assert np.all(m[flags == 0][m[flags == 0] >= 0] != np.nonzero(flags == 0)[0][m[flags == 0] >= 0])
+
+
+def test_tracking_golden(golden_dir):
+    """The tracking matchers' restatements against the committed fixture (real-image pair from the reference's
+    test set): pins the oracle against regressions."""
+    p = np.load(os.path.join(golden_dir, "pipeline_hut_320x240.npz"))
+    g = np.load(os.path.join(golden_dir, "tracking_hut_320x240.npz"))
+    e = orbo.Extractor(500)
+    kC, dC, _ = e.compute(g["C"])
+    assert kp_equal(kC, g["kC"]) and np.array_equal(dC, g["dC"])
+    T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    sf = e.tables()["scale"]
+    none = np.full(len(kC), -1, np.float32)
+    n, m, _ = orbo.search_by_projection_frame(g["Tcw"], T0, g["cam"], 15, p["kL"], g["flags"], g["x3"], p["dL"], kC, dC,
+                                              none, sf, 320, 240)
+    assert n == int(g["sbp_nmatches"]) and np.array_equal(m, g["sbp_match"])
+    n, m = orbo.search_by_projection_mappoints(g["mps"], p["dL"], kC, dC, none, sf, 320, 240, 3.0, 0.8, g["occ"])
+    assert n == int(g["mp_nmatches"]) and np.array_equal(m, g["mp_match"])
+    assert np.array_equal(orbo.distinctive_descriptors(g["dist_desc"], g["dist_off"]), g["dist_best"])
