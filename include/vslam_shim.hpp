@@ -2,7 +2,8 @@
  *
  * What a maintainer of KMS-TEAM/vi_slam includes instead of (the bodies of)
  *   include/vi_slam/geometry/fextractor.h:26-91   -> FExtractor
- *   include/vi_slam/geometry/fmatcher.h:70-147    -> FMatcher (hot-path subset)
+ *   include/vi_slam/geometry/fmatcher.h:70-147    -> FMatcher (hot-path subset + the two pinhole SearchByProjection
+ *                                                     overloads used by tracking)
  *   src/datastructures/frame.cpp:823-997          -> ComputeStereoMatches
  * Everything forwards to the C ABI in vslam_fe.h; nothing is computed here.
  *
@@ -258,6 +259,68 @@ public:
                                               F2.mnMaxY, reinterpret_cast<float*>(vbPrevMatched.data()),
                                               vnMatches12.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
                                               &nm));
+        return nm;
+    }
+
+    /* fmatcher.cpp:2471-2687 (pinhole frames).  What the function reads of the two Frames:
+     *   cur : pose rows [Rcw | tcw] (T_w_c_ as the reference uses it), intrinsics, mbf, mb, mvuRight, grid bounds,
+     *         and the extractor slot that still holds its keypoints/descriptors in HBM
+     *   last: ukeypoints_ (octave, angle), pose, and per keypoint its MapPoint (flags bit0 = present and not an
+     *         outlier, bit1 = Observations() > 0, world position, descriptor)
+     * mvpMapPointIndex[i2] = index into the last frame whose MapPoint ends up in CurrentFrame.mvpMapPoints[i2]. */
+    struct CurrentFrameView {
+        FrameView frame;
+        float Tcw[12];
+        float fx, fy, cx, cy, mbf, mb;
+        const std::vector<float>* mvuRight = nullptr; /* NULL: monocular */
+    };
+    struct LastFrameView {
+        const std::vector<KeyPoint>* ukeypoints = nullptr;
+        float Tlw[12];
+        const std::vector<uint8_t>* mapPointFlags = nullptr;
+        const std::vector<float>* mapPointWorldPos = nullptr;    /* 3 per keypoint */
+        const std::vector<uint8_t>* mapPointDescriptors = nullptr; /* 32 per keypoint */
+    };
+    int SearchByProjection(const CurrentFrameView& cur, const LastFrameView& last, const float th, const bool bMono,
+                           std::vector<int>& mvpMapPointIndex) {
+        vslam_proj_params p;
+        std::memset(&p, 0, sizeof(p));
+        std::memcpy(p.Tcw, cur.Tcw, sizeof(p.Tcw));
+        p.fx = cur.fx; p.fy = cur.fy; p.cx = cur.cx; p.cy = cur.cy; p.mbf = cur.mbf; p.th = th;
+        p.check_orientation = mbCheckOrientation ? 1 : 0;
+        p.img_w = cur.frame.mnMaxX;
+        p.img_h = cur.frame.mnMaxY;
+        check(vslam_projection_direction(cur.Tcw, last.Tlw, cur.mb, bMono ? 1 : 0, 0, &p.forward, &p.backward));
+        const vslam_kp* dk = nullptr;
+        const uint8_t* dd = nullptr;
+        int n2 = 0, nm = 0;
+        check(vslam_fe_slot_buffers(cur.frame.extractor->context(), 0, &dk, &dd, &n2));
+        mvpMapPointIndex.assign(n2, -1);
+        const int n = (int)last.ukeypoints->size();
+        check(vslam_search_by_projection_frame(cur.frame.extractor->context(), &p,
+                                               reinterpret_cast<const vslam_kp*>(last.ukeypoints->data()), n,
+                                               last.mapPointFlags->data(), last.mapPointWorldPos->data(),
+                                               last.mapPointDescriptors->data(), dk, dd, n2,
+                                               cur.mvuRight ? cur.mvuRight->data() : nullptr, nullptr,
+                                               mvpMapPointIndex.data(), &nm));
+        return nm;
+    }
+
+    /* fmatcher.cpp:321-411 (pinhole frames): vpMapPoints as vslam_mp_track records + descriptors; occupied marks
+     * keypoints of F whose mvpMapPoints entry already holds a MapPoint with observations */
+    int SearchByProjection(const FrameView& F, const std::vector<float>* mvuRight, const std::vector<vslam_mp_track>& vpMapPoints,
+                           const std::vector<uint8_t>& mapPointDescriptors, const std::vector<uint8_t>* occupied,
+                           const float th, std::vector<int>& mvpMapPointIndex) {
+        const vslam_kp* dk = nullptr;
+        const uint8_t* dd = nullptr;
+        int n2 = 0, nm = 0;
+        check(vslam_fe_slot_buffers(F.extractor->context(), 0, &dk, &dd, &n2));
+        mvpMapPointIndex.assign(n2, -1);
+        check(vslam_search_by_projection_mappoints(F.extractor->context(), vpMapPoints.data(), mapPointDescriptors.data(),
+                                                   (int)vpMapPoints.size(), dk, dd, n2,
+                                                   mvuRight ? mvuRight->data() : nullptr,
+                                                   occupied ? occupied->data() : nullptr, F.mnMaxX, F.mnMaxY, th,
+                                                   mfNNratio, mvpMapPointIndex.data(), &nm));
         return nm;
     }
 

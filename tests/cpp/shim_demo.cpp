@@ -69,19 +69,42 @@ int main(int argc, char** argv) {
         ComputeStereoMatches(left, right, 386.1448f, 718.856f, (int)kL.size(), uR, depth);
         int nst = 0;
         for (float u : uR) nst += u >= 0.f;
+        /* ---- tracking: SearchByProjection(right-now = frame b, last = frame a with fake stereo points) */
+        std::vector<uint8_t> fl(k1.size(), 3), mpd((size_t)k1.size() * 32);
+        std::vector<float> xw((size_t)k1.size() * 3);
+        for (size_t i = 0; i < k1.size(); i++) {
+            const float z = 8.0f;
+            xw[3 * i] = (k1[i].pt.x - w / 2.0f) * z * (1.0f / 500.0f);
+            xw[3 * i + 1] = (k1[i].pt.y - h / 2.0f) * z * (1.0f / 500.0f);
+            xw[3 * i + 2] = z;
+            std::memcpy(&mpd[32 * i], d1.ptr((int)i), 32);
+        }
+        FMatcher::CurrentFrameView cv;
+        cv.frame = F2;
+        const float Tc[12] = {1, 0, 0, 3.0f / 500.0f * 8.0f, 0, 1, 0, 1.0f / 500.0f * 8.0f, 0, 0, 1, 0};
+        std::memcpy(cv.Tcw, Tc, sizeof(Tc));
+        cv.fx = 500.f; cv.fy = 500.f; cv.cx = w / 2.0f; cv.cy = h / 2.0f; cv.mbf = 40.f; cv.mb = 0.08f;
+        FMatcher::LastFrameView lv;
+        lv.ukeypoints = &k1;
+        const float Tl[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        std::memcpy(lv.Tlw, Tl, sizeof(Tl));
+        lv.mapPointFlags = &fl; lv.mapPointWorldPos = &xw; lv.mapPointDescriptors = &mpd;
+        std::vector<int> mpi;
+        const int nsbp = matcher.SearchByProjection(cv, lv, 15.f, true, mpi);
+
         int lw = 0, lh = 0;
         std::vector<uint8_t> lvl3 = left.ImagePyramidLevel(3, &lw, &lh);
 
         std::printf("{\"n1\": %zu, \"n2\": %zu, \"mono1\": %d, \"mono2\": %d, \"rc_empty\": %d, \"nmatches\": %d, "
                     "\"dd01\": %d, \"kp1\": %llu, \"desc1\": %llu, \"kp2\": %llu, \"desc2\": %llu, \"m12\": %llu, "
                     "\"prev\": %llu, \"nL\": %zu, \"nR\": %zu, \"nstereo\": %d, \"uR\": %llu, \"depth\": %llu, "
-                    "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g}\n",
+                    "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g, \"nsbp\": %d, \"sbp\": %llu}\n",
                     k1.size(), k2.size(), mono1, mono2, rc_empty, nm, dd, fnv(k1.data(), k1.size() * sizeof(KeyPoint)),
                     fnv(d1.data, (size_t)d1.rows * 32), fnv(k2.data(), k2.size() * sizeof(KeyPoint)),
                     fnv(d2.data, (size_t)d2.rows * 32), fnv(m12.data(), m12.size() * 4),
                     fnv(prev.data(), prev.size() * 8), kL.size(), kR.size(), nst, fnv(uR.data(), uR.size() * 4),
                     fnv(depth.data(), depth.size() * 4), lw, lh, fnv(lvl3.data(), lvl3.size()), left.GetLevels(),
-                    (double)left.GetScaleFactors()[7]);
+                    (double)left.GetScaleFactors()[7], nsbp, fnv(mpi.data(), mpi.size() * 4));
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -62,6 +62,17 @@ def test_shim_program_equals_ctypes_path(tmp_path):
         _, pd2, _ = f2.slot_buffers(0)
         nm, m12, pm = V.FMatcher(f2, 0.9, True).SearchForInitialization(k1, pd1, k2, pd2,
                                                                        np.stack([k1["x"], k1["y"]], 1), 100)
+        z = np.float32(8.0)
+        xw = np.stack([(k1["x"] - np.float32(W / 2)) * z * (np.float32(1) / np.float32(500)),
+                       (k1["y"] - np.float32(H / 2)) * z * (np.float32(1) / np.float32(500)),
+                       np.full(len(k1), z, np.float32)], 1).astype(np.float32)
+        Tcw = np.array([[1, 0, 0, np.float32(3.0) / np.float32(500.0) * np.float32(8.0)],
+                        [0, 1, 0, np.float32(1.0) / np.float32(500.0) * np.float32(8.0)], [0, 0, 1, 0]], np.float32)
+        T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+        ck, cd, _ = f2.slot_dev_ptrs(0)
+        nsbp, msbp, _ = V.FMatcher(f2, 0.9, True).SearchByProjection(
+            Tcw, T0, (500.0, 500.0, W / 2, H / 2, 40.0, 0.08), 15, k1, np.full(len(k1), 3, np.uint8), xw, d1, ck, cd,
+            len(k2), None, True, (W, H))
         kL, dL, _ = f1.compute(L)
         kR, dR, _ = f2.compute(R)
         u, dep = V.ComputeStereoMatches(f1, 0, f2, 0, 386.1448, 718.856)
@@ -78,4 +89,5 @@ def test_shim_program_equals_ctypes_path(tmp_path):
     assert got["nstereo"] == int((u >= 0).sum()) and got["nstereo"] > 100
     assert got["uR"] == _fnv(u) and got["depth"] == _fnv(dep)
     assert got["lvl3"] == [lvl3.shape[1], lvl3.shape[0], _fnv(lvl3)]
+    assert got["nsbp"] == nsbp and nsbp > 50 and got["sbp"] == _fnv(msbp)
     assert got["levels"] == 8 and abs(got["sf7"] - 3.5831816196) < 1e-6  # mvScaleFactor[7], SURVEY.md 8
