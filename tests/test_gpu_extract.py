@@ -243,3 +243,33 @@ def test_large_feature_count_uses_a_big_node_list():
         _assert_same(fe.compute(img, (0, 1000)), orbo.Extractor(10000).compute(img, lap=(0, 1000)), "n10000")
     finally:
         fe.close()
+
+
+def test_two_host_threads_two_contexts_like_frame_ctor():
+    """Frame::Frame(stereo) runs the left and right extractor on two std::threads (frame.cpp:107-111): two
+    contexts driven concurrently from two host threads must not disturb each other."""
+    import threading
+    L, R = synth.make_stereo_pair(752, 480, seed=5)
+    fl = V.FExtractor(800, 1.2, 8, 20, 7, 752, 480)
+    fr = V.FExtractor(800, 1.2, 8, 20, 7, 752, 480)
+    try:
+        wl, wr = orbo.Extractor(800).compute(L), orbo.Extractor(800).compute(R)
+        out = {}
+
+        def run(name, fe, img, n):
+            res = []
+            for _ in range(n):
+                k, d, m = fe.compute(img)
+                res.append((k.copy(), d.copy(), m))
+            out[name] = res
+
+        ta = threading.Thread(target=run, args=("l", fl, L, 25))
+        tb = threading.Thread(target=run, args=("r", fr, R, 25))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        for r in out["l"]:
+            _assert_same(r, wl, "left thread")
+        for r in out["r"]:
+            _assert_same(r, wr, "right thread")
+    finally:
+        fl.close()
+        fr.close()
