@@ -176,11 +176,9 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
 
     /* FAST cells */
-    size_t total_px = 0;
     for (int l = 0; l < p.nlevels; l++) {
         fe->level_cell_first[l] = (int)fe->cells.size();
         vslam::build_cells(l, fe->geom.lv[l].w, fe->geom.lv[l].h, fe->cells);
-        total_px += (size_t)fe->geom.lv[l].w * fe->geom.lv[l].h;
     }
     fe->level_cell_first[p.nlevels] = (int)fe->cells.size();
     int maxw = 8, maxh = 8;

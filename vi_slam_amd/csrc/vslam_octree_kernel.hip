@@ -475,13 +475,12 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     const int MAXN = P.maxNodes;
     ONode* cur = (ONode*)osm;
     ONode* nxt = cur + MAXN;
-    u64* Sbeg = (u64*)(nxt + MAXN);
-    u64* Cnt = Sbeg + MAXN;               /* Send during a pass, then quadrant counts */
+    u64* Sbeg = (u64*)(nxt + MAXN);       /* v2: only used as the arg-max array of the final selection */
+    u64* Cnt = Sbeg + MAXN;               /* packed per-quadrant key counts of a node (histogram) */
     uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
     uint16_t* newIdx = cb + MAXN;             /* list index of a survivor after the pass */
     uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
     uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
-    __shared__ u64 s_w64[OT / 64];
     __shared__ uint32_t s_w32[OT / 64];
     __shared__ int s_size, s_M, s_nexp, s_cut;
 
