@@ -322,6 +322,33 @@ int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float** dev_x3dw, 
 int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_host, const int32_t* offsets, int nsets,
                                   int32_t* best);
 
+/* Frame::ComputeBoW (frame.cpp:455-461) = DBoW3::Vocabulary::transform(features, BowVector&, FeatureVector&,
+ * levelsup) (thirdparty/DBoW3/DBoW3/src/Vocabulary.cpp:754-878).
+ * vslam_voc_create uploads a flat copy of DBoW3's m_nodes: node i has the children child_ids[child_start[i] ..
+ * + child_count[i]) in their stored order (it decides ties), a 32-byte descriptor, and for leaves a word id and a
+ * weight; depth_levels = m_L; weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; norm (the scoring object's
+ * mustNormalize): 0 none, 1 L1, 2 L2.  Node ids must be larger than their parent's (DBoW3's creation order).
+ * vslam_bow_transform walks the tree for n device-resident descriptors and returns per feature the word id, the
+ * word weight and the node id at level depth_levels - levelsup; the _slots forms do the same for image slots of the
+ * context (counts stay in HBM) in one launch.  vslam_bow_assemble (pure host) turns those into the BowVector
+ * (ascending word ids / values) and the FeatureVector (ascending node ids, fv_off[n_fv+1] offsets into fv_feat)
+ * exactly as DBoW3 does (std::map accumulation in feature order, double arithmetic); arrays hold n entries
+ * (fv_off: n + 1). */
+typedef struct vslam_voc vslam_voc;
+int vslam_voc_create(int device, int depth_levels, int weighting, int norm, int n_nodes, const int32_t* child_start,
+                     const int32_t* child_count, const int32_t* child_ids, int n_child_ids, const uint8_t* node_desc,
+                     const double* node_weight, const int32_t* node_word_id, vslam_voc** out);
+void vslam_voc_destroy(vslam_voc* voc);
+int vslam_voc_info(const vslam_voc* voc, int* depth_levels, int* weighting, int* norm, int* n_nodes);
+int vslam_bow_transform(vslam_fe* fe, const vslam_voc* voc, const uint8_t* dev_desc, int n, int levelsup,
+                        int32_t* word_id, double* weight, int32_t* node_id);
+int vslam_bow_transform_slots_async(vslam_fe* fe, const vslam_voc* voc, int first_slot, int nslots, int levelsup);
+int vslam_bow_transform_slots_wait(vslam_fe* fe, const int* n, int32_t* const* word_id, double* const* weight,
+                                   int32_t* const* node_id);
+int vslam_bow_assemble(int weighting, int norm, const int32_t* word_id, const double* weight, const int32_t* node_id,
+                       int n, int32_t* bow_ids, double* bow_vals, int* n_bow, int32_t* fv_nodes, int32_t* fv_off,
+                       int32_t* fv_feat, int* n_fv);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

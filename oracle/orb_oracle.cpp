@@ -9,6 +9,8 @@
  * builds, CMakeLists.txt:14-15 has no -march, so no FMA contraction in fextractor.cpp arithmetic).
  */
 #include "orb_oracle.h"
+#include <limits>
+#include <map>
 
 #include <algorithm>
 #include <climits>
@@ -1004,6 +1006,64 @@ int distinctive_descriptor(const uint8_t* desc, int n) { /* mappoint.cpp:358-385
         }
     }
     return BestIdx;
+}
+
+void bow_transform_feature(const Vocabulary& v, const uint8_t* feature, int levelsup, int& word, double& weight,
+                           int& nid) { /* Vocabulary.cpp:838-878 */
+    const int nid_level = v.L - levelsup;
+    nid = 0;                 /* if (nid_level <= 0) *nid = 0 (root); otherwise set on the way down */
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        double best_d = std::numeric_limits<double>::max();
+        const int c0 = v.childStart[final_id], cn = v.childCount[final_id];
+        int next = final_id;
+        for (int j = 0; j < cn; j++) {
+            const int id = v.childIds[c0 + j];
+            const double d = (double)descriptor_distance(feature, &v.desc[32 * (size_t)id]); /* DescManip::distance */
+            if (d < best_d) {
+                best_d = d;
+                next = id;
+            }
+        }
+        final_id = next;
+        if (current_level == nid_level) nid = final_id;
+    } while (v.childCount[final_id] != 0);
+    word = v.wordId[final_id];
+    weight = v.weight[final_id];
+}
+
+void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup, BowResult& out) {
+    /* Vocabulary.cpp:754-826 with BowVector (std::map<WordId, WordValue>) and FeatureVector semantics */
+    std::map<int, double> bow;
+    std::map<int, std::vector<unsigned>> fv;
+    const bool tf = v.weighting == 0 || v.weighting == 1;
+    for (int i = 0; i < n; i++) {
+        int id, nid;
+        double w;
+        bow_transform_feature(v, desc + 32 * (size_t)i, levelsup, id, w, nid);
+        if (w > 0) { /* not stopped */
+            if (tf) bow[id] += w;                     /* addWeight */
+            else if (!bow.count(id)) bow[id] = w;     /* addIfNotExist */
+            fv[nid].push_back((unsigned)i);
+        }
+    }
+    if (tf && !bow.empty() && v.norm == 0) {
+        const double nd = (double)bow.size();
+        for (auto& kv : bow) kv.second /= nd;
+    }
+    if (v.norm) { /* BowVector::normalize */
+        double norm = 0.0;
+        if (v.norm == 1) for (auto& kv : bow) norm += std::fabs(kv.second);
+        else {
+            for (auto& kv : bow) norm += kv.second * kv.second;
+            norm = std::sqrt(norm);
+        }
+        if (norm > 0.0) for (auto& kv : bow) kv.second /= norm;
+    }
+    out.words.clear(); out.values.clear(); out.nodes.clear(); out.features.clear();
+    for (auto& kv : bow) { out.words.push_back(kv.first); out.values.push_back(kv.second); }
+    for (auto& kv : fv) { out.nodes.push_back(kv.first); out.features.push_back(kv.second); }
 }
 
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,

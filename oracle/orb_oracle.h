@@ -20,6 +20,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <vector>
 
 namespace orbo {
@@ -153,6 +154,29 @@ int search_by_projection_mappoints(const std::vector<MapPointTrack>& mps, const 
 /* MapPoint::ComputeDistinctiveDescriptors (mappoint.cpp:322-390): index of the descriptor with the least median
  * Hamming distance to the others (median = sorted[int(0.5*(N-1))], first wins); -1 for an empty set. */
 int distinctive_descriptor(const uint8_t* desc, int n);
+
+/* Frame::ComputeBoW (frame.cpp:455-461) = DBoW3::Vocabulary::transform(features, BowVector&, FeatureVector&, 4)
+ * (thirdparty/DBoW3/DBoW3/src/Vocabulary.cpp:754-826, :838-878; BowVector.cpp addWeight/normalize;
+ * FeatureVector.cpp:31-45; DescManip.cpp:92-119).  The vocabulary is a flat copy of m_nodes: node i has children
+ * childIds[childStart[i] .. +childCount[i]) in their stored order (order decides ties), a 32-byte descriptor,
+ * and -- if it is a leaf -- a word id and a weight. */
+struct Vocabulary {
+    int L = 0;                       /* m_L */
+    int weighting = 0;               /* 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (DBoW3::WeightingType) */
+    int norm = 1;                    /* scoring object's mustNormalize: 0 none, 1 L1, 2 L2 */
+    std::vector<int> childStart, childCount, childIds, wordId;
+    std::vector<uint8_t> desc;
+    std::vector<double> weight;
+};
+void bow_transform_feature(const Vocabulary& v, const uint8_t* feature, int levelsup, int& word, double& weight,
+                           int& nid);
+struct BowResult {
+    std::vector<int> words;              /* BowVector keys, ascending */
+    std::vector<double> values;          /* BowVector values */
+    std::vector<int> nodes;              /* FeatureVector keys, ascending */
+    std::vector<std::vector<unsigned>> features; /* FeatureVector values */
+};
+void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup, BowResult& out);
 
 /* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,

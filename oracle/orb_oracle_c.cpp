@@ -211,6 +211,36 @@ void orbo_distinctive_descriptors(const uint8_t* desc, const int* offsets, int n
     for (int s = 0; s < nsets; s++) best[s] = distinctive_descriptor(desc + 32 * (size_t)offsets[s], offsets[s + 1] - offsets[s]);
 }
 
+/* vocabulary as flat arrays; outputs: per-feature word/weight/nid and the assembled vectors (caller arrays of n) */
+int orbo_bow_transform(int L, int weighting, int norm, int nNodes, const int* childStart, const int* childCount,
+                       const int* childIds, int nChildIds, const uint8_t* nodeDesc, const double* nodeWeight,
+                       const int* nodeWord, const uint8_t* desc, int n, int levelsup, int* fWord, double* fWeight,
+                       int* fNid, int* bowIds, double* bowVals, int* nBow, int* fvNodes, int* fvOff, int* fvFeat,
+                       int* nFv) {
+    Vocabulary v;
+    v.L = L; v.weighting = weighting; v.norm = norm;
+    v.childStart.assign(childStart, childStart + nNodes);
+    v.childCount.assign(childCount, childCount + nNodes);
+    v.childIds.assign(childIds, childIds + nChildIds);
+    v.wordId.assign(nodeWord, nodeWord + nNodes);
+    v.desc.assign(nodeDesc, nodeDesc + (size_t)nNodes * 32);
+    v.weight.assign(nodeWeight, nodeWeight + nNodes);
+    for (int i = 0; i < n; i++) bow_transform_feature(v, desc + 32 * (size_t)i, levelsup, fWord[i], fWeight[i], fNid[i]);
+    BowResult r;
+    bow_transform(v, desc, n, levelsup, r);
+    *nBow = (int)r.words.size();
+    for (size_t i = 0; i < r.words.size(); i++) { bowIds[i] = r.words[i]; bowVals[i] = r.values[i]; }
+    *nFv = (int)r.nodes.size();
+    int off = 0;
+    for (size_t i = 0; i < r.nodes.size(); i++) {
+        fvNodes[i] = r.nodes[i];
+        fvOff[i] = off;
+        for (unsigned f : r.features[i]) fvFeat[off++] = (int)f;
+    }
+    fvOff[r.nodes.size()] = off;
+    return 0;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

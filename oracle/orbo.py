@@ -67,6 +67,7 @@ def lib():
         vp = C.c_void_p
         L.orbo_search_by_projection_mappoints.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                                           C.c_int, C.c_float, C.c_float, vp]
+        L.orbo_bow_transform.argtypes = [C.c_int] * 4 + [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int] + [vp] * 10
         L.orbo_distinctive_descriptors.argtypes = [vp, vp, C.c_int, vp]
         L.orbo_distinctive_descriptors.restype = None
         L.orbo_unproject_stereo.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
@@ -326,3 +327,26 @@ def distinctive_descriptors(desc, offsets):
     best = np.zeros(len(off) - 1, np.int32)
     lib().orbo_distinctive_descriptors(_p(desc), _p(off), len(off) - 1, _p(best))
     return best
+
+
+def bow_transform(voc, desc, levelsup=4):
+    """Frame::ComputeBoW = DBoW3 Vocabulary::transform(features, BowVector, FeatureVector, levelsup)
+    (Vocabulary.cpp:754-878).  voc: dict from vi_slam_amd.synth.make_vocabulary (flat node arrays).
+    -> dict(word, weight, nid per feature; bow_ids, bow_vals; fv_nodes, fv_off, fv_feat)."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    cs = np.ascontiguousarray(voc["child_start"], np.int32)
+    cc = np.ascontiguousarray(voc["child_count"], np.int32)
+    ci = np.ascontiguousarray(voc["child_ids"], np.int32)
+    nd = np.ascontiguousarray(voc["desc"], np.uint8)
+    nw = np.ascontiguousarray(voc["weight"], np.float64)
+    wi = np.ascontiguousarray(voc["word_id"], np.int32)
+    fw, fwt, fn = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64), np.zeros(max(n, 1), np.int32)
+    bi, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    fvn, fvo, fvf = np.zeros(max(n, 1), np.int32), np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.int32)
+    nb, nf = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    lib().orbo_bow_transform(int(voc["L"]), int(voc.get("weighting", 0)), int(voc.get("norm", 1)), len(cs), _p(cs), _p(cc),
+                             _p(ci), len(ci), _p(nd), _p(nw), _p(wi), _p(desc), n, levelsup, _p(fw), _p(fwt), _p(fn),
+                             _p(bi), _p(bv), _p(nb), _p(fvn), _p(fvo), _p(fvf), _p(nf))
+    return dict(word=fw[:n], weight=fwt[:n], nid=fn[:n], bow_ids=bi[:nb[0]], bow_vals=bv[:nb[0]],
+                fv_nodes=fvn[:nf[0]], fv_off=fvo[:nf[0] + 1], fv_feat=fvf[:fvo[nf[0]]])

@@ -369,3 +369,41 @@ def test_compute_distinctive_descriptors_batched(fe):
     want = orbo.distinctive_descriptors(desc, off)
     assert np.array_equal(got, want)
     assert got[0] == -1 and got[1] == 0
+
+
+def test_compute_bow_tree_walk_and_vectors(fe):
+    """Frame::ComputeBoW (DBoW3 Vocabulary::transform, levelsup 4): tree walk on the GPU for real descriptors and
+    for descriptors engineered to tie between children; BowVector / FeatureVector equal the restatement."""
+    voc = synth.make_vocabulary(10, 5, seed=11)           # 111 111 nodes, 100 000 words
+    res = fe.compute_batch([synth.make_frame(1241, 376, step=s) for s in range(3)])
+    V_ = V.Vocabulary(voc)
+    try:
+        for s in range(3):
+            _, pd, n = fe.slot_buffers(s)
+            got = V_.transform(fe, pd, n, 4)
+            want = orbo.bow_transform(voc, res[s][1], 4)
+            for k in ("word", "weight", "nid", "bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+                assert np.array_equal(got[k], want[k]), (s, k)
+            assert abs(got["bow_vals"].sum() - 1.0) < 1e-9 and len(got["bow_ids"]) > 500
+        # all slots in one launch, counts read from HBM
+        V_.transform_slots_async(fe, 0, 3, 4)
+        out = V_.transform_slots_wait([len(res[s][0]) for s in range(3)])
+        for s in range(3):
+            want = orbo.bow_transform(voc, res[s][1], 4)
+            for k in ("word", "nid", "bow_ids", "bow_vals", "fv_feat"):
+                assert np.array_equal(out[s][k], want[k]), (s, k)
+    finally:
+        V_.close()
+    # ties: every child of the root identical -> the first child must win at every such node
+    tie = synth.make_vocabulary(4, 3, seed=2)
+    tie["desc"][1:5] = tie["desc"][1]
+    Vt = V.Vocabulary(tie)
+    try:
+        import torch
+        q = np.repeat(tie["desc"][1][None, :], 8, 0)
+        dq = torch.from_numpy(q).cuda()
+        got = Vt.transform(fe, dq.data_ptr(), 8, 1)
+        want = orbo.bow_transform(tie, q, 1)
+        assert np.array_equal(got["word"], want["word"]) and np.array_equal(got["nid"], want["nid"])
+    finally:
+        Vt.close()

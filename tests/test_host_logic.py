@@ -181,3 +181,24 @@ def test_create_rejects_bad_parameters_and_missing_gpu():
         with pytest.raises(V.VslamError) as ei:
             V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376)
         assert ei.value.code == V.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("weighting,norm", [(0, 1), (0, 0), (1, 2), (2, 1), (3, 0)])
+def test_bow_assemble_equals_dbow3_restatement(weighting, norm):
+    """vslam_bow_assemble (host half of Frame::ComputeBoW, GPU-free) vs the oracle's restatement of
+    DBoW3::Vocabulary::transform: BowVector / FeatureVector identical, doubles bit for bit."""
+    import vi_slam_amd as V
+    from oracle import orbo
+    from vi_slam_amd import synth
+    voc = synth.make_vocabulary(6, 3, seed=3, stop_fraction=0.1, weighting=weighting, norm=norm)
+    rng = np.random.default_rng(5)
+    leaves = np.nonzero(voc["child_count"] == 0)[0]
+    d = voc["desc"][rng.choice(leaves, 400)].copy()
+    for i in range(len(d)):
+        for f in rng.integers(0, 256, 8):
+            d[i, f >> 3] ^= np.uint8(1 << (f & 7))
+    want = orbo.bow_transform(voc, d, 2)
+    got = V.bow_assemble(weighting, norm, want["word"], want["weight"], want["nid"])
+    for k in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+        assert np.array_equal(got[k], want[k]), k
+    assert len(got["bow_ids"]) > 20 and (want["weight"] == 0).any()

@@ -39,7 +39,9 @@ ABI_SYMBOLS = [
     "vslam_search_init_dev_wait", "vslam_fe_slot_count_ptr", "vslam_fe_pack_slot_range_async", "vslam_fe_wait_for", "vslam_fe_event_record",
     "vslam_fe_event_wait", "vslam_projection_direction", "vslam_search_by_projection_frame",
     "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
-    "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors",
+    "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors", "vslam_voc_create", "vslam_voc_destroy",
+    "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
+    "vslam_bow_assemble",
 ]
 
 
@@ -115,6 +117,14 @@ def lib():
         L.vslam_search_by_projection_mappoints.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, C.c_float, C.c_float,
                                                            vp, vp]
         L.vslam_distinctive_descriptors.argtypes = [vp, vp, vp, i, vp]
+        L.vslam_voc_create.argtypes = [i, i, i, i, i, vp, vp, vp, i, vp, vp, vp, vp]
+        L.vslam_voc_destroy.argtypes = [vp]
+        L.vslam_voc_destroy.restype = None
+        L.vslam_voc_info.argtypes = [vp, vp, vp, vp, vp]
+        L.vslam_bow_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
+        L.vslam_bow_transform_slots_async.argtypes = [vp, vp, i, i, i]
+        L.vslam_bow_transform_slots_wait.argtypes = [vp, vp, vp, vp, vp]
+        L.vslam_bow_assemble.argtypes = [i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
         L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
@@ -617,6 +627,85 @@ class FMatcher:
             vpa(*[a.ctypes.data for a in pm]), vpa(*[a.ctypes.data for a in m]), windowSize, self.mfNNratio,
             int(self.mbCheckOrientation), nm))
         return [(nm[j], m[j][:len(k1[j])], pm[j][:len(k1[j])]) for j in range(npairs)]
+
+
+def bow_assemble(weighting, norm, word, weight, nid):
+    """Host half of DBoW3::Vocabulary::transform (vslam_bow_assemble, GPU-free): per-feature (word, weight, node)
+    -> dict(bow_ids, bow_vals, fv_nodes, fv_off, fv_feat)."""
+    n = len(word)
+    word = np.ascontiguousarray(word, np.int32)
+    weight = np.ascontiguousarray(weight, np.float64)
+    nid = np.ascontiguousarray(nid, np.int32)
+    bi, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    fn, fo, ff = np.zeros(max(n, 1), np.int32), np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.int32)
+    nb, nf = C.c_int(), C.c_int()
+    rc = lib().vslam_bow_assemble(weighting, norm, _p(word), _p(weight), _p(nid), n, _p(bi), _p(bv), C.byref(nb), _p(fn),
+                                  _p(fo), _p(ff), C.byref(nf))
+    if rc:
+        raise VslamError(rc, "vslam_bow_assemble: invalid arguments")
+    return dict(bow_ids=bi[:nb.value], bow_vals=bv[:nb.value], fv_nodes=fn[:nf.value], fv_off=fo[:nf.value + 1],
+                fv_feat=ff[:fo[nf.value]])
+
+
+class Vocabulary:
+    """DBoW3::Vocabulary on the device (flat node arrays, see vi_slam_amd.synth.make_vocabulary for the layout)."""
+
+    def __init__(self, voc, device=0):
+        self.weighting, self.norm, self.L = int(voc.get("weighting", 0)), int(voc.get("norm", 1)), int(voc["L"])
+        cs = np.ascontiguousarray(voc["child_start"], np.int32)
+        cc = np.ascontiguousarray(voc["child_count"], np.int32)
+        ci = np.ascontiguousarray(voc["child_ids"], np.int32)
+        nd = np.ascontiguousarray(voc["desc"], np.uint8)
+        nw = np.ascontiguousarray(voc["weight"], np.float64)
+        wi = np.ascontiguousarray(voc["word_id"], np.int32)
+        h = C.c_void_p()
+        _check(lib().vslam_voc_create(device, self.L, self.weighting, self.norm, len(cs), _p(cs), _p(cc), _p(ci), len(ci),
+                                      _p(nd), _p(nw), _p(wi), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vslam_voc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def assemble(self, word, weight, nid):
+        """Host half of Vocabulary::transform -> dict(bow_ids, bow_vals, fv_nodes, fv_off, fv_feat)."""
+        return bow_assemble(self.weighting, self.norm, word, weight, nid)
+
+    def transform(self, fe, dev_desc, n, levelsup=4):
+        """Frame::ComputeBoW for n device-resident descriptors -> per-feature (word, weight, nid) + assembled vectors."""
+        w, wt, nd = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64), np.zeros(max(n, 1), np.int32)
+        _check(lib().vslam_bow_transform(fe._h, self._h, C.c_void_p(dev_desc), n, levelsup, _p(w), _p(wt), _p(nd)))
+        out = self.assemble(w[:n], wt[:n], nd[:n])
+        out.update(word=w[:n], weight=wt[:n], nid=nd[:n])
+        return out
+
+    def transform_slots_async(self, fe, first_slot, nslots, levelsup=4):
+        self._pending = (fe, nslots)
+        _check(lib().vslam_bow_transform_slots_async(fe._h, self._h, first_slot, nslots, levelsup))
+
+    def transform_slots_wait(self, n, assemble=True):
+        fe, ns = self._pending
+        cap = fe.cap
+        if getattr(self, "_bufs", None) is None or self._bufs[0].shape != (MAX_BATCH, cap):
+            self._bufs = (np.zeros((MAX_BATCH, cap), np.int32), np.zeros((MAX_BATCH, cap), np.float64),
+                          np.zeros((MAX_BATCH, cap), np.int32))
+            self._ptrs = [(C.c_void_p * MAX_BATCH)(*[b[i].ctypes.data for i in range(MAX_BATCH)]) for b in self._bufs]
+        _check(lib().vslam_bow_transform_slots_wait(fe._h, (C.c_int * ns)(*n), self._ptrs[0], self._ptrs[1],
+                                                    self._ptrs[2]))
+        res = []
+        for j in range(ns):
+            w, wt, nd = self._bufs[0][j, :n[j]], self._bufs[1][j, :n[j]], self._bufs[2][j, :n[j]]
+            out = self.assemble(w, wt, nd) if assemble else {}
+            out.update(word=w, weight=wt, nid=nd)
+            res.append(out)
+        return res
 
 
 def ComputeDistinctiveDescriptors(fe, desc, offsets):

@@ -181,6 +181,11 @@ struct vslam_fe {
     uint8_t* h_proj = nullptr;  /* pinned mirror (inputs, then results) */
     size_t h_proj_bytes = 0;
     bool proj_lds_set = false, dist_lds_set = false;
+    uint8_t* d_bow = nullptr;   /* ComputeBoW: per-feature weight | word | node for nslots x cap features */
+    size_t bow_bytes = 0;
+    uint8_t* h_bow = nullptr;   /* pinned mirror */
+    size_t h_bow_bytes = 0;
+    int bow_jobs = 0;
     uint8_t* h_img = nullptr;   /* pinned staging for host images: B x height x level-0 pitch */
     uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */
     size_t sbp_bytes = 0;

@@ -72,6 +72,8 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_mpflags);
     if (fe->h_proj) hipHostFree(fe->h_proj);
     if (fe->h_img) hipHostFree(fe->h_img);
+    hipFree(fe->d_bow);
+    if (fe->h_bow) hipHostFree(fe->h_bow);
     hipFree(fe->d_init_fb);
     if (fe->h_init) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);

@@ -580,3 +580,65 @@ int vslamh_search_init(const vslam_kp* kps1, int n1, const vslam_kp* kps2, int n
 }
 
 } /* extern "C" */
+
+/* ------------------------------------------------------------------ ComputeBoW, host half
+ * DBoW3::Vocabulary::transform (Vocabulary.cpp:754-826) after the per-feature tree walk: BowVector::addWeight /
+ * addIfNotExist in feature order (std::map, double), the "divide by the number of words" step when the scoring
+ * object does not normalise, BowVector::normalize (BowVector.cpp), FeatureVector::addFeature. */
+extern "C" int vslam_bow_assemble(int weighting, int norm, const int32_t* word_id, const double* weight,
+                                  const int32_t* node_id, int n, int32_t* bow_ids, double* bow_vals, int* n_bow,
+                                  int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int* n_fv) {
+    if (n < 0 || (n && (!word_id || !weight || !node_id || !bow_ids || !bow_vals || !fv_nodes || !fv_off || !fv_feat)) ||
+        !n_bow || !n_fv || weighting < 0 || weighting > 3 || norm < 0 || norm > 2)
+        return -1;
+    /* std::map semantics without the tree: a STABLE sort of the kept feature indices by word id (by node id) keeps
+     * the feature order inside each key, so every word's weights are summed in exactly the order addWeight saw them */
+    std::vector<int32_t> kept;
+    kept.reserve(n);
+    for (int i = 0; i < n; i++)
+        if (weight[i] > 0) kept.push_back(i); /* not stopped */
+    const bool tf = weighting == 0 || weighting == 1; /* TF_IDF, TF */
+    std::vector<int32_t> byWord(kept);
+    std::stable_sort(byWord.begin(), byWord.end(), [&](int32_t a, int32_t b) { return word_id[a] < word_id[b]; });
+    int k = 0;
+    for (size_t p = 0; p < byWord.size();) {
+        const int32_t w = word_id[byWord[p]];
+        double v = 0.0;
+        bool first = true;
+        size_t q = p;
+        for (; q < byWord.size() && word_id[byWord[q]] == w; q++) {
+            if (tf) v = first ? weight[byWord[q]] : v + weight[byWord[q]]; /* insert, then += */
+            else if (first) v = weight[byWord[q]];                       /* addIfNotExist */
+            first = false;
+        }
+        bow_ids[k] = w;
+        bow_vals[k++] = v;
+        p = q;
+    }
+    if (tf && k > 0 && norm == 0) {
+        const double nd = (double)k;
+        for (int i = 0; i < k; i++) bow_vals[i] /= nd;
+    }
+    if (norm) {
+        double nv = 0.0;
+        if (norm == 1) for (int i = 0; i < k; i++) nv += std::fabs(bow_vals[i]);
+        else {
+            for (int i = 0; i < k; i++) nv += bow_vals[i] * bow_vals[i];
+            nv = std::sqrt(nv);
+        }
+        if (nv > 0.0) for (int i = 0; i < k; i++) bow_vals[i] /= nv;
+    }
+    *n_bow = k;
+    std::vector<int32_t> byNode(kept);
+    std::stable_sort(byNode.begin(), byNode.end(), [&](int32_t a, int32_t b) { return node_id[a] < node_id[b]; });
+    int f = 0, off = 0;
+    for (size_t p = 0; p < byNode.size();) {
+        const int32_t nd = node_id[byNode[p]];
+        fv_nodes[f] = nd;
+        fv_off[f++] = off;
+        for (; p < byNode.size() && node_id[byNode[p]] == nd; p++) fv_feat[off++] = byNode[p];
+    }
+    fv_off[f] = off;
+    *n_fv = f;
+    return 0;
+}

@@ -100,3 +100,42 @@ def make_frame(width, height, seed=20250215, step=0, right=False, n_rects=None, 
 def make_stereo_pair(width, height, seed=20250215, step=0, **kw):
     return (make_frame(width, height, seed, step, right=False, **kw),
             make_frame(width, height, seed, step, right=True, **kw))
+
+
+def make_vocabulary(k=10, L=4, seed=7, stop_fraction=0.02, weighting=0, norm=1):
+    """A synthetic DBoW3-shaped vocabulary tree (the reference's ORBvoc blob is not in the tree): k children per
+    inner node, L levels, nodes numbered breadth-first like DBoW3's m_nodes, children descriptors = the parent's with
+    random bit flips, leaves get consecutive word ids in node order (Vocabulary::createWords) and an idf-like
+    weight; a few leaves get weight 0 ("stopped" words).  Flat arrays, ready for vslam_voc_create / the oracle."""
+    rng = np.random.default_rng(seed)
+    n_nodes = (k ** (L + 1) - 1) // (k - 1)
+    desc = np.zeros((n_nodes, 32), np.uint8)
+    child_start = np.zeros(n_nodes, np.int32)
+    child_count = np.zeros(n_nodes, np.int32)
+    child_ids = np.zeros(n_nodes - 1, np.int32)
+    word_id = np.zeros(n_nodes, np.int32)
+    weight = np.zeros(n_nodes, np.float64)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    first, nxt, pos = 0, 1, 0
+    for level in range(L):
+        cnt = k ** level
+        for node in range(first, first + cnt):
+            child_start[node], child_count[node] = pos, k
+            ids = np.arange(nxt, nxt + k, dtype=np.int32)
+            child_ids[pos:pos + k] = ids
+            flips = rng.integers(0, 256, (k, max(4, 48 >> level)))
+            d = np.repeat(desc[node][None, :], k, 0)
+            for c in range(k):
+                for f in flips[c]:
+                    d[c, f >> 3] ^= np.uint8(1 << (f & 7))
+            desc[ids] = d
+            nxt += k
+            pos += k
+        first += cnt
+    leaves = np.arange(first, n_nodes)
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    w = rng.uniform(0.5, 9.0, len(leaves))
+    w[rng.random(len(leaves)) < stop_fraction] = 0.0
+    weight[leaves] = w
+    return dict(k=k, L=L, weighting=weighting, norm=norm, child_start=child_start, child_count=child_count,
+                child_ids=child_ids, desc=desc, weight=weight, word_id=word_id)
