@@ -349,6 +349,18 @@ int vslam_bow_assemble(int weighting, int norm, const int32_t* word_id, const do
                        int n, int32_t* bow_ids, double* bow_vals, int* n_bow, int32_t* fv_nodes, int32_t* fv_off,
                        int32_t* fv_feat, int* n_fv);
 
+/* FMatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (fmatcher.cpp:546-748,
+ * pinhole frames).  FeatureVectors as produced by vslam_bow_assemble (ascending node ids, offsets, feature
+ * indices); kf_flags[i] != 0 iff pKF's i-th keypoint has a MapPoint that is not bad; keypoints only contribute
+ * their angles; descriptors are device arrays.  match_f[iF] = KeyFrame feature index whose MapPoint is written to
+ * vpMapPointMatches[iF], -1 = NULL; *nmatches as the reference counts it. */
+int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t* dev_kf_desc,
+                        const uint8_t* kf_flags_host, int n_kf, const int32_t* kf_fv_nodes, const int32_t* kf_fv_off,
+                        const int32_t* kf_fv_feat, int n_kf_nodes, const vslam_kp* f_kps_host,
+                        const uint8_t* dev_f_desc, int n_f, const int32_t* f_fv_nodes, const int32_t* f_fv_off,
+                        const int32_t* f_fv_feat, int n_f_nodes, float nnratio, int check_orientation,
+                        int32_t* match_f, int* nmatches);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

@@ -1066,6 +1066,73 @@ void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup
     for (auto& kv : fv) { out.nodes.push_back(kv.first); out.features.push_back(kv.second); }
 }
 
+int search_by_bow(const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>& kfDesc, const std::vector<uint8_t>& kfFlags,
+                  const std::vector<int>& kfNodes, const std::vector<int>& kfOff, const std::vector<int>& kfFeat,
+                  const std::vector<KeyPoint>& fKps, const std::vector<uint8_t>& fDesc, const std::vector<int>& fNodes,
+                  const std::vector<int>& fOff, const std::vector<int>& fFeat, float mfNNratio, bool checkOri,
+                  std::vector<int>& vpMapPointMatches) { /* fmatcher.cpp:546-748, F.Nleft == -1 */
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    vpMapPointMatches.assign(fKps.size(), -1);
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    size_t KFit = 0, Fit = 0;
+    const size_t KFend = kfNodes.size(), Fend = fNodes.size();
+    while (KFit != KFend && Fit != Fend) {
+        if (kfNodes[KFit] == fNodes[Fit]) {
+            for (int a = kfOff[KFit]; a < kfOff[KFit + 1]; a++) {
+                const int realIdxKF = kfFeat[a];
+                if (!kfFlags[realIdxKF]) continue; /* !pMP || pMP->isBad() */
+                const uint8_t* dKF = &kfDesc[32 * (size_t)realIdxKF];
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int b = fOff[Fit]; b < fOff[Fit + 1]; b++) {
+                    const int realIdxF = fFeat[b];
+                    if (vpMapPointMatches[realIdxF] >= 0) continue;
+                    const int dist = descriptor_distance(dKF, &fDesc[32 * (size_t)realIdxF]);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < mfNNratio * (float)bestDist2) {
+                        vpMapPointMatches[bestIdxF] = realIdxKF;
+                        if (checkOri) {
+                            float rot = kfKps[realIdxKF].angle - fKps[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++;
+            Fit++;
+        } else if (kfNodes[KFit] < fNodes[Fit]) {
+            KFit = std::lower_bound(kfNodes.begin(), kfNodes.end(), fNodes[Fit]) - kfNodes.begin();
+        } else {
+            Fit = std::lower_bound(fNodes.begin(), fNodes.end(), kfNodes[KFit]) - fNodes.begin();
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) {
+                vpMapPointMatches[idx] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -178,6 +178,16 @@ struct BowResult {
 };
 void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup, BowResult& out);
 
+/* FMatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (fmatcher.cpp:546-748,
+ * pinhole: F.Nleft == -1).  FeatureVectors as (ascending node ids, offsets, feature indices); kfFlags[i] != 0 iff
+ * vpMapPointsKF[i] exists and is not bad.  matchF[iF] = KeyFrame feature index whose MapPoint lands in
+ * vpMapPointMatches[iF], -1 = NULL.  Returns nmatches. */
+int search_by_bow(const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>& kfDesc, const std::vector<uint8_t>& kfFlags,
+                  const std::vector<int>& kfNodes, const std::vector<int>& kfOff, const std::vector<int>& kfFeat,
+                  const std::vector<KeyPoint>& fKps, const std::vector<uint8_t>& fDesc, const std::vector<int>& fNodes,
+                  const std::vector<int>& fOff, const std::vector<int>& fFeat, float nnratio, bool checkOri,
+                  std::vector<int>& matchF);
+
 /* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]);

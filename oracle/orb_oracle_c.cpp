@@ -241,6 +241,20 @@ int orbo_bow_transform(int L, int weighting, int norm, int nNodes, const int* ch
     return 0;
 }
 
+int orbo_search_by_bow(const KeyPoint* kfKps, int nKF, const uint8_t* kfDesc, const uint8_t* kfFlags, const int* kfNodes,
+                       const int* kfOff, const int* kfFeat, int nKFnodes, const KeyPoint* fKps, int nF,
+                       const uint8_t* fDesc, const int* fNodes, const int* fOff, const int* fFeat, int nFnodes,
+                       float nnratio, int checkOri, int* matchF) {
+    std::vector<KeyPoint> kk(kfKps, kfKps + nKF), fk(fKps, fKps + nF);
+    std::vector<uint8_t> kd(kfDesc, kfDesc + (size_t)nKF * 32), fd(fDesc, fDesc + (size_t)nF * 32), kfl(kfFlags, kfFlags + nKF);
+    std::vector<int> kn(kfNodes, kfNodes + nKFnodes), ko(kfOff, kfOff + nKFnodes + 1), kf(kfFeat, kfFeat + kfOff[nKFnodes]);
+    std::vector<int> fn(fNodes, fNodes + nFnodes), fo(fOff, fOff + nFnodes + 1), ff(fFeat, fFeat + fOff[nFnodes]);
+    std::vector<int> m;
+    const int nm = search_by_bow(kk, kd, kfl, kn, ko, kf, fk, fd, fn, fo, ff, nnratio, checkOri != 0, m);
+    if (nF) memcpy(matchF, m.data(), (size_t)nF * sizeof(int));
+    return nm;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

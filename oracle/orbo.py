@@ -67,6 +67,8 @@ def lib():
         vp = C.c_void_p
         L.orbo_search_by_projection_mappoints.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                                           C.c_int, C.c_float, C.c_float, vp]
+        L.orbo_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                         C.c_float, C.c_int, vp]
         L.orbo_bow_transform.argtypes = [C.c_int] * 4 + [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int] + [vp] * 10
         L.orbo_distinctive_descriptors.argtypes = [vp, vp, C.c_int, vp]
         L.orbo_distinctive_descriptors.restype = None
@@ -350,3 +352,20 @@ def bow_transform(voc, desc, levelsup=4):
                              _p(bi), _p(bv), _p(nb), _p(fvn), _p(fvo), _p(fvf), _p(nf))
     return dict(word=fw[:n], weight=fwt[:n], nid=fn[:n], bow_ids=bi[:nb[0]], bow_vals=bv[:nb[0]],
                 fv_nodes=fvn[:nf[0]], fv_off=fvo[:nf[0] + 1], fv_feat=fvf[:fvo[nf[0]]])
+
+
+def search_by_bow(kf_kps, kf_desc, kf_flags, kf_fv, f_kps, f_desc, f_fv, nnratio=0.7, check_ori=True):
+    """FMatcher::SearchByBoW(pKF, F, vpMapPointMatches) (fmatcher.cpp:546-748, pinhole).  *_fv: dict with fv_nodes,
+    fv_off, fv_feat (bow_transform / bow_assemble).  -> (nmatches, matchF[nF] = KeyFrame feature index or -1)."""
+    kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE)
+    f_kps = np.ascontiguousarray(f_kps, KP_DTYPE)
+    kd = np.ascontiguousarray(kf_desc, np.uint8)
+    fd = np.ascontiguousarray(f_desc, np.uint8)
+    kfl = np.ascontiguousarray(kf_flags, np.uint8)
+    a = [np.ascontiguousarray(kf_fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    b = [np.ascontiguousarray(f_fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    m = np.full(max(len(f_kps), 1), -1, np.int32)
+    nm = lib().orbo_search_by_bow(_p(kf_kps), len(kf_kps), _p(kd), _p(kfl), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                  _p(f_kps), len(f_kps), _p(fd), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), nnratio,
+                                  int(check_ori), _p(m))
+    return nm, m[:len(f_kps)]

@@ -407,3 +407,30 @@ def test_compute_bow_tree_walk_and_vectors(fe):
         assert np.array_equal(got["word"], want["word"]) and np.array_equal(got["nid"], want["nid"])
     finally:
         Vt.close()
+
+
+@pytest.mark.parametrize("k,L,levelsup,ratio,ori", [(10, 4, 2, 0.7, True), (10, 5, 4, 0.9, False), (4, 3, 3, 0.75, True)])
+def test_search_by_bow_equals_oracle(fe, k, L, levelsup, ratio, ori):
+    """FMatcher::SearchByBoW (fmatcher.cpp:546-748): ComputeBoW of both frames on the device, then one wave per
+    shared vocabulary node; (4,3,3): a single node holds every feature (more than 64 candidates per lane group)."""
+    voc = synth.make_vocabulary(k, L, seed=17)
+    res = fe.compute_batch([synth.make_frame(1241, 376, step=s) for s in range(2)])
+    res = [(a.copy(), b.copy(), c) for a, b, c in res]
+    vv = V.Vocabulary(voc)
+    try:
+        vv.transform_slots_async(fe, 0, 2, levelsup)
+        bw = vv.transform_slots_wait([len(res[0][0]), len(res[1][0])])
+        for s in range(2):
+            want = orbo.bow_transform(voc, res[s][1], levelsup)
+            assert np.array_equal(bw[s]["fv_feat"], want["fv_feat"]) and np.array_equal(bw[s]["fv_nodes"], want["fv_nodes"])
+        rng = np.random.default_rng(4)
+        flags = (rng.random(len(res[0][0])) < 0.8).astype(np.uint8)
+        _, dk, _ = fe.slot_buffers(0)
+        _, df, _ = fe.slot_buffers(1)
+        m = V.FMatcher(fe, ratio, ori)
+        nm, mf = m.SearchByBoW(res[0][0], dk, flags, bw[0], res[1][0], df, bw[1])
+        wn, wm = orbo.search_by_bow(res[0][0], res[0][1], flags, bw[0], res[1][0], res[1][1], bw[1], ratio, ori)
+        assert nm == wn and np.array_equal(mf, wm)
+        assert nm > 100 and np.all(flags[mf[mf >= 0]] == 1)
+    finally:
+        vv.close()

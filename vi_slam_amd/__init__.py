@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
     "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors", "vslam_voc_create", "vslam_voc_destroy",
     "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
-    "vslam_bow_assemble",
+    "vslam_bow_assemble", "vslam_search_by_bow",
 ]
 
 
@@ -124,6 +124,7 @@ def lib():
         L.vslam_bow_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
         L.vslam_bow_transform_slots_async.argtypes = [vp, vp, i, i, i]
         L.vslam_bow_transform_slots_wait.argtypes = [vp, vp, vp, vp, vp]
+        L.vslam_search_by_bow.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, C.c_float, i, vp, vp]
         L.vslam_bow_assemble.argtypes = [i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
@@ -595,6 +596,22 @@ class FMatcher:
         nm = (C.c_int * n)()
         _check(lib().vslam_search_by_projection_dev_wait(self.fe._h, (C.c_int * n)(*n_cur), self._sbp_ptrs, nm))
         return [(nm[j], self._sbp_buf[j, :n_cur[j]]) for j in range(n)]
+
+    def SearchByBoW(self, kf_kps, dev_kf_desc, kf_flags, kf_fv, f_kps, dev_f_desc, f_fv):
+        """FMatcher::SearchByBoW(pKF, F, vpMapPointMatches) (fmatcher.cpp:546-748, pinhole).  *_fv: dicts with
+        fv_nodes / fv_off / fv_feat.  -> (nmatches, match_f[nF] = KeyFrame feature index or -1)."""
+        kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE)
+        f_kps = np.ascontiguousarray(f_kps, KP_DTYPE)
+        kfl = np.ascontiguousarray(kf_flags, np.uint8)
+        a = [np.ascontiguousarray(kf_fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        b = [np.ascontiguousarray(f_fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        m = np.full(max(len(f_kps), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_bow(self.fe._h, _p(kf_kps), C.c_void_p(dev_kf_desc), _p(kfl), len(kf_kps), _p(a[0]),
+                                         _p(a[1]), _p(a[2]), len(a[0]), _p(f_kps), C.c_void_p(dev_f_desc), len(f_kps),
+                                         _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(self.mfNNratio),
+                                         int(self.mbCheckOrientation), _p(m), C.byref(nm)))
+        return nm.value, m[:len(f_kps)]
 
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""

@@ -250,3 +250,238 @@ extern "C" int vslam_bow_transform_slots_wait(vslam_fe* fe, const int* n, int32_
     }
     return VSLAM_OK;
 }
+
+/* ==================================================================================================
+ * FMatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * (fmatcher.cpp:546-748, pinhole frames).  Only features under the same vocabulary node are compared, and a
+ * frame feature belongs to exactly one node, so the "already matched" bookkeeping never crosses nodes: one wave
+ * per shared node walks that node's KeyFrame features in order (the sequential part is ~20 steps), its lanes hold
+ * the node's frame features.  best = wave-min of dist << 16 | position (first wins), second = multiset second
+ * minimum; TH_LOW and the ratio test as in the reference.  The rotation histogram spans all nodes: k_sbow_finish.
+ * ================================================================================================== */
+#include "vslam_wave.h"
+#define SBOW_TH_LOW 50
+#define SBOW_HISTO 30
+#define SBOW_MAXC 32 /* candidates per lane: 2048 frame features under one node */
+
+struct SbowArgs {
+    const uint8_t *kfDesc, *fDesc, *kfFlags;
+    const float *kfAngle, *fAngle;
+    const int32_t *kfNodes, *kfOff, *kfFeat, *fNodes, *fOff, *fFeat;
+    int32_t nKFnodes, nFnodes, nF, checkOri;
+    float nnratio;
+    int32_t* matchF;   /* nF, initialised to -1 by the kernel launch wrapper */
+    uint8_t* matchBin; /* nF */
+    int32_t* nmatches;
+    int32_t* overflow;
+};
+
+__global__ void __launch_bounds__(64) k_sbow_nodes(SbowArgs A) {
+    const int lane = threadIdx.x;
+    const int kn = blockIdx.x;
+    if (kn >= A.nKFnodes) return;
+    const int node = A.kfNodes[kn];
+    int lo = 0, hi = A.nFnodes; /* lower_bound in F's node list */
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A.fNodes[mid] < node) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= A.nFnodes || A.fNodes[lo] != node) return;
+    const int f0 = A.fOff[lo], cF = A.fOff[lo + 1] - f0;
+    if (cF > 64 * SBOW_MAXC) {
+        if (lane == 0) atomicExch(A.overflow, 1);
+        return;
+    }
+    uint32_t occ = 0; /* bit c: my c-th candidate already carries a MapPoint */
+    const float factor = 1.0f / SBOW_HISTO;
+    for (int a = A.kfOff[kn]; a < A.kfOff[kn + 1]; a++) {
+        const int realIdxKF = A.kfFeat[a];
+        if (!A.kfFlags[realIdxKF]) continue; /* !pMP || pMP->isBad() */
+        const uint4 da = ((const uint4*)A.kfDesc)[(size_t)realIdxKF * 2], db = ((const uint4*)A.kfDesc)[(size_t)realIdxKF * 2 + 1];
+        uint32_t k1 = 0xFFFFFFFFu, d2 = 256u; /* my best key, my second-best distance */
+        for (int c = 0, b = lane; b < cF; c++, b += 64) {
+            if (occ & (1u << c)) continue; /* vpMapPointMatches[realIdxF] */
+            const int realIdxF = A.fFeat[f0 + b];
+            const uint4 ta = ((const uint4*)A.fDesc)[(size_t)realIdxF * 2], tb = ((const uint4*)A.fDesc)[(size_t)realIdxF * 2 + 1];
+            const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
+                                  __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
+            const uint32_t key = (dist << 16) | (uint32_t)b;
+            if (key < k1) {
+                if (k1 != 0xFFFFFFFFu) d2 = min(d2, k1 >> 16);
+                k1 = key;
+            } else {
+                d2 = min(d2, dist);
+            }
+        }
+        const uint32_t g = wave_min_u32(k1);
+        if (g == 0xFFFFFFFFu) continue; /* no free candidate: bestDist1 stays 256 */
+        const uint32_t contrib = (k1 == g) ? d2 : (k1 == 0xFFFFFFFFu ? 256u : min(k1 >> 16, 256u));
+        const uint32_t second = wave_min_u32(contrib);
+        const uint32_t bestDist1 = g >> 16;
+        if (bestDist1 <= SBOW_TH_LOW && (float)(int)bestDist1 < __fmul_rn(A.nnratio, (float)(int)second)) {
+            const int bpos = (int)(g & 0xFFFFu);
+            if ((bpos & 63) == lane) occ |= 1u << (bpos >> 6);
+            if (lane == 0) {
+                const int bestIdxF = A.fFeat[f0 + bpos];
+                A.matchF[bestIdxF] = realIdxKF;
+                uint8_t bin = 255;
+                if (A.checkOri) {
+                    float rot = __fsub_rn(A.kfAngle[realIdxKF], A.fAngle[bestIdxF]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bi = (int)roundf(__fmul_rn(rot, factor));
+                    if (bi == SBOW_HISTO) bi = 0;
+                    bin = (uint8_t)bi;
+                }
+                A.matchBin[bestIdxF] = bin;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sbow_finish(SbowArgs A) {
+    __shared__ int s_hist[SBOW_HISTO];
+    __shared__ int s_n, s_removed;
+    const int tid = threadIdx.x;
+    if (tid < SBOW_HISTO) s_hist[tid] = 0;
+    if (tid == 0) {
+        s_n = 0;
+        s_removed = 0;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < A.nF; i += 256)
+        if (A.matchF[i] >= 0) {
+            mine++;
+            if (A.checkOri) atomicAdd(&s_hist[A.matchBin[i]], 1);
+        }
+    atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0; /* ComputeThreeMaxima, fmatcher.cpp:2813-2854 */
+        for (int i = 0; i < SBOW_HISTO; i++) {
+            const int sv = s_hist[i];
+            if (sv > max1) {
+                max3 = max2; max2 = max1; max1 = sv;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (sv > max2) {
+                max3 = max2; max2 = sv;
+                ind3 = ind2; ind2 = i;
+            } else if (sv > max3) {
+                max3 = sv;
+                ind3 = i;
+            }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        int rem = 0;
+        for (int i = tid; i < A.nF; i += 256)
+            if (A.matchF[i] >= 0) {
+                const int b = A.matchBin[i];
+                if (b != ind1 && b != ind2 && b != ind3) {
+                    A.matchF[i] = -1;
+                    rem++;
+                }
+            }
+        atomicAdd(&s_removed, rem);
+    }
+    __syncthreads();
+    if (tid == 0) A.nmatches[0] = s_n - s_removed;
+}
+
+__global__ void k_fill_i32(int32_t* p, int n, int32_t v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t* dev_kf_desc,
+                                   const uint8_t* kf_flags_host, int n_kf, const int32_t* kf_fv_nodes,
+                                   const int32_t* kf_fv_off, const int32_t* kf_fv_feat, int n_kf_nodes,
+                                   const vslam_kp* f_kps_host, const uint8_t* dev_f_desc, int n_f,
+                                   const int32_t* f_fv_nodes, const int32_t* f_fv_off, const int32_t* f_fv_feat,
+                                   int n_f_nodes, float nnratio, int check_orientation, int32_t* match_f,
+                                   int* nmatches) {
+    if (!fe || n_kf < 0 || n_f < 0 || n_kf_nodes < 0 || n_f_nodes < 0 || !nmatches ||
+        (n_kf && (!kf_kps_host || !dev_kf_desc || !kf_flags_host)) || (n_f && (!f_kps_host || !dev_f_desc || !match_f)) ||
+        (n_kf_nodes && (!kf_fv_nodes || !kf_fv_off || !kf_fv_feat)) || (n_f_nodes && (!f_fv_nodes || !f_fv_off || !f_fv_feat))) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    if (n_kf == 0 || n_f == 0 || n_kf_nodes == 0 || n_f_nodes == 0) return VSLAM_OK;
+    for (int j = 0; j < n_kf_nodes; j++)
+        for (int a = kf_fv_off[j]; a < kf_fv_off[j + 1]; a++)
+            if (kf_fv_feat[a] < 0 || kf_fv_feat[a] >= n_kf) {
+                g_err = "KeyFrame FeatureVector index out of range";
+                return VSLAM_ERR_INVALID;
+            }
+    for (int j = 0; j < n_f_nodes; j++)
+        for (int a = f_fv_off[j]; a < f_fv_off[j + 1]; a++)
+            if (f_fv_feat[a] < 0 || f_fv_feat[a] >= n_f) {
+                g_err = "Frame FeatureVector index out of range";
+                return VSLAM_ERR_INVALID;
+            }
+    HIPCHK(hipSetDevice(fe->p.device));
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const int tk = kf_fv_off[n_kf_nodes], tf = f_fv_off[n_f_nodes];
+    const size_t o_kfl = 0, o_ka = al(o_kfl + (size_t)n_kf), o_fa = al(o_ka + (size_t)n_kf * 4),
+                 o_kn = al(o_fa + (size_t)n_f * 4), o_ko = al(o_kn + (size_t)n_kf_nodes * 4),
+                 o_kf = al(o_ko + (size_t)(n_kf_nodes + 1) * 4), o_fn = al(o_kf + (size_t)tk * 4),
+                 o_fo = al(o_fn + (size_t)n_f_nodes * 4), o_ff = al(o_fo + (size_t)(n_f_nodes + 1) * 4),
+                 in_bytes = al(o_ff + (size_t)tf * 4);
+    const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n_f * 4), o_n = al(o_b + (size_t)n_f), total = o_n + 16;
+    int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < total) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
+        fe->h_proj_bytes = total;
+    }
+    uint8_t *h = fe->h_proj, *d = fe->d_proj;
+    memcpy(h + o_kfl, kf_flags_host, (size_t)n_kf);
+    for (int i = 0; i < n_kf; i++) ((float*)(h + o_ka))[i] = kf_kps_host[i].angle;
+    for (int i = 0; i < n_f; i++) ((float*)(h + o_fa))[i] = f_kps_host[i].angle;
+    memcpy(h + o_kn, kf_fv_nodes, (size_t)n_kf_nodes * 4);
+    memcpy(h + o_ko, kf_fv_off, (size_t)(n_kf_nodes + 1) * 4);
+    memcpy(h + o_kf, kf_fv_feat, (size_t)tk * 4);
+    memcpy(h + o_fn, f_fv_nodes, (size_t)n_f_nodes * 4);
+    memcpy(h + o_fo, f_fv_off, (size_t)(n_f_nodes + 1) * 4);
+    memcpy(h + o_ff, f_fv_feat, (size_t)tf * 4);
+    hipStream_t st = fe->stream;
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = d;
+    R.src[0] = h;
+    R.bytes[0] = in_bytes;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    SbowArgs A;
+    memset(&A, 0, sizeof(A));
+    A.kfDesc = dev_kf_desc; A.fDesc = dev_f_desc; A.kfFlags = d + o_kfl;
+    A.kfAngle = (const float*)(d + o_ka); A.fAngle = (const float*)(d + o_fa);
+    A.kfNodes = (const int32_t*)(d + o_kn); A.kfOff = (const int32_t*)(d + o_ko); A.kfFeat = (const int32_t*)(d + o_kf);
+    A.fNodes = (const int32_t*)(d + o_fn); A.fOff = (const int32_t*)(d + o_fo); A.fFeat = (const int32_t*)(d + o_ff);
+    A.nKFnodes = n_kf_nodes; A.nFnodes = n_f_nodes; A.nF = n_f; A.checkOri = check_orientation; A.nnratio = nnratio;
+    A.matchF = (int32_t*)(d + o_m); A.matchBin = d + o_b; A.nmatches = (int32_t*)(d + o_n);
+    A.overflow = (int32_t*)(d + o_n) + 1;
+    hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, st, A.matchF, n_f, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, st, A.nmatches, 4, 0);
+    hipLaunchKernelGGL(k_sbow_nodes, dim3(n_kf_nodes), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, A);
+    R.dst[0] = h + o_m;
+    R.src[0] = d + o_m;
+    R.bytes[0] = (o_n + 16) - o_m;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (((const int32_t*)(h + o_n))[1]) {
+        g_err = "SearchByBoW: more than 2048 frame features under one vocabulary node";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    memcpy(match_f, h + o_m, (size_t)n_f * 4);
+    *nmatches = *(const int32_t*)(h + o_n);
+    return VSLAM_OK;
+}

@@ -1,0 +1,24 @@
+/* vslam_wave.h -- wave64 helpers shared by the matcher kernels (device code only). */
+#ifndef VSLAM_WAVE_H
+#define VSLAM_WAVE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* wave64 min-reduction on DPP (no LDS traffic, a few cycles per step instead of a ds_bpermute round trip):
+ * quad swaps, row rotations, then row_bcast:15 / row_bcast:31; the result sits in lane 63 and is returned
+ * wave-uniform through v_readlane. */
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_mov<0xb1, 0xf>(v));  /* quad_perm [1,0,3,2] */
+    v = min(v, dpp_mov<0x4e, 0xf>(v));  /* quad_perm [2,3,0,1] */
+    v = min(v, dpp_mov<0x124, 0xf>(v)); /* row_ror:4 */
+    v = min(v, dpp_mov<0x128, 0xf>(v)); /* row_ror:8 */
+    v = min(v, dpp_mov<0x142, 0xa>(v)); /* row_bcast:15 into rows 1,3 */
+    v = min(v, dpp_mov<0x143, 0xc>(v)); /* row_bcast:31 into rows 2,3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+#endif /* VSLAM_WAVE_H */
