@@ -361,6 +361,16 @@ int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t
                         const int32_t* f_fv_feat, int n_f_nodes, float nnratio, int check_orientation,
                         int32_t* match_f, int* nmatches);
 
+/* FMatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (fmatcher.cpp:1100-1240):
+ * both sides carry MapPoint flags (exists and not bad), the threshold is bestDist1 < TH_LOW, and the result is
+ * indexed by the first KeyFrame: match12[idx1] = idx2 (vpMatches12[idx1] = vpMapPoints2[idx2]) or -1. */
+int vslam_search_by_bow_keyframes(vslam_fe* fe, const vslam_kp* kps1_host, const uint8_t* dev_desc1,
+                                  const uint8_t* flags1_host, int n1, const int32_t* fv1_nodes, const int32_t* fv1_off,
+                                  const int32_t* fv1_feat, int n1_nodes, const vslam_kp* kps2_host,
+                                  const uint8_t* dev_desc2, const uint8_t* flags2_host, int n2,
+                                  const int32_t* fv2_nodes, const int32_t* fv2_off, const int32_t* fv2_feat,
+                                  int n2_nodes, float nnratio, int check_orientation, int32_t* match12, int* nmatches);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);

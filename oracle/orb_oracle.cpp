@@ -1133,6 +1133,75 @@ int search_by_bow(const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>
     return nmatches;
 }
 
+int search_by_bow_keyframes(const std::vector<KeyPoint>& vKeysUn1, const std::vector<uint8_t>& Descriptors1,
+                            const std::vector<uint8_t>& flags1, const std::vector<int>& nodes1, const std::vector<int>& off1,
+                            const std::vector<int>& feat1, const std::vector<KeyPoint>& vKeysUn2,
+                            const std::vector<uint8_t>& Descriptors2, const std::vector<uint8_t>& flags2,
+                            const std::vector<int>& nodes2, const std::vector<int>& off2, const std::vector<int>& feat2,
+                            float mfNNratio, bool checkOri, std::vector<int>& vpMatches12) { /* fmatcher.cpp:1100-1240 */
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    vpMatches12.assign(vKeysUn1.size(), -1);
+    std::vector<bool> vbMatched2(vKeysUn2.size(), false);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    size_t f1it = 0, f2it = 0;
+    while (f1it != nodes1.size() && f2it != nodes2.size()) {
+        if (nodes1[f1it] == nodes2[f2it]) {
+            for (int a = off1[f1it]; a < off1[f1it + 1]; a++) {
+                const int idx1 = feat1[a];
+                if (!flags1[idx1]) continue; /* !pMP1 || pMP1->isBad() */
+                const uint8_t* d1 = &Descriptors1[32 * (size_t)idx1];
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = off2[f2it]; b < off2[f2it + 1]; b++) {
+                    const int idx2 = feat2[b];
+                    if (vbMatched2[idx2] || !flags2[idx2]) continue;
+                    const int dist = descriptor_distance(d1, &Descriptors2[32 * (size_t)idx2]);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < TH_LOW) {
+                    if ((float)bestDist1 < mfNNratio * (float)bestDist2) {
+                        vpMatches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (checkOri) {
+                            float rot = vKeysUn1[idx1].angle - vKeysUn2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (nodes1[f1it] < nodes2[f2it]) {
+            f1it = std::lower_bound(nodes1.begin(), nodes1.end(), nodes2[f2it]) - nodes1.begin();
+        } else {
+            f2it = std::lower_bound(nodes2.begin(), nodes2.end(), nodes1[f1it]) - nodes2.begin();
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) {
+                vpMatches12[idx] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -188,6 +188,15 @@ int search_by_bow(const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>
                   const std::vector<int>& fOff, const std::vector<int>& fFeat, float nnratio, bool checkOri,
                   std::vector<int>& matchF);
 
+/* FMatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>& vpMatches12) (fmatcher.cpp:1100-1240):
+ * match12[idx1] = idx2 or -1; flags: MapPoint exists and is not bad. */
+int search_by_bow_keyframes(const std::vector<KeyPoint>& kps1, const std::vector<uint8_t>& desc1,
+                            const std::vector<uint8_t>& flags1, const std::vector<int>& nodes1, const std::vector<int>& off1,
+                            const std::vector<int>& feat1, const std::vector<KeyPoint>& kps2,
+                            const std::vector<uint8_t>& desc2, const std::vector<uint8_t>& flags2,
+                            const std::vector<int>& nodes2, const std::vector<int>& off2, const std::vector<int>& feat2,
+                            float nnratio, bool checkOri, std::vector<int>& match12);
+
 /* Frame::UnprojectStereo (frame.cpp:1023-1037): returns false (cv::Mat()) when mvDepth[i] <= 0 */
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]);

@@ -255,6 +255,21 @@ int orbo_search_by_bow(const KeyPoint* kfKps, int nKF, const uint8_t* kfDesc, co
     return nm;
 }
 
+int orbo_search_by_bow_keyframes(const KeyPoint* kps1, int n1, const uint8_t* desc1, const uint8_t* flags1, const int* nodes1,
+                                 const int* off1, const int* feat1, int nn1, const KeyPoint* kps2, int n2,
+                                 const uint8_t* desc2, const uint8_t* flags2, const int* nodes2, const int* off2,
+                                 const int* feat2, int nn2, float nnratio, int checkOri, int* match12) {
+    std::vector<KeyPoint> k1(kps1, kps1 + n1), k2(kps2, kps2 + n2);
+    std::vector<uint8_t> d1(desc1, desc1 + (size_t)n1 * 32), d2(desc2, desc2 + (size_t)n2 * 32), f1(flags1, flags1 + n1),
+        f2(flags2, flags2 + n2);
+    std::vector<int> a1(nodes1, nodes1 + nn1), o1(off1, off1 + nn1 + 1), e1(feat1, feat1 + off1[nn1]);
+    std::vector<int> a2(nodes2, nodes2 + nn2), o2(off2, off2 + nn2 + 1), e2(feat2, feat2 + off2[nn2]);
+    std::vector<int> m;
+    const int nm = search_by_bow_keyframes(k1, d1, f1, a1, o1, e1, k2, d2, f2, a2, o2, e2, nnratio, checkOri != 0, m);
+    if (n1) memcpy(match12, m.data(), (size_t)n1 * sizeof(int));
+    return nm;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

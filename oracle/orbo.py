@@ -69,6 +69,8 @@ def lib():
                                                           C.c_int, C.c_float, C.c_float, vp]
         L.orbo_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int,
                                          C.c_float, C.c_int, vp]
+        L.orbo_search_by_bow_keyframes.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp,
+                                                   C.c_int, C.c_float, C.c_int, vp]
         L.orbo_bow_transform.argtypes = [C.c_int] * 4 + [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int] + [vp] * 10
         L.orbo_distinctive_descriptors.argtypes = [vp, vp, C.c_int, vp]
         L.orbo_distinctive_descriptors.restype = None
@@ -369,3 +371,20 @@ def search_by_bow(kf_kps, kf_desc, kf_flags, kf_fv, f_kps, f_desc, f_fv, nnratio
                                   _p(f_kps), len(f_kps), _p(fd), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), nnratio,
                                   int(check_ori), _p(m))
     return nm, m[:len(f_kps)]
+
+
+def search_by_bow_keyframes(kps1, desc1, flags1, fv1, kps2, desc2, flags2, fv2, nnratio=0.8, check_ori=True):
+    """FMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (fmatcher.cpp:1100-1240) -> (nmatches, match12[n1])."""
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8)
+    d2 = np.ascontiguousarray(desc2, np.uint8)
+    f1 = np.ascontiguousarray(flags1, np.uint8)
+    f2 = np.ascontiguousarray(flags2, np.uint8)
+    a = [np.ascontiguousarray(fv1[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    b = [np.ascontiguousarray(fv2[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    m = np.full(max(len(kps1), 1), -1, np.int32)
+    nm = lib().orbo_search_by_bow_keyframes(_p(kps1), len(kps1), _p(d1), _p(f1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                            _p(kps2), len(kps2), _p(d2), _p(f2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                            nnratio, int(check_ori), _p(m))
+    return nm, m[:len(kps1)]

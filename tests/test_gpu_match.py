@@ -434,3 +434,27 @@ def test_search_by_bow_equals_oracle(fe, k, L, levelsup, ratio, ori):
         assert nm > 100 and np.all(flags[mf[mf >= 0]] == 1)
     finally:
         vv.close()
+
+
+def test_search_by_bow_keyframes_equals_oracle(fe):
+    """FMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (fmatcher.cpp:1100-1240): MapPoint flags on both sides,
+    strict threshold, result indexed by the first KeyFrame."""
+    voc = synth.make_vocabulary(10, 4, seed=23)
+    res = fe.compute_batch([synth.make_frame(1241, 376, step=s) for s in (3, 4)])
+    res = [(a.copy(), b.copy(), c) for a, b, c in res]
+    vv = V.Vocabulary(voc)
+    try:
+        vv.transform_slots_async(fe, 0, 2, 2)
+        bw = vv.transform_slots_wait([len(res[0][0]), len(res[1][0])])
+        rng = np.random.default_rng(9)
+        f1 = (rng.random(len(res[0][0])) < 0.7).astype(np.uint8)
+        f2 = (rng.random(len(res[1][0])) < 0.7).astype(np.uint8)
+        _, d1, _ = fe.slot_buffers(0)
+        _, d2, _ = fe.slot_buffers(1)
+        for ratio, ori in ((0.8, True), (0.6, False)):
+            nm, m12 = V.FMatcher(fe, ratio, ori).SearchByBoWKeyFrames(res[0][0], d1, f1, bw[0], res[1][0], d2, f2, bw[1])
+            wn, wm = orbo.search_by_bow_keyframes(res[0][0], res[0][1], f1, bw[0], res[1][0], res[1][1], f2, bw[1], ratio, ori)
+            assert nm == wn and np.array_equal(m12, wm)
+            assert nm > 50 and np.all(f1[m12 >= 0] == 1) and np.all(f2[m12[m12 >= 0]] == 1)
+    finally:
+        vv.close()

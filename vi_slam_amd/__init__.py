@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_dev_async", "vslam_search_by_projection_dev_wait", "vslam_stereo_points_dev_async",
     "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors", "vslam_voc_create", "vslam_voc_destroy",
     "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
-    "vslam_bow_assemble", "vslam_search_by_bow",
+    "vslam_bow_assemble", "vslam_search_by_bow", "vslam_search_by_bow_keyframes",
 ]
 
 
@@ -125,6 +125,8 @@ def lib():
         L.vslam_bow_transform_slots_async.argtypes = [vp, vp, i, i, i]
         L.vslam_bow_transform_slots_wait.argtypes = [vp, vp, vp, vp, vp]
         L.vslam_search_by_bow.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, C.c_float, i, vp, vp]
+        L.vslam_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i,
+                                                    C.c_float, i, vp, vp]
         L.vslam_bow_assemble.argtypes = [i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
@@ -612,6 +614,23 @@ class FMatcher:
                                          _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(self.mfNNratio),
                                          int(self.mbCheckOrientation), _p(m), C.byref(nm)))
         return nm.value, m[:len(f_kps)]
+
+    def SearchByBoWKeyFrames(self, kps1, dev_desc1, flags1, fv1, kps2, dev_desc2, flags2, fv2):
+        """FMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (fmatcher.cpp:1100-1240) -> (nmatches, match12[n1])."""
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        f1 = np.ascontiguousarray(flags1, np.uint8)
+        f2 = np.ascontiguousarray(flags2, np.uint8)
+        a = [np.ascontiguousarray(fv1[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        b = [np.ascontiguousarray(fv2[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        m = np.full(max(len(kps1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_bow_keyframes(self.fe._h, _p(kps1), C.c_void_p(dev_desc1), _p(f1), len(kps1), _p(a[0]),
+                                                   _p(a[1]), _p(a[2]), len(a[0]), _p(kps2), C.c_void_p(dev_desc2), _p(f2),
+                                                   len(kps2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                                   C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m),
+                                                   C.byref(nm)))
+        return nm.value, m[:len(kps1)]
 
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""

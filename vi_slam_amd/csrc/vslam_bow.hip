@@ -266,12 +266,16 @@ extern "C" int vslam_bow_transform_slots_wait(vslam_fe* fe, const int* n, int32_
 
 struct SbowArgs {
     const uint8_t *kfDesc, *fDesc, *kfFlags;
+    const uint8_t* fFlags; /* KeyFrame-KeyFrame overload: candidate must carry a good MapPoint; null otherwise */
+    int32_t strictTh;      /* KeyFrame-KeyFrame overload tests bestDist1 < TH_LOW, KeyFrame-Frame <= TH_LOW */
+    int32_t outByQuery;    /* 1: out[idx1] = idx2 (vpMatches12); 0: out[idxF] = idxKF (vpMapPointMatches) */
+    int32_t nOut;
     const float *kfAngle, *fAngle;
     const int32_t *kfNodes, *kfOff, *kfFeat, *fNodes, *fOff, *fFeat;
     int32_t nKFnodes, nFnodes, nF, checkOri;
     float nnratio;
-    int32_t* matchF;   /* nF, initialised to -1 by the kernel launch wrapper */
-    uint8_t* matchBin; /* nF */
+    int32_t* matchF;   /* nOut, initialised to -1 by the launch wrapper */
+    uint8_t* matchBin; /* nOut */
     int32_t* nmatches;
     int32_t* overflow;
 };
@@ -301,8 +305,9 @@ __global__ void __launch_bounds__(64) k_sbow_nodes(SbowArgs A) {
         const uint4 da = ((const uint4*)A.kfDesc)[(size_t)realIdxKF * 2], db = ((const uint4*)A.kfDesc)[(size_t)realIdxKF * 2 + 1];
         uint32_t k1 = 0xFFFFFFFFu, d2 = 256u; /* my best key, my second-best distance */
         for (int c = 0, b = lane; b < cF; c++, b += 64) {
-            if (occ & (1u << c)) continue; /* vpMapPointMatches[realIdxF] */
+            if (occ & (1u << c)) continue; /* vpMapPointMatches[realIdxF] / vbMatched2[idx2] */
             const int realIdxF = A.fFeat[f0 + b];
+            if (A.fFlags && !A.fFlags[realIdxF]) continue; /* !pMP2 || pMP2->isBad() */
             const uint4 ta = ((const uint4*)A.fDesc)[(size_t)realIdxF * 2], tb = ((const uint4*)A.fDesc)[(size_t)realIdxF * 2 + 1];
             const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
                                   __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
@@ -319,12 +324,14 @@ __global__ void __launch_bounds__(64) k_sbow_nodes(SbowArgs A) {
         const uint32_t contrib = (k1 == g) ? d2 : (k1 == 0xFFFFFFFFu ? 256u : min(k1 >> 16, 256u));
         const uint32_t second = wave_min_u32(contrib);
         const uint32_t bestDist1 = g >> 16;
-        if (bestDist1 <= SBOW_TH_LOW && (float)(int)bestDist1 < __fmul_rn(A.nnratio, (float)(int)second)) {
+        const bool under = A.strictTh ? bestDist1 < SBOW_TH_LOW : bestDist1 <= SBOW_TH_LOW;
+        if (under && (float)(int)bestDist1 < __fmul_rn(A.nnratio, (float)(int)second)) {
             const int bpos = (int)(g & 0xFFFFu);
             if ((bpos & 63) == lane) occ |= 1u << (bpos >> 6);
             if (lane == 0) {
                 const int bestIdxF = A.fFeat[f0 + bpos];
-                A.matchF[bestIdxF] = realIdxKF;
+                const int oi = A.outByQuery ? realIdxKF : bestIdxF;
+                A.matchF[oi] = A.outByQuery ? bestIdxF : realIdxKF;
                 uint8_t bin = 255;
                 if (A.checkOri) {
                     float rot = __fsub_rn(A.kfAngle[realIdxKF], A.fAngle[bestIdxF]);
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(64) k_sbow_nodes(SbowArgs A) {
                     if (bi == SBOW_HISTO) bi = 0;
                     bin = (uint8_t)bi;
                 }
-                A.matchBin[bestIdxF] = bin;
+                A.matchBin[oi] = bin;
             }
         }
     }
@@ -350,7 +357,7 @@ __global__ void __launch_bounds__(256) k_sbow_finish(SbowArgs A) {
     }
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < A.nF; i += 256)
+    for (int i = tid; i < A.nOut; i += 256)
         if (A.matchF[i] >= 0) {
             mine++;
             if (A.checkOri) atomicAdd(&s_hist[A.matchBin[i]], 1);
@@ -375,7 +382,7 @@ __global__ void __launch_bounds__(256) k_sbow_finish(SbowArgs A) {
         if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
         int rem = 0;
-        for (int i = tid; i < A.nF; i += 256)
+        for (int i = tid; i < A.nOut; i += 256)
             if (A.matchF[i] >= 0) {
                 const int b = A.matchBin[i];
                 if (b != ind1 && b != ind2 && b != ind3) {
@@ -394,21 +401,23 @@ __global__ void k_fill_i32(int32_t* p, int n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
-extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t* dev_kf_desc,
-                                   const uint8_t* kf_flags_host, int n_kf, const int32_t* kf_fv_nodes,
-                                   const int32_t* kf_fv_off, const int32_t* kf_fv_feat, int n_kf_nodes,
-                                   const vslam_kp* f_kps_host, const uint8_t* dev_f_desc, int n_f,
-                                   const int32_t* f_fv_nodes, const int32_t* f_fv_off, const int32_t* f_fv_feat,
-                                   int n_f_nodes, float nnratio, int check_orientation, int32_t* match_f,
-                                   int* nmatches) {
+static int search_by_bow_impl(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t* dev_kf_desc,
+                              const uint8_t* kf_flags_host, int n_kf, const int32_t* kf_fv_nodes,
+                              const int32_t* kf_fv_off, const int32_t* kf_fv_feat, int n_kf_nodes,
+                              const vslam_kp* f_kps_host, const uint8_t* dev_f_desc, const uint8_t* f_flags_host, int n_f,
+                              const int32_t* f_fv_nodes, const int32_t* f_fv_off, const int32_t* f_fv_feat,
+                              int n_f_nodes, float nnratio, int check_orientation, int kf_kf, int32_t* match_f,
+                              int* nmatches) {
+    const int n_out = kf_kf ? n_kf : n_f;
     if (!fe || n_kf < 0 || n_f < 0 || n_kf_nodes < 0 || n_f_nodes < 0 || !nmatches ||
-        (n_kf && (!kf_kps_host || !dev_kf_desc || !kf_flags_host)) || (n_f && (!f_kps_host || !dev_f_desc || !match_f)) ||
+        (n_kf && (!kf_kps_host || !dev_kf_desc || !kf_flags_host)) || (n_f && (!f_kps_host || !dev_f_desc)) ||
+        (n_out && !match_f) || (kf_kf && n_f && !f_flags_host) ||
         (n_kf_nodes && (!kf_fv_nodes || !kf_fv_off || !kf_fv_feat)) || (n_f_nodes && (!f_fv_nodes || !f_fv_off || !f_fv_feat))) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
     *nmatches = 0;
-    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    for (int i = 0; i < n_out; i++) match_f[i] = -1;
     if (n_kf == 0 || n_f == 0 || n_kf_nodes == 0 || n_f_nodes == 0) return VSLAM_OK;
     for (int j = 0; j < n_kf_nodes; j++)
         for (int a = kf_fv_off[j]; a < kf_fv_off[j + 1]; a++)
@@ -429,8 +438,8 @@ extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, co
                  o_kn = al(o_fa + (size_t)n_f * 4), o_ko = al(o_kn + (size_t)n_kf_nodes * 4),
                  o_kf = al(o_ko + (size_t)(n_kf_nodes + 1) * 4), o_fn = al(o_kf + (size_t)tk * 4),
                  o_fo = al(o_fn + (size_t)n_f_nodes * 4), o_ff = al(o_fo + (size_t)(n_f_nodes + 1) * 4),
-                 in_bytes = al(o_ff + (size_t)tf * 4);
-    const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n_f * 4), o_n = al(o_b + (size_t)n_f), total = o_n + 16;
+                 o_ffl = al(o_ff + (size_t)tf * 4), in_bytes = al(o_ffl + (size_t)n_f);
+    const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n_out * 4), o_n = al(o_b + (size_t)n_out), total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
     if (fe->h_proj_bytes < total) {
@@ -450,6 +459,7 @@ extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, co
     memcpy(h + o_fn, f_fv_nodes, (size_t)n_f_nodes * 4);
     memcpy(h + o_fo, f_fv_off, (size_t)(n_f_nodes + 1) * 4);
     memcpy(h + o_ff, f_fv_feat, (size_t)tf * 4);
+    if (f_flags_host) memcpy(h + o_ffl, f_flags_host, (size_t)n_f);
     hipStream_t st = fe->stream;
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -464,10 +474,12 @@ extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, co
     A.kfAngle = (const float*)(d + o_ka); A.fAngle = (const float*)(d + o_fa);
     A.kfNodes = (const int32_t*)(d + o_kn); A.kfOff = (const int32_t*)(d + o_ko); A.kfFeat = (const int32_t*)(d + o_kf);
     A.fNodes = (const int32_t*)(d + o_fn); A.fOff = (const int32_t*)(d + o_fo); A.fFeat = (const int32_t*)(d + o_ff);
+    A.fFlags = f_flags_host ? d + o_ffl : nullptr;
+    A.strictTh = kf_kf; A.outByQuery = kf_kf; A.nOut = n_out;
     A.nKFnodes = n_kf_nodes; A.nFnodes = n_f_nodes; A.nF = n_f; A.checkOri = check_orientation; A.nnratio = nnratio;
     A.matchF = (int32_t*)(d + o_m); A.matchBin = d + o_b; A.nmatches = (int32_t*)(d + o_n);
     A.overflow = (int32_t*)(d + o_n) + 1;
-    hipLaunchKernelGGL(k_fill_i32, dim3((n_f + 255) / 256), dim3(256), 0, st, A.matchF, n_f, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3((n_out + 255) / 256), dim3(256), 0, st, A.matchF, n_out, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, st, A.nmatches, 4, 0);
     hipLaunchKernelGGL(k_sbow_nodes, dim3(n_kf_nodes), dim3(64), 0, st, A);
     hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, A);
@@ -481,7 +493,31 @@ extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, co
         g_err = "SearchByBoW: more than 2048 frame features under one vocabulary node";
         return VSLAM_ERR_UNSUPPORTED;
     }
-    memcpy(match_f, h + o_m, (size_t)n_f * 4);
+    memcpy(match_f, h + o_m, (size_t)n_out * 4);
     *nmatches = *(const int32_t*)(h + o_n);
     return VSLAM_OK;
+}
+
+extern "C" int vslam_search_by_bow(vslam_fe* fe, const vslam_kp* kf_kps_host, const uint8_t* dev_kf_desc,
+                                   const uint8_t* kf_flags_host, int n_kf, const int32_t* kf_fv_nodes,
+                                   const int32_t* kf_fv_off, const int32_t* kf_fv_feat, int n_kf_nodes,
+                                   const vslam_kp* f_kps_host, const uint8_t* dev_f_desc, int n_f,
+                                   const int32_t* f_fv_nodes, const int32_t* f_fv_off, const int32_t* f_fv_feat,
+                                   int n_f_nodes, float nnratio, int check_orientation, int32_t* match_f,
+                                   int* nmatches) {
+    return search_by_bow_impl(fe, kf_kps_host, dev_kf_desc, kf_flags_host, n_kf, kf_fv_nodes, kf_fv_off, kf_fv_feat,
+                              n_kf_nodes, f_kps_host, dev_f_desc, nullptr, n_f, f_fv_nodes, f_fv_off, f_fv_feat, n_f_nodes,
+                              nnratio, check_orientation, 0, match_f, nmatches);
+}
+
+extern "C" int vslam_search_by_bow_keyframes(vslam_fe* fe, const vslam_kp* kps1_host, const uint8_t* dev_desc1,
+                                             const uint8_t* flags1_host, int n1, const int32_t* fv1_nodes,
+                                             const int32_t* fv1_off, const int32_t* fv1_feat, int n1_nodes,
+                                             const vslam_kp* kps2_host, const uint8_t* dev_desc2,
+                                             const uint8_t* flags2_host, int n2, const int32_t* fv2_nodes,
+                                             const int32_t* fv2_off, const int32_t* fv2_feat, int n2_nodes,
+                                             float nnratio, int check_orientation, int32_t* match12, int* nmatches) {
+    return search_by_bow_impl(fe, kps1_host, dev_desc1, flags1_host, n1, fv1_nodes, fv1_off, fv1_feat, n1_nodes, kps2_host,
+                              dev_desc2, flags2_host, n2, fv2_nodes, fv2_off, fv2_feat, n2_nodes, nnratio,
+                              check_orientation, 1, match12, nmatches);
 }
