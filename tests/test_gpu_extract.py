@@ -273,3 +273,31 @@ def test_two_host_threads_two_contexts_like_frame_ctor():
     finally:
         fl.close()
         fr.close()
+
+
+def test_randomised_geometries_and_parameters():
+    """Seeded sweep over image sizes, pyramid shapes, thresholds and feature counts (exercises the kernel
+    generation fallbacks: wide FAST cells, coarse scale factors, few levels); everything bit-exact vs the oracle."""
+    rng = np.random.default_rng(20250215)
+    done = 0
+    for trial in range(40):
+        w = int(rng.integers(200, 1400))
+        h = int(rng.integers(150, min(w, 800)))       # landscape (nIni >= 1)
+        nlevels = int(rng.integers(3, 9))
+        sf = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+        nf = int(rng.choice([80, 300, 1000, 2500]))
+        ini = int(rng.integers(10, 40))
+        mn = int(rng.integers(3, ini + 1))
+        try:
+            fe = V.FExtractor(nf, sf, nlevels, ini, mn, w, h)
+        except V.VslamError:
+            continue  # geometry rejected at create (smallest level too small): the reference would misbehave too
+        try:
+            img = synth.make_frame(w, h, seed=1000 + trial)
+            lap = (0, 0) if trial & 1 else (0, int(rng.integers(0, w)))
+            ref = orbo.Extractor(nf, scale=sf, nlevels=nlevels, ini_th=ini, min_th=mn).compute(img, lap=lap)
+            _assert_same(fe.compute(img, lap), ref, str((w, h, nlevels, sf, nf, ini, mn, lap)))
+            done += 1
+        finally:
+            fe.close()
+    assert done >= 25
