@@ -395,6 +395,22 @@ def main():
         for k, v in c.get_profile().items():
             prof[k] = prof.get(k, 0) + v
         c.set_profiling(False)
+    # After the timed region: the same extraction pass with NOTHING else on the GPU (one context, no matcher), so the
+    # dominant kernel's duration is also known without the other streams' workgroups inside its begin-to-end span.
+    alone = {}
+    if rank == 0:
+        torch.cuda.synchronize()
+        c0 = ctxs[0]
+        c0.set_profiling(True)
+        for _ in range(10):
+            if stereo:
+                c0.frame_stereo_async(ptrs, pitch, BF, FX)
+                c0.frame_stereo_wait()
+            else:
+                c0.compute_batch_async(ptrs, pitch, lap)
+                c0.wait()
+        alone = c0.get_profile()
+        c0.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -416,6 +432,14 @@ def main():
         tr = pmc_traffic(kernel, cfg, B)
         bytes_per_launch = ab[dom] * B / (7.0 if dom == "pyramid" else 1.0)
         achieved = bytes_per_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+        uncontended = None
+        if alone.get("batches"):
+            a_ms = alone[{"pyramid": "pyramid_ms", "fast": "fast_ms", "blur": "blur_ms", "describe": "describe_ms"}[dom]]
+            a_ms = a_ms / alone["batches"] / (7.0 if dom == "pyramid" else 1.0)
+            if a_ms > 0:
+                a_gbs = bytes_per_launch / (a_ms * 1e-3) / 1e9
+                uncontended = {"note": "same kernel, same batch, nothing else on the GPU (10 launches after the timed region)",
+                               "avg_launch_ms": a_ms, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS}
         out = {
             "metric": "frames/sec ORB extract+match",
             "value": value,
@@ -445,7 +469,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_detail": tr,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": per_launch[dom], "stage_ms_per_batch": stage_ms},
+                         "avg_launch_ms": per_launch[dom], "stage_ms_per_batch": stage_ms,
+                         "uncontended": uncontended},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
