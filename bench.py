@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="shift", choices=["shift", "allgather"],
+                    help="N>1 exchange step: ring shift (all_to_all_single, one non-empty split) or all-gather")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: take the N>1 code path (pack + ring shift on the extractor stream) at any world size")
     args = ap.parse_args()
@@ -250,6 +252,31 @@ def main():
     ring_in, ring_out = [0] * world, [0] * world
     ring_in[(rank + 1) % world] = B * slot_bytes
     ring_out[(rank - 1) % world] = B * slot_bytes
+    # Safety net: should this RCCL build reject the uneven all_to_all_single, the exchange falls back to an all-gather
+    # (world times the volume, same result); the left neighbour's block is then read out of the gathered buffer.
+    xchg = {"mode": args.exchange, "gathered": None}
+
+    def left_view(k):
+        """Tensor holding the left neighbour's packed slots of context k."""
+        if xchg["mode"] == "shift":
+            return from_left[k]
+        lo = ((rank - 1) % world) * B * slot_bytes
+        return xchg["gathered"][k][lo:lo + B * slot_bytes]
+
+    def exchange(k):
+        if xchg["mode"] == "shift":
+            try:
+                dist.all_to_all_single(from_left[k], packed[k], output_split_sizes=ring_out, input_split_sizes=ring_in)
+                return
+            except RuntimeError as e:  # pragma: no cover - depends on the collective library
+                if job_cache:
+                    raise
+                print("bench.py: all_to_all_single failed (%s); falling back to all_gather" % str(e).splitlines()[0],
+                      file=sys.stderr)
+                xchg["mode"] = "allgather"
+        if xchg["gathered"] is None:
+            xchg["gathered"] = [torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX)]
+        dist.all_gather_into_tensor(xchg["gathered"][k], packed[k])
     ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if multi else []
     state = {"matches": 0}
     torch.cuda.synchronize()
@@ -306,8 +333,7 @@ def main():
             if args.dist_backend == "nccl":
                 c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
                 with torch.cuda.stream(ext_streams[k]):  # the ring shift is ordered on c's own stream
-                    dist.all_to_all_single(from_left[k], packed[k], output_split_sizes=ring_out,
-                                           input_split_sizes=ring_in)
+                    exchange(k)
             else:  # gloo rehearsal: staged through the host, fully synchronous
                 c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=True)
                 vd.shift_slots(packed[k], from_left[k])
@@ -324,12 +350,12 @@ def main():
                 if prev_step:
                     if t == 0:
                         continue
-                    p = slot_ptrs_in(from_left[(t - 1) % NCTX], B - 1) if multi else prv.slot_dev_ptrs(B - 1)
+                    p = slot_ptrs_in(left_view((t - 1) % NCTX), B - 1) if multi else prv.slot_dev_ptrs(B - 1)
                     uses_prev_step = True
                 elif not multi:
                     p = c.slot_dev_ptrs(ps)
                 else:
-                    p = slot_ptrs_in(from_left[k], ps)  # pr == (rank - 1) % world always
+                    p = slot_ptrs_in(left_view(k), ps)  # pr == (rank - 1) % world always
                 q = c.slot_dev_ptrs(s)
                 jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
             job_cache[ck] = (V.FMatcher.make_init_jobs(jobs) if jobs else None, len(jobs), uses_prev_step)
