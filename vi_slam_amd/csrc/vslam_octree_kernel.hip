@@ -22,6 +22,8 @@
 #include "vslam_kernels.h"
 
 #define OT 1024
+#define OKPT 16  /* k_octree_v2: keys per thread kept in registers (problems up to 16384 keys) */
+#define OBATCH 8 /* k_octree_v2: keys per thread and batch when streaming a larger problem */
 typedef unsigned long long u64;
 
 struct ONode { /* 16 bytes, one entry of the list */
@@ -561,6 +563,51 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 
     STAMP();
 
+    /* Key walks.  A problem of up to OKPT * 1024 keys (every KITTI-size level) keeps its keys and their node labels in
+     * REGISTERS for the whole kernel: after this one read the walks touch no global memory at all.  Larger problems
+     * (1080p level 0: ~100 k keys) stream keys and labels through registers in batches of OBATCH per thread, all
+     * loads of a batch issued before the first use (one L2 round trip per batch instead of one per key). */
+    const bool inReg = n <= OKPT * OT;
+    uint32_t keyR[OKPT];
+    uint32_t nidR[OKPT];
+    if (inReg) {
+#pragma unroll
+        for (int k = 0; k < OKPT; k++) {
+            const int i = tid + k * OT;
+            keyR[k] = i < n ? pa[i] : 0u;
+            nidR[k] = 0u;
+        }
+    }
+    /* body(i, key, nid&): called once per key; writesNid: the walk changes labels */
+    auto walk = [&](auto body, bool writesNid) {
+        if (inReg) {
+#pragma unroll
+            for (int k = 0; k < OKPT; k++) {
+                const int i = tid + k * OT;
+                if (i < n) body(i, keyR[k], nidR[k]);
+            }
+        } else {
+            for (int base = tid; base < n; base += OBATCH * OT) {
+                uint32_t kk[OBATCH], nn[OBATCH];
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++) {
+                    const int i = base + j * OT;
+                    kk[j] = i < n ? pa[i] : 0u;
+                    nn[j] = i < n ? (uint32_t)na[i] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++) {
+                    const int i = base + j * OT;
+                    if (i < n) {
+                        const uint32_t before = nn[j];
+                        body(i, kk[j], nn[j]);
+                        if (writesNid && nn[j] != before) na[i] = (uint16_t)nn[j];
+                    }
+                }
+            }
+        }
+    };
+
     /* ---- 1. initial nodes: stable bucketing by (int)(x / hX) (fextractor.cpp:534-576) */
     const int nIni = P.nIni[level];
     const float hX = P.hX[level];
@@ -568,11 +615,16 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     __shared__ uint32_t s_bcnt[64], s_bidx[64];
     if (tid < 64) s_bcnt[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += OT) {
-        int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+    walk([&](int, uint32_t key, uint32_t&) {
+        int b = (int)__fdiv_rn((float)(key & 0xFFF), hX);
         b = min(b, nIni - 1);
-        atomicAdd(&s_bcnt[b], 1u);
-    }
+        /* a handful of buckets: one LDS atomic per bucket and wave instead of 64 colliding ones */
+        const int lane = tid & 63;
+        for (int j = 0; j < nIni; j++) {
+            const unsigned long long m = __ballot(b == j);
+            if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&s_bcnt[j], (uint32_t)__popcll(m));
+        }
+    }, false);
     __syncthreads();
     if (tid == 0) {
         int li = 0;
@@ -593,11 +645,12 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         s_size = li;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += OT) { /* keys never move: every key carries the list index of its node */
-        int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
+    walk([&](int i, uint32_t key, uint32_t& nid) { /* keys never move: every key carries the list index of its node */
+        int b = (int)__fdiv_rn((float)(key & 0xFFF), hX);
         b = min(b, nIni - 1);
-        na[i] = (uint16_t)s_bidx[b];
-    }
+        nid = s_bidx[b];
+        if (!inReg) na[i] = (uint16_t)nid; /* first label: always stored */
+    }, false);
     __syncthreads();
 
     STAMP();
@@ -612,15 +665,14 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (v < size0) Cnt[v] = 0ull;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = tid; i < n; i += OT) {
-            const int v = na[i];
+        walk([&](int, uint32_t key, uint32_t& nid) {
+            const int v = (int)nid;
             const ONode nd = cur[v];
             if (!ND_NOMORE(nd)) {
-                const int q = quadrant(pa[i], nd);
+                const int q = quadrant(key, nd);
                 if (q < 3) atomicAdd(&Cnt[v], 1ull << (FB * q));
             }
-        }
+        }, false);
         __syncthreads();
         STAMP();
         /* D. node level */
@@ -751,20 +803,19 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         __syncthreads();
         STAMP();
         /* E. relabel every key with the list index of the node that holds it after the pass */
-#pragma unroll 4
-        for (int i = tid; i < n; i += OT) {
-            const int v = na[i];
+        walk([&](int, uint32_t key, uint32_t& nid) {
+            const int v = (int)nid;
             const ONode nd = cur[v];
             if (ND_NOMORE(nd) || prank[v] >= ncut) {
-                na[i] = newIdx[v];
+                nid = newIdx[v];
             } else {
-                const int q = quadrant(pa[i], nd);
+                const int q = quadrant(key, nd);
                 const u64 c = Cnt[v];
                 int kq = 0;
                 for (int q2 = 0; q2 < q; q2++) kq += fld(c, q2) != 0;
-                na[i] = (uint16_t)(cb[v] - kq);
+                nid = (uint32_t)(cb[v] - kq);
             }
-        }
+        }, true);
         __syncthreads();
         { ONode* t = cur; cur = nxt; nxt = t; }
         STAMP();
@@ -782,9 +833,9 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     u64* best = Sbeg;
     for (int v = tid; v < size; v += OT) best[v] = 0ull;
     __syncthreads();
-#pragma unroll 4
-    for (int i = tid; i < n; i += OT)
-        atomicMax(&best[na[i]], ((u64)(pa[i] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+    walk([&](int i, uint32_t key, uint32_t& nid) {
+        atomicMax(&best[nid], ((u64)(key >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+    }, false);
     __syncthreads();
     for (int v = tid; v < size; v += OT) /* every listed node holds at least one key */
         out[v] = best[v] ? pa[0xFFFFFFFFu - (uint32_t)(best[v] & 0xFFFFFFFFull)] : 0u;
