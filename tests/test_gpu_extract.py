@@ -301,3 +301,29 @@ def test_randomised_geometries_and_parameters():
         finally:
             fe.close()
     assert done >= 25
+
+
+def test_host_image_with_row_padding_and_context_churn():
+    """Host images whose rows are padded (pitch > width) go through the pinned staging path row by row; creating and
+    destroying many contexts must neither fail nor disturb results."""
+    import ctypes as C
+    w, h = 500, 300
+    img = synth.make_frame(w, h, seed=77)
+    padded = np.zeros((h, 640), np.uint8)
+    padded[:, :w] = img
+    padded[:, w:] = 255  # garbage beyond the row end must never be read as image
+    ref = orbo.Extractor(400).compute(img)
+    for round_ in range(12):
+        fe = V.FExtractor(400, 1.2, 8, 20, 7, w, h)
+        try:
+            cap = fe.cap
+            kps = np.zeros(cap, V.KP_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            n, mono = C.c_int(), C.c_int()
+            rc = V.lib().vslam_fe_extract(fe._h, padded.ctypes.data_as(C.c_void_p), C.c_size_t(640), 0, 0,
+                                          kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                          C.byref(n), C.byref(mono))
+            assert rc == 0
+            _assert_same((kps[:n.value], desc[:n.value], mono.value), ref, "padded pitch, round %d" % round_)
+        finally:
+            fe.close()
