@@ -458,6 +458,8 @@ def main():
         tr = pmc_traffic(kernel, cfg, B)
         bytes_per_launch = ab[dom] * B / (7.0 if dom == "pyramid" else 1.0)
         achieved = bytes_per_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+        pipe_bytes = ab["pyramid"] + ab["fast"] + ab["blur"] + ab["describe"]
+        images_per_s = B * args.steps / dt  # this rank's images (stereo: two per frame)
         uncontended = None
         if alone.get("batches"):
             a_ms = alone[{"pyramid": "pyramid_ms", "fast": "fast_ms", "blur": "blur_ms", "describe": "describe_ms"}[dom]]
@@ -496,7 +498,11 @@ def main():
                          "traffic_detail": tr,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": per_launch[dom], "stage_ms_per_batch": stage_ms,
-                         "uncontended": uncontended},
+                         "uncontended": uncontended,
+                         # all extraction stages together, algorithmic bytes per image x images/s
+                         "pipeline": {"algorithmic_bytes_per_image": pipe_bytes,
+                                      "achieved": pipe_bytes * images_per_s / 1e9,
+                                      "frac": pipe_bytes * images_per_s / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
