@@ -186,6 +186,10 @@ struct vslam_fe {
     uint8_t* h_bow = nullptr;   /* pinned mirror */
     size_t h_bow_bytes = 0;
     int bow_jobs = 0;
+    bool use_graph = true;          /* host-image passes replay a captured HIP graph (VSLAM_GRAPH=0 disables) */
+    hipGraphExec_t graph_exec = nullptr;
+    long long graph_key = 0;
+    int graph_lap0 = 0, graph_lap1 = 0;
     uint8_t* h_img = nullptr;   /* pinned staging for host images: B x height x level-0 pitch */
     uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */
     size_t sbp_bytes = 0;

@@ -72,6 +72,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_mpflags);
     if (fe->h_proj) hipHostFree(fe->h_proj);
     if (fe->h_img) hipHostFree(fe->h_img);
+    if (fe->graph_exec) hipGraphExecDestroy(fe->graph_exec);
     hipFree(fe->d_bow);
     if (fe->h_bow) hipHostFree(fe->h_bow);
     hipFree(fe->d_init_fb);
@@ -313,6 +314,10 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
 
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
+    {
+        const char* e = getenv("VSLAM_GRAPH"); /* "0": never replay captured graphs */
+        fe->use_graph = !(e && !strcmp(e, "0"));
+    }
     fe->sel_level.resize((size_t)fe->B * p.nlevels);
     fe->cand_level.resize((size_t)fe->B * p.nlevels);
     unsigned hw = std::thread::hardware_concurrency();
@@ -498,28 +503,41 @@ static void decode_candidates(vslam_fe* fe, int s, int l) {
 }
 
 /* steps shared by both quadtree placements: level 0, pyramid, FAST */
-static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device) {
+/* host images: rows into pinned staging (a copy kernel pulls them into HBM afterwards).  hipMemcpy2DAsync from
+ * pageable memory took 2.8 ms per KITTI frame on this stack -- 90 % of a single-frame call. */
+static int stage_host_images(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch) {
     const vslam_fe_params& p = fe->p;
-    const int L = p.nlevels;
-    hipStream_t st = fe->stream;
+    const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
+    if (!fe->h_img) HIPCHK(hipHostMalloc((void**)&fe->h_img, img_bytes * fe->B, hipHostMallocDefault));
     for (int s = 0; s < nimg; s++) {
         if (!imgs[s]) {
             g_err = "null image";
             return VSLAM_ERR_INVALID;
         }
+        uint8_t* hs = fe->h_img + img_bytes * s;
+        if (pitch == lp) memcpy(hs, imgs[s], img_bytes - (lp - p.width));
+        else
+            for (int y = 0; y < p.height; y++) memcpy(hs + (size_t)y * lp, imgs[s] + (size_t)y * pitch, p.width);
+    }
+    return VSLAM_OK;
+}
+
+static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device) {
+    const vslam_fe_params& p = fe->p;
+    const int L = p.nlevels;
+    hipStream_t st = fe->stream;
+    for (int s = 0; s < nimg; s++) {
         if (on_device) {
+            if (!imgs[s]) {
+                g_err = "null image";
+                return VSLAM_ERR_INVALID;
+            }
             fe->src.l0[s] = imgs[s];
             fe->src.pitch0[s] = (uint32_t)pitch;
-        } else {
-            /* host image: rows into pinned staging, then a copy kernel pulls them into HBM.  (hipMemcpy2DAsync
-             * from pageable memory took 2.8 ms per KITTI frame on this stack -- 90 % of a single-frame call.) */
+        } else { /* staged by stage_host_images */
             uint8_t* d = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
             const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
-            if (!fe->h_img) HIPCHK(hipHostMalloc((void**)&fe->h_img, img_bytes * fe->B, hipHostMallocDefault));
             uint8_t* hs = fe->h_img + img_bytes * s;
-            if (pitch == lp) memcpy(hs, imgs[s], img_bytes - (lp - p.width));
-            else
-                for (int y = 0; y < p.height; y++) memcpy(hs + (size_t)y * lp, imgs[s] + (size_t)y * pitch, p.width);
             CopyRanges R;
             memset(&R, 0, sizeof(R));
             R.dst[0] = d;
@@ -718,9 +736,57 @@ void vslam_host_prof_report() {
     for (double& v : g_hp) v = 0;
 }
 
+static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                                 int lap0, int lap1, bool want_host);
+
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
                           int lap0, int lap1, bool want_host) {
     HIPCHK(hipSetDevice(fe->p.device));
+    if (!on_device) {
+        int rc = stage_host_images(fe, nimg, imgs, pitch);
+        if (rc) return rc;
+    }
+    /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
+     * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
+    const bool graphable = fe->use_graph && !on_device && fe->dev_octree && !fe->profiling;
+    if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
+    const long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
+                          (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24);
+    if (fe->graph_exec && fe->graph_key == key && fe->graph_lap0 == lap0 && fe->graph_lap1 == lap1) {
+        fe->last_nimg = nimg;
+        fe->cand_on_host = false;
+        HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
+        return VSLAM_OK;
+    }
+    if (fe->graph_exec) {
+        hipGraphExecDestroy(fe->graph_exec);
+        fe->graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(fe->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        fe->use_graph = false; /* capture unavailable: plain launches from now on */
+        return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
+    }
+    int rc = enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
+    const hipError_t ce = hipStreamEndCapture(fe->stream, &graph);
+    if (rc != VSLAM_OK || ce != hipSuccess || !graph ||
+        hipGraphInstantiate(&fe->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) hipGraphDestroy(graph);
+        fe->graph_exec = nullptr;
+        fe->use_graph = false;
+        if (rc != VSLAM_OK) return rc;
+        return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
+    }
+    hipGraphDestroy(graph);
+    fe->graph_key = key;
+    fe->graph_lap0 = lap0;
+    fe->graph_lap1 = lap1;
+    HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
+    return VSLAM_OK;
+}
+
+static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
+                                 int lap0, int lap1, bool want_host) {
     const double t0 = hp_now();
     int rc = enqueue_front(fe, nimg, imgs, pitch, on_device);
     if (rc) return rc;
