@@ -327,3 +327,25 @@ def test_host_image_with_row_padding_and_context_churn():
             _assert_same((kps[:n.value], desc[:n.value], mono.value), ref, "padded pitch, round %d" % round_)
         finally:
             fe.close()
+
+
+def test_small_geometries_are_rejected_or_exact():
+    """Tiny images / few levels: either vslam_fe_create refuses the geometry (no 30-px FAST cell fits anywhere -- the
+    reference divides by that count) or the result equals the oracle; never a failed launch."""
+    ok = rejected = 0
+    for (w, h) in [(64, 48), (80, 64), (100, 70), (128, 96), (160, 120), (97, 97), (200, 60), (400, 100), (70, 66)]:
+        for nl in (1, 2, 4, 8):
+            for nf in (20, 200):
+                try:
+                    fe = V.FExtractor(nf, 1.2, nl, 20, 7, w, h)
+                except V.VslamError as e:
+                    assert e.code in (-5, -1), e  # VSLAM_ERR_UNSUPPORTED / INVALID, with a message
+                    rejected += 1
+                    continue
+                try:
+                    img = synth.make_frame(w, h, seed=w * 7 + h)
+                    _assert_same(fe.compute(img), orbo.Extractor(nf, nlevels=nl).compute(img), str((w, h, nl, nf)))
+                    ok += 1
+                finally:
+                    fe.close()
+    assert ok >= 30 and rejected >= 20

@@ -184,6 +184,10 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         vslam::build_cells(l, fe->geom.lv[l].w, fe->geom.lv[l].h, fe->cells);
     }
     fe->level_cell_first[p.nlevels] = (int)fe->cells.size();
+    if (fe->cells.empty()) { /* (w-32)/30 or (h-32)/30 is 0 on every level: the reference divides by it (fextractor.cpp:772-778) */
+        g_err = "image too small: no 30-px FAST cell fits on any pyramid level";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
     int maxw = 8, maxh = 8;
     size_t cand_total = 0;
     std::vector<CellDesc> dc(fe->cells.size());
