@@ -458,3 +458,43 @@ def test_search_by_bow_keyframes_equals_oracle(fe):
             assert nm > 50 and np.all(f1[m12 >= 0] == 1) and np.all(f2[m12[m12 >= 0]] == 1)
     finally:
         vv.close()
+
+
+def test_empty_frames_through_every_entry_point():
+    """A flat image yields no keypoints; every matcher entry point must accept empty frames on either side (and a
+    pure-noise image must not overflow anything)."""
+    W, H = 640, 360
+    fe = V.FExtractor(500, 1.2, 8, 20, 7, W, H, max_batch=4)
+    flat = np.full((H, W), 127, np.uint8)
+    tex = synth.make_frame(W, H)
+    noise = np.random.default_rng(0).integers(0, 256, (H, W), dtype=np.uint8)
+    res = fe.compute_batch([flat, tex, noise, flat])
+    for s, im in enumerate([flat, tex, noise, flat]):
+        ref = orbo.Extractor(500).compute(im)
+        assert len(ref[0]) == len(res[s][0]) and np.array_equal(ref[1], res[s][1]), s
+    # stereo with an empty left / empty right
+    for (a, b) in [(0, 1), (1, 0), (0, 3), (2, 1)]:
+        u, d = V.ComputeStereoMatches(fe, a, fe, b, 386.0, 718.0)
+    m = V.FMatcher(fe, 0.9, True)
+    bufs = [fe.slot_buffers(s) for s in range(4)]
+    for (a, b) in [(0, 1), (1, 0), (0, 3), (1, 2)]:
+        k1, k2 = res[a][0], res[b][0]
+        prev = np.stack([k1["x"], k1["y"]], 1) if len(k1) else np.zeros((0, 2), np.float32)
+        nm, m12, pm = m.SearchForInitialization(k1, bufs[a][1], k2, bufs[b][1], prev, 100)
+        wn, wm, wp = orbo.search_for_initialization(k1, res[a][1], k2, res[b][1], W, H, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm), (a, b)
+    # device-resident jobs with empty frames
+    jobs = []
+    for (a, b) in [(0, 1), (1, 0), (0, 3), (1, 2)]:
+        p, c = fe.slot_dev_ptrs(a), fe.slot_dev_ptrs(b)
+        jobs.append((p[0], p[1], p[2], c[0], c[1], c[2], 0))
+    m.search_init_dev_async(jobs, 100)
+    out = m.search_init_dev_wait([len(res[a][0]) for a in (0, 1, 0, 1)])
+    # BoW on empty
+    voc = synth.make_vocabulary(10, 3)
+    vv = V.Vocabulary(voc)
+    vv.transform_slots_async(fe, 0, 4, 2)
+    bw = vv.transform_slots_wait([len(r[0]) for r in res])
+    nm, mf = m.SearchByBoW(res[0][0], bufs[0][1], np.zeros(0, np.uint8), bw[0], res[1][0], bufs[1][1], bw[1])
+    nm, mf = m.SearchByBoW(res[1][0], bufs[1][1], np.ones(len(res[1][0]), np.uint8), bw[1], res[0][0], bufs[0][1], bw[0])
+    vv.close(); fe.close()
