@@ -349,3 +349,31 @@ def test_small_geometries_are_rejected_or_exact():
                 finally:
                     fe.close()
     assert ok >= 30 and rejected >= 20
+
+
+@pytest.mark.parametrize("nf", [1000, 5000])
+def test_adversarial_patterns(nf):
+    """Checkerboards (massive score and size ties in the quadtree), binary noise (densest candidates), stripes and
+    gradients (no corners at all), isolated dots: bit-exact vs the oracle."""
+    W, H = 752, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    rng = np.random.default_rng(3)
+    imgs = {
+        "checker2": (((xx // 2 + yy // 2) & 1) * 255).astype(np.uint8),
+        "checker3": (((xx // 3 + yy // 3) & 1) * 255).astype(np.uint8),
+        "checker5": (((xx // 5 + yy // 5) & 1) * 255).astype(np.uint8),
+        "checker16": (((xx // 16 + yy // 16) & 1) * 255).astype(np.uint8),
+        "binary_noise": (rng.integers(0, 2, (H, W)) * 255).astype(np.uint8),
+        "salt": np.where(rng.random((H, W)) < 0.02, 255, 0).astype(np.uint8),
+        "stripes_v": ((xx // 4 & 1) * 200 + 20).astype(np.uint8),
+        "gradient": ((xx * 255) // W).astype(np.uint8),
+        "dots": np.where(((xx % 7) == 3) & ((yy % 7) == 3), 255, 30).astype(np.uint8),
+        "ramp_noise": np.clip((xx * 255) // W + rng.integers(-25, 26, (H, W)), 0, 255).astype(np.uint8),
+    }
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, W, H)
+    try:
+        e = orbo.Extractor(nf)
+        for name, im in imgs.items():
+            _assert_same(fe.compute(im), e.compute(im), name)
+    finally:
+        fe.close()
