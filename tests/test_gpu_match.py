@@ -498,3 +498,39 @@ def test_empty_frames_through_every_entry_point():
     nm, mf = m.SearchByBoW(res[0][0], bufs[0][1], np.zeros(0, np.uint8), bw[0], res[1][0], bufs[1][1], bw[1])
     nm, mf = m.SearchByBoW(res[1][0], bufs[1][1], np.ones(len(res[1][0]), np.uint8), bw[1], res[0][0], bufs[0][1], bw[0])
     vv.close(); fe.close()
+
+
+@pytest.mark.parametrize("pattern,disp", [("checker5", 23), ("checker16", 10), ("binary_noise", 0), ("dots", 10), ("blocks", 23)])
+def test_matchers_on_tie_heavy_patterns(pattern, disp):
+    """Periodic / binary images make Hamming and SAD ties the rule: 'first wins' and the window order must hold in
+    ComputeStereoMatches and SearchForInitialization."""
+    W, H = 752, 480
+    yy, xx = np.mgrid[0:H, 0:W + 64]
+    rng = np.random.default_rng(5)
+    base = {
+        "checker5": lambda: (((xx // 5 + yy // 5) & 1) * 255).astype(np.uint8),
+        "checker16": lambda: (((xx // 16 + yy // 16) & 1) * 255).astype(np.uint8),
+        "binary_noise": lambda: (rng.integers(0, 2, xx.shape) * 255).astype(np.uint8),
+        "dots": lambda: np.where(((xx % 7) == 3) & ((yy % 7) == 3), 255, 30).astype(np.uint8),
+        "blocks": lambda: rng.integers(0, 256, (H // 8 + 1, (W + 64) // 8 + 1)).repeat(8, 0).repeat(8, 1)[:H, :W + 64].astype(np.uint8),
+    }[pattern]()
+    L = np.ascontiguousarray(base[:, 32:32 + W])
+    R = np.ascontiguousarray(base[:, 32 + disp:32 + disp + W])
+    fe = V.FExtractor(1500, 1.2, 8, 20, 7, W, H, max_batch=2)
+    try:
+        res = fe.compute_batch([L, R])
+        res = [(k.copy(), d.copy(), mm) for k, d, mm in res]
+        u, dep = V.ComputeStereoMatches(fe, 0, fe, 1, 386.0, 718.0)
+        eL, eR = orbo.Extractor(1500), orbo.Extractor(1500)
+        kL, dL, _ = eL.compute(L)
+        kR, dR, _ = eR.compute(R)
+        wu, wd, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, 386.0, 718.0)
+        assert np.array_equal(u, wu) and np.array_equal(dep, wd)
+        _, p0, _ = fe.slot_buffers(0)
+        _, p1, _ = fe.slot_buffers(1)
+        prev = np.stack([res[0][0]["x"], res[0][0]["y"]], 1)
+        nm, m12, pm = V.FMatcher(fe, 0.9, True).SearchForInitialization(res[0][0], p0, res[1][0], p1, prev, 100)
+        wn, wm, wp = orbo.search_for_initialization(kL, dL, kR, dR, W, H, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp)
+    finally:
+        fe.close()
