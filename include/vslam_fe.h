@@ -31,7 +31,7 @@ extern "C" {
 #define VSLAM_ERR_UNSUPPORTED (-5) /* geometry the reference itself cannot process (e.g. nIni == 0) */
 
 #define VSLAM_MAX_LEVELS 16
-#define VSLAM_MAX_BATCH 32
+#define VSLAM_MAX_BATCH 64
 
 /* flags for vslam_fe_params.flags: OpenCV build-dependent arithmetic the reference inherits */
 #define VSLAM_FLAG_ATAN_FMA 1u /* cv::fastAtan2 Horner polynomial FMA-contracted (AVX2/FMA3 dispatch, aarch64) */
@@ -178,13 +178,13 @@ int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8
 int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, float bf, float fx, float* u_right,
                        float* depth);
 
-/* The same for npairs (<= 16) stereo pairs in one pass of the kernels: pair j = (feL slot slotsL[j],
+/* The same for npairs (<= 32) stereo pairs in one pass of the kernels: pair j = (feL slot slotsL[j],
  * feR slot slotsR[j]); u_right[j]/depth[j] are host arrays of that pair's left keypoint count. */
 int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL, const int* slotsR,
                              float bf, float fx, float* const* u_right, float* const* depth);
 
 /* The extraction + stereo-match section of Frame::Frame(imLeft, imRight, ...) (frame.cpp:102-132) for
- * npairs (<= 16, 2*npairs <= max_batch) stereo frames in ONE enqueue on fe's stream: imgs = L0,R0,L1,R1,...
+ * npairs (<= 32, 2*npairs <= max_batch) stereo frames in ONE enqueue on fe's stream: imgs = L0,R0,L1,R1,...
  * (slot 2j = left, 2j+1 = right of frame j; vLappingArea {0,0} as the reference passes, frame.cpp:107-108).
  * _async returns without waiting; _wait delivers keypoints/descriptors of all 2*npairs images (arrays of
  * 2*npairs entries, may be NULL) and mvuRight/mvDepth of the npairs left images. */

@@ -20,7 +20,7 @@ VSLAM_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 FLAG_ATAN_FMA = 1
 FLAG_HOST_OCTREE = 2
-MAX_BATCH = 32
+MAX_BATCH = 64
 
 #: numpy view of vslam_kp == cv::KeyPoint (28 bytes)
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),

@@ -80,7 +80,7 @@ struct StereoJob {
     const int32_t* cntR;
     int32_t slotL, slotR;
 };
-#define VSLAM_MAX_STEREO_JOBS 16
+#define VSLAM_MAX_STEREO_JOBS 32
 struct StereoJobs {
     StereoJob job[VSLAM_MAX_STEREO_JOBS];
 };
@@ -94,7 +94,7 @@ struct MatJob {
     uint32_t q_off, t_off;       /* row offsets of the gathered descriptors in the scratch buffer */
     size_t out_off;              /* byte offset of this pair's nr x nc matrix */
 };
-#define VSLAM_MAX_MAT_JOBS 32
+#define VSLAM_MAX_MAT_JOBS 64
 struct MatJobs {
     MatJob job[VSLAM_MAX_MAT_JOBS];
 };
