@@ -225,6 +225,8 @@ def main():
     B = args.batch
     if stereo and B % 2:
         B += 1
+    if track:
+        B = min(B, 32)  # one SearchByProjection pass takes up to 16 frame pairs
     NCTX = max(3, args.inflight)  # extractor contexts (streams) kept in flight per GPU
     ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B) for _ in range(NCTX)]
     fe = ctxs[0]
