@@ -140,7 +140,7 @@ int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx);
 void* vslam_fe_stream(vslam_fe* fe);
 
 /* Pack the results of slots 0..nslots-1 into caller device memory (e.g. this rank's send buffer of an
- * RCCL all-gather): per slot `slot_bytes` >= 16 + cap*60 laid out as
+ * RCCL exchange): per slot `slot_bytes` >= 16 + cap*60 laid out as
  *   int32 n, mono_index, cap, 0 | vslam_kp[cap] | uint8 desc[cap][32]      (cap = vslam_fe_capacity(fe))
  * Returns after the copies have completed. */
 int vslam_fe_pack_slots(vslam_fe* fe, int nslots, void* dev_dst, size_t slot_bytes);
@@ -195,7 +195,7 @@ int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* 
 
 /* FMatcher::SearchForInitialization (fmatcher.h:106, fmatcher.cpp:983-1098).  Frame 1 / frame 2
  * keypoints+descriptors are device arrays (e.g. from vslam_fe_slot_buffers, or a slot of an RCCL
- * all-gather buffer); kps1_host/kps2_host are the same keypoints on the host.  prev_matched: 2*n1 floats
+ * exchange buffer); kps1_host/kps2_host are the same keypoints on the host.  prev_matched: 2*n1 floats
  * in/out (vbPrevMatched).  matches12: n1 ints out.  Returns the match count in *nmatches. */
 int vslam_search_for_initialization(vslam_fe* fe, const vslam_kp* kps1_host, const uint8_t* dev_desc1,
                                     int n1, const vslam_kp* kps2_host, const uint8_t* dev_desc2, int n2,
@@ -213,7 +213,7 @@ int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, const vslam_
                                           int check_orientation, int* nmatches);
 
 /* Device-resident form: every pointer of a job is a DEVICE pointer -- keypoints/descriptors as returned by
- * vslam_fe_slot_buffers (or a slot of an RCCL all-gather buffer packed by vslam_fe_pack_slots), the keypoint
+ * vslam_fe_slot_buffers (or a slot of an RCCL exchange buffer packed by vslam_fe_pack_slots), the keypoint
  * counts as int32 in HBM (vslam_fe_slot_count_ptr, or the header word of a packed slot).  The whole matcher
  * (window query, Hamming distances, stealing, ratio test, rotation histogram) runs in one kernel, one wave per
  * pair, on fe's stream; _async returns without waiting, _wait delivers n1[j] entries of vnMatches12 and the

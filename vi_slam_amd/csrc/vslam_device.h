@@ -173,7 +173,7 @@ struct CopyRanges {
     int n;
 };
 
-/* One (frame 1, frame 2) problem of k_search_init; every pointer is a device pointer. */
+/* One (frame 1, frame 2) problem of k_si_topm / k_si_replay; every pointer is a device pointer. */
 struct InitJob {
     const vslam_kp* k1;
     const uint8_t* d1;

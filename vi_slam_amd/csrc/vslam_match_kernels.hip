@@ -351,7 +351,7 @@ void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int
 }
 
 /* ------------------------------------------------------------------------------------------------
- * pack result slots for an RCCL all-gather: per slot  int32 n, mono, cap, 0 | vslam_kp[cap] | desc[cap][32].
+ * pack result slots for the RCCL exchange (ring shift, vi_slam_amd/dist.py): per slot  int32 n, mono, cap, 0 | vslam_kp[cap] | desc[cap][32].
  * Counts are read from HBM, so packing can be enqueued before the host knows them.
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
