@@ -371,10 +371,64 @@ int vslam_search_by_bow_keyframes(vslam_fe* fe, const vslam_kp* kps1_host, const
                                   const int32_t* fv2_nodes, const int32_t* fv2_off, const int32_t* fv2_feat,
                                   int n2_nodes, float nnratio, int check_orientation, int32_t* match12, int* nmatches);
 
+/* FMatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (fmatcher.cpp:1242-1482)
+ * and its cv::Matx twin SearchForTriangulation_ (:1484-1725, the one LocalMapping::CreateNewMapPoints calls,
+ * localmapping.cpp:447) for pinhole KeyFrames without a second camera.  F12 is the matrix
+ * Pinhole::epipolarConstrain builds for the pair, K1^-T [t12]x R12 K2^-1 (pinhole.cpp:121-127, row-major; it does
+ * not depend on the keypoints, so the caller computes it once with its own cv::Mat algebra); (ep_x, ep_y) is the
+ * epipole pKF2->mpCamera->project(R2w*Cw + t2w) (fmatcher.cpp:1249-1254).  kps*_host are mvKeysUn, has_mp*[i] != 0
+ * iff GetMapPoint(i) != NULL, u_right* are mvuRight; FeatureVectors as produced by vslam_bow_assemble; the scale
+ * tables of pKF2 are the context's (vslam_fe_tables).  match12[idx1] = idx2 or -1 -- vMatchedPairs is the list of
+ * (idx1, match12[idx1]) with match12[idx1] >= 0 in ascending idx1; the reference never marks KeyFrame-2 features
+ * as taken, so an idx2 may appear more than once.  *nmatches as the reference returns it. */
+typedef struct vslam_tri_params {
+    float F12[9];
+    float ep_x, ep_y;
+    int32_t only_stereo, coarse, check_orientation;
+} vslam_tri_params;
+int vslam_search_for_triangulation(vslam_fe* fe, const vslam_tri_params* p, const vslam_kp* kps1_host,
+                                   const uint8_t* dev_desc1, const uint8_t* has_mp1_host, const float* u_right1_host,
+                                   int n1, const int32_t* fv1_nodes, const int32_t* fv1_off, const int32_t* fv1_feat,
+                                   int n1_nodes, const vslam_kp* kps2_host, const uint8_t* dev_desc2,
+                                   const uint8_t* has_mp2_host, const float* u_right2_host, int n2,
+                                   const int32_t* fv2_nodes, const int32_t* fv2_off, const int32_t* fv2_feat,
+                                   int n2_nodes, int32_t* match12, int* nmatches);
+
+/* The search half of FMatcher::Fuse(pKF, vpMapPoints, th, bRight = false) (fmatcher.cpp:1918-2119) and of
+ * Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:2121-2243; sim3 = 1, Rcw/tcw/Ow as the function derives them from
+ * Scw at :2130-2134): for every MapPoint the projection gates, MapPoint::PredictScale, the window of
+ * KeyFrame::GetFeaturesInArea and the keypoint with the least descriptor distance (first of the window order wins).
+ * best_idx[i] = -1 (best_dist[i] = 256) when a gate rejects the point or no keypoint passes; distances above 255 are
+ * reported as 255.  The caller walks the results in order and does what the reference does when
+ * best_dist[i] <= TH_LOW (50): Replace / AddObservation + AddMapPoint / vpReplacePoint -- re-checking isBad() and
+ * IsInKeyFrame() at that moment, because those are the only inputs an earlier iteration can change.
+ * valid = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF) when the call is made. */
+typedef struct vslam_fuse_point {
+    float pos[3];       /* GetWorldPos() */
+    float normal[3];    /* GetNormal() */
+    float min_distance; /* GetMinDistanceInvariance() */
+    float max_distance; /* GetMaxDistanceInvariance() */
+    int32_t valid;
+} vslam_fuse_point;
+typedef struct vslam_fuse_params {
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy, bf, th;
+    float log_scale_factor; /* pKF->mfLogScaleFactor */
+    int32_t img_w, img_h;   /* mnMaxX, mnMaxY (mnMinX = mnMinY = 0: undistorted pinhole images) */
+    int32_t sim3;
+    int32_t gemm_float;     /* as in vslam_proj_params */
+} vslam_fuse_params;
+int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const vslam_fuse_point* points_host,
+                      const uint8_t* mp_desc_host, int n_points, const vslam_kp* dev_kf_kps,
+                      const uint8_t* dev_kf_desc, int n_kf, const float* kf_u_right_host, int32_t* best_idx,
+                      int32_t* best_dist);
+
 /* Evaluate the device float helpers on host arrays (round trip through HBM): the glibc-exact sinf/cosf
  * used for the rBRIEF rotation (fextractor.cpp:103-104) and cv::fastAtan2 (fextractor.cpp:94). */
 int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float* cos_out);
 int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, int fma, float* deg);
+/* glibc logf as MapPoint::PredictScale uses it (mappoint.cpp:514); normal positive inputs, NaN otherwise */
+int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y);
 /* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
  * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */
 int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);

@@ -1202,6 +1202,207 @@ int search_by_bow_keyframes(const std::vector<KeyPoint>& vKeysUn1, const std::ve
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ glibc logf */
+float glibc_logf(float x) {
+    static const struct { double invc, logc; } T[16] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+        {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    static const double Ln2 = 0x1.62e42fefa39efp-1;
+    static const double A[3] = {-0x1.00ea348b88334p-2, 0x1.5575b0be00b6ap-2, -0x1.ffffef20a4123p-2};
+    uint32_t ix;
+    memcpy(&ix, &x, 4);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) { /* 0, inf, nan, negative, subnormal */
+        if (ix * 2 == 0) return -INFINITY;
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;
+        const float xs = x * 0x1p23f;
+        memcpy(&ix, &xs, 4);
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) % 16);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    float zf;
+    memcpy(&zf, &iz, 4);
+    const double z = (double)zf;
+    const double r = z * T[i].invc - 1;
+    const double y0 = T[i].logc + (double)k * Ln2;
+    const double r2 = r * r;
+    double y = A[1] * r + A[2];
+    y = A[0] * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+/* ------------------------------------------------------------------ FMatcher::SearchForTriangulation */
+int search_for_triangulation(const std::vector<KeyPoint>& vKeysUn1, const std::vector<uint8_t>& Descriptors1,
+                             const std::vector<uint8_t>& hasMp1, const std::vector<float>& mvuRight1,
+                             const std::vector<int>& nodes1, const std::vector<int>& off1, const std::vector<int>& feat1,
+                             const std::vector<KeyPoint>& vKeysUn2, const std::vector<uint8_t>& Descriptors2,
+                             const std::vector<uint8_t>& hasMp2, const std::vector<float>& mvuRight2,
+                             const std::vector<int>& nodes2, const std::vector<int>& off2, const std::vector<int>& feat2,
+                             const std::vector<float>& mvScaleFactors2, const std::vector<float>& mvLevelSigma2_2,
+                             const TriArgs& A, std::vector<int>& vMatches12) { /* fmatcher.cpp:1242-1482 */
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    const float* F12 = A.F12;
+    int nmatches = 0;
+    vMatches12.assign(vKeysUn1.size(), -1);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    size_t f1it = 0, f2it = 0;
+    while (f1it != nodes1.size() && f2it != nodes2.size()) {
+        if (nodes1[f1it] == nodes2[f2it]) {
+            for (int i1 = off1[f1it]; i1 < off1[f1it + 1]; i1++) {
+                const int idx1 = feat1[i1];
+                if (hasMp1[idx1]) continue; /* :1313 */
+                const bool bStereo1 = mvuRight1[idx1] >= 0; /* !mpCamera2 && ... :1318 */
+                if (A.onlyStereo && !bStereo1) continue;
+                const KeyPoint& kp1 = vKeysUn1[idx1];
+                const uint8_t* d1 = &Descriptors1[32 * (size_t)idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = off2[f2it]; i2 < off2[f2it + 1]; i2++) {
+                    const int idx2 = feat2[i2];
+                    if (hasMp2[idx2]) continue; /* vbMatched2 stays false throughout, :1344 */
+                    const bool bStereo2 = mvuRight2[idx2] >= 0;
+                    if (A.onlyStereo && !bStereo2) continue;
+                    const int dist = descriptor_distance(d1, &Descriptors2[32 * (size_t)idx2]);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = vKeysUn2[idx2];
+                    if (!bStereo1 && !bStereo2) { /* :1366-1374 */
+                        const float distex = A.epx - kp2.x;
+                        const float distey = A.epy - kp2.y;
+                        if (distex * distex + distey * distey < 100 * mvScaleFactors2[kp2.octave]) continue;
+                    }
+                    bool ok = A.coarse != 0;
+                    if (!ok) { /* Pinhole::epipolarConstrain, pinhole.cpp:128-142 */
+                        const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                        const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                        const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                        const float num = a * kp2.x + b * kp2.y + c;
+                        const float den = a * a + b * b;
+                        if (den != 0) {
+                            const float dsqr = num * num / den;
+                            ok = dsqr < 3.84 * mvLevelSigma2_2[kp2.octave];
+                        }
+                    }
+                    if (ok) {
+                        bestIdx2 = idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (A.checkOri) {
+                        float rot = kp1.angle - vKeysUn2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (nodes1[f1it] < nodes2[f2it]) {
+            f1it = std::lower_bound(nodes1.begin(), nodes1.end(), nodes2[f2it]) - nodes1.begin();
+        } else {
+            f2it = std::lower_bound(nodes2.begin(), nodes2.end(), nodes1[f1it]) - nodes2.begin();
+        }
+    }
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) {
+                vMatches12[idx] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------ FMatcher::Fuse, search half */
+void fuse_search(const std::vector<FusePoint>& pts, const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& kfKps,
+                 const std::vector<uint8_t>& kfDesc, const std::vector<float>& mvuRight,
+                 const std::vector<float>& mvScaleFactors, const std::vector<float>& mvInvLevelSigma2, const FuseArgs& A,
+                 std::vector<int>& bestIdxOut, std::vector<int>& bestDistOut) { /* fmatcher.cpp:1953-2090, :2144-2222 */
+    const int nMPs = (int)pts.size();
+    bestIdxOut.assign(nMPs, -1);
+    bestDistOut.assign(nMPs, 256);
+    FrameGrid grid(kfKps, A.imgW, A.imgH); /* KeyFrame copies the Frame's grid, keyframe.cpp:40-60 */
+    const int mnScaleLevels = (int)mvScaleFactors.size();
+    for (int i = 0; i < nMPs; i++) {
+        const FusePoint& mp = pts[i];
+        if (!mp.valid) continue;
+        const float* p3Dw = mp.pos;
+        const float xc = gemm_row(A.Rcw + 0, p3Dw, A.tcw[0], A.gemmDouble); /* Rcw*p3Dw + tcw */
+        const float yc = gemm_row(A.Rcw + 3, p3Dw, A.tcw[1], A.gemmDouble);
+        const float zc = gemm_row(A.Rcw + 6, p3Dw, A.tcw[2], A.gemmDouble);
+        if (zc < 0.0f) continue;
+        const float invz = 1 / zc;
+        const float u = A.fx * xc / zc + A.cx; /* Pinhole::project, pinhole.cpp:13-16 */
+        const float v = A.fy * yc / zc + A.cy;
+        if (!(u >= 0.0f && u < (float)A.imgW && v >= 0.0f && v < (float)A.imgH)) continue; /* KeyFrame::IsInImage */
+        const float ur = u - A.bf * invz;
+        const float PO[3] = {p3Dw[0] - A.Ow[0], p3Dw[1] - A.Ow[1], p3Dw[2] - A.Ow[2]};
+        double n2 = 0; /* cv::norm(NORM_L2) on CV_32F accumulates in double */
+        for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+        const float dist3D = (float)std::sqrt(n2);
+        if (dist3D < mp.minDistance || dist3D > mp.maxDistance) continue;
+        double dot = 0; /* cv::Mat::dot on CV_32F accumulates in double */
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)mp.normal[k];
+        if (dot < 0.5 * dist3D) continue;
+        const float ratio = mp.maxDistance / dist3D; /* MapPoint::PredictScale, mappoint.cpp:506-521 */
+        /* `int nScale = ceil(...)`: out-of-range and NaN conversions are what cvttss2si returns on the reference's
+         * x86-64 build (INT_MIN), spelled out here instead of relying on undefined behaviour */
+        const float lv = std::ceil(glibc_logf(ratio) / A.logScaleFactor);
+        int nPredictedLevel = (lv != lv || lv >= 2147483648.0f || lv < -2147483648.0f) ? INT_MIN : (int)lv;
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= mnScaleLevels) nPredictedLevel = mnScaleLevels - 1;
+        const float radius = A.th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = &mpDesc[32 * (size_t)i];
+        int bestDist = A.sim3 ? INT_MAX : 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            const KeyPoint& kp = kfKps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (!A.sim3) {
+                if (mvuRight[idx] >= 0) { /* :2053-2066 */
+                    const float ex = u - kp.x, ey = v - kp.y, er = ur - mvuRight[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * mvInvLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp.x, ey = v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * mvInvLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(dMP, &kfDesc[32 * (size_t)idx]);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestIdx >= 0) {
+            bestIdxOut[i] = bestIdx;
+            bestDistOut[i] = bestDist;
+        }
+    }
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -203,6 +203,54 @@ bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float 
 /* bForward / bBackward of the same function (fmatcher.cpp:2482-2495) */
 void projection_direction(const ProjFrameArgs& a, bool& bForward, bool& bBackward);
 
+/* glibc logf (sysdeps/ieee754/flt-32/e_logf.c with its 16-entry table, glibc 2.35): `log(ratio)` on a float under
+ * `using namespace std` (mappoint.cpp:11,514) is std::log(float) = logf.  The restatement was compared against the
+ * platform libm for every positive finite float (tests/test_oracle.py samples it again). */
+float glibc_logf(float x);
+
+/* FMatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (fmatcher.cpp:1242-1482;
+ * SearchForTriangulation_ :1484-1725 is the same walk on cv::Matx) for pinhole KeyFrames without a second camera
+ * (mpCamera2 == NULL, NLeft == -1).  hasMp[i] != 0 iff GetMapPoint(i) != NULL; F12 is the matrix
+ * Pinhole::epipolarConstrain builds for the pair (pinhole.cpp:121-143; it does not depend on the keypoints), ep the
+ * epipole pKF2->mpCamera->project(R2w*Cw+t2w).  match12[idx1] = idx2 or -1 (vbMatched2 is never set in the
+ * reference, so two idx1 may share an idx2).  Returns nmatches. */
+struct TriArgs {
+    float F12[9];
+    float epx, epy;
+    int onlyStereo, coarse, checkOri;
+};
+int search_for_triangulation(const std::vector<KeyPoint>& kps1, const std::vector<uint8_t>& desc1,
+                             const std::vector<uint8_t>& hasMp1, const std::vector<float>& uRight1,
+                             const std::vector<int>& nodes1, const std::vector<int>& off1, const std::vector<int>& feat1,
+                             const std::vector<KeyPoint>& kps2, const std::vector<uint8_t>& desc2,
+                             const std::vector<uint8_t>& hasMp2, const std::vector<float>& uRight2,
+                             const std::vector<int>& nodes2, const std::vector<int>& off2, const std::vector<int>& feat2,
+                             const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2,
+                             const TriArgs& a, std::vector<int>& match12);
+
+/* The search half of FMatcher::Fuse (fmatcher.cpp:1918-2119 with bRight = false, and the Sim3 overload
+ * :2121-2243): per MapPoint the projection gates, MapPoint::PredictScale (mappoint.cpp:506-521),
+ * KeyFrame::GetFeaturesInArea (keyframe.cpp:656-699) and the best keypoint of the window.  What the reference does
+ * with the result (Replace / AddObservation / vpReplacePoint) mutates the map and stays with the caller.
+ * bestIdx[i] = -1 when a gate rejects the point or no keypoint of the window passes; bestDist[i] = 256 then. */
+struct FusePoint {
+    float pos[3];    /* GetWorldPos() */
+    float normal[3]; /* GetNormal() */
+    float minDistance, maxDistance; /* Get{Min,Max}DistanceInvariance() */
+    int valid;       /* pMP && !isBad() && !IsInKeyFrame(pKF) (Sim3: !isBad() && !spAlreadyFound.count(pMP)) */
+};
+struct FuseArgs {
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy, bf, th, logScaleFactor;
+    int imgW, imgH; /* mnMaxX, mnMaxY; mnMinX = mnMinY = 0 */
+    int sim3;       /* 1: no chi2 gate (fmatcher.cpp:2205-2222) */
+    int gemmDouble;
+};
+void fuse_search(const std::vector<FusePoint>& pts, const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& kfKps,
+                 const std::vector<uint8_t>& kfDesc, const std::vector<float>& kfURight,
+                 const std::vector<float>& scaleFactors, const std::vector<float>& invLevelSigma2, const FuseArgs& a,
+                 std::vector<int>& bestIdx, std::vector<int>& bestDist);
+
 } // namespace orbo
 
 #endif

@@ -270,6 +270,51 @@ int orbo_search_by_bow_keyframes(const KeyPoint* kps1, int n1, const uint8_t* de
     return nm;
 }
 
+float orbo_logf(float x) { return glibc_logf(x); }
+
+int orbo_search_for_triangulation(const KeyPoint* kps1, int n1, const uint8_t* desc1, const uint8_t* hasMp1,
+                                  const float* uRight1, const int* nodes1, const int* off1, const int* feat1, int nn1,
+                                  const KeyPoint* kps2, int n2, const uint8_t* desc2, const uint8_t* hasMp2,
+                                  const float* uRight2, const int* nodes2, const int* off2, const int* feat2, int nn2,
+                                  const float* scaleFactors2, const float* levelSigma2_2, int nlevels, const float* F12,
+                                  float epx, float epy, int onlyStereo, int coarse, int checkOri, int* match12) {
+    std::vector<KeyPoint> k1(kps1, kps1 + n1), k2(kps2, kps2 + n2);
+    std::vector<uint8_t> d1(desc1, desc1 + (size_t)n1 * 32), d2(desc2, desc2 + (size_t)n2 * 32), f1(hasMp1, hasMp1 + n1),
+        f2(hasMp2, hasMp2 + n2);
+    std::vector<float> u1(uRight1, uRight1 + n1), u2(uRight2, uRight2 + n2), sf(scaleFactors2, scaleFactors2 + nlevels),
+        ls(levelSigma2_2, levelSigma2_2 + nlevels);
+    std::vector<int> a1(nodes1, nodes1 + nn1), o1(off1, off1 + nn1 + 1), e1(feat1, feat1 + off1[nn1]);
+    std::vector<int> a2(nodes2, nodes2 + nn2), o2(off2, off2 + nn2 + 1), e2(feat2, feat2 + off2[nn2]);
+    TriArgs A;
+    memcpy(A.F12, F12, sizeof(A.F12));
+    A.epx = epx;
+    A.epy = epy;
+    A.onlyStereo = onlyStereo;
+    A.coarse = coarse;
+    A.checkOri = checkOri;
+    std::vector<int> m;
+    const int nm = search_for_triangulation(k1, d1, f1, u1, a1, o1, e1, k2, d2, f2, u2, a2, o2, e2, sf, ls, A, m);
+    if (n1) memcpy(match12, m.data(), (size_t)n1 * sizeof(int));
+    return nm;
+}
+
+/* pts: n x {pos[3], normal[3], minDistance, maxDistance (float), valid (int)} = 36 bytes; args: FuseArgs */
+void orbo_fuse_search(const FusePoint* pts, int n, const uint8_t* mpDesc, const KeyPoint* kfKps, int nKF,
+                      const uint8_t* kfDesc, const float* kfURight, const float* scaleFactors,
+                      const float* invLevelSigma2, int nlevels, const FuseArgs* args, int* bestIdx, int* bestDist) {
+    std::vector<FusePoint> p(pts, pts + n);
+    std::vector<uint8_t> md(mpDesc, mpDesc + (size_t)n * 32), kd(kfDesc, kfDesc + (size_t)nKF * 32);
+    std::vector<KeyPoint> kk(kfKps, kfKps + nKF);
+    std::vector<float> ur(kfURight, kfURight + nKF), sf(scaleFactors, scaleFactors + nlevels),
+        is(invLevelSigma2, invLevelSigma2 + nlevels);
+    std::vector<int> bi, bd;
+    fuse_search(p, md, kk, kd, ur, sf, is, *args, bi, bd);
+    if (n) {
+        memcpy(bestIdx, bi.data(), (size_t)n * sizeof(int));
+        memcpy(bestDist, bd.data(), (size_t)n * sizeof(int));
+    }
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

@@ -79,6 +79,13 @@ def lib():
         L.orbo_unproject_stereo.restype = None
         L.orbo_search_by_projection_frame.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp,
                                                       C.c_int, vp, vp]
+        L.orbo_logf.restype = C.c_float
+        L.orbo_logf.argtypes = [C.c_float]
+        L.orbo_search_for_triangulation.argtypes = ([vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int] * 2 +
+                                                    [vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                     C.c_int, vp])
+        L.orbo_fuse_search.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+        L.orbo_fuse_search.restype = None
         _lib = L
     return _lib
 
@@ -388,3 +395,70 @@ def search_by_bow_keyframes(kps1, desc1, flags1, fv1, kps2, desc2, flags2, fv2, 
                                             _p(kps2), len(kps2), _p(d2), _p(f2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
                                             nnratio, int(check_ori), _p(m))
     return nm, m[:len(kps1)]
+
+
+FUSE_POINT_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"),
+                             ("max_distance", "<f4"), ("valid", "<i4")])
+assert FUSE_POINT_DTYPE.itemsize == 36
+
+
+class _FuseArgs(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float),
+                ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("th", C.c_float),
+                ("logScaleFactor", C.c_float), ("imgW", C.c_int), ("imgH", C.c_int), ("sim3", C.c_int),
+                ("gemmDouble", C.c_int)]
+
+
+def logf(x):
+    """glibc logf restated (orbo::glibc_logf)."""
+    return float(lib().orbo_logf(C.c_float(x)))
+
+
+def search_for_triangulation(kps1, desc1, has_mp1, u_right1, fv1, kps2, desc2, has_mp2, u_right2, fv2, scale_factors2,
+                             level_sigma2_2, F12, ep, only_stereo=False, coarse=False, check_ori=True):
+    """FMatcher::SearchForTriangulation (fmatcher.cpp:1242-1482, pinhole, no second camera)
+    -> (nmatches, match12[n1] = idx2 or -1)."""
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8)
+    d2 = np.ascontiguousarray(desc2, np.uint8)
+    f1 = np.ascontiguousarray(has_mp1, np.uint8)
+    f2 = np.ascontiguousarray(has_mp2, np.uint8)
+    u1 = np.ascontiguousarray(u_right1, np.float32)
+    u2 = np.ascontiguousarray(u_right2, np.float32)
+    a = [np.ascontiguousarray(fv1[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    b = [np.ascontiguousarray(fv2[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+    sf = np.ascontiguousarray(scale_factors2, np.float32)
+    ls = np.ascontiguousarray(level_sigma2_2, np.float32)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    m = np.full(max(len(kps1), 1), -1, np.int32)
+    nm = lib().orbo_search_for_triangulation(_p(kps1), len(kps1), _p(d1), _p(f1), _p(u1), _p(a[0]), _p(a[1]), _p(a[2]),
+                                             len(a[0]), _p(kps2), len(kps2), _p(d2), _p(f2), _p(u2), _p(b[0]), _p(b[1]),
+                                             _p(b[2]), len(b[0]), _p(sf), _p(ls), len(sf), _p(F), float(ep[0]),
+                                             float(ep[1]), int(only_stereo), int(coarse), int(check_ori), _p(m))
+    return nm, m[:len(kps1)]
+
+
+def fuse_search(points, mp_desc, kf_kps, kf_desc, kf_u_right, scale_factors, inv_level_sigma2, Rcw, tcw, Ow, cam, th,
+                log_scale_factor, W, H, sim3=False, gemm_double=True):
+    """The search half of FMatcher::Fuse (fmatcher.cpp:1918-2119 / :2121-2243) -> (best_idx[n], best_dist[n]).
+    cam = (fx, fy, cx, cy, bf)."""
+    pts = np.ascontiguousarray(points, FUSE_POINT_DTYPE)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    kk = np.ascontiguousarray(kf_kps, KP_DTYPE)
+    kd = np.ascontiguousarray(kf_desc, np.uint8)
+    ur = np.ascontiguousarray(kf_u_right, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    iv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    A = _FuseArgs()
+    A.Rcw[:] = [float(v) for v in np.asarray(Rcw, np.float32).reshape(9)]
+    A.tcw[:] = [float(v) for v in np.asarray(tcw, np.float32).reshape(3)]
+    A.Ow[:] = [float(v) for v in np.asarray(Ow, np.float32).reshape(3)]
+    A.fx, A.fy, A.cx, A.cy, A.bf = [float(v) for v in cam]
+    A.th, A.logScaleFactor, A.imgW, A.imgH = float(th), float(log_scale_factor), int(W), int(H)
+    A.sim3, A.gemmDouble = int(sim3), int(gemm_double)
+    bi = np.full(max(len(pts), 1), -1, np.int32)
+    bd = np.full(max(len(pts), 1), 256, np.int32)
+    lib().orbo_fuse_search(_p(pts), len(pts), _p(md), _p(kk), len(kk), _p(kd), _p(ur), _p(sf), _p(iv), len(sf),
+                           C.byref(A), _p(bi), _p(bd))
+    return bi[:len(pts)], bd[:len(pts)]

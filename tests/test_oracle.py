@@ -276,3 +276,109 @@ def test_tracking_golden(golden_dir):
     n, m = orbo.search_by_projection_mappoints(g["mps"], p["dL"], kC, dC, none, sf, 320, 240, 3.0, 0.8, g["occ"])
     assert n == int(g["mp_nmatches"]) and np.array_equal(m, g["mp_match"])
     assert np.array_equal(orbo.distinctive_descriptors(g["dist_desc"], g["dist_off"]), g["dist_best"])
+
+
+def test_glibc_logf_restatement_matches_libm():
+    """MapPoint::PredictScale's log() is glibc logf (mappoint.cpp:514); the oracle restates it (every positive finite
+    float was compared once) -- sampled again here against the platform libm."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.logf.restype = ctypes.c_float
+    libm.logf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([np.exp(rng.uniform(-80, 80, 4000)), rng.uniform(0.5, 2.0, 4000),
+                         [1.0, 1.2, np.float32(1.4e-45), np.float32(3.4028235e38)]]).astype(np.float32)
+    for v in xs:
+        a, b = np.float32(orbo.logf(float(v))), np.float32(libm.logf(float(v)))
+        assert a.view(np.uint32) == b.view(np.uint32), float(v)
+    assert orbo.logf(0.0) == -np.inf and np.isnan(orbo.logf(-1.0)) and orbo.logf(np.inf) == np.inf
+
+
+def _kps(xy, octave=0, angle=0.0):
+    k = np.zeros(len(xy), orbo.KP_DTYPE)
+    k["x"], k["y"] = np.asarray(xy, np.float32).T
+    k["octave"], k["angle"], k["size"] = octave, angle, 31
+    return k
+
+
+def test_search_for_triangulation_hand_case():
+    """fmatcher.cpp:1242-1482 on six features under one node: MapPoint skip, TH_LOW, epipolar gate, the epipole
+    exclusion for mono-mono pairs, last-wins ties, and an idx2 shared by two queries (vbMatched2 is never set)."""
+    sf = np.array([1.0, 1.2], np.float32)
+    sig2 = sf * sf
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # x1' F x2 = y2 - y1: horizontal epipolar lines
+    base = np.zeros(32, np.uint8)
+    def d(nbits):
+        v = base.copy()
+        v[: nbits // 8] = 0xFF
+        v[nbits // 8] = (1 << (nbits % 8)) - 1
+        return v
+    k1 = _kps([(100, 50), (200, 50), (300, 50), (400, 80)])
+    d1 = np.stack([d(0), d(0), d(0), d(0)])
+    k2 = _kps([(110, 50), (120, 50), (130, 50.5), (140, 60), (150, 80), (160, 80)])
+    d2 = np.stack([d(10), d(10), d(3), d(0), d(60), d(8)])
+    fv1 = dict(fv_nodes=[5], fv_off=[0, 4], fv_feat=[0, 1, 2, 3])
+    fv2 = dict(fv_nodes=[5], fv_off=[0, 6], fv_feat=[0, 1, 2, 3, 4, 5])
+    mono1, mono2 = np.full(4, -1, np.float32), np.full(6, -1, np.float32)
+    has1 = np.array([0, 0, 1, 0], np.uint8)
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, mono1, fv1, k2, d2, np.zeros(6, np.uint8), mono2, fv2, sf, sig2, F,
+                                          (-1e4, -1e4), check_ori=False)
+    # queries 0 and 1 (y = 50): candidate 3 (dist 0) is 10 px off the line -> rejected; 2 (dist 3, 0.5 px) wins for both;
+    # query 2 has a MapPoint; query 3 (y = 80): 4 is above TH_LOW, 5 (dist 8) wins
+    assert nm == 3 and m.tolist() == [2, 2, -1, 5]
+    has2 = np.array([0, 0, 1, 0, 0, 0], np.uint8)
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, mono1, fv1, k2, d2, has2, mono2, fv2, sf, sig2, F, (-1e4, -1e4),
+                                          check_ori=False)
+    assert m.tolist() == [1, 1, -1, 5]  # 0 and 1 tie at distance 10: the later one
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, mono1, fv1, k2, d2, has2, mono2, fv2, sf, sig2, F, (125.0, 50.0),
+                                          check_ori=False)
+    assert m.tolist() == [0, 0, -1, 5]  # the epipole sits within 10 px of candidate 1 only ((125-110)^2 = 225 >= 100)
+    st1 = np.array([30.0, -1, -1, -1], np.float32)
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, st1, fv1, k2, d2, has2, mono2, fv2, sf, sig2, F, (125.0, 50.0),
+                                          check_ori=False)
+    assert m.tolist() == [1, 0, -1, 5]  # a stereo query skips the epipole test
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, st1, fv1, k2, d2, has2, mono2, fv2, sf, sig2, F, (125.0, 50.0),
+                                          only_stereo=True, check_ori=False)
+    assert nm == 0
+    nm, m = orbo.search_for_triangulation(k1, d1, has1, mono1, fv1, k2, d2, np.zeros(6, np.uint8), mono2, fv2, sf, sig2, F,
+                                          (-1e4, -1e4), coarse=True, check_ori=False)
+    assert m.tolist() == [3, 3, -1, 3]  # bCoarse: descriptors alone
+
+
+def test_fuse_search_hand_case():
+    """fmatcher.cpp:1918-2119: gates in order, PredictScale, the chi2 test and first-wins ties."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    isig2 = (1.0 / (sf * sf)).astype(np.float32)
+    W, H, fx, cx, cy, bf = 640, 480, 500.0, 320.0, 240.0, 50.0
+    I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    kf = _kps([(320, 240), (322, 240), (330, 240), (321, 241)], octave=[0, 0, 0, 2])
+    kd = np.zeros((4, 32), np.uint8)
+    kd[2, 0] = 0xFF
+    ur = np.array([-1, 320 - 5.0, -1, -1], np.float32)
+    pts = np.zeros(7, orbo.FUSE_POINT_DTYPE)
+    pts["pos"] = [(0, 0, 10), (0, 0, 10), (0, 0, -1), (100, 0, 10), (0, 0, 10), (0, 0, 10), (0.04, 0, 10)]
+    pts["normal"] = [(0, 0, 1)] * 5 + [(0, 0, -1)] + [(0, 0, 1)]
+    pts["min_distance"], pts["max_distance"] = 5, 11  # ratio 1.1 -> level 1: keypoint levels 0 and 1 pass
+    pts["min_distance"][4] = 11                        # 10 < min
+    pts["valid"] = [1, 0, 1, 1, 1, 1, 1]
+    md = np.zeros((7, 32), np.uint8)
+    bi, bd = orbo.fuse_search(pts, md, kf, kd, ur, sf, isig2, I3, z3, z3, (fx, fx, cx, cy, bf), 3.0, lsf, W, H)
+    # 0: window radius 3.6 holds keypoints 0, 1, 3; 3 is on level 2 (gate); 1 is a stereo keypoint whose right
+    #    coordinate matches (315 = 320 - 50/10) but 2 px away: e2 = 4 <= 7.8 passes; 0 and 1 tie at distance 0 and
+    #    share grid cell (32, 24): index order -> 0
+    assert bi.tolist()[:6] == [0, -1, -1, -1, -1, -1]
+    assert bd[0] == 0 and bd[1] == 256
+    # 6: projects to u = 322: keypoint 0 is 2 px away (mono chi2 4 <= 5.99 passes), keypoint 1 at 0 px; both distance 0
+    assert bi[6] == 0
+    bi2, _ = orbo.fuse_search(pts, md, kf, kd, np.full(4, -1, np.float32), sf, isig2, I3, z3, z3, (fx, fx, cx, cy, bf), 3.0,
+                              lsf, W, H)
+    assert bi2[0] == 0
+    # a stereo keypoint with a wrong right coordinate fails the 3-dof chi2 and drops out
+    ur_bad = np.array([320 - 9.0, -1, -1, -1], np.float32)
+    bi3, _ = orbo.fuse_search(pts, md, kf, kd, ur_bad, sf, isig2, I3, z3, z3, (fx, fx, cx, cy, bf), 3.0, lsf, W, H)
+    assert bi3[0] == 1
+    # the Sim3 overload has no chi2 gate
+    bi4, _ = orbo.fuse_search(pts, md, kf, kd, ur_bad, sf, isig2, I3, z3, z3, (fx, fx, cx, cy, bf), 3.0, lsf, W, H, sim3=True)
+    assert bi4[0] == 0

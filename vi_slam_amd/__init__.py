@@ -42,12 +42,30 @@ ABI_SYMBOLS = [
     "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors", "vslam_voc_create", "vslam_voc_destroy",
     "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
     "vslam_bow_assemble", "vslam_search_by_bow", "vslam_search_by_bow_keyframes",
+    "vslam_search_for_triangulation", "vslam_fuse_search", "vslam_dbg_logf",
 ]
 
 
 #: vslam_mp_track: per-MapPoint tracking record (mappoint.h:73-81 after Frame::isInFrustum)
 MP_TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"),
                            ("level", "<i4"), ("flags", "<u4")])
+
+
+#: vslam_fuse_point: one candidate MapPoint of FMatcher::Fuse
+FUSE_POINT_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"),
+                             ("max_distance", "<f4"), ("valid", "<i4")])
+
+
+class _TriParams(C.Structure):  # vslam_tri_params
+    _fields_ = [("F12", C.c_float * 9), ("ep_x", C.c_float), ("ep_y", C.c_float), ("only_stereo", C.c_int32),
+                ("coarse", C.c_int32), ("check_orientation", C.c_int32)]
+
+
+class _FuseParams(C.Structure):  # vslam_fuse_params
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float),
+                ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("th", C.c_float),
+                ("log_scale_factor", C.c_float), ("img_w", C.c_int32), ("img_h", C.c_int32), ("sim3", C.c_int32),
+                ("gemm_float", C.c_int32)]
 
 
 class _ProjParams(C.Structure):  # vslam_proj_params
@@ -128,6 +146,9 @@ def lib():
         L.vslam_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i,
                                                     C.c_float, i, vp, vp]
         L.vslam_bow_assemble.argtypes = [i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp]
+        L.vslam_search_for_triangulation.argtypes = [vp, vp] + [vp, vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp, vp]
+        L.vslam_fuse_search.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
+        L.vslam_dbg_logf.argtypes = [vp, vp, i, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
         L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
@@ -632,6 +653,56 @@ class FMatcher:
                                                    C.byref(nm)))
         return nm.value, m[:len(kps1)]
 
+    def SearchForTriangulation(self, kps1, dev_desc1, has_mp1, u_right1, fv1, kps2, dev_desc2, has_mp2, u_right2, fv2,
+                               F12, ep, bOnlyStereo=False, bCoarse=False):
+        """FMatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)
+        (fmatcher.cpp:1242-1482 / :1484-1725, pinhole).  F12 as Pinhole::epipolarConstrain builds it, ep the epipole of
+        pKF1's centre in pKF2.  -> (nmatches, vMatchedPairs as an (n, 2) array, match12[n1])."""
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        f1 = np.ascontiguousarray(has_mp1, np.uint8)
+        f2 = np.ascontiguousarray(has_mp2, np.uint8)
+        u1 = np.ascontiguousarray(u_right1, np.float32)
+        u2 = np.ascontiguousarray(u_right2, np.float32)
+        a = [np.ascontiguousarray(fv1[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        b = [np.ascontiguousarray(fv2[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        P = _TriParams()
+        P.F12[:] = [float(v) for v in np.asarray(F12, np.float32).reshape(9)]
+        P.ep_x, P.ep_y = float(ep[0]), float(ep[1])
+        P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(self.mbCheckOrientation)
+        m = np.full(max(len(kps1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_for_triangulation(
+            self.fe._h, C.byref(P), _p(kps1), C.c_void_p(dev_desc1), _p(f1), _p(u1), len(kps1), _p(a[0]), _p(a[1]),
+            _p(a[2]), len(a[0]), _p(kps2), C.c_void_p(dev_desc2), _p(f2), _p(u2), len(kps2), _p(b[0]), _p(b[1]),
+            _p(b[2]), len(b[0]), _p(m), C.byref(nm)))
+        m = m[:len(kps1)]
+        i1 = np.nonzero(m >= 0)[0]
+        return nm.value, np.stack([i1, m[i1]], 1).astype(np.int64), m
+
+    def FuseSearch(self, points, mp_desc, dev_kf_kps, dev_kf_desc, n_kf, kf_u_right, Rcw, tcw, Ow, cam, th,
+                   log_scale_factor, img_size=None, sim3=False, gemm_float=False):
+        """The search half of FMatcher::Fuse (fmatcher.cpp:1918-2119; sim3=True: the Scw overload :2121-2243): points is
+        a FUSE_POINT_DTYPE array, cam = (fx, fy, cx, cy, bf).  -> (best_idx[n], best_dist[n]); the caller applies
+        best_dist <= TH_LOW and the map updates in order."""
+        pts = np.ascontiguousarray(points, FUSE_POINT_DTYPE)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        ur = None if kf_u_right is None else np.ascontiguousarray(kf_u_right, np.float32)
+        w, h = img_size or (self.fe.width, self.fe.height)
+        P = _FuseParams()
+        P.Rcw[:] = [float(v) for v in np.asarray(Rcw, np.float32).reshape(9)]
+        P.tcw[:] = [float(v) for v in np.asarray(tcw, np.float32).reshape(3)]
+        P.Ow[:] = [float(v) for v in np.asarray(Ow, np.float32).reshape(3)]
+        P.fx, P.fy, P.cx, P.cy, P.bf = [float(v) for v in cam]
+        P.th, P.log_scale_factor, P.img_w, P.img_h = float(th), float(log_scale_factor), int(w), int(h)
+        P.sim3, P.gemm_float = int(sim3), int(gemm_float)
+        bi = np.full(max(len(pts), 1), -1, np.int32)
+        bd = np.full(max(len(pts), 1), 256, np.int32)
+        _check(lib().vslam_fuse_search(self.fe._h, C.byref(P), _p(pts), _p(md), len(pts), C.c_void_p(dev_kf_kps),
+                                       C.c_void_p(dev_kf_desc), n_kf, _p(ur) if ur is not None else None, _p(bi),
+                                       _p(bd)))
+        return bi[:len(pts)], bd[:len(pts)]
+
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""
         c = C.c_int()
@@ -782,6 +853,13 @@ def dbg_sincos(fe, x):
     s, c = np.zeros_like(x), np.zeros_like(x)
     _check(lib().vslam_dbg_sincos(fe._h, _p(x), len(x), _p(s), _p(c)))
     return s, c
+
+
+def dbg_logf(fe, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    _check(lib().vslam_dbg_logf(fe._h, _p(x), len(x), _p(y)))
+    return y
 
 
 def dbg_fast_atan2(fe, y, x, fma=0):

@@ -521,3 +521,200 @@ extern "C" int vslam_search_by_bow_keyframes(vslam_fe* fe, const vslam_kp* kps1_
                               dev_desc2, flags2_host, n2, fv2_nodes, fv2_off, fv2_feat, n2_nodes, nnratio,
                               check_orientation, 1, match12, nmatches);
 }
+
+/* ==================================================================================================
+ * FMatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)
+ * (fmatcher.cpp:1242-1482; SearchForTriangulation_ :1484-1725 is the same walk on cv::Matx), pinhole KeyFrames
+ * without a second camera.  The reference never sets vbMatched2, so every KeyFrame-1 feature is an independent
+ * query: among the features of the same vocabulary node in KeyFrame 2 that have no MapPoint, pass the stereo
+ * filter, the epipole distance test and Pinhole::epipolarConstrain (pinhole.cpp:121-143), the one with the least
+ * distance <= TH_LOW wins and the LAST one wins a tie (`dist > bestDist` skips, equality replaces).  One wave per
+ * shared node; lanes hold the node's KeyFrame-2 features, key = dist << 20 | (0xFFFFF - position) -> wave min.
+ * ================================================================================================== */
+struct StriArgs {
+    const uint8_t *desc1, *desc2, *hasMp1, *hasMp2;
+    const float *uRight1, *uRight2;
+    const vslam_kp *kps1, *kps2;
+    const int32_t *nodes1, *off1, *feat1, *nodes2, *off2, *feat2;
+    int32_t nNodes1, nNodes2, onlyStereo, coarse, checkOri, nlevels;
+    float F12[9], epx, epy;
+    float scale2[VSLAM_MAX_LEVELS], sigma2_2[VSLAM_MAX_LEVELS]; /* pKF2->mvScaleFactors, mvLevelSigma2 */
+    int32_t* match12;  /* n1, initialised to -1 */
+    uint8_t* matchBin; /* n1 */
+};
+
+__global__ void __launch_bounds__(64) k_stri_nodes(StriArgs A) {
+    const int lane = threadIdx.x;
+    const int kn = blockIdx.x;
+    if (kn >= A.nNodes1) return;
+    const int node = A.nodes1[kn];
+    int lo = 0, hi = A.nNodes2;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A.nodes2[mid] < node) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= A.nNodes2 || A.nodes2[lo] != node) return;
+    const int f0 = A.off2[lo], c2 = A.off2[lo + 1] - f0;
+    const float factor = 1.0f / SBOW_HISTO;
+    for (int a1 = A.off1[kn]; a1 < A.off1[kn + 1]; a1++) {
+        const int idx1 = A.feat1[a1];
+        if (A.hasMp1[idx1]) continue; /* pMP1 */
+        const bool bStereo1 = A.uRight1[idx1] >= 0.f;
+        if (A.onlyStereo && !bStereo1) continue;
+        const vslam_kp kp1 = A.kps1[idx1];
+        const uint4 da = ((const uint4*)A.desc1)[(size_t)idx1 * 2], db = ((const uint4*)A.desc1)[(size_t)idx1 * 2 + 1];
+        /* epipolar line l = x1' F12 (pinhole.cpp:129-131) */
+        const float ea = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[0]), __fmul_rn(kp1.y, A.F12[3])), A.F12[6]);
+        const float eb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[1]), __fmul_rn(kp1.y, A.F12[4])), A.F12[7]);
+        const float ec = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[2]), __fmul_rn(kp1.y, A.F12[5])), A.F12[8]);
+        const float den = __fadd_rn(__fmul_rn(ea, ea), __fmul_rn(eb, eb));
+        uint32_t best = 0xFFFFFFFFu;
+        for (int b = lane; b < c2; b += 64) {
+            const int idx2 = A.feat2[f0 + b];
+            if (A.hasMp2[idx2]) continue; /* pMP2 (vbMatched2 is never set) */
+            const bool bStereo2 = A.uRight2[idx2] >= 0.f;
+            if (A.onlyStereo && !bStereo2) continue;
+            const uint4 ta = ((const uint4*)A.desc2)[(size_t)idx2 * 2], tb = ((const uint4*)A.desc2)[(size_t)idx2 * 2 + 1];
+            const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
+                                  __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
+            if (dist > SBOW_TH_LOW) continue;
+            const vslam_kp kp2 = A.kps2[idx2];
+            const int oct2 = min(max(kp2.octave, 0), A.nlevels - 1);
+            if (!bStereo1 && !bStereo2) { /* too close to the epipole, :1366-1374 */
+                const float dex = __fsub_rn(A.epx, kp2.x), dey = __fsub_rn(A.epy, kp2.y);
+                if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, A.scale2[oct2])) continue;
+            }
+            if (!A.coarse) {
+                if (den == 0.f) continue;
+                const float num = __fadd_rn(__fadd_rn(__fmul_rn(ea, kp2.x), __fmul_rn(eb, kp2.y)), ec);
+                const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                if (!((double)dsqr < __dmul_rn(3.84, (double)A.sigma2_2[oct2]))) continue;
+            }
+            best = min(best, (dist << 20) | (0xFFFFFu - (uint32_t)b));
+        }
+        const uint32_t g = wave_min_u32(best);
+        if (g == 0xFFFFFFFFu) continue;
+        if (lane == 0) {
+            const int bestIdx2 = A.feat2[f0 + (int)(0xFFFFFu - (g & 0xFFFFFu))];
+            A.match12[idx1] = bestIdx2;
+            uint8_t bin = 255;
+            if (A.checkOri) {
+                float rot = __fsub_rn(kp1.angle, A.kps2[bestIdx2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bi = (int)roundf(__fmul_rn(rot, factor));
+                if (bi == SBOW_HISTO) bi = 0;
+                bin = (uint8_t)bi;
+            }
+            A.matchBin[idx1] = bin;
+        }
+    }
+}
+
+static int fv_in_range(const int32_t* off, const int32_t* feat, int nnodes, int n) {
+    for (int j = 0; j < nnodes; j++)
+        for (int a = off[j]; a < off[j + 1]; a++)
+            if (feat[a] < 0 || feat[a] >= n) return 0;
+    return 1;
+}
+
+extern "C" int vslam_search_for_triangulation(vslam_fe* fe, const vslam_tri_params* p, const vslam_kp* kps1_host,
+                                              const uint8_t* dev_desc1, const uint8_t* has_mp1_host,
+                                              const float* u_right1_host, int n1, const int32_t* fv1_nodes,
+                                              const int32_t* fv1_off, const int32_t* fv1_feat, int n1_nodes,
+                                              const vslam_kp* kps2_host, const uint8_t* dev_desc2,
+                                              const uint8_t* has_mp2_host, const float* u_right2_host, int n2,
+                                              const int32_t* fv2_nodes, const int32_t* fv2_off, const int32_t* fv2_feat,
+                                              int n2_nodes, int32_t* match12, int* nmatches) {
+    if (!fe || !p || n1 < 0 || n2 < 0 || n1_nodes < 0 || n2_nodes < 0 || !nmatches ||
+        (n1 && (!kps1_host || !dev_desc1 || !has_mp1_host || !u_right1_host || !match12)) ||
+        (n2 && (!kps2_host || !dev_desc2 || !has_mp2_host || !u_right2_host)) ||
+        (n1_nodes && (!fv1_nodes || !fv1_off || !fv1_feat)) || (n2_nodes && (!fv2_nodes || !fv2_off || !fv2_feat))) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || n1_nodes == 0 || n2_nodes == 0) return VSLAM_OK;
+    if (!fv_in_range(fv1_off, fv1_feat, n1_nodes, n1) || !fv_in_range(fv2_off, fv2_feat, n2_nodes, n2)) {
+        g_err = "FeatureVector index out of range";
+        return VSLAM_ERR_INVALID;
+    }
+    if (fv2_off[n2_nodes] > 0xFFFFF) {
+        g_err = "SearchForTriangulation: FeatureVector too long";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const int t1 = fv1_off[n1_nodes], t2 = fv2_off[n2_nodes];
+    const size_t o_k1 = 0, o_k2 = al(o_k1 + (size_t)n1 * sizeof(vslam_kp)), o_h1 = al(o_k2 + (size_t)n2 * sizeof(vslam_kp)),
+                 o_h2 = al(o_h1 + (size_t)n1), o_u1 = al(o_h2 + (size_t)n2), o_u2 = al(o_u1 + (size_t)n1 * 4),
+                 o_n1 = al(o_u2 + (size_t)n2 * 4), o_o1 = al(o_n1 + (size_t)n1_nodes * 4),
+                 o_f1 = al(o_o1 + (size_t)(n1_nodes + 1) * 4), o_n2 = al(o_f1 + (size_t)t1 * 4),
+                 o_o2 = al(o_n2 + (size_t)n2_nodes * 4), o_f2 = al(o_o2 + (size_t)(n2_nodes + 1) * 4),
+                 in_bytes = al(o_f2 + (size_t)t2 * 4);
+    const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n1 * 4), o_n = al(o_b + (size_t)n1), total = o_n + 16;
+    int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < total) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
+        fe->h_proj_bytes = total;
+    }
+    uint8_t *h = fe->h_proj, *d = fe->d_proj;
+    memcpy(h + o_k1, kps1_host, (size_t)n1 * sizeof(vslam_kp));
+    memcpy(h + o_k2, kps2_host, (size_t)n2 * sizeof(vslam_kp));
+    memcpy(h + o_h1, has_mp1_host, (size_t)n1);
+    memcpy(h + o_h2, has_mp2_host, (size_t)n2);
+    memcpy(h + o_u1, u_right1_host, (size_t)n1 * 4);
+    memcpy(h + o_u2, u_right2_host, (size_t)n2 * 4);
+    memcpy(h + o_n1, fv1_nodes, (size_t)n1_nodes * 4);
+    memcpy(h + o_o1, fv1_off, (size_t)(n1_nodes + 1) * 4);
+    memcpy(h + o_f1, fv1_feat, (size_t)t1 * 4);
+    memcpy(h + o_n2, fv2_nodes, (size_t)n2_nodes * 4);
+    memcpy(h + o_o2, fv2_off, (size_t)(n2_nodes + 1) * 4);
+    memcpy(h + o_f2, fv2_feat, (size_t)t2 * 4);
+    hipStream_t st = fe->stream;
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = d;
+    R.src[0] = h;
+    R.bytes[0] = in_bytes;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    StriArgs A;
+    memset(&A, 0, sizeof(A));
+    A.desc1 = dev_desc1; A.desc2 = dev_desc2; A.hasMp1 = d + o_h1; A.hasMp2 = d + o_h2;
+    A.uRight1 = (const float*)(d + o_u1); A.uRight2 = (const float*)(d + o_u2);
+    A.kps1 = (const vslam_kp*)(d + o_k1); A.kps2 = (const vslam_kp*)(d + o_k2);
+    A.nodes1 = (const int32_t*)(d + o_n1); A.off1 = (const int32_t*)(d + o_o1); A.feat1 = (const int32_t*)(d + o_f1);
+    A.nodes2 = (const int32_t*)(d + o_n2); A.off2 = (const int32_t*)(d + o_o2); A.feat2 = (const int32_t*)(d + o_f2);
+    A.nNodes1 = n1_nodes; A.nNodes2 = n2_nodes; A.onlyStereo = p->only_stereo; A.coarse = p->coarse;
+    A.checkOri = p->check_orientation; A.nlevels = fe->p.nlevels;
+    for (int i = 0; i < 9; i++) A.F12[i] = p->F12[i];
+    A.epx = p->ep_x; A.epy = p->ep_y;
+    for (int l = 0; l < fe->p.nlevels; l++) {
+        A.scale2[l] = fe->tab.scale[l];
+        A.sigma2_2[l] = fe->tab.sigma2[l];
+    }
+    A.match12 = (int32_t*)(d + o_m); A.matchBin = d + o_b;
+    SbowArgs Fz; /* histogram + ComputeThreeMaxima + count: k_sbow_finish */
+    memset(&Fz, 0, sizeof(Fz));
+    Fz.matchF = A.match12; Fz.matchBin = A.matchBin; Fz.nOut = n1; Fz.checkOri = p->check_orientation;
+    Fz.nmatches = (int32_t*)(d + o_n);
+    hipLaunchKernelGGL(k_fill_i32, dim3((n1 + 255) / 256), dim3(256), 0, st, A.match12, n1, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, st, Fz.nmatches, 4, 0);
+    hipLaunchKernelGGL(k_stri_nodes, dim3(n1_nodes), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, Fz);
+    R.dst[0] = h + o_m;
+    R.src[0] = d + o_m;
+    R.bytes[0] = (o_n + 16) - o_m;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(match12, h + o_m, (size_t)n1 * 4);
+    *nmatches = *(const int32_t*)(h + o_n);
+    return VSLAM_OK;
+}

@@ -115,6 +115,25 @@ struct MpTrack {
     uint32_t flags;
 };
 
+/* vslam_fuse_point / the arguments of one FMatcher::Fuse search (vslam_fuse_search) */
+struct FusePoint {
+    float pos[3], normal[3];
+    float minDistance, maxDistance;
+    int32_t valid;
+};
+struct FuseArgsDev {
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy, bf, th, logScaleFactor;
+    int32_t imgW, imgH, sim3, gemmFloat, nlevels, nPoints, nKF;
+    float scale[VSLAM_MAX_LEVELS], invSigma2[VSLAM_MAX_LEVELS];
+    const FusePoint* pts;
+    const uint8_t* mpDesc;
+    const vslam_kp* kfKps;
+    const uint8_t* kfDesc;
+    const float* kfURight;
+    int32_t *bestIdx, *bestDist;
+};
+
 /* One SearchByProjection(CurrentFrame, LastFrame) problem; every pointer is a DEVICE pointer.  nLast / nCur are
  * the counts, or -- when nLastPtr / nCurPtr are set -- capacities with the real counts read from HBM. */
 struct SbpProj;

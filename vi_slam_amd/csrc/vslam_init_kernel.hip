@@ -902,12 +902,15 @@ size_t vk_sbp_replay_lds(int nCur, int nLast) {
 size_t vk_sbp_scratch_bytes(int nLast, int M) { return (size_t)nLast * (sizeof(SbpProj) + 4 * (size_t)M); }
 size_t vk_sbp_proj_bytes(int nLast) { return (size_t)nLast * sizeof(SbpProj); }
 __global__ void k_sbpm_resolve(SbpJobs JS, int forceSeq); /* defined below */
+__global__ void k_fuse_rank(FuseArgsDev A);
 int vk_sbp_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_sbp_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     rc = (int)hipFuncSetAttribute((const void*)k_sbpm_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     rc = (int)hipFuncSetAttribute((const void*)k_sbp_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    rc = (int)hipFuncSetAttribute((const void*)k_fuse_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
     return (int)hipFuncSetAttribute((const void*)k_sbp_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1147,4 +1150,115 @@ k_unproject_stereo(UnprojJobs U) {
 void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs) {
     if (njobs <= 0) return;
     hipLaunchKernelGGL(k_unproject_stereo, dim3((U.cap + 255) / 256, njobs), dim3(256), 0, st, U);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The search half of FMatcher::Fuse (fmatcher.cpp:1918-2119 with bRight = false; Sim3 overload :2121-2243):
+ * per MapPoint  Rcw*p + tcw (one cv::gemm, sbp_gemm_row), depth >= 0, Pinhole::project, KeyFrame::IsInImage,
+ * cv::norm(p - Ow) inside the scale-invariance range, viewing angle (cv::Mat::dot, both accumulate in double),
+ * MapPoint::PredictScale (mappoint.cpp:506-521: ceil(logf(max/dist) / mfLogScaleFactor), glibc logf), radius =
+ * th * scale[level], KeyFrame::GetFeaturesInArea (keyframe.cpp:656-699), level gate, chi2 gate (7.8 with a right
+ * coordinate, 5.99 without; not in the Sim3 overload), then the least Hamming distance, first of the window order
+ * wins: key = dist << 24 | cell << 12 | index -> wave min.  Nothing here depends on other MapPoints; the map
+ * mutation that follows in the reference (Replace / AddObservation / vpReplacePoint) stays with the caller.
+ * One wave per MapPoint, the KeyFrame's keypoints in LDS as for SearchByProjection.
+ * ---------------------------------------------------------------------------------------------- */
+#include "vslam_trig.h"
+#define FUSE_QPB 16
+__global__ void __launch_bounds__(256)
+k_fuse_rank(FuseArgsDev A) {
+    extern __shared__ __align__(16) uint8_t sbsm[];
+    SbpCand* cand = (SbpCand*)sbsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)A.imgW);
+    const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)A.imgH);
+    for (int i = tid; i < A.nKF; i += 256) {
+        bool ing;
+        cand[i] = sbp_make_cand(A.kfKps[i], A.kfURight[i], invW, invH, &ing);
+    }
+    __syncthreads();
+    for (int q = blockIdx.x * FUSE_QPB + wave; q < min(A.nPoints, (int)(blockIdx.x + 1) * FUSE_QPB); q += 4) {
+        const FusePoint mp = A.pts[q];
+        uint32_t best = 0xFFFFFFFFu;
+        bool go = mp.valid != 0;
+        float u = 0.f, v = 0.f, ur = 0.f, radius = 0.f;
+        int level = 0;
+        if (go) { /* wave-uniform */
+            const float xc = sbp_gemm_row(A.Rcw + 0, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[0], A.gemmFloat);
+            const float yc = sbp_gemm_row(A.Rcw + 3, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[1], A.gemmFloat);
+            const float zc = sbp_gemm_row(A.Rcw + 6, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[2], A.gemmFloat);
+            go = !(zc < 0.0f);
+            if (go) {
+                const float invz = __fdiv_rn(1.0f, zc);
+                u = __fadd_rn(__fdiv_rn(__fmul_rn(A.fx, xc), zc), A.cx);
+                v = __fadd_rn(__fdiv_rn(__fmul_rn(A.fy, yc), zc), A.cy);
+                go = u >= 0.0f && u < (float)A.imgW && v >= 0.0f && v < (float)A.imgH;
+                ur = __fsub_rn(u, __fmul_rn(A.bf, invz));
+            }
+            if (go) {
+                const float p0 = __fsub_rn(mp.pos[0], A.Ow[0]), p1 = __fsub_rn(mp.pos[1], A.Ow[1]),
+                            p2 = __fsub_rn(mp.pos[2], A.Ow[2]);
+                double n2 = __dmul_rn((double)p0, (double)p0);
+                n2 = __dadd_rn(n2, __dmul_rn((double)p1, (double)p1));
+                n2 = __dadd_rn(n2, __dmul_rn((double)p2, (double)p2));
+                const float dist3D = (float)__dsqrt_rn(n2);
+                go = !(dist3D < mp.minDistance || dist3D > mp.maxDistance);
+                if (go) {
+                    double dot = __dmul_rn((double)p0, (double)mp.normal[0]);
+                    dot = __dadd_rn(dot, __dmul_rn((double)p1, (double)mp.normal[1]));
+                    dot = __dadd_rn(dot, __dmul_rn((double)p2, (double)mp.normal[2]));
+                    go = !(dot < __dmul_rn(0.5, (double)dist3D));
+                }
+                if (go) {
+                    const float ratio = __fdiv_rn(mp.maxDistance, dist3D);
+                    /* NaN and out-of-range quotients convert to INT_MIN on the reference's x86-64 build
+                     * (cvttss2si) and so clamp to level 0 */
+                    const float lv = ceilf(__fdiv_rn(vslam_trig::glibc_logf(ratio), A.logScaleFactor));
+                    level = (lv != lv || lv >= 2147483648.0f || lv < 0.f) ? 0 : min((int)lv, A.nlevels - 1);
+                    radius = __fmul_rn(A.th, A.scale[level]);
+                }
+            }
+        }
+        if (go) {
+            const SiWindow win = si_window(u, v, radius, invW, invH);
+            if (!win.empty) {
+                const uint4 da = ((const uint4*)A.mpDesc)[(size_t)q * 2], db = ((const uint4*)A.mpDesc)[(size_t)q * 2 + 1];
+                for (int c = lane; c < A.nKF; c += 64) {
+                    const SbpCand cd = cand[c];
+                    if (cd.cell == 0xFFFF) continue;
+                    const int gx = cd.cell >> 6, gy = cd.cell & 63;
+                    if (gx < win.minX || gx > win.maxX || gy < win.minY || gy > win.maxY) continue;
+                    const float ex = __fsub_rn(cd.x, u), ey = __fsub_rn(cd.y, v);
+                    if (!(fabsf(ex) < radius && fabsf(ey) < radius)) continue;
+                    const int kpLevel = cd.octave;
+                    if (kpLevel < level - 1 || kpLevel > level) continue;
+                    if (!A.sim3) {
+                        /* ex = uv.x - kpx in the reference; only its square is used */
+                        const float is2 = A.invSigma2[min(kpLevel, A.nlevels - 1)];
+                        const float exx = __fsub_rn(u, cd.x), eyy = __fsub_rn(v, cd.y);
+                        if (cd.uRight >= 0.f) {
+                            const float er = __fsub_rn(ur, cd.uRight);
+                            const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(exx, exx), __fmul_rn(eyy, eyy)), __fmul_rn(er, er));
+                            if ((double)__fmul_rn(e2, is2) > 7.8) continue;
+                        } else {
+                            const float e2 = __fadd_rn(__fmul_rn(exx, exx), __fmul_rn(eyy, eyy));
+                            if ((double)__fmul_rn(e2, is2) > 5.99) continue;
+                        }
+                    }
+                    const uint4 ta = ((const uint4*)A.kfDesc)[(size_t)c * 2], tb = ((const uint4*)A.kfDesc)[(size_t)c * 2 + 1];
+                    best = min(best, (min(si_hamming(da, db, ta, tb), 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c);
+                }
+            }
+        }
+        const uint32_t g = wave_min_u32(best);
+        if (lane == 0) {
+            A.bestIdx[q] = g == 0xFFFFFFFFu ? -1 : (int32_t)(g & 0xFFFu);
+            A.bestDist[q] = g == 0xFFFFFFFFu ? 256 : (int32_t)(g >> 24);
+        }
+    }
+}
+
+void vk_fuse_search(hipStream_t st, const FuseArgsDev& A) {
+    if (A.nPoints <= 0) return;
+    hipLaunchKernelGGL(k_fuse_rank, dim3((A.nPoints + FUSE_QPB - 1) / FUSE_QPB), dim3(256), vk_sbp_rank_lds(A.nKF), st, A);
 }

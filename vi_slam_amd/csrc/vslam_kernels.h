@@ -57,6 +57,7 @@ void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* b
                             int cap, int atan_fma, int nslots);
 
 void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c);
+void vk_dbg_logf(hipStream_t st, const float* x, int n, float* y);
 void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma, float* a);
 
 void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
@@ -84,6 +85,7 @@ void vk_search_by_projection(hipStream_t st, const SbpJobs& JS, int njobs, int m
 int vk_distinctive_set_max_lds(size_t bytes);
 void vk_distinctive(hipStream_t st, const uint8_t* desc, const int32_t* offsets, int nsets, int maxN, int32_t* best);
 void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs);
+void vk_fuse_search(hipStream_t st, const FuseArgsDev& A);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
 void vk_copy_ranges(hipStream_t st, const CopyRanges& R);

@@ -533,6 +533,13 @@ __global__ void k_dbg_atan2(const float* __restrict__ y, const float* __restrict
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = fast_atan2_deg(y[i], x[i], fma);
 }
+__global__ void k_dbg_logf(const float* __restrict__ x, int n, float* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = vslam_trig::glibc_logf(x[i]);
+}
+void vk_dbg_logf(hipStream_t st, const float* x, int n, float* y) {
+    if (n > 0) hipLaunchKernelGGL(k_dbg_logf, dim3((n + 255) / 256), dim3(256), 0, st, x, n, y);
+}
 void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c) {
     if (n > 0) hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, st, x, n, s, c);
 }

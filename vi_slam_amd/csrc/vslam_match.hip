@@ -425,6 +425,20 @@ extern "C" int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_
     return VSLAM_OK;
 }
 
+extern "C" int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y) {
+    if (!fe || n < 0 || (n && (!x || !y))) return VSLAM_ERR_INVALID;
+    if (!n) return VSLAM_OK;
+    HIPCHK(hipSetDevice(fe->p.device));
+    float *dx, *dy, *dz;
+    int rc = dbg_buffers(fe, n, &dx, &dy, &dz);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, fe->stream));
+    vk_dbg_logf(fe->stream, dx, n, dy);
+    HIPCHK(hipMemcpyAsync(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipStreamSynchronize(fe->stream));
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, int fma, float* deg) {
     if (!fe || n < 0 || (n && (!x || !y || !deg))) return VSLAM_ERR_INVALID;
     if (!n) return VSLAM_OK;
@@ -924,5 +938,88 @@ extern "C" int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_h
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     memcpy(best, h + o_b, (size_t)nsets * 4);
+    return VSLAM_OK;
+}
+
+/* ---- the search half of FMatcher::Fuse (fmatcher.cpp:1918-2119, :2121-2243): k_fuse_rank ---- */
+extern "C" int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const vslam_fuse_point* points_host,
+                                 const uint8_t* mp_desc_host, int n_points, const vslam_kp* dev_kf_kps,
+                                 const uint8_t* dev_kf_desc, int n_kf, const float* kf_u_right_host, int32_t* best_idx,
+                                 int32_t* best_dist) {
+    static_assert(sizeof(vslam_fuse_point) == sizeof(FusePoint), "vslam_fuse_point layout");
+    if (!fe || !p || n_points < 0 || n_kf < 0 || (n_points && (!points_host || !mp_desc_host || !best_idx || !best_dist)) ||
+        (n_kf && (!dev_kf_kps || !dev_kf_desc)) || p->img_w < 1 || p->img_h < 1) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    for (int i = 0; i < n_points; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (n_points == 0 || n_kf == 0) return VSLAM_OK;
+    if (n_kf > 4096) {
+        g_err = "Fuse on the device supports at most 4096 keypoints per KeyFrame";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    int M;
+    int rc = sbp_prepare(fe, &M);
+    if (rc) return rc;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_p = 0, o_d = al(o_p + (size_t)n_points * sizeof(FusePoint)), o_u = al(o_d + (size_t)n_points * 32),
+                 in_bytes = al(o_u + (size_t)n_kf * 4);
+    const size_t o_bi = in_bytes, o_bd = al(o_bi + (size_t)n_points * 4), total = al(o_bd + (size_t)n_points * 4);
+    rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
+    if (rc) return rc;
+    if (fe->h_proj_bytes < total) {
+        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
+        fe->h_proj = nullptr;
+        fe->h_proj_bytes = 0;
+        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
+        fe->h_proj_bytes = total;
+    }
+    uint8_t *h = fe->h_proj, *d = fe->d_proj;
+    memcpy(h + o_p, points_host, (size_t)n_points * sizeof(FusePoint));
+    memcpy(h + o_d, mp_desc_host, (size_t)n_points * 32);
+    for (int i = 0; i < n_kf; i++) ((float*)(h + o_u))[i] = kf_u_right_host ? kf_u_right_host[i] : -1.0f;
+    hipStream_t st = fe->stream;
+    CopyRanges R;
+    memset(&R, 0, sizeof(R));
+    R.dst[0] = d;
+    R.src[0] = h;
+    R.bytes[0] = in_bytes;
+    R.n = 1;
+    vk_copy_ranges(st, R);
+    FuseArgsDev A;
+    memset(&A, 0, sizeof(A));
+    for (int i = 0; i < 9; i++) A.Rcw[i] = p->Rcw[i];
+    for (int i = 0; i < 3; i++) {
+        A.tcw[i] = p->tcw[i];
+        A.Ow[i] = p->Ow[i];
+    }
+    A.fx = p->fx; A.fy = p->fy; A.cx = p->cx; A.cy = p->cy; A.bf = p->bf; A.th = p->th;
+    A.logScaleFactor = p->log_scale_factor;
+    A.imgW = p->img_w; A.imgH = p->img_h; A.sim3 = p->sim3; A.gemmFloat = p->gemm_float;
+    A.nlevels = fe->p.nlevels; A.nPoints = n_points; A.nKF = n_kf;
+    for (int l = 0; l < fe->p.nlevels; l++) {
+        A.scale[l] = fe->tab.scale[l];
+        A.invSigma2[l] = fe->tab.inv_sigma2[l];
+    }
+    A.pts = (const FusePoint*)(d + o_p);
+    A.mpDesc = d + o_d;
+    A.kfKps = dev_kf_kps;
+    A.kfDesc = dev_kf_desc;
+    A.kfURight = (const float*)(d + o_u);
+    A.bestIdx = (int32_t*)(d + o_bi);
+    A.bestDist = (int32_t*)(d + o_bd);
+    vk_fuse_search(st, A);
+    R.dst[0] = h + o_bi;
+    R.src[0] = d + o_bi;
+    R.bytes[0] = total - o_bi;
+    vk_copy_ranges(st, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(best_idx, h + o_bi, (size_t)n_points * 4);
+    memcpy(best_dist, h + o_bd, (size_t)n_points * 4);
     return VSLAM_OK;
 }
