@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Mapping-side matchers on the GPU box: SearchForTriangulation and the search half of Fuse (synchronous host-facing
+calls: upload, kernels, download) vs the oracle on one host core, KITTI-size KeyFrames with 2000 features."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import vi_slam_amd as V
+from oracle import orbo
+from vi_slam_amd import synth
+
+W, H, NF = 1241, 376, 2000
+FX, FY, CX, CY, BF = 718.856, 718.856, 607.1928, 185.2157, 386.1448
+fe = V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=4)
+L0, R0 = synth.make_stereo_pair(W, H, step=0)
+L1, R1 = synth.make_stereo_pair(W, H, step=1)
+res = [(k.copy(), d.copy(), m) for k, d, m in fe.compute_batch([L0, R0, L1, R1])]
+(u0, z0), (u1, z1) = V.ComputeStereoMatchesBatch(fe, [0, 2], fe, [1, 3], BF, FX)
+k0, de0 = res[0][0], res[0][1]
+k1, de1 = res[2][0], res[2][1]
+voc = synth.make_vocabulary(10, 6, seed=4)
+vv = V.Vocabulary(voc)
+vv.transform_slots_async(fe, 0, 3, 4)
+bw = vv.transform_slots_wait([len(res[s][0]) for s in range(3)])
+fv0, fv1 = bw[0], bw[2]
+dev0, dev1 = fe.slot_dev_ptrs(0), fe.slot_dev_ptrs(2)
+sf, sig2, isig2 = fe.GetScaleFactors(), fe.GetScaleSigmaSquares(), fe.GetInverseScaleSigmaSquares()
+m = V.FMatcher(fe, 0.6, True)
+
+
+def timed(f, n):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = f()
+    return (time.perf_counter() - t0) / n, r
+
+
+F = np.array([[0, 0, 1], [0, 0, -3], [-1, 3, 0]], np.float32)
+none0, none1 = np.zeros(len(k0), np.uint8), np.zeros(len(k1), np.uint8)
+t_g, (nm, pairs, m12) = timed(lambda: m.SearchForTriangulation(k0, dev0[1], none0, u0, fv0, k1, dev1[1], none1, u1, fv1, F,
+                                                               (600.0, 180.0)), 50)
+# the same call with the arguments marshalled once (numpy's .ctypes costs more than the kernels)
+import ctypes as C
+P = V._TriParams()
+P.F12[:] = [float(v) for v in F.reshape(9)]
+P.ep_x, P.ep_y, P.check_orientation = 600.0, 180.0, 1
+a = [np.ascontiguousarray(fv0[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+b = [np.ascontiguousarray(fv1[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+mm, nmc = np.full(len(k0), -1, np.int32), C.c_int(0)
+args = [fe._h, C.byref(P), V._p(k0), C.c_void_p(dev0[1]), V._p(none0), V._p(u0), len(k0), V._p(a[0]), V._p(a[1]), V._p(a[2]),
+        len(a[0]), V._p(k1), C.c_void_p(dev1[1]), V._p(none1), V._p(u1), len(k1), V._p(b[0]), V._p(b[1]), V._p(b[2]), len(b[0]),
+        V._p(mm), C.byref(nmc)]
+t_raw, _ = timed(lambda: V.lib().vslam_search_for_triangulation(*args), 200)
+t_c, (wn, wm) = timed(lambda: orbo.search_for_triangulation(k0, de0, none0, u0, fv0, k1, de1, none1, u1, fv1, sf, sig2, F,
+                                                            (600.0, 180.0)), 5)
+print({"op": "SearchForTriangulation", "n1": len(k0), "n2": len(k1), "shared_nodes": int(len(np.intersect1d(fv0["fv_nodes"], fv1["fv_nodes"]))),
+       "matches": nm, "gpu_call_ms": t_raw * 1e3, "through_python_wrapper_ms": t_g * 1e3, "oracle_1core_ms": t_c * 1e3, "equal": bool(nm == wn and np.array_equal(m12, wm))})
+
+z = np.where(z0 > 0, z0, 25.0).astype(np.float32)
+X = np.stack([(k0["x"] - CX) / FX * z, (k0["y"] - CY) / FY * z, z], 1).astype(np.float32)
+d = np.linalg.norm(X, axis=1).astype(np.float32)
+pts = np.zeros(len(k0), V.FUSE_POINT_DTYPE)
+pts["pos"], pts["normal"], pts["valid"] = X, X / d[:, None], 1
+pts["max_distance"] = 1.2 * d * sf[k0["octave"]]
+pts["min_distance"] = 0.8 * d * sf[k0["octave"]] / sf[-1]
+zmed = float(np.median(z0[z0 > 0]))
+R = np.eye(3, dtype=np.float32)
+t = np.array([3.0 / FX * zmed, 1.0 / FY * zmed, 0.0], np.float32)
+lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+cam = (FX, FY, CX, CY, BF)
+t_g, (bi, bd) = timed(lambda: m.FuseSearch(pts, de0, dev1[0], dev1[1], len(k1), u1, R, t, -t, cam, 3.0, lsf, (W, H)), 50)
+t_c, (wi, wd) = timed(lambda: orbo.fuse_search(pts, de0, k1, de1, u1, sf, isig2, R, t, -t, cam, 3.0, lsf, W, H), 5)
+print({"op": "Fuse (search half)", "map_points": len(pts), "kf_keypoints": len(k1), "fused_candidates": int(((bi >= 0) & (bd <= 50)).sum()),
+       "gpu_call_ms": t_g * 1e3, "oracle_1core_ms": t_c * 1e3, "equal": bool(np.array_equal(bi, wi))})
+vv.close(); fe.close()

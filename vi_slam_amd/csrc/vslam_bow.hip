@@ -529,26 +529,33 @@ extern "C" int vslam_search_by_bow_keyframes(vslam_fe* fe, const vslam_kp* kps1_
  * query: among the features of the same vocabulary node in KeyFrame 2 that have no MapPoint, pass the stereo
  * filter, the epipole distance test and Pinhole::epipolarConstrain (pinhole.cpp:121-143), the one with the least
  * distance <= TH_LOW wins and the LAST one wins a tie (`dist > bestDist` skips, equality replaces).  One wave per
- * shared node; lanes hold the node's KeyFrame-2 features, key = dist << 20 | (0xFFFFF - position) -> wave min.
+ * KeyFrame-1 feature (a wave per node would serialise the few heavy nodes: 1.0 ms -> see DESIGN.md); its lanes hold
+ * the node's KeyFrame-2 features, key = dist << 20 | (0xFFFFF - position) -> wave min.
  * ================================================================================================== */
 struct StriArgs {
     const uint8_t *desc1, *desc2, *hasMp1, *hasMp2;
     const float *uRight1, *uRight2;
     const vslam_kp *kps1, *kps2;
     const int32_t *nodes1, *off1, *feat1, *nodes2, *off2, *feat2;
-    int32_t nNodes1, nNodes2, onlyStereo, coarse, checkOri, nlevels;
+    int32_t nNodes1, nNodes2, nFeat1, onlyStereo, coarse, checkOri, nlevels;
     float F12[9], epx, epy;
     float scale2[VSLAM_MAX_LEVELS], sigma2_2[VSLAM_MAX_LEVELS]; /* pKF2->mvScaleFactors, mvLevelSigma2 */
     int32_t* match12;  /* n1, initialised to -1 */
     uint8_t* matchBin; /* n1 */
 };
 
-__global__ void __launch_bounds__(64) k_stri_nodes(StriArgs A) {
-    const int lane = threadIdx.x;
-    const int kn = blockIdx.x;
-    if (kn >= A.nNodes1) return;
-    const int node = A.nodes1[kn];
-    int lo = 0, hi = A.nNodes2;
+__global__ void __launch_bounds__(256) k_stri_queries(StriArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int a1 = blockIdx.x * 4 + (threadIdx.x >> 6); /* position in KeyFrame 1's flattened FeatureVector */
+    if (a1 >= A.nFeat1) return; /* wave-uniform */
+    int lo = 0, hi = A.nNodes1; /* node of a1: last kn with off1[kn] <= a1 (empty nodes cannot own a position) */
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.off1[mid] <= a1) lo = mid;
+        else hi = mid;
+    }
+    const int node = A.nodes1[lo];
+    lo = 0, hi = A.nNodes2;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (A.nodes2[mid] < node) lo = mid + 1;
@@ -557,57 +564,55 @@ __global__ void __launch_bounds__(64) k_stri_nodes(StriArgs A) {
     if (lo >= A.nNodes2 || A.nodes2[lo] != node) return;
     const int f0 = A.off2[lo], c2 = A.off2[lo + 1] - f0;
     const float factor = 1.0f / SBOW_HISTO;
-    for (int a1 = A.off1[kn]; a1 < A.off1[kn + 1]; a1++) {
-        const int idx1 = A.feat1[a1];
-        if (A.hasMp1[idx1]) continue; /* pMP1 */
-        const bool bStereo1 = A.uRight1[idx1] >= 0.f;
-        if (A.onlyStereo && !bStereo1) continue;
-        const vslam_kp kp1 = A.kps1[idx1];
-        const uint4 da = ((const uint4*)A.desc1)[(size_t)idx1 * 2], db = ((const uint4*)A.desc1)[(size_t)idx1 * 2 + 1];
-        /* epipolar line l = x1' F12 (pinhole.cpp:129-131) */
-        const float ea = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[0]), __fmul_rn(kp1.y, A.F12[3])), A.F12[6]);
-        const float eb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[1]), __fmul_rn(kp1.y, A.F12[4])), A.F12[7]);
-        const float ec = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[2]), __fmul_rn(kp1.y, A.F12[5])), A.F12[8]);
-        const float den = __fadd_rn(__fmul_rn(ea, ea), __fmul_rn(eb, eb));
-        uint32_t best = 0xFFFFFFFFu;
-        for (int b = lane; b < c2; b += 64) {
-            const int idx2 = A.feat2[f0 + b];
-            if (A.hasMp2[idx2]) continue; /* pMP2 (vbMatched2 is never set) */
-            const bool bStereo2 = A.uRight2[idx2] >= 0.f;
-            if (A.onlyStereo && !bStereo2) continue;
-            const uint4 ta = ((const uint4*)A.desc2)[(size_t)idx2 * 2], tb = ((const uint4*)A.desc2)[(size_t)idx2 * 2 + 1];
-            const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
-                                  __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
-            if (dist > SBOW_TH_LOW) continue;
-            const vslam_kp kp2 = A.kps2[idx2];
-            const int oct2 = min(max(kp2.octave, 0), A.nlevels - 1);
-            if (!bStereo1 && !bStereo2) { /* too close to the epipole, :1366-1374 */
-                const float dex = __fsub_rn(A.epx, kp2.x), dey = __fsub_rn(A.epy, kp2.y);
-                if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, A.scale2[oct2])) continue;
-            }
-            if (!A.coarse) {
-                if (den == 0.f) continue;
-                const float num = __fadd_rn(__fadd_rn(__fmul_rn(ea, kp2.x), __fmul_rn(eb, kp2.y)), ec);
-                const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-                if (!((double)dsqr < __dmul_rn(3.84, (double)A.sigma2_2[oct2]))) continue;
-            }
-            best = min(best, (dist << 20) | (0xFFFFFu - (uint32_t)b));
+    const int idx1 = A.feat1[a1];
+    if (A.hasMp1[idx1]) return; /* pMP1 */
+    const bool bStereo1 = A.uRight1[idx1] >= 0.f;
+    if (A.onlyStereo && !bStereo1) return;
+    const vslam_kp kp1 = A.kps1[idx1];
+    const uint4 da = ((const uint4*)A.desc1)[(size_t)idx1 * 2], db = ((const uint4*)A.desc1)[(size_t)idx1 * 2 + 1];
+    /* epipolar line l = x1' F12 (pinhole.cpp:129-131) */
+    const float ea = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[0]), __fmul_rn(kp1.y, A.F12[3])), A.F12[6]);
+    const float eb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[1]), __fmul_rn(kp1.y, A.F12[4])), A.F12[7]);
+    const float ec = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, A.F12[2]), __fmul_rn(kp1.y, A.F12[5])), A.F12[8]);
+    const float den = __fadd_rn(__fmul_rn(ea, ea), __fmul_rn(eb, eb));
+    uint32_t best = 0xFFFFFFFFu;
+    for (int b = lane; b < c2; b += 64) {
+        const int idx2 = A.feat2[f0 + b];
+        if (A.hasMp2[idx2]) continue; /* pMP2 (vbMatched2 is never set) */
+        const bool bStereo2 = A.uRight2[idx2] >= 0.f;
+        if (A.onlyStereo && !bStereo2) continue;
+        const uint4 ta = ((const uint4*)A.desc2)[(size_t)idx2 * 2], tb = ((const uint4*)A.desc2)[(size_t)idx2 * 2 + 1];
+        const uint32_t dist = __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
+                              __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
+        if (dist > SBOW_TH_LOW) continue;
+        const vslam_kp kp2 = A.kps2[idx2];
+        const int oct2 = min(max(kp2.octave, 0), A.nlevels - 1);
+        if (!bStereo1 && !bStereo2) { /* too close to the epipole, :1366-1374 */
+            const float dex = __fsub_rn(A.epx, kp2.x), dey = __fsub_rn(A.epy, kp2.y);
+            if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, A.scale2[oct2])) continue;
         }
-        const uint32_t g = wave_min_u32(best);
-        if (g == 0xFFFFFFFFu) continue;
-        if (lane == 0) {
-            const int bestIdx2 = A.feat2[f0 + (int)(0xFFFFFu - (g & 0xFFFFFu))];
-            A.match12[idx1] = bestIdx2;
-            uint8_t bin = 255;
-            if (A.checkOri) {
-                float rot = __fsub_rn(kp1.angle, A.kps2[bestIdx2].angle);
-                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                int bi = (int)roundf(__fmul_rn(rot, factor));
-                if (bi == SBOW_HISTO) bi = 0;
-                bin = (uint8_t)bi;
-            }
-            A.matchBin[idx1] = bin;
+        if (!A.coarse) {
+            if (den == 0.f) continue;
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(ea, kp2.x), __fmul_rn(eb, kp2.y)), ec);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < __dmul_rn(3.84, (double)A.sigma2_2[oct2]))) continue;
         }
+        best = min(best, (dist << 20) | (0xFFFFFu - (uint32_t)b));
+    }
+    const uint32_t g = wave_min_u32(best);
+    if (g == 0xFFFFFFFFu) return;
+    if (lane == 0) {
+        const int bestIdx2 = A.feat2[f0 + (int)(0xFFFFFu - (g & 0xFFFFFu))];
+        A.match12[idx1] = bestIdx2;
+        uint8_t bin = 255;
+        if (A.checkOri) {
+            float rot = __fsub_rn(kp1.angle, A.kps2[bestIdx2].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bi = (int)roundf(__fmul_rn(rot, factor));
+            if (bi == SBOW_HISTO) bi = 0;
+            bin = (uint8_t)bi;
+        }
+        A.matchBin[idx1] = bin;
     }
 }
 
@@ -691,7 +696,7 @@ extern "C" int vslam_search_for_triangulation(vslam_fe* fe, const vslam_tri_para
     A.kps1 = (const vslam_kp*)(d + o_k1); A.kps2 = (const vslam_kp*)(d + o_k2);
     A.nodes1 = (const int32_t*)(d + o_n1); A.off1 = (const int32_t*)(d + o_o1); A.feat1 = (const int32_t*)(d + o_f1);
     A.nodes2 = (const int32_t*)(d + o_n2); A.off2 = (const int32_t*)(d + o_o2); A.feat2 = (const int32_t*)(d + o_f2);
-    A.nNodes1 = n1_nodes; A.nNodes2 = n2_nodes; A.onlyStereo = p->only_stereo; A.coarse = p->coarse;
+    A.nNodes1 = n1_nodes; A.nNodes2 = n2_nodes; A.nFeat1 = t1; A.onlyStereo = p->only_stereo; A.coarse = p->coarse;
     A.checkOri = p->check_orientation; A.nlevels = fe->p.nlevels;
     for (int i = 0; i < 9; i++) A.F12[i] = p->F12[i];
     A.epx = p->ep_x; A.epy = p->ep_y;
@@ -706,7 +711,7 @@ extern "C" int vslam_search_for_triangulation(vslam_fe* fe, const vslam_tri_para
     Fz.nmatches = (int32_t*)(d + o_n);
     hipLaunchKernelGGL(k_fill_i32, dim3((n1 + 255) / 256), dim3(256), 0, st, A.match12, n1, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(256), 0, st, Fz.nmatches, 4, 0);
-    hipLaunchKernelGGL(k_stri_nodes, dim3(n1_nodes), dim3(64), 0, st, A);
+    if (t1 > 0) hipLaunchKernelGGL(k_stri_queries, dim3((t1 + 3) / 4), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, Fz);
     R.dst[0] = h + o_m;
     R.src[0] = d + o_m;
