@@ -86,6 +86,13 @@ def lib():
                                                      C.c_int, vp])
         L.orbo_fuse_search.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp]
         L.orbo_fuse_search.restype = None
+        L.orbo_fg_halfsample.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
+        L.orbo_fg_halfsample.restype = None
+        L.orbo_fg_response.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
+        L.orbo_fg_response.restype = None
+        L.orbo_fg_detect.argtypes = [vp, C.c_int, C.c_int, C.c_size_t] + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int,
+                                                                                          C.c_int, vp, vp, vp]
+        L.orbo_fg_detect.restype = None
         _lib = L
     return _lib
 
@@ -100,6 +107,9 @@ def ref_rosten():
         R = C.CDLL(path)
         R.ref_fast9_detect_nonmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_int]
+        if hasattr(R, "ref_fast_detect_nonmax"):
+            R.ref_fast_detect_nonmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_int]
         _ref = R
     return _ref
 
@@ -462,3 +472,50 @@ def fuse_search(points, mp_desc, kf_kps, kf_desc, kf_u_right, scale_factors, inv
     lib().orbo_fuse_search(_p(pts), len(pts), _p(md), _p(kk), len(kk), _p(kd), _p(ur), _p(sf), _p(iv), len(sf),
                            C.byref(A), _p(bi), _p(bd))
     return bi[:len(pts)], bd[:len(pts)]
+
+
+# ---- the vilib grid detector behind geometry::FAST::detect (oracle/fastgrid_oracle.cpp) ----
+FG_SCORE = {"SUM_OF_ABS_DIFF_ALL": 0, "SUM_OF_ABS_DIFF_ON_ARC": 1, "MAX_THRESHOLD": 2}
+
+
+def fg_halfsample(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h >> 1, w >> 1), np.uint8)
+    lib().orbo_fg_halfsample(_p(img), w, h, w, _p(out), w >> 1)
+    return out
+
+
+def fg_response(img, hb=3, vb=3, threshold=10.0, arc=10, score=1):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    lib().orbo_fg_response(_p(img), w, h, w, hb, vb, float(threshold), arc, score, _p(out))
+    return out
+
+
+def fg_detect(img, cell=(32, 32), min_level=0, max_level=1, border=(0, 0), threshold=10.0, arc=10, score=1, tie_rule=0):
+    """vilib::FASTGPU::detect (fast_gpu.cpp:97-136) -> (pos[cells, 2], score[cells], level[cells]), row-major cells."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    nc, nr = (w + cell[0] - 1) // cell[0], (h + cell[1] - 1) // cell[1]
+    pos = np.zeros((nc * nr, 2), np.float32)
+    sc = np.zeros(nc * nr, np.float32)
+    lv = np.zeros(nc * nr, np.int32)
+    lib().orbo_fg_detect(_p(img), w, h, w, cell[0], cell[1], min_level, max_level, border[0], border[1], float(threshold),
+                         arc, score, tie_rule, _p(pos), _p(sc), _p(lv))
+    return pos, sc, lv
+
+
+def ref_fast_detect_nonmax(img, b, arc=10, new_score=False):
+    """The reference's rosten::fastN_detect_nonmax<new_score> (oracle/_ref) -> (n, 3) int32 rows x, y, score; None if
+    oracle/_ref is absent."""
+    R = ref_rosten()
+    if R is None or not hasattr(R, "ref_fast_detect_nonmax"):
+        return None
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    out = np.zeros((cap, 3), np.int32)
+    n = R.ref_fast_detect_nonmax(_p(img), w, h, w, int(b), arc, int(new_score), _p(out), cap)
+    return out[:n].copy()

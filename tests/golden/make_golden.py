@@ -93,5 +93,37 @@ def main():
     print("wrote golden fixtures:", sorted(os.listdir(OUT)))
 
 
+def make_fastgrid():
+    """tests/golden/fastgrid.npz: the grid detector behind geometry::FAST::detect on the crops of fast_rosten.npz
+    (cut from the reference's own test images): the oracle's feature grids for several configurations, and the
+    output of the REFERENCE's rosten::fast10_detect_nonmax<false> / <true> (oracle/_ref) per pyramid level."""
+    z = np.load(os.path.join(OUT, "fast_rosten.npz"))
+    out = {}
+    cfgs = [(0, 1, 0, 0, 10, 1, 0, 100), (0, 3, 0, 0, 10, 1, 0, 100), (0, 3, 0, 0, 10, 1, 1, 100), (1, 3, 8, 5, 9, 2, 0, 200),
+            (0, 2, 0, 0, 12, 0, 0, 105), (0, 2, 16, 16, 11, 1, 0, 75)]
+    for name, key in (("lenna", "lenna_256x192_img"), ("hut", "hut_320x200_img")):
+        img = z[key]
+        h, w = img.shape
+        img = np.ascontiguousarray(img[:h & ~3, :w & ~3])
+        for c in cfgs:
+            pos, sc, lv = orbo.fg_detect(img, (32, 32), c[0], c[1], (c[2], c[3]), c[7] / 10.0, c[4], c[5], c[6])
+            k = "%s__%s" % (name, "_".join(str(v) for v in c))
+            out[k + "_pos"], out[k + "_score"], out[k + "_level"] = pos, sc, lv
+        cur = img
+        for level in range(3):
+            if level:
+                cur = orbo.fg_halfsample(cur)
+            for new in (0, 1):
+                r = orbo.ref_fast_detect_nonmax(cur, 10, 10, bool(new))
+                if r is not None:
+                    out["ref_%s_l%d_fast10_%s" % (name, level, "new" if new else "old")] = r
+    np.savez_compressed(os.path.join(OUT, "fastgrid.npz"), **out)
+    print("wrote fastgrid.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fastgrid":
+        make_fastgrid()
+    else:
+        main()
+        make_fastgrid()

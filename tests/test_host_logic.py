@@ -151,8 +151,8 @@ def test_search_init_replay_equals_oracle(H):
 
 
 # ---------------------------------------------------------------- C ABI library (no GPU needed)
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "vslam_fe.h")).read()
+def _declared_functions(header="vslam_fe.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vslam_\w+)\s*\(", src)))
 
@@ -164,8 +164,28 @@ def test_header_and_python_mirror_agree():
 def test_product_library_exports_every_declared_symbol():
     assert os.path.exists(V.LIB_PATH), "build it: python -c 'import __graft_entry__ as g; g.build()'"
     L = C.CDLL(V.LIB_PATH)
-    for name in _declared_functions():
+    for name in _declared_functions() + _declared_functions("vslam_fastgrid.h"):
         assert hasattr(L, name), name
+
+
+def test_fastgrid_create_rejects_bad_parameters_and_has_no_cpu_fallback():
+    """include/vslam_fastgrid.h: parameter checks mirror the reference's assertions (fast_gpu.cpp:75,
+    detector_base_gpu.cpp:61-62, pyramid_pool.cpp:58-59); without a device the constructor fails."""
+    import torch
+    from vi_slam_amd import fastgrid
+    assert _declared_functions("vslam_fastgrid.h") == sorted(
+        ["vslam_fg_create", "vslam_fg_destroy", "vslam_fg_grid", "vslam_fg_detect", "vslam_fg_detect_batch",
+         "vslam_fg_level_copy", "vslam_fg_response_copy"])
+    for bad in (dict(cell_size_width=48), dict(min_arc_length=8), dict(min_arc_length=13), dict(max_level=0), dict(score=3),
+                dict(max_level=3, image_width=130), dict(max_batch=0), dict(threshold=-1.0)):
+        kw = dict(image_width=128, image_height=64)
+        kw.update(bad)
+        with pytest.raises(V.VslamError) as ei:
+            fastgrid.FASTGPU(**kw)
+        assert ei.value.code == V.ERR_INVALID
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(V.VslamError):
+            fastgrid.FASTGPU(128, 64)
 
 
 def test_create_rejects_bad_parameters_and_missing_gpu():
