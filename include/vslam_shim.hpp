@@ -22,9 +22,11 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "vslam_fe.h"
+#include "vslam_fastgrid.h"
 
 #ifdef VSLAM_SHIM_WITH_OPENCV
 #include <opencv2/core/core.hpp>
@@ -338,6 +340,121 @@ inline void ComputeStereoMatches(const FExtractor& left, const FExtractor& right
     if (N == 0) return;
     check(vslam_stereo_match(left.context(), 0, right.context(), 0, mbf, fx, mvuRight.data(), mvDepth.data()));
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * The grid FAST detector of fast_cuda.h:19-25 / fast_cuda.cpp:70-132.  FASTGPU carries vilib::FASTGPU's
+ * constructor (fast_gpu.h:46-56) and DetectorBase's read side (detector_base.h:48-57,75-80): detect() on an
+ * 8-bit image replaces `Frame(image, 0, levels)` + `detect(frame->pyramid_)`; getPoints() holds one FeaturePoint
+ * per grid cell and isOccupied(i) says whether cell i found a corner (OccupancyGrid2D::isOccupied).
+ * FAST::detect is the reference's wrapper with its fixed parameters (fast_cuda.cpp:24-39: one level, 32x32
+ * cells, epsilon 10, arc 10, SUM_OF_ABS_DIFF_ON_ARC); unlike the reference, which prints the grid and leaves
+ * `keypoints` empty, it returns the occupied cells as key points (pt, response = score, octave = level).
+ * ------------------------------------------------------------------------------------------------- */
+class FASTGPU {
+public:
+    struct FeaturePoint {
+        double x_, y_, score_;
+        unsigned int level_;
+    };
+    FASTGPU(std::size_t image_width, std::size_t image_height, std::size_t cell_size_width, std::size_t cell_size_height,
+            std::size_t min_level, std::size_t max_level, std::size_t horizontal_border, std::size_t vertical_border,
+            float threshold, int min_arc_length, int score, int device = 0) {
+        vslam_fg_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.image_width = (int32_t)image_width;
+        p.image_height = (int32_t)image_height;
+        p.cell_size_width = (int32_t)cell_size_width;
+        p.cell_size_height = (int32_t)cell_size_height;
+        p.min_level = (int32_t)min_level;
+        p.max_level = (int32_t)max_level;
+        p.horizontal_border = (int32_t)horizontal_border;
+        p.vertical_border = (int32_t)vertical_border;
+        p.threshold = threshold;
+        p.min_arc_length = min_arc_length;
+        p.score = score;
+        p.tie_rule = 0;
+        p.device = device;
+        p.max_batch = 1;
+        check(vslam_fg_create(&p, &fg_));
+        int nc = 0, nr = 0;
+        vslam_fg_grid(fg_, &nc, &nr);
+        n_cols_ = (std::size_t)nc;
+        n_rows_ = (std::size_t)nr;
+        reset();
+    }
+    ~FASTGPU() { vslam_fg_destroy(fg_); }
+    FASTGPU(const FASTGPU&) = delete;
+    FASTGPU& operator=(const FASTGPU&) = delete;
+
+    void reset() { /* DetectorBase::reset + the constructor's keypoints_ fill (detector_base.cpp:67,76-84) */
+        keypoints_.assign(n_cols_ * n_rows_, FeaturePoint{0.0, 0.0, 0.0, (unsigned int)-1});
+        occupied_.assign(n_cols_ * n_rows_, 0);
+    }
+    void detect(const uint8_t* image, std::size_t pitch) { /* detectBase + processGrid, detector_base_gpu.cpp:204-218 */
+        const std::size_t n = n_cols_ * n_rows_;
+        pos_.resize(2 * n);
+        score_.resize(n);
+        level_.resize(n);
+        check(vslam_fg_detect(fg_, image, pitch, pos_.data(), score_.data(), level_.data()));
+        for (std::size_t i = 0; i < n; i++)
+            if (score_[i] > 0.0f) {
+                keypoints_[i] = FeaturePoint{(double)pos_[2 * i], (double)pos_[2 * i + 1], (double)score_[i], (unsigned int)level_[i]};
+                occupied_[i] = 1;
+            }
+    }
+    const std::vector<FeaturePoint>& getPoints() const { return keypoints_; }
+    bool isOccupied(std::size_t i) const { return occupied_[i] != 0; }
+    std::size_t count() const {
+        std::size_t c = 0;
+        for (uint8_t o : occupied_) c += o;
+        return c;
+    }
+    std::size_t getCellCountHorizontal() const { return n_cols_; }
+    std::size_t getCellCountVertical() const { return n_rows_; }
+
+private:
+    vslam_fg* fg_ = nullptr;
+    std::size_t n_cols_ = 0, n_rows_ = 0;
+    std::vector<FeaturePoint> keypoints_;
+    std::vector<uint8_t> occupied_;
+    std::vector<float> pos_, score_;
+    std::vector<int32_t> level_;
+};
+
+class FAST {
+public:
+    /* image: 8-bit grey (the reference converts BGR first, fast_cuda.cpp:45-47) */
+    void detect(const uint8_t* image, int width, int height, std::size_t pitch, std::vector<KeyPoint>& keypoints) {
+        if (!det_ || w_ != width || h_ != height) {
+            det_.reset(new FASTGPU((std::size_t)width, (std::size_t)height, 32, 32, 0, 1, 0, 0, 10.0f, 10,
+                                   VSLAM_FG_SUM_OF_ABS_DIFF_ON_ARC));
+            w_ = width;
+            h_ = height;
+        }
+        det_->reset();
+        det_->detect(image, pitch);
+        keypoints.clear();
+        const std::vector<FASTGPU::FeaturePoint>& pts = det_->getPoints();
+        for (std::size_t i = 0; i < pts.size(); i++) {
+            if (!det_->isOccupied(i)) continue;
+            KeyPoint k;
+            std::memset(&k, 0, sizeof(k));
+            k.pt.x = (float)pts[i].x_;
+            k.pt.y = (float)pts[i].y_;
+            k.size = 7.0f;
+            k.angle = -1.0f;
+            k.response = (float)pts[i].score_;
+            k.octave = (int)pts[i].level_;
+            k.class_id = -1;
+            keypoints.push_back(k);
+        }
+    }
+    const FASTGPU* detector() const { return det_.get(); }
+
+private:
+    std::unique_ptr<FASTGPU> det_;
+    int w_ = 0, h_ = 0;
+};
 
 } /* namespace geometry */
 } /* namespace VSLAM_SHIM_NAMESPACE */

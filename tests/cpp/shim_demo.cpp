@@ -95,16 +95,33 @@ int main(int argc, char** argv) {
         int lw = 0, lh = 0;
         std::vector<uint8_t> lvl3 = left.ImagePyramidLevel(3, &lw, &lh);
 
+        /* ---- the grid detector of fast_cuda.cpp:70-132 on frame a (width cut to a multiple of 4) */
+        FAST fast;
+        std::vector<KeyPoint> kf;
+        fast.detect(a.data, w & ~3, h & ~3, a.step, kf);
+        FASTGPU multi((size_t)(w & ~3), (size_t)(h & ~3), 32, 32, 0, 3, 0, 0, 10.0f, 10, VSLAM_FG_SUM_OF_ABS_DIFF_ON_ARC);
+        multi.detect(a.data, a.step);
+        std::vector<double> flat;
+        for (size_t i = 0; i < multi.getPoints().size(); i++)
+            if (multi.isOccupied(i)) {
+                flat.push_back(multi.getPoints()[i].x_);
+                flat.push_back(multi.getPoints()[i].y_);
+                flat.push_back(multi.getPoints()[i].score_);
+                flat.push_back((double)multi.getPoints()[i].level_);
+            }
+
         std::printf("{\"n1\": %zu, \"n2\": %zu, \"mono1\": %d, \"mono2\": %d, \"rc_empty\": %d, \"nmatches\": %d, "
                     "\"dd01\": %d, \"kp1\": %llu, \"desc1\": %llu, \"kp2\": %llu, \"desc2\": %llu, \"m12\": %llu, "
                     "\"prev\": %llu, \"nL\": %zu, \"nR\": %zu, \"nstereo\": %d, \"uR\": %llu, \"depth\": %llu, "
-                    "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g, \"nsbp\": %d, \"sbp\": %llu}\n",
+                    "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g, \"nsbp\": %d, \"sbp\": %llu, "
+                    "\"fast_n\": %zu, \"fast_kp\": %llu, \"fast3_n\": %zu, \"fast3\": %llu}\n",
                     k1.size(), k2.size(), mono1, mono2, rc_empty, nm, dd, fnv(k1.data(), k1.size() * sizeof(KeyPoint)),
                     fnv(d1.data, (size_t)d1.rows * 32), fnv(k2.data(), k2.size() * sizeof(KeyPoint)),
                     fnv(d2.data, (size_t)d2.rows * 32), fnv(m12.data(), m12.size() * 4),
                     fnv(prev.data(), prev.size() * 8), kL.size(), kR.size(), nst, fnv(uR.data(), uR.size() * 4),
                     fnv(depth.data(), depth.size() * 4), lw, lh, fnv(lvl3.data(), lvl3.size()), left.GetLevels(),
-                    (double)left.GetScaleFactors()[7], nsbp, fnv(mpi.data(), mpi.size() * 4));
+                    (double)left.GetScaleFactors()[7], nsbp, fnv(mpi.data(), mpi.size() * 4), kf.size(),
+                    fnv(kf.data(), kf.size() * sizeof(KeyPoint)), multi.count(), fnv(flat.data(), flat.size() * 8));
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -77,9 +77,27 @@ def test_shim_program_equals_ctypes_path(tmp_path):
         kR, dR, _ = f2.compute(R)
         u, dep = V.ComputeStereoMatches(f1, 0, f2, 0, 386.1448, 718.856)
         lvl3 = f1.mvImagePyramid(3)
+        from vi_slam_amd.fastgrid import FASTGPU
+        aw = np.ascontiguousarray(a[:H & ~3, :W & ~3])
+        g1 = FASTGPU(W & ~3, H & ~3)
+        g3 = FASTGPU(W & ~3, H & ~3, max_level=3)
+        try:
+            p1, s1, l1 = g1.detect(aw)
+            p3, s3, l3 = g3.detect(aw)
+        finally:
+            g1.close()
+            g3.close()
     finally:
         f1.close()
         f2.close()
+    occ = np.nonzero(s1 > 0)[0]
+    kf = np.zeros(len(occ), V.KP_DTYPE)
+    kf["x"], kf["y"], kf["size"], kf["angle"], kf["response"], kf["octave"], kf["class_id"] = (
+        p1[occ, 0], p1[occ, 1], 7.0, -1.0, s1[occ], l1[occ], -1)
+    assert got["fast_n"] == len(occ) and len(occ) > 50 and got["fast_kp"] == _fnv(kf)
+    occ3 = np.nonzero(s3 > 0)[0]
+    flat = np.stack([p3[occ3, 0], p3[occ3, 1], s3[occ3], l3[occ3]], 1).astype(np.float64)
+    assert got["fast3_n"] == len(occ3) and got["fast3"] == _fnv(flat)
     assert got["n1"] == len(k1) and got["n2"] == len(k2) and got["mono1"] == mono1 and got["mono2"] == mono2
     assert got["rc_empty"] == -1
     assert got["kp1"] == _fnv(k1) and got["desc1"] == _fnv(d1) and got["kp2"] == _fnv(k2) and got["desc2"] == _fnv(d2)

@@ -56,7 +56,14 @@ k_fg_gather(FgPtrs src, size_t src_pitch, uint8_t* pyr, FgLevel d) { /* device i
     const uint8_t* sp = src.p[s] + (size_t)y * src_pitch + (size_t)x16 * 16;
     uint8_t* dp = pyr + d.base + (size_t)s * d.bytes + (size_t)y * d.pitch + (size_t)x16 * 16;
     const int n = min(16, d.w - x16 * 16);
-    for (int i = 0; i < n; i++) dp[i] = sp[i];
+    if (n == 16 && (((uintptr_t)sp) & 15) == 0) {
+        *(uint4*)dp = *(const uint4*)sp;
+    } else if (n == 16 && (((uintptr_t)sp) & 3) == 0) {
+        const uint32_t* s4 = (const uint32_t*)sp;
+        *(uint4*)dp = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+    } else {
+        for (int i = 0; i < n; i++) dp[i] = sp[i];
+    }
 }
 
 /* K5: (a + b + c + d) >> 2 */
@@ -87,17 +94,22 @@ __device__ __forceinline__ bool fg_is_corner(uint32_t m, int arc) {
 }
 __device__ __forceinline__ uint32_t fg_sign(float v) { return __float_as_uint(v) >> 31; } /* signbit() */
 
-/* K2 for one pixel whose window address is p (LDS, pitch wp) */
+/* fast_gpu_prechecks (fast_gpu_cuda_tools.cu:116-139): true = cannot be a corner.  Exact for arcs >= 9 (which
+ * the constructor asserts): an arc of 9 contains one pixel of every opposite pair. */
+__device__ __forceinline__ bool fg_precheck_fails(const uint8_t* p, int wp, float thr) {
+    const float c = (float)p[0];
+    const float ct = __fadd_rn(c, thr), c_t = __fsub_rn(c, thr);
+    float a = (float)p[-3], b = (float)p[3];
+    if ((fg_sign(__fsub_rn(a, c_t)) | fg_sign(__fsub_rn(b, c_t)) | fg_sign(__fsub_rn(ct, a)) | fg_sign(__fsub_rn(ct, b))) == 0) return true;
+    a = (float)p[3 * wp];
+    b = (float)p[-3 * wp];
+    return (fg_sign(__fsub_rn(a, c_t)) | fg_sign(__fsub_rn(b, c_t)) | fg_sign(__fsub_rn(ct, a)) | fg_sign(__fsub_rn(ct, b))) == 0;
+}
+
+/* K2 for one pixel that passed the prechecks; its window address is p (LDS, pitch wp) */
 __device__ float fg_response_px(const uint8_t* p, int wp, float thr, int arc, int score) {
     const float c = (float)p[0];
     const float ct = __fadd_rn(c, thr), c_t = __fsub_rn(c, thr);
-    { /* fast_gpu_prechecks (:116-139): exact for arcs >= 9, which the constructor asserts */
-        float a = (float)p[-3], b = (float)p[3];
-        if ((fg_sign(__fsub_rn(a, c_t)) | fg_sign(__fsub_rn(b, c_t)) | fg_sign(__fsub_rn(ct, a)) | fg_sign(__fsub_rn(ct, b))) == 0) return 0.0f;
-        a = (float)p[3 * wp];
-        b = (float)p[-3 * wp];
-        if ((fg_sign(__fsub_rn(a, c_t)) | fg_sign(__fsub_rn(b, c_t)) | fg_sign(__fsub_rn(ct, a)) | fg_sign(__fsub_rn(ct, b))) == 0) return 0.0f;
-    }
     /* ring order of bresenham_circle_offset_pitch (:41-95) */
     const int off[16] = {3 * wp,      3 * wp - 1,  2 * wp - 2,  wp - 3,  -3,     -wp - 3,    -2 * wp - 2, -3 * wp - 1,
                          -3 * wp,     -3 * wp + 1, -2 * wp + 2, -wp + 3, 3,      wp + 3,     2 * wp + 2,  3 * wp + 1};
@@ -148,6 +160,7 @@ __global__ void __launch_bounds__(256)
 k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* resp_out, int resp_level, int resp_slot) {
     extern __shared__ __align__(16) uint8_t fgsm[];
     __shared__ unsigned long long s_best;
+    __shared__ int s_nlist;
     const int tid = threadIdx.x, slot = blockIdx.y;
     const int ncell = G.n_cols * G.n_rows;
     const int per_xcd = (ncell + 7) >> 3; /* workgroups b and b+8 share an XCD: neighbouring cells per L2 */
@@ -166,30 +179,69 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         const int WP = cwl + 8, WH = chl + 8, RP = cwl + 2, RH = chl + 2;
         uint8_t* win = fgsm;
         float* respS = (float*)(fgsm + ((WP * WH + 15) & ~15));
-        for (int i = tid; i < WP * WH; i += 256) {
-            const int wy = i / WP, wx = i - wy * WP;
-            const int gx = min(max(x0 - 4 + wx, 0), lg.w - 1), gy = min(max(y0 - 4 + wy, 0), lg.h - 1);
-            win[i] = img[(size_t)gy * lg.pitch + gx];
+        uint16_t* list = (uint16_t*)(respS + RP * RH);
+        const uint32_t mRP = ((1u << 20) + RP - 1) / RP; /* i / RP == (i * mRP) >> 20 for i < 2^20 / RP */
+        /* window origin x0 - 4 is a multiple of 4 (cell widths are), rows are 64-byte aligned: aligned dwords.
+         * Bytes outside the image are never used by a pixel inside the detection border, so the dword and row
+         * indices are merely clamped into the allocation. */
+        if (cwl >= 4) {
+            const int WD = WP >> 2, maxd = (lg.pitch >> 2) - 1, d0 = (x0 - 4) >> 2; /* arithmetic shift: -1 for x0 = 0 */
+            const uint32_t mD = ((1u << 20) + WD - 1) / WD;
+            for (int i = tid; i < WD * WH; i += 256) {
+                const int wy = (int)(((uint32_t)i * mD) >> 20), wd = i - wy * WD;
+                const int gy = min(max(y0 - 4 + wy, 0), lg.h - 1), gd = min(max(d0 + wd, 0), maxd);
+                ((uint32_t*)win)[i] = ((const uint32_t*)(img + (size_t)gy * lg.pitch))[gd];
+            }
+        } else { /* 1- and 2-pixel cells of very coarse levels */
+            for (int i = tid; i < WP * WH; i += 256) {
+                const int wy = i / WP, wx = i - wy * WP;
+                const int gx = min(max(x0 - 4 + wx, 0), lg.w - 1), gy = min(max(y0 - 4 + wy, 0), lg.h - 1);
+                win[i] = img[(size_t)gy * lg.pitch + gx];
+            }
         }
-        if (tid == 0) s_best = 0ull;
+        if (tid == 0) {
+            s_best = 0ull;
+            s_nlist = 0;
+        }
         __syncthreads();
-        for (int i = tid; i < RP * RH; i += 256) { /* K2 on the cell and its 1-px halo */
-            const int ry = i / RP, rx = i - ry * RP;
+        /* K2 on the cell and its 1-px halo, in two passes: the cheap prechecks on every pixel, the survivors
+         * (a quarter of the pixels on textured images) compacted into a list so that the expensive part -- ring
+         * gather, masks, arc test, score -- runs on dense lanes */
+        for (int i = tid; i < RP * RH; i += 256) {
+            const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
             const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
-            float r = 0.0f;
-            if (gx >= G.dhb && gy >= G.dvb && gx < lg.w - G.dhb && gy < lg.h - G.dvb)
-                r = fg_response_px(win + (ry + 3) * WP + rx + 3, WP, G.thr, G.arc, G.score);
-            respS[i] = r;
-            if (resp_out && l == resp_level && slot == resp_slot && rx >= 1 && rx <= cwl && ry >= 1 && ry <= chl &&
-                gx < lg.w && gy < lg.h)
-                resp_out[(size_t)gy * lg.w + gx] = r;
+            respS[i] = 0.0f;
+            const bool cand = gx >= G.dhb && gy >= G.dvb && gx < lg.w - G.dhb && gy < lg.h - G.dvb &&
+                              !fg_precheck_fails(win + (ry + 3) * WP + rx + 3, WP, G.thr);
+            const unsigned long long m = __ballot(cand);
+            if (m) { /* wave-uniform */
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nlist, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            }
         }
         __syncthreads();
+        const int nlist = s_nlist;
+        for (int k = tid; k < nlist; k += 256) {
+            const int i = list[k];
+            const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
+            respS[i] = fg_response_px(win + (ry + 3) * WP + rx + 3, WP, G.thr, G.arc, G.score);
+        }
+        __syncthreads();
+        if (resp_out && l == resp_level && slot == resp_slot)
+            for (int i = tid; i < RP * RH; i += 256) {
+                const int ry = i / RP, rx = i - ry * RP;
+                const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
+                if (rx >= 1 && rx <= cwl && ry >= 1 && ry <= chl && gx < lg.w && gy < lg.h) resp_out[(size_t)gy * lg.w + gx] = respS[i];
+            }
         /* K3: 3x3 suppression (strictly_greater) + cell arg-max with the reference's tie order */
         const int bdx = cwl, bdy = max(1, min(128 / cwl, chl)); /* K3's block, detector_base_gpu_cuda_tools.cu:898-903 */
         const int yoff = max(0, G.vb - chl * cy);
+        const int cshift = 31 - __clz(cwl); /* cell widths are powers of two */
         for (int i = tid; i < cwl * chl; i += 256) {
-            const int py = i / cwl, px = i - py * cwl;
+            const int py = i >> cshift, px = i & (cwl - 1);
             const int gx = x0 + px, gy = y0 + py;
             if (py < yoff || gx < G.hb || gx >= lg.w - G.hb || gy >= lg.h - G.vb) continue;
             const float* rp = respS + (py + 1) * RP + px + 1;
@@ -203,7 +255,7 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
             if (!(c > 0.0f)) continue;
             uint32_t prio;
             if (G.tie == 0) {
-                const int ty = (py - yoff) % bdy;
+                const int ty = (py - yoff) & (bdy - 1); /* bdy is a power of two */
                 const uint32_t t = (uint32_t)(px + bdx * ty);
                 prio = ((t >> 5) << 17) | (fg_brev5(t & 31u) << 12) | (uint32_t)py;
             } else {
@@ -248,7 +300,7 @@ static size_t fg_lds_bytes(const FgGeom& G) {
     for (int l = G.min_level; l < G.max_level; l++) {
         const int cwl = G.cw >> l, chl = G.ch >> l;
         if (cwl < 1 || chl < 1) break;
-        m = std::max(m, (size_t)(((cwl + 8) * (chl + 8) + 15) & ~15) + (size_t)(cwl + 2) * (chl + 2) * 4);
+        m = std::max(m, (size_t)(((cwl + 8) * (chl + 8) + 15) & ~15) + (size_t)(cwl + 2) * (chl + 2) * 6);
     }
     return m;
 }
