@@ -3,7 +3,7 @@
 (1- and 2-pixel cells), wide borders, both cell sizes, every score and tie rule, fractional thresholds."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import orbo
 from vi_slam_amd import synth
 from vi_slam_amd.fastgrid import FASTGPU

@@ -2,7 +2,7 @@
 """Stage-by-stage parity probe (GPU box): HIP extractor vs the CPU oracle on synthetic frames."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import vi_slam_amd as V
 from vi_slam_amd import synth
 from oracle import orbo

@@ -3,7 +3,7 @@
 32 image slots in one launch vs the oracle on one host core."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import vi_slam_amd as V
 from oracle import orbo
 from vi_slam_amd import synth

@@ -3,7 +3,7 @@
 the oracle and vs the REFERENCE's own CPU detector (rosten::fast10_detect_nonmax, oracle/_ref) on one host core."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from oracle import orbo
 from vi_slam_amd import synth

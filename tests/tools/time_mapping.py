@@ -3,7 +3,7 @@
 calls: upload, kernels, download) vs the oracle on one host core, KITTI-size KeyFrames with 2000 features."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import vi_slam_amd as V
 from oracle import orbo
 from vi_slam_amd import synth
