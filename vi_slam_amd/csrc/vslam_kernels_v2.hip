@@ -492,19 +492,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
                 const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
-                int iniTh, int minTh, int tile_rows) {
+                int iniTh, int minTh, int tile_rows, int lcap) {
     extern __shared__ __align__(16) uint8_t smem3[];
     uint8_t* win = smem3;                        /* tile_rows x FP; window column c at LDS column c + 1 */
     uint8_t* sc = win + tile_rows * FP;          /* (tile_rows-4) x FP, interior at (1..ih, 1..iw) */
     uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * FP); /* 2 words per interior row */
-    const int lcap = (tile_rows - 6) * 64;
     uint16_t* listD = (uint16_t*)(keep + (tile_rows - 6) * 2); /* dark-only up from 0, "both" down from lcap-1 */
     uint16_t* listB = listD + lcap;                             /* bright-only */
     __shared__ unsigned long long s_cnt; /* nD | nB << 21 | nX << 42 */
-    __shared__ uint32_t s_wave_tot[4];
+    __shared__ uint32_t s_wave_tot[NT / 64];
     __shared__ int s_any;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -525,13 +525,14 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
      * (= the LDS pitch), 28 rows per sweep */
     {
         const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
+        constexpr int RPS = NT / 9; /* rows per sweep */
         const int srow = tid / 9, scol = (tid - srow * 9) * 8;
-        if (tid < 252 && scol < ww + 1)
-            for (int y = srow; y < wh; y += 28)
+        if (tid < RPS * 9 && scol < ww + 1)
+            for (int y = srow; y < wh; y += RPS)
                 *(uint2*)(win + y * FP + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
     }
-    for (int i = tid; i < (ih + 2) * (FP / 4); i += 256) ((uint32_t*)sc)[i] = 0;
-    if (tid < nwords) keep[tid] = 0;
+    for (int i = tid; i < (ih + 2) * (FP / 4); i += NT) ((uint32_t*)sc)[i] = 0;
+    for (int i = tid; i < nwords; i += NT) keep[i] = 0;
     if (tid == 0) {
         s_any = 0;
         s_cnt = 0ull;
@@ -545,7 +546,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     int T = iniTh;
     for (int stage = 0; stage < 2; stage++) {
         const uint32_t TT = (uint32_t)T | ((uint32_t)T << 16);
-        for (int ly0 = 0; ly0 < ih; ly0 += (256 >> qsh)) { /* block-uniform trip count */
+        for (int ly0 = 0; ly0 < ih; ly0 += (NT >> qsh)) { /* block-uniform trip count */
             const int ly = ly0 + qly;
             uint32_t mD = 0, mB = 0;
             if (qx < QW && ly < ih) {
@@ -620,8 +621,8 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         /* one pass of the networks over three disjoint lists (no two threads touch the same score byte).  Dark
          * entries are handed out from thread 0 upwards, bright ones from thread 255 downwards, so with the usual
          * ~110 + ~110 entries no wave has to run both networks */
-        for (int base = 0; base < max(nD, nB); base += 256) {
-            const int iD = base + tid, iB = base + 255 - tid;
+        for (int base = 0; base < max(nD, nB); base += NT) {
+            const int iD = base + tid, iB = base + NT - 1 - tid;
             if (iD < nD) {
                 const int code = listD[iD];
                 const int a = fast_half_score<1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
@@ -633,7 +634,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
                 sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
         }
-        for (int i = tid; i < nX; i += 256) { /* rare: both polarities possible */
+        for (int i = tid; i < nX; i += NT) { /* rare: both polarities possible */
             const int code = listD[lcap - 1 - i];
             const uint8_t* c = win + ((code >> 6) + 3) * FP + (code & 63) + 4;
             const int a = max(fast_half_score<1>(c), fast_half_score<-1>(c));
@@ -642,7 +643,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         __syncthreads();
         /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
         int any = 0;
-        for (int i = tid; i < ntot; i += 256) {
+        for (int i = tid; i < ntot; i += NT) {
             const int code = i < nD ? listD[i] : i < nD + nB ? listB[i - nD] : listD[lcap - 1 - (i - nD - nB)];
             const int ly = code >> 6, x = code & 63;
             const uint8_t* q = sc + (ly + 1) * FP + x + 1;
@@ -666,17 +667,20 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         __syncthreads();
     }
 
-    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..) */
-    uint32_t bits = 0;
-    const int kly = tid >> 1, kxb = (tid & 1) * 32;
-    if (tid < nwords) bits = keep[tid];
-    const uint32_t cnt = __popc(bits);
+    /* ordered compaction: thread t owns the keep words [t*WPT, (t+1)*WPT) -- word w = (row w>>1, columns (w&1)*32 ..) --
+     * so raster order is kept across threads */
+    const int WPT = (nwords + NT - 1) / NT; /* 1 for NT = 256 */
+    uint32_t cnt = 0;
+    for (int j = 0; j < WPT; j++) {
+        const int w = tid * WPT + j;
+        if (w < nwords) cnt += __popc(keep[w]);
+    }
     const uint32_t incl = wave_incl_scan(cnt);
     if (lane == 63) s_wave_tot[wv] = incl;
     __syncthreads();
     uint32_t wave_off = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NT / 64; k++) {
         if (k < wv) wave_off += s_wave_tot[k];
         total += s_wave_tot[k];
     }
@@ -687,23 +691,59 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         cout[cell].base = cd.base;
         cout[cell].count = total;
     }
-    if (bits == 0) return;
+    if (cnt == 0) return;
     uint32_t o = cd.base + wave_off + incl - cnt;
-    const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
-    while (bits) {
-        const int k = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
-        cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+    for (int j = 0; j < WPT; j++) {
+        const int w = tid * WPT + j;
+        if (w >= nwords) break;
+        uint32_t bits = keep[w];
+        const int kly = w >> 1, kxb = (w & 1) * 32;
+        const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
+        while (bits) {
+            const int k = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
+            cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+        }
     }
+}
+
+/* threads per cell: a cell is 900 pixels, and ~150 of the ~420 instructions a thread executes do not depend on how many
+ * pixels it owns (prologue, NMS bookkeeping, compaction), so fewer, busier threads per cell cost fewer instructions in
+ * total; VSLAM_FAST_NT = 64 | 128 | 256 selects the variant for A/B runs */
+static int fast_v3_nt() {
+    static int nt = -1;
+    if (nt < 0) {
+        nt = 128;
+        if (const char* e = getenv("VSLAM_FAST_NT")) {
+            const int v = atoi(e);
+            if (v == 64 || v == 128 || v == 256) nt = v;
+        }
+    }
+    return nt;
 }
 
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int nslots) {
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_px, int nslots) {
+    /* survivor lists: dark-only + "both" share one list (from both ends), bright-only the other; neither can hold
+     * more entries than the largest cell interior has pixels */
+    const int lcap = (max_px + 7) & ~3;
     const size_t shm = (size_t)tile_rows * FP + (size_t)(tile_rows - 4) * FP + (size_t)(tile_rows - 6) * 8 +
-                       (size_t)(tile_rows - 6) * 64 * 2 * 2 + 16;
-    hipLaunchKernelGGL(k_fast_cells_v3, dim3(((ncells + 7) / 8) * 8, nslots), dim3(256), shm, st, pyr, slot_stride,
-                       src, g, cells, cand_region, cand_stride, ncells, std::min(iniTh, 256), std::min(minTh, 256),
-                       tile_rows);
+                       (size_t)lcap * 2 * 2 + 16;
+    const dim3 grid(((ncells + 7) / 8) * 8, nslots);
+    const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
+    switch (fast_v3_nt()) {
+        case 64:
+            hipLaunchKernelGGL(k_fast_cells_v3<64>, grid, dim3(64), shm, st, pyr, slot_stride, src, g, cells, cand_region,
+                               cand_stride, ncells, it, mt, tile_rows, lcap);
+            break;
+        case 128:
+            hipLaunchKernelGGL(k_fast_cells_v3<128>, grid, dim3(128), shm, st, pyr, slot_stride, src, g, cells, cand_region,
+                               cand_stride, ncells, it, mt, tile_rows, lcap);
+            break;
+        default:
+            hipLaunchKernelGGL(k_fast_cells_v3<256>, grid, dim3(256), shm, st, pyr, slot_stride, src, g, cells, cand_region,
+                               cand_stride, ncells, it, mt, tile_rows, lcap);
+    }
 }
