@@ -156,7 +156,8 @@ __device__ float fg_response_px(const uint8_t* p, int wp, float thr, int arc, in
 
 __device__ __forceinline__ uint32_t fg_brev5(uint32_t v) { return __brev(v) >> 27; }
 
-__global__ void __launch_bounds__(256)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* resp_out, int resp_level, int resp_slot) {
     extern __shared__ __align__(16) uint8_t fgsm[];
     __shared__ unsigned long long s_best;
@@ -187,13 +188,13 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         if (cwl >= 4) {
             const int WD = WP >> 2, maxd = (lg.pitch >> 2) - 1, d0 = (x0 - 4) >> 2; /* arithmetic shift: -1 for x0 = 0 */
             const uint32_t mD = ((1u << 20) + WD - 1) / WD;
-            for (int i = tid; i < WD * WH; i += 256) {
+            for (int i = tid; i < WD * WH; i += NT) {
                 const int wy = (int)(((uint32_t)i * mD) >> 20), wd = i - wy * WD;
                 const int gy = min(max(y0 - 4 + wy, 0), lg.h - 1), gd = min(max(d0 + wd, 0), maxd);
                 ((uint32_t*)win)[i] = ((const uint32_t*)(img + (size_t)gy * lg.pitch))[gd];
             }
         } else { /* 1- and 2-pixel cells of very coarse levels */
-            for (int i = tid; i < WP * WH; i += 256) {
+            for (int i = tid; i < WP * WH; i += NT) {
                 const int wy = i / WP, wx = i - wy * WP;
                 const int gx = min(max(x0 - 4 + wx, 0), lg.w - 1), gy = min(max(y0 - 4 + wy, 0), lg.h - 1);
                 win[i] = img[(size_t)gy * lg.pitch + gx];
@@ -207,7 +208,7 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         /* K2 on the cell and its 1-px halo, in two passes: the cheap prechecks on every pixel, the survivors
          * (a quarter of the pixels on textured images) compacted into a list so that the expensive part -- ring
          * gather, masks, arc test, score -- runs on dense lanes */
-        for (int i = tid; i < RP * RH; i += 256) {
+        for (int i = tid; i < RP * RH; i += NT) {
             const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
             const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
             respS[i] = 0.0f;
@@ -224,14 +225,14 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         }
         __syncthreads();
         const int nlist = s_nlist;
-        for (int k = tid; k < nlist; k += 256) {
+        for (int k = tid; k < nlist; k += NT) {
             const int i = list[k];
             const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
             respS[i] = fg_response_px(win + (ry + 3) * WP + rx + 3, WP, G.thr, G.arc, G.score);
         }
         __syncthreads();
         if (resp_out && l == resp_level && slot == resp_slot)
-            for (int i = tid; i < RP * RH; i += 256) {
+            for (int i = tid; i < RP * RH; i += NT) {
                 const int ry = i / RP, rx = i - ry * RP;
                 const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
                 if (rx >= 1 && rx <= cwl && ry >= 1 && ry <= chl && gx < lg.w && gy < lg.h) resp_out[(size_t)gy * lg.w + gx] = respS[i];
@@ -240,7 +241,7 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         const int bdx = cwl, bdy = max(1, min(128 / cwl, chl)); /* K3's block, detector_base_gpu_cuda_tools.cu:898-903 */
         const int yoff = max(0, G.vb - chl * cy);
         const int cshift = 31 - __clz(cwl); /* cell widths are powers of two */
-        for (int i = tid; i < cwl * chl; i += 256) {
+        for (int i = tid; i < cwl * chl; i += NT) {
             const int py = i >> cshift, px = i & (cwl - 1);
             const int gx = x0 + px, gy = y0 + py;
             if (py < yoff || gx < G.hb || gx >= lg.w - G.hb || gy >= lg.h - G.vb) continue;
@@ -400,10 +401,35 @@ extern "C" int vslam_fg_grid(const vslam_fg* fg, int* n_cols, int* n_rows) {
     return VSLAM_OK;
 }
 
+static int fg_nt() { /* threads per cell, see vk_fast_cells_v3; VSLAM_FG_NT = 64 | 128 | 256 for A/B runs */
+    static int nt = -1;
+    if (nt < 0) {
+        nt = 128;
+        if (const char* e = getenv("VSLAM_FG_NT")) {
+            const int v = atoi(e);
+            if (v == 64 || v == 128 || v == 256) nt = v;
+        }
+    }
+    return nt;
+}
+
 static void fg_launch_detect(vslam_fg* fg, int n, float* resp_out, int resp_level, int resp_slot) {
     const FgGeom& G = fg->G;
-    hipLaunchKernelGGL(k_fg_detect, dim3(((fg->cells + 7) / 8) * 8, n), dim3(256), fg_lds_bytes(G), fg->stream, fg->d_pyr, G,
-                       fg->d_grid, resp_out, resp_level, resp_slot);
+    const dim3 grid(((fg->cells + 7) / 8) * 8, n);
+    const size_t lds = fg_lds_bytes(G);
+    switch (fg_nt()) {
+        case 64:
+            hipLaunchKernelGGL(k_fg_detect<64>, grid, dim3(64), lds, fg->stream, fg->d_pyr, G, fg->d_grid, resp_out, resp_level,
+                               resp_slot);
+            break;
+        case 128:
+            hipLaunchKernelGGL(k_fg_detect<128>, grid, dim3(128), lds, fg->stream, fg->d_pyr, G, fg->d_grid, resp_out,
+                               resp_level, resp_slot);
+            break;
+        default:
+            hipLaunchKernelGGL(k_fg_detect<256>, grid, dim3(256), lds, fg->stream, fg->d_pyr, G, fg->d_grid, resp_out,
+                               resp_level, resp_slot);
+    }
 }
 
 extern "C" int vslam_fg_detect_batch(vslam_fg* fg, int n, const uint8_t* const* imgs, size_t pitch, int on_device, float* pos,
