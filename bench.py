@@ -60,7 +60,7 @@ def pmc_traffic(kernel, cfg, batch):
     a coalesced stream (MI355X_MICROARCH.md 'HBM'): calibrated here on the FAST kernel, whose unique input is
     the pyramid pixels (1.44 MB per image) and whose raw FETCH_SIZE reads half of that -> the factor 2 is applied.
     Only valid for the geometry/batch the profile was taken with; otherwise None."""
-    name = "r01f_pmc_traffic_kitti_b%d.json" % batch
+    name = "r01g_pmc_traffic_kitti_b%d.json" % batch
     path = os.path.join(ROOT, "profiles", name)
     if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376):
         return None

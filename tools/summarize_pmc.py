@@ -18,6 +18,9 @@ for sub in ("fetch", "write", "sq"):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
         k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):  # template instantiations are printed with their return type
+            k = k[5:]
+        k = k.split("<")[0]
         if k.startswith("k_"):
             acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in acc.items():
