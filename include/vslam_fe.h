@@ -267,6 +267,20 @@ int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p, c
                                      const uint8_t* dev_cur_desc, int n_cur, const float* cur_u_right_host,
                                      const uint8_t* cur_occupied_host, int32_t* match_cur, int* nmatches);
 
+/* FMatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (fmatcher.cpp:2689-2811) -- the matcher of Tracking::Relocalization.  p carries T_w_c_'s Rcw | tcw in Tcw, the camera,
+ * th, check_orientation, the image bounds and gemm_float (forward / backward / mbf are not used); Ow = -Rcw^T tcw as the
+ * function computes it (:2695); log_scale_factor = CurrentFrame.mfLogScaleFactor; orb_dist 1..255.  Per KeyFrame
+ * keypoint i: kf_kps_host = pKF->mvKeysUn, mp_flags[i] & 1 iff vpMPs[i] && !isBad() && !sAlreadyFound.count(it),
+ * world position, Get{Min,Max}DistanceInvariance(), descriptor.  cur_occupied_host marks CurrentFrame.mvpMapPoints
+ * entries that are not NULL.  match_cur[i2] = i (pKF's keypoint whose MapPoint is written to mvpMapPoints[i2]) or -1. */
+int vslam_search_by_projection_keyframe(vslam_fe* fe, const vslam_proj_params* p, const float* Ow, float log_scale_factor,
+                                        int orb_dist, const vslam_kp* kf_kps_host, int n_kf, const uint8_t* mp_flags,
+                                        const float* mp_x3dw, const float* mp_min_dist, const float* mp_max_dist,
+                                        const uint8_t* mp_desc_host, const vslam_kp* dev_cur_kps,
+                                        const uint8_t* dev_cur_desc, int n_cur, const uint8_t* cur_occupied_host,
+                                        int32_t* match_cur, int* nmatches);
+
 /* FMatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
  * (fmatcher.cpp:321-411; pinhole frames) -- the local-map matcher of Tracking::SearchLocalPoints.  Each MapPoint
  * arrives with what Frame::isInFrustum left in it (mappoint.h:73-81):

@@ -1403,6 +1403,85 @@ void fuse_search(const std::vector<FusePoint>& pts, const std::vector<uint8_t>& 
     }
 }
 
+/* ------------------------------------------------------------------ SearchByProjection(CurrentFrame, pKF, ...) */
+int search_by_projection_keyframe(const float Tcw[12], const float Ow[3], float fx, float fy, float cx, float cy, float th,
+                                  int ORBdist, float mfLogScaleFactor, bool checkOri, int imgW, int imgH, int gemmDouble,
+                                  const std::vector<KeyPoint>& mvKeysUn, const std::vector<uint8_t>& flags,
+                                  const std::vector<float>& x3Dws, const std::vector<float>& minDist,
+                                  const std::vector<float>& maxDist, const std::vector<uint8_t>& mpDesc,
+                                  const std::vector<KeyPoint>& curKps, const std::vector<uint8_t>& curDesc,
+                                  const std::vector<uint8_t>& occupied0, const std::vector<float>& mvScaleFactors,
+                                  std::vector<int>& matchCur) { /* fmatcher.cpp:2689-2811 */
+    const int HISTO_LENGTH = 30;
+    int nmatches = 0;
+    const int N2 = (int)curKps.size();
+    matchCur.assign(N2, -1);
+    std::vector<uint8_t> has(N2, 0); /* CurrentFrame.mvpMapPoints[i2] != NULL */
+    for (int i = 0; i < N2 && i < (int)occupied0.size(); i++) has[i] = occupied0[i];
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    FrameGrid grid(curKps, imgW, imgH);
+    const int mnScaleLevels = (int)mvScaleFactors.size();
+    const float mnMinX = 0.0f, mnMaxX = (float)imgW, mnMinY = 0.0f, mnMaxY = (float)imgH;
+    for (size_t i = 0; i < mvKeysUn.size(); i++) {
+        if (!(flags[i] & 1)) continue;
+        const float* x3Dw = &x3Dws[3 * i];
+        const float xc = gemm_row(Tcw + 0, x3Dw, Tcw[3], gemmDouble);
+        const float yc = gemm_row(Tcw + 4, x3Dw, Tcw[7], gemmDouble);
+        const float zc = gemm_row(Tcw + 8, x3Dw, Tcw[11], gemmDouble);
+        const float u = fx * xc / zc + cx; /* mpCamera->project(x3Dc): no depth test in this overload */
+        const float v = fy * yc / zc + cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+        double n2 = 0;
+        for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+        const float dist3D = (float)std::sqrt(n2); /* cv::norm */
+        if (dist3D < minDist[i] || dist3D > maxDist[i]) continue;
+        const float ratio = maxDist[i] / dist3D; /* MapPoint::PredictScale(dist3D, &CurrentFrame), mappoint.cpp:523-538 */
+        const float lv = std::ceil(glibc_logf(ratio) / mfLogScaleFactor);
+        int nPredictedLevel = (lv != lv || lv >= 2147483648.0f || lv < -2147483648.0f) ? INT_MIN : (int)lv;
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= mnScaleLevels) nPredictedLevel = mnScaleLevels - 1;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices2 = grid.GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = &mpDesc[32 * i];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (has[i2]) continue;
+            const int dist = descriptor_distance(dMP, &curDesc[32 * (size_t)i2]);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= ORBdist) {
+            matchCur[bestIdx2] = (int)i;
+            has[bestIdx2] = 1;
+            nmatches++;
+            if (checkOri) {
+                float rot = mvKeysUn[i].angle - curKps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) {
+                    matchCur[idx] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

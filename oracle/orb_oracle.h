@@ -251,6 +251,18 @@ void fuse_search(const std::vector<FusePoint>& pts, const std::vector<uint8_t>& 
                  const std::vector<float>& scaleFactors, const std::vector<float>& invLevelSigma2, const FuseArgs& a,
                  std::vector<int>& bestIdx, std::vector<int>& bestDist);
 
+/* FMatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (fmatcher.cpp:2689-2811), pinhole: flags[i] & 1 iff vpMPs[i] && !isBad() && !sAlreadyFound.count(vpMPs[i]);
+ * occupied: CurrentFrame.mvpMapPoints[i2] != NULL on entry.  matchCur[i2] = i or -1; returns nmatches. */
+int search_by_projection_keyframe(const float Tcw[12], const float Ow[3], float fx, float fy, float cx, float cy, float th,
+                                  int ORBdist, float logScaleFactor, bool checkOri, int imgW, int imgH, int gemmDouble,
+                                  const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>& flags,
+                                  const std::vector<float>& x3Dw, const std::vector<float>& minDist,
+                                  const std::vector<float>& maxDist, const std::vector<uint8_t>& mpDesc,
+                                  const std::vector<KeyPoint>& curKps, const std::vector<uint8_t>& curDesc,
+                                  const std::vector<uint8_t>& occupied, const std::vector<float>& scaleFactors,
+                                  std::vector<int>& matchCur);
+
 } // namespace orbo
 
 #endif

@@ -315,6 +315,25 @@ void orbo_fuse_search(const FusePoint* pts, int n, const uint8_t* mpDesc, const 
     }
 }
 
+int orbo_search_by_projection_keyframe(const float* Tcw, const float* Ow, const float* cam /*fx,fy,cx,cy*/, float th,
+                                       int ORBdist, float logScaleFactor, int checkOri, int imgW, int imgH, int gemmDouble,
+                                       const KeyPoint* kfKps, int nKF, const uint8_t* flags, const float* x3Dw,
+                                       const float* minDist, const float* maxDist, const uint8_t* mpDesc,
+                                       const KeyPoint* curKps, int nCur, const uint8_t* curDesc, const uint8_t* occupied,
+                                       const float* scaleFactors, int nlevels, int* matchCur) {
+    std::vector<KeyPoint> kk(kfKps, kfKps + nKF), ck(curKps, curKps + nCur);
+    std::vector<uint8_t> fl(flags, flags + nKF), md(mpDesc, mpDesc + (size_t)nKF * 32), cd(curDesc, curDesc + (size_t)nCur * 32),
+        oc;
+    if (occupied) oc.assign(occupied, occupied + nCur);
+    std::vector<float> x(x3Dw, x3Dw + (size_t)nKF * 3), mn(minDist, minDist + nKF), mx(maxDist, maxDist + nKF),
+        sf(scaleFactors, scaleFactors + nlevels);
+    std::vector<int> m;
+    const int nm = search_by_projection_keyframe(Tcw, Ow, cam[0], cam[1], cam[2], cam[3], th, ORBdist, logScaleFactor,
+                                                 checkOri != 0, imgW, imgH, gemmDouble, kk, fl, x, mn, mx, md, ck, cd, oc, sf, m);
+    if (nCur) memcpy(matchCur, m.data(), (size_t)nCur * sizeof(int));
+    return nm;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

@@ -86,6 +86,9 @@ def lib():
                                                      C.c_int, vp])
         L.orbo_fuse_search.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp]
         L.orbo_fuse_search.restype = None
+        L.orbo_search_by_projection_keyframe.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                         C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                                         C.c_int, vp]
         L.orbo_fg_halfsample.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
         L.orbo_fg_halfsample.restype = None
         L.orbo_fg_response.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
@@ -519,3 +522,29 @@ def ref_fast_detect_nonmax(img, b, arc=10, new_score=False):
     out = np.zeros((cap, 3), np.int32)
     n = R.ref_fast_detect_nonmax(_p(img), w, h, w, int(b), arc, int(new_score), _p(out), cap)
     return out[:n].copy()
+
+
+def search_by_projection_keyframe(Tcw, Ow, cam, th, orb_dist, log_scale_factor, kf_kps, flags, x3dw, min_dist, max_dist,
+                                  mp_desc, cur_kps, cur_desc, scale_factors, W, H, check_ori=True, occupied=None,
+                                  gemm_double=True):
+    """FMatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (fmatcher.cpp:2689-2811)
+    -> (nmatches, match_cur[n_cur] = KeyFrame keypoint index or -1).  cam = (fx, fy, cx, cy)."""
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    O = np.ascontiguousarray(Ow, np.float32).reshape(3)
+    c = np.ascontiguousarray(cam[:4], np.float32)
+    kk = np.ascontiguousarray(kf_kps, KP_DTYPE)
+    ck = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    x = np.ascontiguousarray(x3dw, np.float32)
+    mn = np.ascontiguousarray(min_dist, np.float32)
+    mx = np.ascontiguousarray(max_dist, np.float32)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    cd = np.ascontiguousarray(cur_desc, np.uint8)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(ck), 1), -1, np.int32)
+    nm = lib().orbo_search_by_projection_keyframe(_p(T), _p(O), _p(c), float(th), int(orb_dist), float(log_scale_factor),
+                                                  int(check_ori), int(W), int(H), int(gemm_double), _p(kk), len(kk), _p(fl),
+                                                  _p(x), _p(mn), _p(mx), _p(md), _p(ck), len(ck), _p(cd),
+                                                  _p(oc) if oc is not None else None, _p(sf), len(sf), _p(m))
+    return nm, m[:len(ck)]

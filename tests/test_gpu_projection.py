@@ -282,3 +282,65 @@ def test_tracking_matchers_against_golden_fixture(golden_dir):
         assert np.array_equal(V.ComputeDistinctiveDescriptors(fe, g["dist_desc"], g["dist_off"]), g["dist_best"])
     finally:
         fe.close()
+
+
+# ---------------------------------------------------------------- relocalisation matcher (fmatcher.cpp:2689-2811)
+def _kf_points(scene, rng=None):
+    """The last frame as a KeyFrame: its stereo points as MapPoints with the scale-invariance range
+    MapPoint::UpdateNormalAndDepth gives them (dist * scale[level] upwards, / scale[nlevels-1] downwards)."""
+    k0, sf = scene["k0"], scene["sf"]
+    X = scene["X"]
+    d = np.linalg.norm(X, axis=1).astype(np.float32)
+    mx = (np.float32(1.2) * d * sf[k0["octave"]]).astype(np.float32)
+    mn = (np.float32(0.8) * d * sf[k0["octave"]] / sf[-1]).astype(np.float32)
+    return mn, mx
+
+
+def _run_kf(scene, Tcw, th, orb_dist, flags, mn, mx, check_ori=True, occupied=None, gemm_float=False):
+    R, t = Tcw[:, :3], Tcw[:, 3]
+    Ow = (-R.T @ t).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    m = V.FMatcher(scene["fe"], 0.9, check_ori)
+    nm, mc = m.SearchByProjectionKeyFrame(Tcw, Ow, (FX, FY, CX, CY), th, orb_dist, lsf, scene["k0"], flags, scene["X"], mn,
+                                          mx, scene["de0"], scene["cur"][0], scene["cur"][1], len(scene["k1"]), occupied,
+                                          (W, H), gemm_float)
+    wn, wm = orbo.search_by_projection_keyframe(Tcw, Ow, (FX, FY, CX, CY), th, orb_dist, lsf, scene["k0"], flags, scene["X"],
+                                                mn, mx, scene["de0"], scene["k1"], scene["de1"], scene["sf"], W, H, check_ori,
+                                                occupied, not gemm_float)
+    assert nm == wn, (nm, wn)
+    assert np.array_equal(mc, wm)
+    return nm, mc
+
+
+def test_search_by_projection_keyframe_equals_oracle(scene):
+    rng = np.random.default_rng(12)
+    mn, mx = _kf_points(scene)
+    zmed = float(np.median(scene["z"][scene["has_depth"]]))
+    Tcw = _pose(tx=3.0 / FX * zmed, ty=1.0 / FY * zmed)
+    flags = np.ones(len(scene["k0"]), np.uint8)
+    nm, mc = _run_kf(scene, Tcw, 10, 100, flags, mn, mx)       # tracking.cpp Relocalization: th 10, ORBdist 100
+    assert nm > 200
+    _run_kf(scene, Tcw, 3, 64, flags, mn, mx)                   # second pass: th 3, ORBdist 64
+    _run_kf(scene, Tcw, 10, 100, flags, mn, mx, check_ori=False)
+    _run_kf(scene, Tcw, 10, 100, flags, mn, mx, gemm_float=True)
+    # sAlreadyFound / bad MapPoints, and keypoints of the current frame that already hold a MapPoint
+    fl = (rng.random(len(flags)) < 0.6).astype(np.uint8)
+    occ = (rng.random(len(scene["k1"])) < 0.3).astype(np.uint8)
+    n2, m2 = _run_kf(scene, Tcw, 10, 100, fl, mn, mx, occupied=occ)
+    assert np.all(m2[occ == 1] == -1) and np.all(fl[m2[m2 >= 0]] == 1)
+    # ranges that exclude a third of the points, a tight accept threshold, a wide window (prefix exhaustion)
+    mx2 = mx.copy()
+    mx2[rng.random(len(mx)) < 0.33] *= 0.3
+    _run_kf(scene, Tcw, 10, 30, flags, mn, mx2)
+    _run_kf(scene, Tcw, 40, 100, flags, mn, mx)
+    # this overload has no depth test: a camera looking the other way still "projects"
+    _run_kf(scene, _pose(tz=-60.0), 10, 100, flags, mn, mx)
+    _run_kf(scene, _pose(tx=0.5, yaw=0.1, tz=-3.0), 10, 100, flags, mn, mx)
+
+
+def test_search_by_projection_keyframe_sequential_path(scene, monkeypatch):
+    monkeypatch.setenv("VSLAM_SBP_MODE", "seq")
+    mn, mx = _kf_points(scene)
+    zmed = float(np.median(scene["z"][scene["has_depth"]]))
+    flags = np.ones(len(scene["k0"]), np.uint8)
+    _run_kf(scene, _pose(tx=3.0 / FX * zmed, ty=1.0 / FY * zmed), 20, 80, flags, mn, mx)

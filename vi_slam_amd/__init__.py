@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "vslam_stereo_points_buffers", "vslam_search_by_projection_mappoints", "vslam_distinctive_descriptors", "vslam_voc_create", "vslam_voc_destroy",
     "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
     "vslam_bow_assemble", "vslam_search_by_bow", "vslam_search_by_bow_keyframes",
-    "vslam_search_for_triangulation", "vslam_fuse_search", "vslam_dbg_logf",
+    "vslam_search_for_triangulation", "vslam_fuse_search", "vslam_dbg_logf", "vslam_search_by_projection_keyframe",
 ]
 
 
@@ -149,6 +149,8 @@ def lib():
         L.vslam_search_for_triangulation.argtypes = [vp, vp] + [vp, vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp, vp]
         L.vslam_fuse_search.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
         L.vslam_dbg_logf.argtypes = [vp, vp, i, vp]
+        L.vslam_search_by_projection_keyframe.argtypes = [vp, vp, vp, C.c_float, i, vp, i, vp, vp, vp, vp, vp, vp, vp, i, vp,
+                                                          vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
         L.vslam_search_by_projection_dev_wait.argtypes = [vp, vp, vp, vp]
         L.vslam_stereo_points_dev_async.argtypes = [vp, i, vp, C.c_float, C.c_float, C.c_float, C.c_float, i, i]
@@ -652,6 +654,36 @@ class FMatcher:
                                                    C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m),
                                                    C.byref(nm)))
         return nm.value, m[:len(kps1)]
+
+    def SearchByProjectionKeyFrame(self, Tcw, Ow, cam, th, ORBdist, log_scale_factor, kf_kps, mp_flags, mp_x3dw,
+                                   mp_min_dist, mp_max_dist, mp_desc, dev_cur_kps, dev_cur_desc, n_cur, occupied=None,
+                                   img_size=None, gemm_float=False):
+        """FMatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (fmatcher.cpp:2689-2811), the
+        relocalisation matcher.  cam = (fx, fy, cx, cy).  -> (nmatches, match_cur[n_cur] = pKF keypoint index or -1)."""
+        kk = np.ascontiguousarray(kf_kps, KP_DTYPE)
+        fl = np.ascontiguousarray(mp_flags, np.uint8)
+        x = np.ascontiguousarray(mp_x3dw, np.float32)
+        mn = np.ascontiguousarray(mp_min_dist, np.float32)
+        mx = np.ascontiguousarray(mp_max_dist, np.float32)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        O = np.ascontiguousarray(Ow, np.float32).reshape(3)
+        w, h = img_size or (self.fe.width, self.fe.height)
+        P = _ProjParams()
+        T = np.asarray(Tcw, np.float32).reshape(-1)
+        for k in range(12):
+            P.Tcw[k] = float(T[k])
+        P.fx, P.fy, P.cx, P.cy = [float(v) for v in cam[:4]]
+        P.mbf, P.th = 0.0, float(th)
+        P.forward = P.backward = 0
+        P.check_orientation, P.img_w, P.img_h, P.gemm_float = int(self.mbCheckOrientation), int(w), int(h), int(gemm_float)
+        m = np.full(max(n_cur, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_projection_keyframe(
+            self.fe._h, C.byref(P), _p(O), C.c_float(log_scale_factor), int(ORBdist), _p(kk), len(kk), _p(fl), _p(x), _p(mn),
+            _p(mx), _p(md), C.c_void_p(dev_cur_kps), C.c_void_p(dev_cur_desc), n_cur, _p(oc) if oc is not None else None,
+            _p(m), C.byref(nm)))
+        return nm.value, m[:n_cur]
 
     def SearchForTriangulation(self, kps1, dev_desc1, has_mp1, u_right1, fv1, kps2, dev_desc2, has_mp2, u_right2, fv2,
                                F12, ep, bOnlyStereo=False, bCoarse=False):

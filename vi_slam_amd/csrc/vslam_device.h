@@ -162,11 +162,22 @@ struct SbpJobDev {
     float nnratio;
     int32_t mode;
 };
+/* mode 2 = SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation; one job per call): the
+ * KeyFrame's MapPoints are projected with PredictScale; accept threshold ORBdist instead of TH_HIGH */
+struct SbpKfDev {
+    int32_t thHigh; /* 0 = TH_HIGH */
+    float logScaleFactor;
+    const float* minDist;
+    const float* maxDist;
+    float ow[3];
+    float pad;
+};
 #define VSLAM_MAX_SBP_JOBS 16
 struct SbpJobs { /* by-value kernel argument (< 4 KB) */
     SbpJobDev job[VSLAM_MAX_SBP_JOBS];
     float scale[VSLAM_MAX_LEVELS];
     int32_t nlevels, M;
+    SbpKfDev kf;
 };
 
 /* k_unproject_stereo: one stereo pair's left keypoints -> world points (Frame::UnprojectStereo) */

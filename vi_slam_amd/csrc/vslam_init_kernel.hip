@@ -24,6 +24,7 @@
  */
 #include "vslam_kernels.h"
 #include "vslam_wave.h"
+#include "vslam_trig.h"
 
 #define SI_TH_LOW 50
 #define SI_HISTO 30
@@ -558,6 +559,34 @@ k_sbp_rank(SbpJobs JS) {
                 pr.maxLevel = mp.level;
                 pr.valid = 1;
             }
+        } else if (J.mode == 2) { /* KeyFrame MapPoints into the current frame, fmatcher.cpp:2705-2743 */
+            if (J.flags[q] & 1) { /* pMP && !isBad() && !sAlreadyFound.count(pMP) */
+                const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
+                const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
+                const float yc = sbp_gemm_row(J.Tcw + 4, X, Y, Z, J.Tcw[7], J.gemmFloat);
+                const float zc = sbp_gemm_row(J.Tcw + 8, X, Y, Z, J.Tcw[11], J.gemmFloat);
+                const float u = __fadd_rn(__fdiv_rn(__fmul_rn(J.fx, xc), zc), J.cx); /* no depth test here */
+                const float v = __fadd_rn(__fdiv_rn(__fmul_rn(J.fy, yc), zc), J.cy);
+                if (!(u < 0.f || u > (float)J.imgW) && !(v < 0.f || v > (float)J.imgH)) {
+                    /* Ow = -Rcw^T tcw is cv::Mat algebra on the caller's side: it arrives in JS.kf.ow */
+                    const float p0 = __fsub_rn(X, JS.kf.ow[0]), p1 = __fsub_rn(Y, JS.kf.ow[1]), p2 = __fsub_rn(Z, JS.kf.ow[2]);
+                    double n2 = __dmul_rn((double)p0, (double)p0); /* cv::norm: double accumulation */
+                    n2 = __dadd_rn(n2, __dmul_rn((double)p1, (double)p1));
+                    n2 = __dadd_rn(n2, __dmul_rn((double)p2, (double)p2));
+                    const float dist3D = (float)__dsqrt_rn(n2);
+                    const float mn = JS.kf.minDist[q], mx = JS.kf.maxDist[q];
+                    if (!(dist3D < mn || dist3D > mx)) {
+                        const float lv = ceilf(__fdiv_rn(vslam_trig::glibc_logf(__fdiv_rn(mx, dist3D)), JS.kf.logScaleFactor));
+                        const int level = (lv != lv || lv >= 2147483648.0f || lv < 0.f) ? 0 : min((int)lv, JS.nlevels - 1);
+                        pr.u = u;
+                        pr.v = v;
+                        pr.radius = __fmul_rn(J.th, JS.scale[level]);
+                        pr.minLevel = level - 1;
+                        pr.maxLevel = level + 1;
+                        pr.valid = 1;
+                    }
+                }
+            }
         } else if (J.flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
             const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
             const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
@@ -653,6 +682,7 @@ __global__ void __launch_bounds__(SBP_RT)
 k_sbp_resolve(SbpJobs JS, int forceSeq) {
     extern __shared__ __align__(16) uint8_t sbsm[];
     const SbpJobDev& J = JS.job[blockIdx.x];
+    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)JS.kf.thHigh : (uint32_t)SBP_TH_HIGH;
     const int M = JS.M;
     const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
     const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
@@ -686,7 +716,7 @@ k_sbp_resolve(SbpJobs JS, int forceSeq) {
         if (tid == 0) s_changed = 0;
 #pragma unroll
         for (int k = 0; k < SBP_QPT; k++)
-            if (key[k] != 0xFFFFFFFFu && blocking[k] && (key[k] >> 24) <= SBP_TH_HIGH)
+            if (key[k] != 0xFFFFFFFFu && blocking[k] && (key[k] >> 24) <= thHigh)
                 atomicMin(&holder[key[k] & 0xFFF], tid + k * SBP_RT);
         __syncthreads();
 #pragma unroll
@@ -717,7 +747,7 @@ k_sbp_resolve(SbpJobs JS, int forceSeq) {
     for (int k = 0; k < SBP_QPT; k++) {
         const int q = tid + k * SBP_RT;
         bin[k] = 255;
-        if (key[k] != 0xFFFFFFFFu && (key[k] >> 24) <= SBP_TH_HIGH) {
+        if (key[k] != 0xFFFFFFFFu && (key[k] >> 24) <= thHigh) {
             const int i2 = (int)(key[k] & 0xFFF);
             atomicMax(&owner[i2], q);
             atomicAdd(&s_nlog, 1);
@@ -769,6 +799,7 @@ __global__ void __launch_bounds__(64)
 k_sbp_replay(SbpJobs JS, int* fallbacks) {
     extern __shared__ __align__(16) uint8_t sbsm[];
     const SbpJobDev& J = JS.job[blockIdx.x];
+    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)JS.kf.thHigh : (uint32_t)SBP_TH_HIGH;
     const int M = JS.M;
     const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
     const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
@@ -832,7 +863,7 @@ k_sbp_replay(SbpJobs JS, int* fallbacks) {
                                       occupied, invW, invH, lane);
                 if (gBest == 0xFFFFFFFFu) continue;
             }
-            if ((gBest >> 24) > SBP_TH_HIGH) continue; /* bestDist <= TH_HIGH */
+            if ((gBest >> 24) > thHigh) continue; /* bestDist <= TH_HIGH (ORBdist in the KeyFrame overload) */
             const uint32_t i2 = gBest & 0xFFF;
             const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)myflags, tq);
             if (lane == 0) {
@@ -1163,7 +1194,6 @@ void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs) {
  * mutation that follows in the reference (Replace / AddObservation / vpReplacePoint) stays with the caller.
  * One wave per MapPoint, the KeyFrame's keypoints in LDS as for SearchByProjection.
  * ---------------------------------------------------------------------------------------------- */
-#include "vslam_trig.h"
 #define FUSE_QPB 16
 __global__ void __launch_bounds__(256)
 k_fuse_rank(FuseArgsDev A) {

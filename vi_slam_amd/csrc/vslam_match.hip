@@ -496,12 +496,18 @@ extern "C" int vslam_projection_direction(const float* Tcw, const float* Tlw, fl
     return VSLAM_OK;
 }
 
-extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p,
-                                                const vslam_kp* last_kps_host, int n_last, const uint8_t* last_flags,
-                                                const float* last_x3dw, const uint8_t* mp_desc_host,
-                                                const vslam_kp* dev_cur_kps, const uint8_t* dev_cur_desc, int n_cur,
-                                                const float* cur_u_right_host, const uint8_t* cur_occupied_host,
-                                                int32_t* match_cur, int* nmatches) {
+/* extras of the KeyFrame overload (fmatcher.cpp:2689-2811); null for SearchByProjection(CurrentFrame, LastFrame) */
+struct SbpKfExtras {
+    const float *min_dist, *max_dist;
+    float ow[3], log_scale_factor;
+    int orb_dist;
+};
+
+static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_kp* last_kps_host, int n_last,
+                          const uint8_t* last_flags, const float* last_x3dw, const uint8_t* mp_desc_host,
+                          const vslam_kp* dev_cur_kps, const uint8_t* dev_cur_desc, int n_cur,
+                          const float* cur_u_right_host, const uint8_t* cur_occupied_host, const SbpKfExtras* kf,
+                          int32_t* match_cur, int* nmatches) {
     if (!fe || !p || n_last < 0 || n_cur < 0 || !nmatches || (n_cur && (!dev_cur_kps || !dev_cur_desc || !match_cur)) ||
         (n_last && (!last_kps_host || !last_flags || !last_x3dw || !mp_desc_host)) || p->img_w < 1 || p->img_h < 1) {
         g_err = "invalid arguments";
@@ -535,7 +541,8 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_kps = 0, o_x = al(o_kps + (size_t)n_last * sizeof(vslam_kp)), o_d = al(o_x + (size_t)n_last * 12),
                  o_f = al(o_d + (size_t)n_last * 32), o_u = al(o_f + (size_t)n_last), o_o = al(o_u + (size_t)n_cur * 4),
-                 in_bytes = al(o_o + (size_t)n_cur);
+                 o_mn = al(o_o + (size_t)n_cur), o_mx = al(o_mn + (kf ? (size_t)n_last * 4 : 0)),
+                 in_bytes = al(o_mx + (kf ? (size_t)n_last * 4 : 0));
     const size_t o_scr = in_bytes, o_m = al(o_scr + vk_sbp_scratch_bytes(n_last, M)), o_n = al(o_m + (size_t)n_cur * 4),
                  total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
@@ -558,6 +565,11 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     memcpy(h + o_f, last_flags, (size_t)n_last);
     if (cur_u_right_host) memcpy(h + o_u, cur_u_right_host, (size_t)n_cur * 4);
     if (cur_occupied_host) memcpy(h + o_o, cur_occupied_host, (size_t)n_cur);
+    if (kf) {
+        for (int i = 0; i < n_last; i++) h[o_f + i] = (last_flags[i] & 1) ? 3 : 0; /* every accepted MapPoint blocks its keypoint */
+        memcpy(h + o_mn, kf->min_dist, (size_t)n_last * 4);
+        memcpy(h + o_mx, kf->max_dist, (size_t)n_last * 4);
+    }
     hipStream_t st = fe->stream;
     HIPCHK(hipMemcpyAsync(fe->d_proj, h, in_bytes, hipMemcpyHostToDevice, st));
     static_assert(sizeof(SbpJobs) <= 4000, "SbpJobs travels as a kernel argument");
@@ -586,6 +598,14 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     J.matchCur = (int32_t*)(d + o_m);
     J.nmatches = (int32_t*)(d + o_n);
     J.needSeq = (int32_t*)(d + o_n) + 1;
+    if (kf) {
+        J.mode = 2;
+        JS.kf.thHigh = kf->orb_dist;
+        JS.kf.logScaleFactor = kf->log_scale_factor;
+        JS.kf.minDist = (const float*)(d + o_mn);
+        JS.kf.maxDist = (const float*)(d + o_mx);
+        for (int i = 0; i < 3; i++) JS.kf.ow[i] = kf->ow[i];
+    }
     const char* mode = getenv("VSLAM_SBP_MODE"); /* "seq": skip the parallel resolution (cross-check path) */
     vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb, mode && !strcmp(mode, "seq"));
     HIPCHK(hipGetLastError());
@@ -601,6 +621,43 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
     memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
     *nmatches = *(const int32_t*)(h + o_n);
     return VSLAM_OK;
+}
+
+extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_params* p,
+                                                const vslam_kp* last_kps_host, int n_last, const uint8_t* last_flags,
+                                                const float* last_x3dw, const uint8_t* mp_desc_host,
+                                                const vslam_kp* dev_cur_kps, const uint8_t* dev_cur_desc, int n_cur,
+                                                const float* cur_u_right_host, const uint8_t* cur_occupied_host,
+                                                int32_t* match_cur, int* nmatches) {
+    return sbp_frame_impl(fe, p, last_kps_host, n_last, last_flags, last_x3dw, mp_desc_host, dev_cur_kps, dev_cur_desc, n_cur,
+                          cur_u_right_host, cur_occupied_host, nullptr, match_cur, nmatches);
+}
+
+/* FMatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (fmatcher.cpp:2689-2811): same ranking / resolution kernels, mode 2 */
+extern "C" int vslam_search_by_projection_keyframe(vslam_fe* fe, const vslam_proj_params* p, const float* Ow,
+                                                   float log_scale_factor, int orb_dist, const vslam_kp* kf_kps_host,
+                                                   int n_kf, const uint8_t* mp_flags, const float* mp_x3dw,
+                                                   const float* mp_min_dist, const float* mp_max_dist,
+                                                   const uint8_t* mp_desc_host, const vslam_kp* dev_cur_kps,
+                                                   const uint8_t* dev_cur_desc, int n_cur,
+                                                   const uint8_t* cur_occupied_host, int32_t* match_cur, int* nmatches) {
+    if (!Ow || (n_kf > 0 && (!mp_min_dist || !mp_max_dist)) || orb_dist < 1 || orb_dist > 255) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    if (n_kf > 4096) {
+        g_err = "SearchByProjection on the device supports at most 4096 KeyFrame keypoints";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    SbpKfExtras kf;
+    kf.min_dist = mp_min_dist;
+    kf.max_dist = mp_max_dist;
+    for (int i = 0; i < 3; i++) kf.ow[i] = Ow[i];
+    kf.log_scale_factor = log_scale_factor;
+    kf.orb_dist = orb_dist;
+    return sbp_frame_impl(fe, p, kf_kps_host, n_kf, mp_flags, mp_x3dw, mp_desc_host, dev_cur_kps, dev_cur_desc, n_cur, nullptr,
+                          cur_occupied_host, &kf, match_cur, nmatches);
 }
 
 static int sbp_prepare(vslam_fe* fe, int* M_out) {
