@@ -259,6 +259,40 @@ def test_search_by_projection_oracle_identity_pose():
     assert np.all(m[flags == 0][m[flags == 0] >= 0] != np.nonzero(flags == 0)[0][m[flags == 0] >= 0])
 
 
+def test_search_by_projection_keyframe_oracle_identity_pose():
+    """fmatcher.cpp:2689-2811 restated (relocalisation matcher): a KeyFrame's own points seen from its own pose find
+    themselves; ORBdist, sAlreadyFound flags, occupied keypoints and the distance range gate behave as written."""
+    from vi_slam_amd import synth
+    W, H = 640, 360
+    e = orbo.Extractor(800)
+    k, d, _ = e.compute(synth.make_frame(W, H))
+    sf = e.tables()["scale"]
+    fx = fy = 500.0
+    z = np.full(len(k), 8.0, np.float32)
+    X = np.stack([(k["x"] - W / 2) / fx * z, (k["y"] - H / 2) / fy * z, z], 1).astype(np.float32)
+    dist = np.linalg.norm(X, axis=1).astype(np.float32)
+    mx = (np.float32(1.05) * dist * sf[k["octave"]]).astype(np.float32)  # PredictScale -> octave + 1 (or the top level)
+    mn = np.zeros(len(k), np.float32)
+    T = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    flags = np.ones(len(k), np.uint8)
+    flags[::5] = 0
+    nm, m = orbo.search_by_projection_keyframe(T, np.zeros(3), (fx, fy, W / 2, H / 2), 3, 50, lsf, k, flags, X, mn, mx, d, k, d,
+                                               sf, W, H, check_ori=False)
+    sel = np.nonzero(flags)[0]
+    assert nm >= len(sel) - 5 and (m[sel] == sel).sum() >= len(sel) - 5
+    occ = np.zeros(len(k), np.uint8)
+    occ[sel[::2]] = 1
+    nm2, m2 = orbo.search_by_projection_keyframe(T, np.zeros(3), (fx, fy, W / 2, H / 2), 3, 50, lsf, k, flags, X, mn, mx, d, k,
+                                                 d, sf, W, H, check_ori=False, occupied=occ)
+    assert np.all(m2[occ == 1] == -1) and nm2 < nm
+    mx_bad = mx.copy()
+    mx_bad[sel[:50]] = dist[sel[:50]] * np.float32(0.5)  # dist3D > maxDistance: skipped
+    nm3, m3 = orbo.search_by_projection_keyframe(T, np.zeros(3), (fx, fy, W / 2, H / 2), 3, 50, lsf, k, flags, X, mn, mx_bad, d,
+                                                 k, d, sf, W, H, check_ori=False)
+    assert not np.any(np.isin(m3, sel[:50]))
+
+
 def test_tracking_golden(golden_dir):
     """The tracking matchers' restatements against the committed fixture (real-image pair from the reference's
     test set): pins the oracle against regressions."""
