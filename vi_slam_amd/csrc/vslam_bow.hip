@@ -442,13 +442,7 @@ static int search_by_bow_impl(vslam_fe* fe, const vslam_kp* kf_kps_host, const u
     const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n_out * 4), o_n = al(o_b + (size_t)n_out), total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
-    if (fe->h_proj_bytes < total) {
-        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
-        fe->h_proj = nullptr;
-        fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
-        fe->h_proj_bytes = total;
-    }
+    if ((rc = vslam_ensure_pinned(&fe->h_proj, &fe->h_proj_bytes, total))) return rc;
     uint8_t *h = fe->h_proj, *d = fe->d_proj;
     memcpy(h + o_kfl, kf_flags_host, (size_t)n_kf);
     for (int i = 0; i < n_kf; i++) ((float*)(h + o_ka))[i] = kf_kps_host[i].angle;
@@ -661,13 +655,7 @@ extern "C" int vslam_search_for_triangulation(vslam_fe* fe, const vslam_tri_para
     const size_t o_m = in_bytes, o_b = al(o_m + (size_t)n1 * 4), o_n = al(o_b + (size_t)n1), total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
-    if (fe->h_proj_bytes < total) {
-        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
-        fe->h_proj = nullptr;
-        fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
-        fe->h_proj_bytes = total;
-    }
+    if ((rc = vslam_ensure_pinned(&fe->h_proj, &fe->h_proj_bytes, total))) return rc;
     uint8_t *h = fe->h_proj, *d = fe->d_proj;
     memcpy(h + o_k1, kps1_host, (size_t)n1 * sizeof(vslam_kp));
     memcpy(h + o_k2, kps2_host, (size_t)n2 * sizeof(vslam_kp));

@@ -994,6 +994,16 @@ int vslam_ensure(void** p, size_t* have, size_t want) {
     return VSLAM_OK;
 }
 
+int vslam_ensure_pinned(uint8_t** p, size_t* have, size_t want) {
+    if (*have >= want) return VSLAM_OK;
+    if (*p) HIPCHK(hipHostFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipHostMalloc((void**)p, want, hipHostMallocDefault));
+    *have = want;
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
                                   int32_t* idx2, int32_t* dist2) {
     if (!fe || nq < 0 || nt < 0 || nt > 65535 || (nq && (!dev_q || !idx2 || !dist2)) || (nt && !dev_t)) {

@@ -547,13 +547,7 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
                  total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
-    if (fe->h_proj_bytes < total) {
-        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
-        fe->h_proj = nullptr;
-        fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
-        fe->h_proj_bytes = total;
-    }
+    if ((rc = vslam_ensure_pinned(&fe->h_proj, &fe->h_proj_bytes, total))) return rc;
     if (!fe->d_init_fb) {
         HIPCHK(hipMalloc((void**)&fe->d_init_fb, 16));
         HIPCHK(hipMemset(fe->d_init_fb, 0, 16));
@@ -866,13 +860,7 @@ extern "C" int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp
                  total = o_n + 16;
     rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
-    if (fe->h_proj_bytes < total) {
-        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
-        fe->h_proj = nullptr;
-        fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
-        fe->h_proj_bytes = total;
-    }
+    if ((rc = vslam_ensure_pinned(&fe->h_proj, &fe->h_proj_bytes, total))) return rc;
     uint8_t* h = fe->h_proj;
     memcpy(h + o_mp, mps_host, (size_t)n_mp * sizeof(MpTrack));
     memcpy(h + o_d, mp_desc_host, (size_t)n_mp * 32);
@@ -1028,13 +1016,7 @@ extern "C" int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const
     const size_t o_bi = in_bytes, o_bd = al(o_bi + (size_t)n_points * 4), total = al(o_bd + (size_t)n_points * 4);
     rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
     if (rc) return rc;
-    if (fe->h_proj_bytes < total) {
-        if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
-        fe->h_proj = nullptr;
-        fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, total, hipHostMallocDefault));
-        fe->h_proj_bytes = total;
-    }
+    if ((rc = vslam_ensure_pinned(&fe->h_proj, &fe->h_proj_bytes, total))) return rc;
     uint8_t *h = fe->h_proj, *d = fe->d_proj;
     memcpy(h + o_p, points_host, (size_t)n_points * sizeof(FusePoint));
     memcpy(h + o_d, mp_desc_host, (size_t)n_points * 32);
