@@ -156,6 +156,17 @@ def test_knobs_fma_and_legacy_gauss_taps():
         fe.close()
 
 
+def test_asymmetric_gauss_taps_take_the_general_column_pass():
+    """k_blur7_v2 folds mirrored rows when the taps are symmetric; any other kernel (sum 256) takes the 7-product form."""
+    img = synth.make_frame(640, 360, seed=6)
+    taps = [10, 30, 50, 60, 52, 36, 18]
+    fe = V.FExtractor(800, 1.2, 8, 20, 7, 640, 360, gauss_taps=taps)
+    try:
+        _assert_same(fe.compute(img), orbo.Extractor(800, taps=taps).compute(img), "asymmetric taps")
+    finally:
+        fe.close()
+
+
 def test_device_trig_is_glibc_exact(kitti):
     """Every float the rotation can see: angle(deg in [0,360]) * (float)(pi/180) plus a dense sweep."""
     rng = np.random.default_rng(0)

@@ -44,6 +44,7 @@ struct BlurTapsV2 {
     uint32_t k[7];
 };
 
+template <bool SYM> /* SYM: k[j] == k[6-j] (every Gaussian): the column pass folds mirrored rows first */
 __global__ void __launch_bounds__(256)
 k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
            const uint32_t* __restrict__ tasks, int ntasks, int nslots, int rows_per_task, BlurTapsV2 T) {
@@ -115,8 +116,15 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     uint32_t acc = 32768u;
+                    if (SYM) { /* sums of two row-pass values stay below 2^24: the 24-bit multiplies are exact */
+                        acc += __umul24(T.k[3], hq[(u + 3) % 7][c]);
+                        acc += __umul24(T.k[0], hq[u % 7][c] + hq[(u + 6) % 7][c]);
+                        acc += __umul24(T.k[1], hq[(u + 1) % 7][c] + hq[(u + 5) % 7][c]);
+                        acc += __umul24(T.k[2], hq[(u + 2) % 7][c] + hq[(u + 4) % 7][c]);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 7; k++) acc += __umul24(T.k[k], hq[(u + k) % 7][c]);
+                        for (int k = 0; k < 7; k++) acc += __umul24(T.k[k], hq[(u + k) % 7][c]);
+                    }
                     px[c] = min(acc >> 16, 255u);
                 }
                 if (writer) {
@@ -146,7 +154,12 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
     T.c3 = pk(k0, k1, k2, k3); T.r3 = pk(k4, k5, k6, 0);
     for (int i = 0; i < 7; i++) T.k[i] = taps[i];
     const int nwork = ((ntasks + 3) / 4) * nslots;
-    hipLaunchKernelGGL(k_blur7_v2, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
+    const bool sym = taps[0] == taps[6] && taps[1] == taps[5] && taps[2] == taps[4];
+    if (sym)
+        hipLaunchKernelGGL(k_blur7_v2<true>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
+                       ntasks, nslots, rows_per_task, T);
+    else
+        hipLaunchKernelGGL(k_blur7_v2<false>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
                        ntasks, nslots, rows_per_task, T);
 }
 
