@@ -571,7 +571,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
     if (fe->use_v2_fast && fe->use_v3_fast)
         vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
-                         fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->max_px, nimg);
+                         fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg);
     else if (fe->use_v2_fast)
         vk_fast_cells_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
                          fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_rows, nimg);

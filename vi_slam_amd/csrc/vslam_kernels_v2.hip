@@ -183,15 +183,15 @@ __device__ __forceinline__ int imax3v(int a, int b, int c) {
 /* One polarity of the FAST score: max over the 16 nine-pixel arcs of min_k d_k, with d_k = sign*(v - ring_k).
  * sign = +1 -> dark corners (cornerScore's a0), sign = -1 -> bright corners (its -b0).  The OpenCV score is
  * max(dark, bright) - 1. */
-template <int SIGN>
+template <int SIGN, int P = FP> /* P: LDS pitch of the window */
 __device__ __forceinline__ int fast_half_score(const uint8_t* c) {
     const int v = c[0];
     int d[16];
 #define RD(k, off) d[k] = SIGN > 0 ? v - (int)c[off] : (int)c[off] - v
-    RD(0, 3 * FP);   RD(1, 3 * FP + 1);   RD(2, 2 * FP + 2);    RD(3, FP + 3);
-    RD(4, 3);        RD(5, -FP + 3);      RD(6, -2 * FP + 2);   RD(7, -3 * FP + 1);
-    RD(8, -3 * FP);  RD(9, -3 * FP - 1);  RD(10, -2 * FP - 2);  RD(11, -FP - 3);
-    RD(12, -3);      RD(13, FP - 3);      RD(14, 2 * FP - 2);   RD(15, 3 * FP - 1);
+    RD(0, 3 * P);   RD(1, 3 * P + 1);   RD(2, 2 * P + 2);    RD(3, P + 3);
+    RD(4, 3);        RD(5, -P + 3);      RD(6, -2 * P + 2);   RD(7, -3 * P + 1);
+    RD(8, -3 * P);  RD(9, -3 * P - 1);  RD(10, -2 * P - 2);  RD(11, -P - 3);
+    RD(12, -3);      RD(13, P - 3);      RD(14, 2 * P - 2);   RD(15, 3 * P - 1);
 #undef RD
     int lo3[16];
 #pragma unroll
@@ -505,15 +505,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-template <int NT>
+template <int NT, int P> /* P: LDS pitch, 48 for windows up to 42 px, else 72 */
 __global__ void __launch_bounds__(NT)
 k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
                 const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
                 int iniTh, int minTh, int tile_rows, int lcap) {
     extern __shared__ __align__(16) uint8_t smem3[];
-    uint8_t* win = smem3;                        /* tile_rows x FP; window column c at LDS column c + 1 */
-    uint8_t* sc = win + tile_rows * FP;          /* (tile_rows-4) x FP, interior at (1..ih, 1..iw) */
-    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * FP); /* 2 words per interior row */
+    uint8_t* win = smem3;                        /* tile_rows x P; window column c at LDS column c + 1 */
+    uint8_t* sc = win + tile_rows * P;          /* (tile_rows-4) x P, interior at (1..ih, 1..iw) */
+    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * P); /* 2 words per interior row */
     uint16_t* listD = (uint16_t*)(keep + (tile_rows - 6) * 2); /* dark-only up from 0, "both" down from lcap-1 */
     uint16_t* listB = listD + lcap;                             /* bright-only */
     __shared__ unsigned long long s_cnt; /* nD | nB << 21 | nX << 42 */
@@ -538,13 +538,13 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
      * (= the LDS pitch), 28 rows per sweep */
     {
         const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
-        constexpr int RPS = NT / 9; /* rows per sweep */
-        const int srow = tid / 9, scol = (tid - srow * 9) * 8;
-        if (tid < RPS * 9 && scol < ww + 1)
+        constexpr int LPR = P / 8, RPS = NT / LPR; /* 8-byte lanes per row, rows per sweep */
+        const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
+        if (tid < RPS * LPR && scol < ww + 1)
             for (int y = srow; y < wh; y += RPS)
-                *(uint2*)(win + y * FP + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
+                *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
     }
-    for (int i = tid; i < (ih + 2) * (FP / 4); i += NT) ((uint32_t*)sc)[i] = 0;
+    for (int i = tid; i < (ih + 2) * (P / 4); i += NT) ((uint32_t*)sc)[i] = 0;
     for (int i = tid; i < nwords; i += NT) keep[i] = 0;
     if (tid == 0) {
         s_any = 0;
@@ -563,9 +563,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
             const int ly = ly0 + qly;
             uint32_t mD = 0, mB = 0;
             if (qx < QW && ly < ih) {
-                const uint32_t* rowc = W32 + (ly + 3) * (FP / 4) + qx;
+                const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
                 const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
-                const uint32_t U = W32[ly * (FP / 4) + qx + 1], Dn = W32[(ly + 6) * (FP / 4) + qx + 1];
+                const uint32_t U = W32[ly * (P / 4) + qx + 1], Dn = W32[(ly + 6) * (P / 4) + qx + 1];
                 const uint32_t Lf = __builtin_amdgcn_alignbyte(C, A0, 1); /* columns x-3 */
                 const uint32_t Rt = __builtin_amdgcn_alignbyte(E, C, 3);  /* columns x+3 */
 #define EVN(x) __builtin_amdgcn_perm(0u, (x), 0x0c020c00u) /* pixels 0,2 as u16 halves */
@@ -638,20 +638,20 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
             const int iD = base + tid, iB = base + NT - 1 - tid;
             if (iD < nD) {
                 const int code = listD[iD];
-                const int a = fast_half_score<1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
-                sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+                const int a = fast_half_score<1, P>(win + ((code >> 6) + 3) * P + (code & 63) + 4);
+                sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
             if (iB < nB) {
                 const int code = listB[iB];
-                const int a = fast_half_score<-1>(win + ((code >> 6) + 3) * FP + (code & 63) + 4);
-                sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+                const int a = fast_half_score<-1, P>(win + ((code >> 6) + 3) * P + (code & 63) + 4);
+                sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
         }
         for (int i = tid; i < nX; i += NT) { /* rare: both polarities possible */
             const int code = listD[lcap - 1 - i];
-            const uint8_t* c = win + ((code >> 6) + 3) * FP + (code & 63) + 4;
-            const int a = max(fast_half_score<1>(c), fast_half_score<-1>(c));
-            sc[((code >> 6) + 1) * FP + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+            const uint8_t* c = win + ((code >> 6) + 3) * P + (code & 63) + 4;
+            const int a = max(fast_half_score<1, P>(c), fast_half_score<-1, P>(c));
+            sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
         }
         __syncthreads();
         /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
@@ -659,11 +659,11 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         for (int i = tid; i < ntot; i += NT) {
             const int code = i < nD ? listD[i] : i < nD + nB ? listB[i - nD] : listD[lcap - 1 - (i - nD - nB)];
             const int ly = code >> 6, x = code & 63;
-            const uint8_t* q = sc + (ly + 1) * FP + x + 1;
+            const uint8_t* q = sc + (ly + 1) * P + x + 1;
             const int s = q[0];
             if (s >= T) {
-                const int mx = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
-                                   max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
+                const int mx = max(max(max((int)q[-P - 1], (int)q[-P]), max((int)q[-P + 1], (int)q[-1])),
+                                   max(max((int)q[1], (int)q[P - 1]), max((int)q[P], (int)q[P + 1])));
                 if (s > mx) {
                     atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
                     any = 1;
@@ -715,7 +715,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         while (bits) {
             const int k = __ffs(bits) - 1;
             bits &= bits - 1;
-            const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
+            const uint32_t s = sc[(kly + 1) * P + kxb + k + 1];
             cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
         }
     }
@@ -738,25 +738,28 @@ static int fast_v3_nt() {
 
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_px, int nslots) {
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots) {
     /* survivor lists: dark-only + "both" share one list (from both ends), bright-only the other; neither can hold
-     * more entries than the largest cell interior has pixels */
+     * more entries than the largest cell interior has pixels.  Windows up to 42 px wide (KITTI, 1080p: 38) fit an
+     * LDS pitch of 48 bytes instead of 72: 9.7 KB per cell, 16 cells resident per CU. */
     const int lcap = (max_px + 7) & ~3;
-    const size_t shm = (size_t)tile_rows * FP + (size_t)(tile_rows - 4) * FP + (size_t)(tile_rows - 6) * 8 +
+    const int P = max_window_w <= 42 ? 48 : 72;
+    const size_t shm = (size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 +
                        (size_t)lcap * 2 * 2 + 16;
     const dim3 grid(((ncells + 7) / 8) * 8, nslots);
     const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
-    switch (fast_v3_nt()) {
-        case 64:
-            hipLaunchKernelGGL(k_fast_cells_v3<64>, grid, dim3(64), shm, st, pyr, slot_stride, src, g, cells, cand_region,
-                               cand_stride, ncells, it, mt, tile_rows, lcap);
-            break;
-        case 128:
-            hipLaunchKernelGGL(k_fast_cells_v3<128>, grid, dim3(128), shm, st, pyr, slot_stride, src, g, cells, cand_region,
-                               cand_stride, ncells, it, mt, tile_rows, lcap);
-            break;
-        default:
-            hipLaunchKernelGGL(k_fast_cells_v3<256>, grid, dim3(256), shm, st, pyr, slot_stride, src, g, cells, cand_region,
-                               cand_stride, ncells, it, mt, tile_rows, lcap);
+#define FAST3_LAUNCH(NT_, P_)                                                                                              \
+    hipLaunchKernelGGL((k_fast_cells_v3<NT_, P_>), grid, dim3(NT_), shm, st, pyr, slot_stride, src, g, cells, cand_region, \
+                       cand_stride, ncells, it, mt, tile_rows, lcap)
+    const int nt = fast_v3_nt();
+    if (P == 48) {
+        if (nt == 64) FAST3_LAUNCH(64, 48);
+        else if (nt == 128) FAST3_LAUNCH(128, 48);
+        else FAST3_LAUNCH(256, 48);
+    } else {
+        if (nt == 64) FAST3_LAUNCH(64, 72);
+        else if (nt == 128) FAST3_LAUNCH(128, 72);
+        else FAST3_LAUNCH(256, 72);
     }
+#undef FAST3_LAUNCH
 }
