@@ -743,7 +743,12 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
      * more entries than the largest cell interior has pixels.  Windows up to 42 px wide (KITTI, 1080p: 38) fit an
      * LDS pitch of 48 bytes instead of 72: 9.7 KB per cell, 16 cells resident per CU. */
     const int lcap = (max_px + 7) & ~3;
-    const int P = max_window_w <= 42 ? 48 : 72;
+    static int force72 = -1; /* VSLAM_FAST_PITCH=72: the wider pitch everywhere, for A/B runs */
+    if (force72 < 0) {
+        const char* e = getenv("VSLAM_FAST_PITCH");
+        force72 = e && atoi(e) == 72;
+    }
+    const int P = (max_window_w <= 42 && !force72) ? 48 : 72;
     const size_t shm = (size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 +
                        (size_t)lcap * 2 * 2 + 16;
     const dim3 grid(((ncells + 7) / 8) * 8, nslots);
