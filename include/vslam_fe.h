@@ -281,6 +281,21 @@ int vslam_search_by_projection_keyframe(vslam_fe* fe, const vslam_proj_params* p
                                         const uint8_t* dev_cur_desc, int n_cur, const uint8_t* cur_occupied_host,
                                         int32_t* match_cur, int* nmatches);
 
+/* FMatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched,
+ * int th, float ratioHamming) (fmatcher.cpp:750-863; proj_variant 0) and the overload that also fills vpMatchedKF from
+ * vpPointsKFs (:865-981; it projects as fx*(x*(1/z))+cx, proj_variant 1) -- the loop-closing matchers.  p carries
+ * Rcw | tcw (= sRcw/scw, Scw's translation/scw, :760-763) in Tcw, the camera, th, the image bounds and gemm_float;
+ * Ow = -Rcw^T tcw; log_scale_factor = pKF->mfLogScaleFactor.  Per candidate MapPoint: flag (!isBad() &&
+ * !spAlreadyFound.count(pMP)), world position, normal, Get{Min,Max}DistanceInvariance(), descriptor.
+ * kf_matched_host[idx] != 0 iff vpMatched[idx] != NULL on entry.  match_kf[idx] = iMP (vpMatched[idx] = vpPoints[iMP],
+ * vpMatchedKF[idx] = vpPointsKFs[iMP]) or -1 for the keypoints this call assigns; *nmatches as returned. */
+int vslam_search_by_projection_sim3(vslam_fe* fe, const vslam_proj_params* p, const float* Ow, float log_scale_factor,
+                                    float ratio_hamming, int proj_variant, const uint8_t* mp_flags, const float* mp_x3dw,
+                                    const float* mp_normals, const float* mp_min_dist, const float* mp_max_dist,
+                                    const uint8_t* mp_desc_host, int n_points, const vslam_kp* dev_kf_kps,
+                                    const uint8_t* dev_kf_desc, int n_kf, const uint8_t* kf_matched_host,
+                                    int32_t* match_kf, int* nmatches);
+
 /* FMatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
  * (fmatcher.cpp:321-411; pinhole frames) -- the local-map matcher of Tracking::SearchLocalPoints.  Each MapPoint
  * arrives with what Frame::isInFrustum left in it (mappoint.h:73-81):

@@ -1482,6 +1482,78 @@ int search_by_projection_keyframe(const float Tcw[12], const float Ow[3], float 
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ SearchByProjection(pKF, Scw, ...) x2 */
+int search_by_projection_sim3(const float Tcw[12], const float Ow[3], float fx, float fy, float cx, float cy, int th,
+                              float ratioHamming, float mfLogScaleFactor, int projVariant, int imgW, int imgH, int gemmDouble,
+                              const std::vector<uint8_t>& flags, const std::vector<float>& x3Dws,
+                              const std::vector<float>& normals, const std::vector<float>& minDist,
+                              const std::vector<float>& maxDist, const std::vector<uint8_t>& mpDesc,
+                              const std::vector<KeyPoint>& mvKeysUn, const std::vector<uint8_t>& mDescriptors,
+                              const std::vector<uint8_t>& matched0, const std::vector<float>& mvScaleFactors,
+                              std::vector<int>& matchKf) { /* fmatcher.cpp:750-863, :865-981 */
+    const int TH_LOW = 50;
+    int nmatches = 0;
+    const int N = (int)mvKeysUn.size();
+    matchKf.assign(N, -1);
+    std::vector<uint8_t> vpMatched(N, 0);
+    for (int i = 0; i < N && i < (int)matched0.size(); i++) vpMatched[i] = matched0[i];
+    FrameGrid grid(mvKeysUn, imgW, imgH);
+    const int mnScaleLevels = (int)mvScaleFactors.size();
+    for (size_t iMP = 0; iMP < flags.size(); iMP++) {
+        if (!(flags[iMP] & 1)) continue;
+        const float* p3Dw = &x3Dws[3 * iMP];
+        const float xc = gemm_row(Tcw + 0, p3Dw, Tcw[3], gemmDouble);
+        const float yc = gemm_row(Tcw + 4, p3Dw, Tcw[7], gemmDouble);
+        const float zc = gemm_row(Tcw + 8, p3Dw, Tcw[11], gemmDouble);
+        if (zc < 0.0) continue;
+        float u, v;
+        if (projVariant == 0) { /* pKF->mpCamera->project(cv::Point3f(x, y, z)) */
+            u = fx * xc / zc + cx;
+            v = fy * yc / zc + cy;
+        } else { /* :908-913 */
+            const float invz = 1 / zc;
+            const float x = xc * invz, y = yc * invz;
+            u = fx * x + cx;
+            v = fy * y + cy;
+        }
+        if (!(u >= 0.0f && u < (float)imgW && v >= 0.0f && v < (float)imgH)) continue; /* KeyFrame::IsInImage */
+        const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+        double n2 = 0;
+        for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+        const float dist = (float)std::sqrt(n2);
+        if (dist < minDist[iMP] || dist > maxDist[iMP]) continue;
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)normals[3 * iMP + k];
+        if (dot < 0.5 * dist) continue;
+        const float ratio = maxDist[iMP] / dist;
+        const float lv = std::ceil(glibc_logf(ratio) / mfLogScaleFactor);
+        int nPredictedLevel = (lv != lv || lv >= 2147483648.0f || lv < -2147483648.0f) ? INT_MIN : (int)lv;
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= mnScaleLevels) nPredictedLevel = mnScaleLevels - 1;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = &mpDesc[32 * iMP];
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (vpMatched[idx]) continue;
+            const int kpLevel = mvKeysUn[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int d = descriptor_distance(dMP, &mDescriptors[32 * (size_t)idx]);
+            if (d < bestDist) {
+                bestDist = d;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_LOW * ratioHamming) {
+            vpMatched[bestIdx] = 1;
+            matchKf[bestIdx] = (int)iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

@@ -263,6 +263,19 @@ int search_by_projection_keyframe(const float Tcw[12], const float Ow[3], float 
                                   const std::vector<uint8_t>& occupied, const std::vector<float>& scaleFactors,
                                   std::vector<int>& matchCur);
 
+/* FMatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th, ratioHamming) (fmatcher.cpp:750-863;
+ * projVariant 0) and the vpPointsKFs / vpMatchedKF overload (:865-981; projVariant 1: u = fx*(x*(1/z))+cx).
+ * flags[i] & 1 iff !isBad() && !spAlreadyFound.count(vpPoints[i]); matched0: vpMatched[idx] != NULL on entry.
+ * matchKf[idx] = iMP for the keypoints assigned by this call, else -1; returns nmatches. */
+int search_by_projection_sim3(const float Tcw[12], const float Ow[3], float fx, float fy, float cx, float cy, int th,
+                              float ratioHamming, float logScaleFactor, int projVariant, int imgW, int imgH, int gemmDouble,
+                              const std::vector<uint8_t>& flags, const std::vector<float>& x3Dw,
+                              const std::vector<float>& normals, const std::vector<float>& minDist,
+                              const std::vector<float>& maxDist, const std::vector<uint8_t>& mpDesc,
+                              const std::vector<KeyPoint>& kfKps, const std::vector<uint8_t>& kfDesc,
+                              const std::vector<uint8_t>& matched0, const std::vector<float>& scaleFactors,
+                              std::vector<int>& matchKf);
+
 } // namespace orbo
 
 #endif

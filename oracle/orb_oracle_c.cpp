@@ -334,6 +334,25 @@ int orbo_search_by_projection_keyframe(const float* Tcw, const float* Ow, const 
     return nm;
 }
 
+int orbo_search_by_projection_sim3(const float* Tcw, const float* Ow, const float* cam, int th, float ratioHamming,
+                                   float logScaleFactor, int projVariant, int imgW, int imgH, int gemmDouble, int nPoints,
+                                   const uint8_t* flags, const float* x3Dw, const float* normals, const float* minDist,
+                                   const float* maxDist, const uint8_t* mpDesc, const KeyPoint* kfKps, int nKF,
+                                   const uint8_t* kfDesc, const uint8_t* matched, const float* scaleFactors, int nlevels,
+                                   int* matchKf) {
+    std::vector<KeyPoint> kk(kfKps, kfKps + nKF);
+    std::vector<uint8_t> fl(flags, flags + nPoints), md(mpDesc, mpDesc + (size_t)nPoints * 32), kd(kfDesc, kfDesc + (size_t)nKF * 32),
+        mt;
+    if (matched) mt.assign(matched, matched + nKF);
+    std::vector<float> x(x3Dw, x3Dw + (size_t)nPoints * 3), nr(normals, normals + (size_t)nPoints * 3),
+        mn(minDist, minDist + nPoints), mx(maxDist, maxDist + nPoints), sf(scaleFactors, scaleFactors + nlevels);
+    std::vector<int> m;
+    const int nm = search_by_projection_sim3(Tcw, Ow, cam[0], cam[1], cam[2], cam[3], th, ratioHamming, logScaleFactor,
+                                             projVariant, imgW, imgH, gemmDouble, fl, x, nr, mn, mx, md, kk, kd, mt, sf, m);
+    if (nKF) memcpy(matchKf, m.data(), (size_t)nKF * sizeof(int));
+    return nm;
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

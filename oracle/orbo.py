@@ -89,6 +89,9 @@ def lib():
         L.orbo_search_by_projection_keyframe.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                                          C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                                          C.c_int, vp]
+        L.orbo_search_by_projection_sim3.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                                     C.c_int, vp]
         L.orbo_fg_halfsample.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
         L.orbo_fg_halfsample.restype = None
         L.orbo_fg_response.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
@@ -548,3 +551,28 @@ def search_by_projection_keyframe(Tcw, Ow, cam, th, orb_dist, log_scale_factor, 
                                                   _p(x), _p(mn), _p(mx), _p(md), _p(ck), len(ck), _p(cd),
                                                   _p(oc) if oc is not None else None, _p(sf), len(sf), _p(m))
     return nm, m[:len(ck)]
+
+
+def search_by_projection_sim3(Tcw, Ow, cam, th, ratio_hamming, log_scale_factor, flags, x3dw, normals, min_dist, max_dist,
+                              mp_desc, kf_kps, kf_desc, scale_factors, W, H, proj_variant=0, matched=None, gemm_double=True):
+    """FMatcher::SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming)
+    (fmatcher.cpp:750-863 / :865-981) -> (nmatches, match_kf[n_kf] = iMP or -1).  cam = (fx, fy, cx, cy)."""
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    O = np.ascontiguousarray(Ow, np.float32).reshape(3)
+    c = np.ascontiguousarray(cam[:4], np.float32)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    x = np.ascontiguousarray(x3dw, np.float32)
+    nr = np.ascontiguousarray(normals, np.float32)
+    mn = np.ascontiguousarray(min_dist, np.float32)
+    mx = np.ascontiguousarray(max_dist, np.float32)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    kk = np.ascontiguousarray(kf_kps, KP_DTYPE)
+    kd = np.ascontiguousarray(kf_desc, np.uint8)
+    mt = None if matched is None else np.ascontiguousarray(matched, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(kk), 1), -1, np.int32)
+    nm = lib().orbo_search_by_projection_sim3(_p(T), _p(O), _p(c), int(th), float(ratio_hamming), float(log_scale_factor),
+                                              int(proj_variant), int(W), int(H), int(gemm_double), len(fl), _p(fl), _p(x),
+                                              _p(nr), _p(mn), _p(mx), _p(md), _p(kk), len(kk), _p(kd),
+                                              _p(mt) if mt is not None else None, _p(sf), len(sf), _p(m))
+    return nm, m[:len(kk)]

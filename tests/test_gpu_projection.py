@@ -344,3 +344,47 @@ def test_search_by_projection_keyframe_sequential_path(scene, monkeypatch):
     zmed = float(np.median(scene["z"][scene["has_depth"]]))
     flags = np.ones(len(scene["k0"]), np.uint8)
     _run_kf(scene, _pose(tx=3.0 / FX * zmed, ty=1.0 / FY * zmed), 20, 80, flags, mn, mx)
+
+
+# ---------------------------------------------------------------- loop-closing matchers (fmatcher.cpp:750-863, :865-981)
+def _run_sim3(scene, Tcw, th, ratio, flags, normals, mn, mx, variant=0, matched=None, gemm_float=False):
+    R, t = Tcw[:, :3], Tcw[:, 3]
+    Ow = (-R.T @ t).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    m = V.FMatcher(scene["fe"], 0.9, True)
+    nm, mk = m.SearchByProjectionSim3(Tcw, Ow, (FX, FY, CX, CY), th, ratio, lsf, flags, scene["X"], normals, mn, mx,
+                                      scene["de0"], scene["cur"][0], scene["cur"][1], len(scene["k1"]), matched, (W, H),
+                                      variant, gemm_float)
+    wn, wm = orbo.search_by_projection_sim3(Tcw, Ow, (FX, FY, CX, CY), th, ratio, lsf, flags, scene["X"], normals, mn, mx,
+                                            scene["de0"], scene["k1"], scene["de1"], scene["sf"], W, H, variant, matched,
+                                            not gemm_float)
+    assert nm == wn, (nm, wn)
+    assert np.array_equal(mk, wm)
+    return nm, mk
+
+
+def test_search_by_projection_sim3_overloads_equal_oracle(scene):
+    rng = np.random.default_rng(21)
+    mn, mx = _kf_points(scene)
+    X = scene["X"]
+    normals = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    zmed = float(np.median(scene["z"][scene["has_depth"]]))
+    Tcw = _pose(tx=3.0 / FX * zmed, ty=1.0 / FY * zmed)
+    flags = np.ones(len(X), np.uint8)
+    nm, mk = _run_sim3(scene, Tcw, 8, 1.5, flags, normals, mn, mx)          # loopclosing.cpp: th 8, ratioHamming 1.5
+    assert nm > 200 and len(set(mk[mk >= 0].tolist())) == nm                  # a candidate lands on one keypoint at most
+    _run_sim3(scene, Tcw, 8, 1.5, flags, normals, mn, mx, variant=1)
+    _run_sim3(scene, Tcw, 3, 1.0, flags, normals, mn, mx)
+    _run_sim3(scene, Tcw, 8, 0.45, flags, normals, mn, mx, variant=1)        # threshold 22.5 -> distances <= 22
+    _run_sim3(scene, Tcw, 8, 1.5, flags, normals, mn, mx, gemm_float=True)
+    fl = (rng.random(len(flags)) < 0.6).astype(np.uint8)
+    matched = (rng.random(len(scene["k1"])) < 0.3).astype(np.uint8)
+    n2, m2 = _run_sim3(scene, Tcw, 8, 1.5, fl, normals, mn, mx, matched=matched)
+    assert np.all(m2[matched == 1] == -1)
+    nr2 = normals.copy()
+    flip = rng.random(len(X)) < 0.5
+    nr2[flip] *= -1.0                                                         # viewing angle beyond 60 degrees
+    n3, m3 = _run_sim3(scene, Tcw, 8, 1.5, flags, nr2, mn, mx)
+    assert not np.any(np.isin(m3[m3 >= 0], np.nonzero(flip)[0]))
+    _run_sim3(scene, _pose(tz=-60.0), 8, 1.5, flags, normals, mn, mx)         # everything behind the camera
+    _run_sim3(scene, _pose(tx=0.5, yaw=0.1, tz=-3.0), 30, 1.5, flags, normals, mn, mx, variant=1)

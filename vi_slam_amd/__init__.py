@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "vslam_voc_info", "vslam_bow_transform", "vslam_bow_transform_slots_async", "vslam_bow_transform_slots_wait",
     "vslam_bow_assemble", "vslam_search_by_bow", "vslam_search_by_bow_keyframes",
     "vslam_search_for_triangulation", "vslam_fuse_search", "vslam_dbg_logf", "vslam_search_by_projection_keyframe",
+    "vslam_search_by_projection_sim3",
 ]
 
 
@@ -149,6 +150,8 @@ def lib():
         L.vslam_search_for_triangulation.argtypes = [vp, vp] + [vp, vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp, vp]
         L.vslam_fuse_search.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
         L.vslam_dbg_logf.argtypes = [vp, vp, i, vp]
+        L.vslam_search_by_projection_sim3.argtypes = [vp, vp, vp, C.c_float, C.c_float, i, vp, vp, vp, vp, vp, vp, i, vp, vp, i,
+                                                      vp, vp, vp]
         L.vslam_search_by_projection_keyframe.argtypes = [vp, vp, vp, C.c_float, i, vp, i, vp, vp, vp, vp, vp, vp, vp, i, vp,
                                                           vp, vp]
         L.vslam_search_by_projection_dev_async.argtypes = [vp, i, vp]
@@ -684,6 +687,37 @@ class FMatcher:
             _p(mx), _p(md), C.c_void_p(dev_cur_kps), C.c_void_p(dev_cur_desc), n_cur, _p(oc) if oc is not None else None,
             _p(m), C.byref(nm)))
         return nm.value, m[:n_cur]
+
+    def SearchByProjectionSim3(self, Tcw, Ow, cam, th, ratioHamming, log_scale_factor, mp_flags, mp_x3dw, mp_normals,
+                               mp_min_dist, mp_max_dist, mp_desc, dev_kf_kps, dev_kf_desc, n_kf, matched=None,
+                               img_size=None, proj_variant=0, gemm_float=False):
+        """FMatcher::SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming)
+        (fmatcher.cpp:750-863; proj_variant=1: :865-981), the loop-closing matchers.  Tcw = Rcw | tcw after the
+        decomposition of Scw.  -> (nmatches, match_kf[n_kf] = candidate index or -1)."""
+        fl = np.ascontiguousarray(mp_flags, np.uint8)
+        x = np.ascontiguousarray(mp_x3dw, np.float32)
+        nr = np.ascontiguousarray(mp_normals, np.float32)
+        mn = np.ascontiguousarray(mp_min_dist, np.float32)
+        mx = np.ascontiguousarray(mp_max_dist, np.float32)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        mt = None if matched is None else np.ascontiguousarray(matched, np.uint8)
+        O = np.ascontiguousarray(Ow, np.float32).reshape(3)
+        w, h = img_size or (self.fe.width, self.fe.height)
+        P = _ProjParams()
+        T = np.asarray(Tcw, np.float32).reshape(-1)
+        for k in range(12):
+            P.Tcw[k] = float(T[k])
+        P.fx, P.fy, P.cx, P.cy = [float(v) for v in cam[:4]]
+        P.mbf, P.th = 0.0, float(int(th))
+        P.forward = P.backward = P.check_orientation = 0
+        P.img_w, P.img_h, P.gemm_float = int(w), int(h), int(gemm_float)
+        m = np.full(max(n_kf, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().vslam_search_by_projection_sim3(
+            self.fe._h, C.byref(P), _p(O), C.c_float(log_scale_factor), C.c_float(ratioHamming), int(proj_variant), _p(fl),
+            _p(x), _p(nr), _p(mn), _p(mx), _p(md), len(fl), C.c_void_p(dev_kf_kps), C.c_void_p(dev_kf_desc), n_kf,
+            _p(mt) if mt is not None else None, _p(m), C.byref(nm)))
+        return nm.value, m[:n_kf]
 
     def SearchForTriangulation(self, kps1, dev_desc1, has_mp1, u_right1, fv1, kps2, dev_desc2, has_mp2, u_right2, fv2,
                                F12, ep, bOnlyStereo=False, bCoarse=False):

@@ -165,12 +165,16 @@ struct SbpJobDev {
 /* mode 2 = SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation; one job per call): the
  * KeyFrame's MapPoints are projected with PredictScale; accept threshold ORBdist instead of TH_HIGH */
 struct SbpKfDev {
-    int32_t thHigh; /* 0 = TH_HIGH */
+    int32_t thHigh; /* accept threshold + 1; 0 = TH_HIGH */
     float logScaleFactor;
     const float* minDist;
     const float* maxDist;
     float ow[3];
-    float pad;
+    /* mode 3 = SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming)
+     * (loop closing): depth test, viewing-angle test against the MapPoint normals, levels [l-1, l];
+     * projKind 0: Pinhole::project (fmatcher.cpp:796), 1: invz = 1/z, u = fx*(x*invz)+cx (:908-913) */
+    int32_t projKind;
+    const float* normals;
 };
 #define VSLAM_MAX_SBP_JOBS 16
 struct SbpJobs { /* by-value kernel argument (< 4 KB) */

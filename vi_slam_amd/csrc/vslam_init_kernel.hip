@@ -587,6 +587,50 @@ k_sbp_rank(SbpJobs JS) {
                     }
                 }
             }
+        } else if (J.mode == 3) { /* candidate MapPoints into a KeyFrame under Scw, fmatcher.cpp:773-825 / :890-941 */
+            if (J.flags[q] & 1) { /* !pMP->isBad() && !spAlreadyFound.count(pMP) */
+                const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
+                const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
+                const float yc = sbp_gemm_row(J.Tcw + 4, X, Y, Z, J.Tcw[7], J.gemmFloat);
+                const float zc = sbp_gemm_row(J.Tcw + 8, X, Y, Z, J.Tcw[11], J.gemmFloat);
+                if (!(zc < 0.0f)) {
+                    float u, v;
+                    if (JS.kf.projKind == 0) {
+                        u = __fadd_rn(__fdiv_rn(__fmul_rn(J.fx, xc), zc), J.cx);
+                        v = __fadd_rn(__fdiv_rn(__fmul_rn(J.fy, yc), zc), J.cy);
+                    } else {
+                        const float invz = __fdiv_rn(1.0f, zc);
+                        u = __fadd_rn(__fmul_rn(J.fx, __fmul_rn(xc, invz)), J.cx);
+                        v = __fadd_rn(__fmul_rn(J.fy, __fmul_rn(yc, invz)), J.cy);
+                    }
+                    if (u >= 0.f && u < (float)J.imgW && v >= 0.f && v < (float)J.imgH) { /* KeyFrame::IsInImage */
+                        const float p0 = __fsub_rn(X, JS.kf.ow[0]), p1 = __fsub_rn(Y, JS.kf.ow[1]), p2 = __fsub_rn(Z, JS.kf.ow[2]);
+                        double n2 = __dmul_rn((double)p0, (double)p0);
+                        n2 = __dadd_rn(n2, __dmul_rn((double)p1, (double)p1));
+                        n2 = __dadd_rn(n2, __dmul_rn((double)p2, (double)p2));
+                        const float dist3D = (float)__dsqrt_rn(n2);
+                        const float mn = JS.kf.minDist[q], mx = JS.kf.maxDist[q];
+                        bool ok = !(dist3D < mn || dist3D > mx);
+                        if (ok) { /* PO.dot(Pn) < 0.5*dist: cv::Mat::dot accumulates in double */
+                            const float* Pn = JS.kf.normals + 3 * q;
+                            double dot = __dmul_rn((double)p0, (double)Pn[0]);
+                            dot = __dadd_rn(dot, __dmul_rn((double)p1, (double)Pn[1]));
+                            dot = __dadd_rn(dot, __dmul_rn((double)p2, (double)Pn[2]));
+                            ok = !(dot < __dmul_rn(0.5, (double)dist3D));
+                        }
+                        if (ok) {
+                            const float lv = ceilf(__fdiv_rn(vslam_trig::glibc_logf(__fdiv_rn(mx, dist3D)), JS.kf.logScaleFactor));
+                            const int level = (lv != lv || lv >= 2147483648.0f || lv < 0.f) ? 0 : min((int)lv, JS.nlevels - 1);
+                            pr.u = u;
+                            pr.v = v;
+                            pr.radius = __fmul_rn(J.th, JS.scale[level]);
+                            pr.minLevel = level - 1;
+                            pr.maxLevel = level;
+                            pr.valid = 1;
+                        }
+                    }
+                }
+            }
         } else if (J.flags[q] & 1) { /* pMP && !LastFrame.mvbOutlier[i] */
             const float X = J.x3Dw[3 * q], Y = J.x3Dw[3 * q + 1], Z = J.x3Dw[3 * q + 2];
             const float xc = sbp_gemm_row(J.Tcw + 0, X, Y, Z, J.Tcw[3], J.gemmFloat);
@@ -682,7 +726,7 @@ __global__ void __launch_bounds__(SBP_RT)
 k_sbp_resolve(SbpJobs JS, int forceSeq) {
     extern __shared__ __align__(16) uint8_t sbsm[];
     const SbpJobDev& J = JS.job[blockIdx.x];
-    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)JS.kf.thHigh : (uint32_t)SBP_TH_HIGH;
+    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)(JS.kf.thHigh - 1) : (uint32_t)SBP_TH_HIGH;
     const int M = JS.M;
     const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
     const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;
@@ -799,7 +843,7 @@ __global__ void __launch_bounds__(64)
 k_sbp_replay(SbpJobs JS, int* fallbacks) {
     extern __shared__ __align__(16) uint8_t sbsm[];
     const SbpJobDev& J = JS.job[blockIdx.x];
-    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)JS.kf.thHigh : (uint32_t)SBP_TH_HIGH;
+    const uint32_t thHigh = JS.kf.thHigh ? (uint32_t)(JS.kf.thHigh - 1) : (uint32_t)SBP_TH_HIGH;
     const int M = JS.M;
     const int nLast = J.nLastPtr ? min(*J.nLastPtr, J.nLast) : J.nLast;
     const int nCur = J.nCurPtr ? min(*J.nCurPtr, J.nCur) : J.nCur;

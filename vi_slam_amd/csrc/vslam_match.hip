@@ -501,6 +501,8 @@ struct SbpKfExtras {
     const float *min_dist, *max_dist;
     float ow[3], log_scale_factor;
     int orb_dist;
+    const float* normals = nullptr; /* non-null: the Scw overloads (mode 3) */
+    int proj_kind = 0;
 };
 
 static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_kp* last_kps_host, int n_last,
@@ -542,7 +544,8 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
     const size_t o_kps = 0, o_x = al(o_kps + (size_t)n_last * sizeof(vslam_kp)), o_d = al(o_x + (size_t)n_last * 12),
                  o_f = al(o_d + (size_t)n_last * 32), o_u = al(o_f + (size_t)n_last), o_o = al(o_u + (size_t)n_cur * 4),
                  o_mn = al(o_o + (size_t)n_cur), o_mx = al(o_mn + (kf ? (size_t)n_last * 4 : 0)),
-                 in_bytes = al(o_mx + (kf ? (size_t)n_last * 4 : 0));
+                 o_nr = al(o_mx + (kf ? (size_t)n_last * 4 : 0)),
+                 in_bytes = al(o_nr + ((kf && kf->normals) ? (size_t)n_last * 12 : 0));
     const size_t o_scr = in_bytes, o_m = al(o_scr + vk_sbp_scratch_bytes(n_last, M)), o_n = al(o_m + (size_t)n_cur * 4),
                  total = o_n + 16;
     int rc = vslam_ensure((void**)&fe->d_proj, &fe->proj_bytes, total);
@@ -563,6 +566,7 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
         for (int i = 0; i < n_last; i++) h[o_f + i] = (last_flags[i] & 1) ? 3 : 0; /* every accepted MapPoint blocks its keypoint */
         memcpy(h + o_mn, kf->min_dist, (size_t)n_last * 4);
         memcpy(h + o_mx, kf->max_dist, (size_t)n_last * 4);
+        if (kf->normals) memcpy(h + o_nr, kf->normals, (size_t)n_last * 12);
     }
     hipStream_t st = fe->stream;
     HIPCHK(hipMemcpyAsync(fe->d_proj, h, in_bytes, hipMemcpyHostToDevice, st));
@@ -593,8 +597,10 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
     J.nmatches = (int32_t*)(d + o_n);
     J.needSeq = (int32_t*)(d + o_n) + 1;
     if (kf) {
-        J.mode = 2;
-        JS.kf.thHigh = kf->orb_dist;
+        J.mode = kf->normals ? 3 : 2;
+        JS.kf.projKind = kf->proj_kind;
+        JS.kf.normals = kf->normals ? (const float*)(d + o_nr) : nullptr;
+        JS.kf.thHigh = kf->orb_dist + 1;
         JS.kf.logScaleFactor = kf->log_scale_factor;
         JS.kf.minDist = (const float*)(d + o_mn);
         JS.kf.maxDist = (const float*)(d + o_mx);
@@ -625,6 +631,45 @@ extern "C" int vslam_search_by_projection_frame(vslam_fe* fe, const vslam_proj_p
                                                 int32_t* match_cur, int* nmatches) {
     return sbp_frame_impl(fe, p, last_kps_host, n_last, last_flags, last_x3dw, mp_desc_host, dev_cur_kps, dev_cur_desc, n_cur,
                           cur_u_right_host, cur_occupied_host, nullptr, match_cur, nmatches);
+}
+
+/* FMatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched,
+ * int th, float ratioHamming) (fmatcher.cpp:750-863) and the overload that also records the KeyFrames
+ * (:865-981; its projection is spelled differently, proj_variant 1): mode 3 of the projection kernels */
+extern "C" int vslam_search_by_projection_sim3(vslam_fe* fe, const vslam_proj_params* p, const float* Ow,
+                                               float log_scale_factor, float ratio_hamming, int proj_variant,
+                                               const uint8_t* mp_flags, const float* mp_x3dw, const float* mp_normals,
+                                               const float* mp_min_dist, const float* mp_max_dist,
+                                               const uint8_t* mp_desc_host, int n_points, const vslam_kp* dev_kf_kps,
+                                               const uint8_t* dev_kf_desc, int n_kf, const uint8_t* kf_matched_host,
+                                               int32_t* match_kf, int* nmatches) {
+    if (!Ow || !p || (n_points > 0 && (!mp_min_dist || !mp_max_dist || !mp_normals)) || proj_variant < 0 || proj_variant > 1 ||
+        !(ratio_hamming >= 0.0f)) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    if (n_points > 4096) {
+        g_err = "SearchByProjection on the device supports at most 4096 candidate MapPoints per call";
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    /* bestDist <= TH_LOW*ratioHamming with an integer bestDist: the float product, floored */
+    const float lim = 50 * ratio_hamming;
+    int thr = lim >= 255.0f ? 255 : (int)floorf(lim);
+    if (thr < 0) thr = 0;
+    SbpKfExtras kf;
+    kf.min_dist = mp_min_dist;
+    kf.max_dist = mp_max_dist;
+    for (int i = 0; i < 3; i++) kf.ow[i] = Ow[i];
+    kf.log_scale_factor = log_scale_factor;
+    kf.orb_dist = thr;
+    kf.normals = mp_normals;
+    kf.proj_kind = proj_variant;
+    vslam_proj_params q = *p;
+    q.check_orientation = 0; /* these overloads have no rotation histogram */
+    std::vector<vslam_kp> dummy((size_t)std::max(n_points, 1));
+    memset(dummy.data(), 0, dummy.size() * sizeof(vslam_kp));
+    return sbp_frame_impl(fe, &q, dummy.data(), n_points, mp_flags, mp_x3dw, mp_desc_host, dev_kf_kps, dev_kf_desc, n_kf, nullptr,
+                          kf_matched_host, &kf, match_kf, nmatches);
 }
 
 /* FMatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
