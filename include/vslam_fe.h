@@ -444,9 +444,17 @@ typedef struct vslam_fuse_params {
     float fx, fy, cx, cy, bf, th;
     float log_scale_factor; /* pKF->mfLogScaleFactor */
     int32_t img_w, img_h;   /* mnMaxX, mnMaxY (mnMinX = mnMinY = 0: undistorted pinhole images) */
-    int32_t sim3;
+    int32_t sim3;           /* 0 / 1: the two Fuse overloads; 2: one direction of SearchBySim3, see below */
     int32_t gemm_float;     /* as in vslam_proj_params */
+    float Rb[9], tb[3];     /* sim3 == 2 only */
 } vslam_fuse_params;
+/* FMatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (fmatcher.cpp:2245-2469) is two such searches
+ * (sim3 = 2) and an agreement check.  Direction 1 -> 2: Rcw | tcw = R1w | t1w, Rb | tb = sR21 | t21 (:2262-2264),
+ * the points are pKF1's MapPoints that are not bad and not matched yet, the KeyFrame is pKF2; direction 2 -> 1 with
+ * R2w | t2w and sR12 | t12.  A point is p2 = Rb*(Rcw*p + tcw) + tb, depth >= 0, u = fx*(x*(1.0/z)) + cx, IsInImage,
+ * |p2| within the scale-invariance range, PredictScale, window, levels [l-1, l], least distance (first wins); Ow,
+ * normals, bf are unused.  The caller keeps vnMatch1[i1] = best_idx where best_dist <= TH_HIGH (100), likewise
+ * vnMatch2, and accepts (i1, idx2) iff vnMatch2[idx2] == i1 (:2453-2466). */
 int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const vslam_fuse_point* points_host,
                       const uint8_t* mp_desc_host, int n_points, const vslam_kp* dev_kf_kps,
                       const uint8_t* dev_kf_desc, int n_kf, const float* kf_u_right_host, int32_t* best_idx,

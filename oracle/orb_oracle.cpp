@@ -1554,6 +1554,56 @@ int search_by_projection_sim3(const float Tcw[12], const float Ow[3], float fx, 
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ SearchBySim3, one direction */
+void search_by_sim3_direction(const float Ra[9], const float ta[3], const float Rb[9], const float tb[3], float fx, float fy,
+                              float cx, float cy, float th, float mfLogScaleFactor, int imgW, int imgH, int gemmDouble,
+                              const std::vector<uint8_t>& valid, const std::vector<float>& x3Dws,
+                              const std::vector<float>& minDist, const std::vector<float>& maxDist,
+                              const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& mvKeysUn,
+                              const std::vector<uint8_t>& mDescriptors, const std::vector<float>& mvScaleFactors,
+                              std::vector<int>& vnMatch) { /* fmatcher.cpp:2291-2368 */
+    const int TH_HIGH = 100;
+    vnMatch.assign(valid.size(), -1);
+    FrameGrid grid(mvKeysUn, imgW, imgH);
+    const int mnScaleLevels = (int)mvScaleFactors.size();
+    for (size_t i1 = 0; i1 < valid.size(); i1++) {
+        if (!valid[i1]) continue;
+        const float* p3Dw = &x3Dws[3 * i1];
+        const float c1[3] = {gemm_row(Ra + 0, p3Dw, ta[0], gemmDouble), gemm_row(Ra + 3, p3Dw, ta[1], gemmDouble),
+                             gemm_row(Ra + 6, p3Dw, ta[2], gemmDouble)}; /* p3Dc1 = R1w*p3Dw + t1w */
+        const float c2[3] = {gemm_row(Rb + 0, c1, tb[0], gemmDouble), gemm_row(Rb + 3, c1, tb[1], gemmDouble),
+                             gemm_row(Rb + 6, c1, tb[2], gemmDouble)}; /* p3Dc2 = sR21*p3Dc1 + t21 */
+        if (c2[2] < 0.0) continue;
+        const float invz = 1.0 / c2[2];
+        const float x = c2[0] * invz, y = c2[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= 0.0f && u < (float)imgW && v >= 0.0f && v < (float)imgH)) continue;
+        double n2 = 0;
+        for (int k = 0; k < 3; k++) n2 += (double)c2[k] * (double)c2[k];
+        const float dist3D = (float)std::sqrt(n2); /* cv::norm(p3Dc2) */
+        if (dist3D < minDist[i1] || dist3D > maxDist[i1]) continue;
+        const float lv = std::ceil(glibc_logf(maxDist[i1] / dist3D) / mfLogScaleFactor);
+        int nPredictedLevel = (lv != lv || lv >= 2147483648.0f || lv < -2147483648.0f) ? INT_MIN : (int)lv;
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= mnScaleLevels) nPredictedLevel = mnScaleLevels - 1;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = &mpDesc[32 * i1];
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const KeyPoint& kp = mvKeysUn[idx];
+            if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+            const int dist = descriptor_distance(dMP, &mDescriptors[32 * (size_t)idx]);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i1] = bestIdx;
+    }
+}
+
 bool unproject_stereo(const KeyPoint& kpUn, float z, const float Twc[12], float cx, float cy, float invfx, float invfy,
                       int gemmDouble, float out[3]) { /* frame.cpp:1023-1037 */
     if (!(z > 0)) return false;

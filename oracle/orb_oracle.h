@@ -276,6 +276,17 @@ int search_by_projection_sim3(const float Tcw[12], const float Ow[3], float fx, 
                               const std::vector<uint8_t>& matched0, const std::vector<float>& scaleFactors,
                               std::vector<int>& matchKf);
 
+/* One direction of FMatcher::SearchBySim3 (fmatcher.cpp:2291-2368 with Ra|ta = R1w|t1w, Rb|tb = sR21|t21 and pKF2's
+ * keypoints; :2371-2448 with R2w|t2w, sR12|t12 and pKF1's): vnMatch[i] = best keypoint (bestDist <= TH_HIGH) or -1.
+ * valid[i]: the keypoint has a MapPoint that is not bad and is not matched yet. */
+void search_by_sim3_direction(const float Ra[9], const float ta[3], const float Rb[9], const float tb[3], float fx, float fy,
+                              float cx, float cy, float th, float logScaleFactor, int imgW, int imgH, int gemmDouble,
+                              const std::vector<uint8_t>& valid, const std::vector<float>& x3Dw,
+                              const std::vector<float>& minDist, const std::vector<float>& maxDist,
+                              const std::vector<uint8_t>& mpDesc, const std::vector<KeyPoint>& kfKps,
+                              const std::vector<uint8_t>& kfDesc, const std::vector<float>& scaleFactors,
+                              std::vector<int>& vnMatch);
+
 } // namespace orbo
 
 #endif

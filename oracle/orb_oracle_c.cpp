@@ -353,6 +353,21 @@ int orbo_search_by_projection_sim3(const float* Tcw, const float* Ow, const floa
     return nm;
 }
 
+void orbo_search_by_sim3_direction(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* cam,
+                                   float th, float logScaleFactor, int imgW, int imgH, int gemmDouble, int n,
+                                   const uint8_t* valid, const float* x3Dw, const float* minDist, const float* maxDist,
+                                   const uint8_t* mpDesc, const KeyPoint* kfKps, int nKF, const uint8_t* kfDesc,
+                                   const float* scaleFactors, int nlevels, int* vnMatch) {
+    std::vector<KeyPoint> kk(kfKps, kfKps + nKF);
+    std::vector<uint8_t> va(valid, valid + n), md(mpDesc, mpDesc + (size_t)n * 32), kd(kfDesc, kfDesc + (size_t)nKF * 32);
+    std::vector<float> x(x3Dw, x3Dw + (size_t)n * 3), mn(minDist, minDist + n), mx(maxDist, maxDist + n),
+        sf(scaleFactors, scaleFactors + nlevels);
+    std::vector<int> m;
+    search_by_sim3_direction(Ra, ta, Rb, tb, cam[0], cam[1], cam[2], cam[3], th, logScaleFactor, imgW, imgH, gemmDouble, va, x,
+                             mn, mx, md, kk, kd, sf, m);
+    if (n) memcpy(vnMatch, m.data(), (size_t)n * sizeof(int));
+}
+
 /* x3dw: n x 3 out, flags: n out (0 / 1) */
 void orbo_unproject_stereo(const KeyPoint* kps, int n, const float* depth, const float* Twc, float cx, float cy,
                            float invfx, float invfy, int gemmDouble, float* x3dw, uint8_t* flags) {

@@ -92,6 +92,9 @@ def lib():
         L.orbo_search_by_projection_sim3.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
                                                      C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                                      C.c_int, vp]
+        L.orbo_search_by_sim3_direction.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
+        L.orbo_search_by_sim3_direction.restype = None
         L.orbo_fg_halfsample.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
         L.orbo_fg_halfsample.restype = None
         L.orbo_fg_response.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
@@ -576,3 +579,31 @@ def search_by_projection_sim3(Tcw, Ow, cam, th, ratio_hamming, log_scale_factor,
                                               _p(nr), _p(mn), _p(mx), _p(md), _p(kk), len(kk), _p(kd),
                                               _p(mt) if mt is not None else None, _p(sf), len(sf), _p(m))
     return nm, m[:len(kk)]
+
+
+def search_by_sim3(valid1, x1, mn1, mx1, desc1, kps1, R1w, t1w, valid2, x2, mn2, mx2, desc2, kps2, R2w, t2w, sR12, t12, sR21,
+                   t21, cam, th, log_scale_factor, scale_factors, W, H, gemm_double=True):
+    """FMatcher::SearchBySim3 (fmatcher.cpp:2245-2469) from its two directions and the agreement check
+    -> (nFound, match12[n1] = idx2 or -1).  sR12 / sR21 / t21 as the function derives them (:2262-2264)."""
+    def direction(valid, x, mn, mx, desc, Ra, ta, Rb, tb, kf_kps, kf_desc):
+        va = np.ascontiguousarray(valid, np.uint8)
+        xx = np.ascontiguousarray(x, np.float32)
+        a = [np.ascontiguousarray(v, np.float32) for v in (Ra, ta, Rb, tb, cam[:4], mn, mx, scale_factors)]
+        md = np.ascontiguousarray(desc, np.uint8)
+        kk = np.ascontiguousarray(kf_kps, KP_DTYPE)
+        kd = np.ascontiguousarray(kf_desc, np.uint8)
+        out = np.full(max(len(va), 1), -1, np.int32)
+        lib().orbo_search_by_sim3_direction(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), float(th), float(log_scale_factor),
+                                            int(W), int(H), int(gemm_double), len(va), _p(va), _p(xx), _p(a[5]), _p(a[6]),
+                                            _p(md), _p(kk), len(kk), _p(kd), _p(a[7]), len(a[7]), _p(out))
+        return out[:len(va)]
+    vn1 = direction(valid1, x1, mn1, mx1, desc1, R1w, t1w, sR21, t21, kps2, desc2)
+    vn2 = direction(valid2, x2, mn2, mx2, desc2, R2w, t2w, sR12, t12, kps1, desc1)
+    m12 = np.full(len(vn1), -1, np.int32)
+    n = 0
+    for i1 in range(len(vn1)):
+        idx2 = vn1[i1]
+        if idx2 >= 0 and vn2[idx2] == i1:
+            m12[i1] = idx2
+            n += 1
+    return n, m12

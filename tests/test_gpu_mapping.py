@@ -247,3 +247,47 @@ def test_mapping_matchers_empty_inputs(scene):
     bi, bd = m.FuseSearch(pts, np.zeros((3, 32), np.uint8), scene["dev1"][0], scene["dev1"][1], 0, None, F, np.zeros(3),
                           np.zeros(3), (FX, FY, CX, CY, BF), 3.0, 0.18)
     assert np.all(bi == -1) and np.all(bd == 256)
+
+
+def test_search_by_sim3_equals_oracle(scene):
+    """FMatcher::SearchBySim3 (fmatcher.cpp:2245-2469): both directions on the device (sim3 = 2 of the Fuse kernel), the
+    agreement check on the host; the two KeyFrames are the two stereo frames with their stereo points as MapPoints."""
+    rng = np.random.default_rng(33)
+    fe, sf = scene["fe"], scene["sf"]
+    lsf = float(np.log(np.float32(1.2)).astype(np.float32))
+    zmed = float(np.median(scene["z0"][scene["z0"] > 0]))
+    # KeyFrame 1 = world; KeyFrame 2 is displaced by the scene motion: T2w = [I | t]
+    t2w = np.array([3.0 / FX * zmed, 1.0 / FY * zmed, 0.0], np.float32)
+    I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+
+    def points(k, zdep, Rw, tw):
+        z = np.where(zdep > 0, zdep, 25.0).astype(np.float32)
+        Xc = np.stack([(k["x"] - CX) / FX * z, (k["y"] - CY) / FY * z, z], 1).astype(np.float32)
+        Xw = ((Xc - tw) @ Rw).astype(np.float32)  # Rw^T (Xc - tw)
+        d = np.linalg.norm(Xc, axis=1).astype(np.float32)
+        pts = np.zeros(len(k), V.FUSE_POINT_DTYPE)
+        pts["pos"] = Xw
+        pts["max_distance"] = np.float32(1.2) * d * sf[k["octave"]]
+        pts["min_distance"] = np.float32(0.8) * d * sf[k["octave"]] / sf[-1]
+        pts["valid"] = (rng.random(len(k)) < 0.85).astype(np.int32)
+        return pts
+
+    p1 = points(scene["k0"], scene["z0"], I3, z3)
+    p2 = points(scene["k1"], scene["z1"], I3, t2w)
+    m = V.FMatcher(fe, 0.75, True)
+    for s12, th in ((1.0, 7.5), (1.03, 7.5), (0.97, 10.0)):
+        # camera 1 from camera 2: x1 = s12 * R12 * x2 + t12 with R12 = I, t12 = -t2w (up to the scale error under test)
+        R12, t12 = I3, (-t2w).astype(np.float32)
+        for gf in (False, True):
+            nF, m12, (sR21, t21, sR12) = m.SearchBySim3(p1, scene["de0"], scene["dev0"][0], scene["dev0"][1], len(scene["k0"]),
+                                                        I3, z3, p2, scene["de1"], scene["dev1"][0], scene["dev1"][1],
+                                                        len(scene["k1"]), I3, t2w, s12, R12, t12, th, (FX, FY, CX, CY), lsf,
+                                                        (W, H), gf)
+            wn, wm = orbo.search_by_sim3(p1["valid"], p1["pos"], p1["min_distance"], p1["max_distance"], scene["de0"],
+                                         scene["k0"], I3, z3, p2["valid"], p2["pos"], p2["min_distance"], p2["max_distance"],
+                                         scene["de1"], scene["k1"], I3, t2w, sR12, t12, sR21, t21, (FX, FY, CX, CY), th, lsf,
+                                         sf, W, H, not gf)
+            assert nF == wn and np.array_equal(m12, wm), (s12, th, gf, nF, wn)
+        if s12 == 1.0:
+            assert nF > 80
+            assert np.all(p1["valid"][m12 >= 0] == 1) and np.all(p2["valid"][m12[m12 >= 0]] == 1)

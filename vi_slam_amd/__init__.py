@@ -66,7 +66,7 @@ class _FuseParams(C.Structure):  # vslam_fuse_params
     _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float),
                 ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("th", C.c_float),
                 ("log_scale_factor", C.c_float), ("img_w", C.c_int32), ("img_h", C.c_int32), ("sim3", C.c_int32),
-                ("gemm_float", C.c_int32)]
+                ("gemm_float", C.c_int32), ("Rb", C.c_float * 9), ("tb", C.c_float * 3)]
 
 
 class _ProjParams(C.Structure):  # vslam_proj_params
@@ -747,7 +747,7 @@ class FMatcher:
         return nm.value, np.stack([i1, m[i1]], 1).astype(np.int64), m
 
     def FuseSearch(self, points, mp_desc, dev_kf_kps, dev_kf_desc, n_kf, kf_u_right, Rcw, tcw, Ow, cam, th,
-                   log_scale_factor, img_size=None, sim3=False, gemm_float=False):
+                   log_scale_factor, img_size=None, sim3=False, gemm_float=False, Rb=None, tb=None):
         """The search half of FMatcher::Fuse (fmatcher.cpp:1918-2119; sim3=True: the Scw overload :2121-2243): points is
         a FUSE_POINT_DTYPE array, cam = (fx, fy, cx, cy, bf).  -> (best_idx[n], best_dist[n]); the caller applies
         best_dist <= TH_LOW and the map updates in order."""
@@ -762,12 +762,39 @@ class FMatcher:
         P.fx, P.fy, P.cx, P.cy, P.bf = [float(v) for v in cam]
         P.th, P.log_scale_factor, P.img_w, P.img_h = float(th), float(log_scale_factor), int(w), int(h)
         P.sim3, P.gemm_float = int(sim3), int(gemm_float)
+        if Rb is not None:
+            P.Rb[:] = [float(v) for v in np.asarray(Rb, np.float32).reshape(9)]
+            P.tb[:] = [float(v) for v in np.asarray(tb, np.float32).reshape(3)]
         bi = np.full(max(len(pts), 1), -1, np.int32)
         bd = np.full(max(len(pts), 1), 256, np.int32)
         _check(lib().vslam_fuse_search(self.fe._h, C.byref(P), _p(pts), _p(md), len(pts), C.c_void_p(dev_kf_kps),
                                        C.c_void_p(dev_kf_desc), n_kf, _p(ur) if ur is not None else None, _p(bi),
                                        _p(bd)))
         return bi[:len(pts)], bd[:len(pts)]
+
+    def SearchBySim3(self, pts1, desc1, dev_kps1, dev_desc1, n1, R1w, t1w, pts2, desc2, dev_kps2, dev_desc2, n2, R2w, t2w,
+                     s12, R12, t12, th, cam, log_scale_factor, img_size=None, gemm_float=False):
+        """FMatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (fmatcher.cpp:2245-2469).  pts1 / pts2:
+        FUSE_POINT_DTYPE records per keypoint of pKF1 / pKF2 (valid = has a MapPoint, not bad, not matched yet).
+        -> (nFound, match12[n1] = idx2 or -1)."""
+        R12 = np.asarray(R12, np.float32).reshape(3, 3)
+        t12 = np.asarray(t12, np.float32).reshape(3)
+        sR12 = (np.float32(s12) * R12).astype(np.float32)
+        sR21 = ((1.0 / s12) * R12.T).astype(np.float32)  # cv::Mat algebra on the caller's side, :2262-2264
+        t21 = (-(sR21.astype(np.float64) @ t12.astype(np.float64))).astype(np.float32)
+        z3, camb = np.zeros(3, np.float32), tuple(cam[:4]) + (0.0,)
+        b1, d1 = self.FuseSearch(pts1, desc1, dev_kps2, dev_desc2, n2, None, R1w, t1w, z3, camb, th, log_scale_factor,
+                                 img_size, 2, gemm_float, sR21, t21)
+        b2, d2 = self.FuseSearch(pts2, desc2, dev_kps1, dev_desc1, n1, None, R2w, t2w, z3, camb, th, log_scale_factor,
+                                 img_size, 2, gemm_float, sR12, t12)
+        vn1 = np.where((b1 >= 0) & (d1 <= 100), b1, -1)
+        vn2 = np.where((b2 >= 0) & (d2 <= 100), b2, -1)
+        m12 = np.full(len(vn1), -1, np.int32)
+        ok = vn1 >= 0
+        idx = np.nonzero(ok)[0]
+        agree = vn2[vn1[idx]] == idx
+        m12[idx[agree]] = vn1[idx[agree]]
+        return int(agree.sum()), m12, (sR21, t21, sR12)
 
     def search_init_fallbacks(self):
         """Diagnostics: queries whose whole window had to be re-scanned since the last call (read-and-reset)."""

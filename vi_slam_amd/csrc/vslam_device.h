@@ -123,6 +123,7 @@ struct FusePoint {
 };
 struct FuseArgsDev {
     float Rcw[9], tcw[3], Ow[3];
+    float Rb[9], tb[3]; /* sim3 == 2 (SearchBySim3): second transform, p2 = Rb * (Rcw * p + tcw) + tb */
     float fx, fy, cx, cy, bf, th, logScaleFactor;
     int32_t imgW, imgH, sim3, gemmFloat, nlevels, nPoints, nKF;
     float scale[VSLAM_MAX_LEVELS], invSigma2[VSLAM_MAX_LEVELS];

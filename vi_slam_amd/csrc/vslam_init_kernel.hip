@@ -1257,7 +1257,33 @@ k_fuse_rank(FuseArgsDev A) {
         bool go = mp.valid != 0;
         float u = 0.f, v = 0.f, ur = 0.f, radius = 0.f;
         int level = 0;
-        if (go) { /* wave-uniform */
+        if (go && A.sim3 == 2) { /* SearchBySim3, one direction (fmatcher.cpp:2301-2332 / :2381-2412) */
+            const float x1 = sbp_gemm_row(A.Rcw + 0, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[0], A.gemmFloat);
+            const float y1 = sbp_gemm_row(A.Rcw + 3, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[1], A.gemmFloat);
+            const float z1 = sbp_gemm_row(A.Rcw + 6, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[2], A.gemmFloat);
+            const float xc = sbp_gemm_row(A.Rb + 0, x1, y1, z1, A.tb[0], A.gemmFloat);
+            const float yc = sbp_gemm_row(A.Rb + 3, x1, y1, z1, A.tb[1], A.gemmFloat);
+            const float zc = sbp_gemm_row(A.Rb + 6, x1, y1, z1, A.tb[2], A.gemmFloat);
+            go = !(zc < 0.0f);
+            if (go) {
+                const float invz = (float)__ddiv_rn(1.0, (double)zc); /* const float invz = 1.0/z */
+                u = __fadd_rn(__fmul_rn(A.fx, __fmul_rn(xc, invz)), A.cx);
+                v = __fadd_rn(__fmul_rn(A.fy, __fmul_rn(yc, invz)), A.cy);
+                go = u >= 0.0f && u < (float)A.imgW && v >= 0.0f && v < (float)A.imgH;
+            }
+            if (go) {
+                double n2 = __dmul_rn((double)xc, (double)xc); /* cv::norm(p3Dc2) */
+                n2 = __dadd_rn(n2, __dmul_rn((double)yc, (double)yc));
+                n2 = __dadd_rn(n2, __dmul_rn((double)zc, (double)zc));
+                const float dist3D = (float)__dsqrt_rn(n2);
+                go = !(dist3D < mp.minDistance || dist3D > mp.maxDistance);
+                if (go) {
+                    const float lv = ceilf(__fdiv_rn(vslam_trig::glibc_logf(__fdiv_rn(mp.maxDistance, dist3D)), A.logScaleFactor));
+                    level = (lv != lv || lv >= 2147483648.0f || lv < 0.f) ? 0 : min((int)lv, A.nlevels - 1);
+                    radius = __fmul_rn(A.th, A.scale[level]);
+                }
+            }
+        } else if (go) { /* wave-uniform */
             const float xc = sbp_gemm_row(A.Rcw + 0, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[0], A.gemmFloat);
             const float yc = sbp_gemm_row(A.Rcw + 3, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[1], A.gemmFloat);
             const float zc = sbp_gemm_row(A.Rcw + 6, mp.pos[0], mp.pos[1], mp.pos[2], A.tcw[2], A.gemmFloat);

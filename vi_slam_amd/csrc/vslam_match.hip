@@ -1081,6 +1081,8 @@ extern "C" int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const
         A.tcw[i] = p->tcw[i];
         A.Ow[i] = p->Ow[i];
     }
+    for (int i = 0; i < 9; i++) A.Rb[i] = p->Rb[i];
+    for (int i = 0; i < 3; i++) A.tb[i] = p->tb[i];
     A.fx = p->fx; A.fy = p->fy; A.cx = p->cx; A.cy = p->cy; A.bf = p->bf; A.th = p->th;
     A.logScaleFactor = p->log_scale_factor;
     A.imgW = p->img_w; A.imgH = p->img_h; A.sim3 = p->sim3; A.gemmFloat = p->gemm_float;
