@@ -513,16 +513,19 @@ static int stage_host_images(vslam_fe* fe, int nimg, const uint8_t* const* imgs,
     const vslam_fe_params& p = fe->p;
     const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
     if (!fe->h_img) HIPCHK(hipHostMalloc((void**)&fe->h_img, img_bytes * fe->B, hipHostMallocDefault));
-    for (int s = 0; s < nimg; s++) {
+    for (int s = 0; s < nimg; s++)
         if (!imgs[s]) {
             g_err = "null image";
             return VSLAM_ERR_INVALID;
         }
+    /* one task per image on the context's worker pool: a single thread copies ~18 GB/s, which bounded the
+     * host-image batch path at 0.85 ms per 32 KITTI frames */
+    fe->pool->parallel_for(nimg, [&](int s) {
         uint8_t* hs = fe->h_img + img_bytes * s;
         if (pitch == lp) memcpy(hs, imgs[s], img_bytes - (lp - p.width));
         else
             for (int y = 0; y < p.height; y++) memcpy(hs + (size_t)y * lp, imgs[s] + (size_t)y * pitch, p.width);
-    }
+    });
     return VSLAM_OK;
 }
 
