@@ -29,9 +29,15 @@ extern "C" {
 #define VSLAM_ERR_HIP (-3)         /* a HIP runtime call failed; see vslam_last_error() */
 #define VSLAM_ERR_CAPACITY (-4)    /* caller buffer or an internal candidate buffer too small */
 #define VSLAM_ERR_UNSUPPORTED (-5) /* geometry the reference itself cannot process (e.g. nIni == 0) */
+#define VSLAM_ERR_COMM (-6)        /* RCCL missing or a collective failed; see vslam_last_error() */
 
 #define VSLAM_MAX_LEVELS 16
 #define VSLAM_MAX_BATCH 64
+
+/* values of the imgs_on_device argument (where the input images live) */
+#define VSLAM_IMGS_HOST 0
+#define VSLAM_IMGS_DEVICE 1
+#define VSLAM_IMGS_PINNED 2
 
 /* flags for vslam_fe_params.flags: OpenCV build-dependent arithmetic the reference inherits */
 #define VSLAM_FLAG_ATAN_FMA 1u /* cv::fastAtan2 Horner polynomial FMA-contracted (AVX2/FMA3 dispatch, aarch64) */
@@ -83,8 +89,15 @@ int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, i
                      uint8_t* desc, int cap, int* n, int* mono_index);
 
 /* Batched form: nimg (<= max_batch) images in one pass of the kernels; slot i <- imgs[i].
- *   imgs_on_device != 0: imgs[i] are device pointers that stay valid until the call returns (zero-copy
- *   level 0); otherwise host pointers (uploaded).  kps/desc/n/mono_index are host arrays of nimg entries;
+ *   imgs_on_device == VSLAM_IMGS_DEVICE (1): imgs[i] are device pointers, used in place as level 0 (zero
+ *   copy).  They must stay valid until the LAST consumer of this pass's level 0 has run: the stereo refinement of
+ *   vslam_stereo_match(_batch) / vslam_frame_stereo_* and vslam_fe_level_copy(level 0) read them again -- i.e.
+ *   until the next extraction on this context, or until the context is destroyed.
+ *   == VSLAM_IMGS_HOST (0): pageable host pointers; rows are copied into the context's pinned staging by its
+ *   worker pool, then pulled over PCIe.   == VSLAM_IMGS_PINNED (2): host pointers into pinned (hipHostMalloc /
+ *   hipHostRegister'ed, e.g. vslam_host_alloc) memory that the GPU reads directly -- no host-side copy at all;
+ *   the memory must stay untouched until the pass has been waited for.
+ *   kps/desc/n/mono_index are host arrays of nimg entries;
  *   kps[i] holds cap keypoints, desc[i] cap*32 bytes.  kps/desc may be NULL to keep results on the
  *   device only (read them with vslam_fe_slot_buffers). */
 int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
@@ -94,8 +107,8 @@ int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, s
 /* The same in two halves, so a caller can keep several contexts (streams) in flight: _async enqueues the
  * whole pass and returns without waiting for the GPU (with the device quadtree nothing in it touches the
  * host); _wait blocks until that pass is done and delivers the results like vslam_fe_extract_batch.
- * want_host != 0 also enqueues the D2H of keypoints and descriptors.  Device images passed to _async must
- * stay valid until _wait returns. */
+ * want_host != 0 also enqueues the D2H of keypoints and descriptors.  Device images: lifetime as above; pinned
+ * host images must stay untouched until _wait returns. */
 int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                  int imgs_on_device, int lap0, int lap1, int want_host);
 int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
@@ -149,6 +162,33 @@ int vslam_fe_pack_slot_range(vslam_fe* fe, int first, int nslots, void* dev_dst,
 /* enqueue-only variant: the copies run on fe's stream after the pass that produced the slots; the caller
  * orders later readers (stream sync / event) itself */
 int vslam_fe_pack_slot_range_async(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t slot_bytes);
+
+/* ---------------------------------------------------------------- multi-GPU exchange step (RCCL over xGMI)
+ *
+ * The reference is single-GPU/CPU; BASELINE.json's north_star shards frames one per GPU and names
+ * ONE exchange: the predecessor frame's descriptors + keypoint geometry for the cross-frame matchers
+ * (FMatcher::SearchForInitialization fmatcher.cpp:983-1098, SearchByProjection(Current, Last) :2471-2687).
+ * One process per GPU; rank 0 makes an id (vslam_comm_unique_id), the launcher distributes its 128 bytes (any
+ * channel: torch.distributed store, MPI, a file), every rank calls vslam_comm_create.  The exchange functions only
+ * ENQUEUE on fe's stream (behind vslam_fe_pack_slot_range_async, ahead of the matcher): no host synchronisation.
+ * RCCL is loaded at run time (librccl.so.1); without it these return VSLAM_ERR_COMM and everything else works. */
+#define VSLAM_COMM_ID_BYTES 128
+typedef struct vslam_comm vslam_comm;
+int vslam_comm_unique_id(uint8_t id[VSLAM_COMM_ID_BYTES]);
+int vslam_comm_create(int device, int rank, int world, const uint8_t id[VSLAM_COMM_ID_BYTES], vslam_comm** out);
+void vslam_comm_destroy(vslam_comm* comm);
+int vslam_comm_rank(const vslam_comm* comm);
+int vslam_comm_world(const vslam_comm* comm);
+/* Ring shift: `bytes` of dev_send go to rank+1, dev_recv receives rank-1's block (frame g lives on rank g % world,
+ * so every predecessor frame lives on the left neighbour): one ncclSend/ncclRecv pair in a group. */
+int vslam_exchange_ring(vslam_fe* fe, vslam_comm* comm, const void* dev_send, void* dev_recv, size_t bytes);
+/* The north_star-literal variant: all-gather, dev_recv_all = world x bytes_per_rank (rank r's block at r*bytes). */
+int vslam_exchange_allgather(vslam_fe* fe, vslam_comm* comm, const void* dev_send, void* dev_recv_all,
+                             size_t bytes_per_rank);
+
+/* Pinned host memory for VSLAM_IMGS_PINNED inputs (hipHostMalloc: the GPU reads it over PCIe without a staging copy). */
+int vslam_host_alloc(size_t bytes, void** out);
+void vslam_host_free(void* p);
 
 /* Stage timing with HIP events on the context's stream (the reference's REGISTER_TIMES spans,
  * frame.cpp:103-132, broken down per kernel stage): stage_ms[0..4] = pyramid (7 launches), FAST cells,

@@ -222,3 +222,16 @@ def test_bow_assemble_equals_dbow3_restatement(weighting, norm):
     for k in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
         assert np.array_equal(got[k], want[k]), k
     assert len(got["bow_ids"]) > 20 and (want["weight"] == 0).any()
+
+
+def test_worker_pool_stress_under_thread_sanitizer(tmp_path):
+    """The context's worker pool (vslam_pool.h): alternating small/large parallel_for calls with stack lambdas;
+    every index runs exactly once and ThreadSanitizer reports nothing (stale-index race)."""
+    import subprocess
+    exe = str(tmp_path / "pool_stress")
+    src = os.path.join(ROOT, "tests", "cpp", "pool_stress.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-o", exe, src])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    r = subprocess.run([exe, "6000"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "pool_stress ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr

@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libvslam_fe.so")
 HOST_LIB_PATH = os.path.join(_HERE, "libvslam_host.so")
 
 VSLAM_OK = 0
-ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+IMGS_HOST, IMGS_DEVICE, IMGS_PINNED = 0, 1, 2  # where the input images live (vslam_fe.h VSLAM_IMGS_*)
+COMM_ID_BYTES = 128
 FLAG_ATAN_FMA = 1
 FLAG_HOST_OCTREE = 2
 MAX_BATCH = 64
@@ -44,6 +46,8 @@ ABI_SYMBOLS = [
     "vslam_bow_assemble", "vslam_search_by_bow", "vslam_search_by_bow_keyframes",
     "vslam_search_for_triangulation", "vslam_fuse_search", "vslam_dbg_logf", "vslam_search_by_projection_keyframe",
     "vslam_search_by_projection_sim3",
+    "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
+    "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
 ]
 
 
@@ -185,6 +189,17 @@ def lib():
                                                             vp]
         L.vslam_dbg_sincos.argtypes = [vp, vp, i, vp, vp]
         L.vslam_dbg_fast_atan2.argtypes = [vp, vp, vp, i, i, vp]
+        L.vslam_comm_unique_id.argtypes = [vp]
+        L.vslam_comm_create.argtypes = [i, i, i, vp, C.POINTER(vp)]
+        L.vslam_comm_destroy.argtypes = [vp]
+        L.vslam_comm_destroy.restype = None
+        L.vslam_comm_rank.argtypes = [vp]
+        L.vslam_comm_world.argtypes = [vp]
+        L.vslam_exchange_ring.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.vslam_exchange_allgather.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.vslam_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.vslam_host_free.argtypes = [vp]
+        L.vslam_host_free.restype = None
         _lib = L
     return _lib
 
@@ -196,6 +211,64 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class PinnedImages:
+    """`count` images of `height` x `width` bytes in ONE pinned host allocation (vslam_host_alloc = hipHostMalloc), rows
+    `pitch` bytes apart: what a capture driver's DMA ring looks like.  `.array[i]` is a numpy view to fill, `.ptrs` the
+    ctypes pointer table for compute_batch_async(..., where=IMGS_PINNED)."""
+
+    def __init__(self, count, height, width, pitch=None):
+        self.pitch = pitch or width
+        self.count, self.height, self.width = count, height, width
+        nbytes = count * height * self.pitch
+        h = C.c_void_p()
+        _check(lib().vslam_host_alloc(nbytes, C.byref(h)))
+        self._h = h
+        self._flat = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(h.value))
+        self.array = self._flat.reshape(count, height, self.pitch)[:, :, :width]
+        self.ptrs = (C.c_void_p * count)(*[h.value + i * height * self.pitch for i in range(count)])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.array = self._flat = None
+            lib().vslam_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """vslam_comm: one RCCL communicator per process/GPU for the exchange step (vslam_exchange_ring / _allgather).
+    `unique_id()` on rank 0 -> distribute its 128 bytes by any channel -> `Comm(device, rank, world, id)` everywhere."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().vslam_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, device, rank, world, uid):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(lib().vslam_comm_create(device, rank, world, buf, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def ring(self, fe, dev_send, dev_recv, nbytes):
+        """enqueue on fe's stream: nbytes of dev_send -> rank+1, dev_recv <- rank-1"""
+        _check(lib().vslam_exchange_ring(fe._h, self._h, dev_send, dev_recv, nbytes))
+
+    def allgather(self, fe, dev_send, dev_recv_all, nbytes_per_rank):
+        _check(lib().vslam_exchange_allgather(fe._h, self._h, dev_send, dev_recv_all, nbytes_per_rank))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vslam_comm_destroy(self._h)
+            self._h = None
 
 
 class FExtractor:
@@ -305,13 +378,14 @@ class FExtractor:
             return [(n[i], mono[i]) for i in range(nimg)]
         return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
 
-    def compute_batch_async(self, device_ptrs, pitch, vLappingArea=(0, 0), to_host=True):
-        """Enqueue one batched pass on HBM-resident images and return immediately (see
-        vslam_fe_extract_batch_async); collect with wait()."""
+    def compute_batch_async(self, device_ptrs, pitch, vLappingArea=(0, 0), to_host=True, where=IMGS_DEVICE):
+        """Enqueue one batched pass and return immediately (vslam_fe_extract_batch_async); collect with wait().
+        `device_ptrs`: image addresses, HBM-resident (where=IMGS_DEVICE, zero copy) or pinned host memory
+        (where=IMGS_PINNED, e.g. PinnedImages.ptrs: pulled over PCIe by the pass itself)."""
         nimg = len(device_ptrs)
         ptrs = device_ptrs if isinstance(device_ptrs, C.Array) else (C.c_void_p * nimg)(*device_ptrs)
         self._pending = (nimg, to_host)
-        _check(lib().vslam_fe_extract_batch_async(self._h, nimg, ptrs, pitch, 1, vLappingArea[0], vLappingArea[1],
+        _check(lib().vslam_fe_extract_batch_async(self._h, nimg, ptrs, pitch, where, vLappingArea[0], vLappingArea[1],
                                                   int(to_host)))
 
     def wait(self, copy=False):
@@ -342,13 +416,14 @@ class FExtractor:
                 .reshape(self.max_batch, self.cap, 32)
 
     # ---- Frame::Frame(stereo) hot section (frame.cpp:102-132), several frames per enqueue
-    def frame_stereo_async(self, device_ptrs, pitch, bf, fx, to_host=True):
-        """device_ptrs = [L0, R0, L1, R1, ...] HBM-resident images.  Enqueues extraction of all images and
-        ComputeStereoMatches of every (L,R) pair; returns immediately.  Collect with frame_stereo_wait()."""
+    def frame_stereo_async(self, device_ptrs, pitch, bf, fx, to_host=True, where=IMGS_DEVICE):
+        """device_ptrs = [L0, R0, L1, R1, ...] images, HBM-resident or (where=IMGS_PINNED) in pinned host memory.
+        Enqueues extraction of all images and ComputeStereoMatches of every (L,R) pair; returns immediately.
+        Collect with frame_stereo_wait()."""
         nimg = len(device_ptrs)
         ptrs = device_ptrs if isinstance(device_ptrs, C.Array) else (C.c_void_p * nimg)(*device_ptrs)
         self._pending = (nimg, to_host)
-        _check(lib().vslam_frame_stereo_batch_async(self._h, nimg // 2, ptrs, pitch, 1, bf, fx, int(to_host)))
+        _check(lib().vslam_frame_stereo_batch_async(self._h, nimg // 2, ptrs, pitch, where, bf, fx, int(to_host)))
 
     def frame_stereo_wait(self):
         """-> (list of (keypoints, descriptors) per image, list of (mvuRight, mvDepth) per stereo frame);

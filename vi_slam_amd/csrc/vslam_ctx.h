@@ -18,6 +18,7 @@
 
 #include "../../include/vslam_orb_pattern.h"
 #include "vslam_host.h"
+#include "vslam_pool.h"
 #include "vslam_kernels.h"
 
 std::string& vslam_err();
@@ -31,74 +32,6 @@ std::string& vslam_err();
             return VSLAM_ERR_HIP;                                                                \
         }                                                                                        \
     } while (0)
-
-/* ------------------------------------------------------------------ tiny worker pool */
-class WorkerPool {
-public:
-    explicit WorkerPool(int n) : stop_(false), next_(0), total_(0), pending_(0), gen_(0) {
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-            gen_++;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    void parallel_for(int n, const std::function<void(int)>& fn) {
-        if (n <= 0) return;
-        if (th_.empty() || n == 1) {
-            for (int i = 0; i < n; i++) fn(i);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn;
-            next_.store(0);
-            total_ = n;
-            pending_ = n;
-            gen_++;
-        }
-        cv_.notify_all();
-        run();
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-private:
-    void run() {
-        for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= total_) break;
-            (*fn_)(i);
-            std::lock_guard<std::mutex> l(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-            }
-            run();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    bool stop_;
-    std::atomic<int> next_;
-    int total_, pending_;
-    unsigned long gen_;
-    const std::function<void(int)>* fn_ = nullptr;
-};
 
 /* ------------------------------------------------------------------ context */
 struct vslam_fe {
@@ -120,7 +53,7 @@ struct vslam_fe {
     int16_t* d_xa[VSLAM_MAX_LEVELS] = {};
     uint16_t* d_ytab[VSLAM_MAX_LEVELS] = {};
     int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
-    uint16_t* d_qbase[VSLAM_MAX_LEVELS] = {};    /* k_resize_level_v2 quad tables (nullptr: level uses v1) */
+    uint16_t* d_qbase[VSLAM_MAX_LEVELS] = {};    /* k_resize_level_v2 quad tables (nullptr: generic k_resize_level) */
     ResizeQuad* d_quads[VSLAM_MAX_LEVELS] = {};
     /* FAST cells */
     std::vector<vslam::HostCell> cells;
@@ -132,13 +65,7 @@ struct vslam_fe {
     uint8_t* h_cand = nullptr; /* pinned */
     size_t cand_stride = 0;
     int cand_cap = 0;
-    /* blur tiles */
-    uint32_t* d_blur_tiles = nullptr;
-    int n_blur_tiles = 0;
     int32_t taps[7];
-    /* v2 kernels (vslam_kernels_v2.hip); VSLAM_KERNELS=v1 in the environment selects the first generation */
-    bool use_v2_fast = false, use_v2_blur = false, use_v3_fast = false;
-    int octree_gen = 2; /* k_octree_v2 (keys never move); VSLAM_OCTREE=v1 selects the first generation */
     uint32_t* d_blur_tasks = nullptr;
     int n_blur_tasks = 0;
     int blur_rows = 32; /* output rows per wave task of k_blur7_v2 (VSLAM_BLUR_ROWS) */
@@ -189,6 +116,8 @@ struct vslam_fe {
     bool use_graph = true;          /* host-image passes replay a captured HIP graph (VSLAM_GRAPH=0 disables) */
     hipGraphExec_t graph_exec = nullptr;
     long long graph_key = 0;
+    size_t graph_pitch = 0;                          /* pinned-image passes: the captured pull reads these */
+    const uint8_t* graph_imgs[VSLAM_MAX_BATCH] = {};
     int graph_lap0 = 0, graph_lap1 = 0;
     uint8_t* h_img = nullptr;   /* pinned staging for host images: B x height x level-0 pitch */
     uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */

@@ -38,7 +38,6 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_cells);
     hipFree(fe->d_cand);
     if (fe->h_cand) hipHostFree(fe->h_cand);
-    hipFree(fe->d_blur_tiles);
     hipFree(fe->d_blur_tasks);
     hipFree(fe->d_sel);
     if (fe->h_sel) hipHostFree(fe->h_sel);
@@ -171,8 +170,9 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if ((rc = upload(&fe->d_yb[l], r.yb.data(), r.yb.size() * 2))) return rc;
         std::vector<uint16_t> qbase;
         std::vector<uint32_t> quads;
-        const char* gen = getenv("VSLAM_KERNELS");
-        if (!(gen && !strcmp(gen, "v1")) && vslam::build_resize_quads(r, s.w, d.w, qbase, quads)) {
+        /* four outputs whose eight taps do not fit one 8-byte source window (scale factors >~ 1.6): that level uses
+         * the generic one-pixel-per-thread kernel */
+        if (vslam::build_resize_quads(r, s.w, d.w, qbase, quads)) {
             if ((rc = upload(&fe->d_qbase[l], qbase.data(), qbase.size() * 2))) return rc;
             if ((rc = upload(&fe->d_quads[l], quads.data(), quads.size() * 4))) return rc;
         }
@@ -217,17 +217,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     HIPCHK(hipMalloc((void**)&fe->d_cand, fe->cand_stride * fe->B));
     HIPCHK(hipHostMalloc((void**)&fe->h_cand, fe->cand_stride * fe->B, hipHostMallocDefault));
 
-    /* blur tiles */
-    std::vector<uint32_t> tiles;
-    for (int l = 0; l < p.nlevels; l++) {
-        const int tx = (fe->geom.lv[l].w + 63) / 64, ty = (fe->geom.lv[l].h + 15) / 16;
-        for (int y = 0; y < ty; y++)
-            for (int x = 0; x < tx; x++) tiles.push_back(((uint32_t)l << 24) | ((uint32_t)y << 12) | (uint32_t)x);
-    }
-    fe->n_blur_tiles = (int)tiles.size();
     {
         int rc;
-        if ((rc = upload(&fe->d_blur_tiles, tiles.data(), tiles.size() * 4))) return rc;
         if ((rc = upload(&fe->d_pattern, VSLAM_ORB_PATTERN, 1024))) return rc;
     }
     vk_upload_disc(fe->tab.disc_u.data(), fe->tab.disc_v.data(), (int)fe->tab.disc_u.size());
@@ -244,13 +235,12 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         fe->n_blur_tasks = (int)tasks.size();
         int rc;
         if ((rc = upload(&fe->d_blur_tasks, tasks.data(), tasks.size() * 4))) return rc;
-        const char* gen = getenv("VSLAM_KERNELS");
-        const bool v1 = gen && !strcmp(gen, "v1");
-        fe->use_v2_blur = !v1 && fe->geom.lv[p.nlevels - 1].w >= 8; /* its row fetch reads 8-byte windows */
-        fe->use_v2_fast = !v1 && maxw <= vk_fast_v2_max_window() && maxh <= vk_fast_v2_max_rows();
-        fe->use_v3_fast = !(gen && !strcmp(gen, "v2")); /* same limits as v2 (LDS pitch, keep mask) */
-        const char* og = getenv("VSLAM_OCTREE"); /* "v1": scan-based stable partition (first generation) */
-        fe->octree_gen = (og && !strcmp(og, "v1")) ? 1 : 2;
+        /* limits of k_fast_cells_v3 (LDS pitch 72, 2 keep words per interior row) and k_blur7_v2 (8-byte row windows);
+         * cell windows are at most 59 + 6 px on a side and levels at least 40 px wide, so these never trigger */
+        if (maxw > 66 || maxh > 134 || fe->geom.lv[p.nlevels - 1].w < 8) {
+            g_err = "FAST cell window larger than 66 x 134 px";
+            return VSLAM_ERR_UNSUPPORTED;
+        }
     }
 
     const size_t nk = (size_t)fe->B * fe->cap;
@@ -533,28 +523,36 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     const vslam_fe_params& p = fe->p;
     const int L = p.nlevels;
     hipStream_t st = fe->stream;
-    for (int s = 0; s < nimg; s++) {
-        if (on_device) {
+    if (on_device == VSLAM_IMGS_DEVICE) {
+        for (int s = 0; s < nimg; s++) {
             if (!imgs[s]) {
                 g_err = "null image";
                 return VSLAM_ERR_INVALID;
             }
             fe->src.l0[s] = imgs[s];
             fe->src.pitch0[s] = (uint32_t)pitch;
-        } else { /* staged by stage_host_images */
-            uint8_t* d = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
-            const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
-            uint8_t* hs = fe->h_img + img_bytes * s;
-            CopyRanges R;
-            memset(&R, 0, sizeof(R));
-            R.dst[0] = d;
-            R.src[0] = hs;
-            R.bytes[0] = img_bytes;
-            R.n = 1;
-            vk_copy_ranges(st, R);
-            fe->src.l0[s] = d;
-            fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
         }
+    } else {
+        /* host rows (the caller's pinned images, or the pinned staging stage_host_images filled) are pulled into
+         * level 0 of the slots by one kernel */
+        BatchSrc hs;
+        const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
+        for (int s = 0; s < nimg; s++) {
+            if (on_device == VSLAM_IMGS_PINNED) {
+                if (!imgs[s]) {
+                    g_err = "null image";
+                    return VSLAM_ERR_INVALID;
+                }
+                hs.l0[s] = imgs[s];
+                hs.pitch0[s] = (uint32_t)pitch;
+            } else {
+                hs.l0[s] = fe->h_img + img_bytes * s;
+                hs.pitch0[s] = (uint32_t)lp;
+            }
+            fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
+            fe->src.pitch0[s] = (uint32_t)lp;
+        }
+        vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg);
     }
     fe->last_nimg = nimg;
     fe->cand_on_host = false;
@@ -572,16 +570,8 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    if (fe->use_v2_fast && fe->use_v3_fast)
-        vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
-                         fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg);
-    else if (fe->use_v2_fast)
-        vk_fast_cells_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
-                         fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_rows, nimg);
-    else
-        vk_fast_cells(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(),
-                      fe->d_cand, fe->cand_stride, fe->cand_cap, p.ini_th_fast, p.min_th_fast, fe->tile_pitch,
-                      fe->tile_rows, fe->max_px, nimg);
+    vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
+                     fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     return VSLAM_OK;
 }
@@ -614,12 +604,8 @@ static int wait_candidates(vslam_fe* fe, int nimg) {
 }
 
 static void enqueue_blur(vslam_fe* fe, int nimg) {
-    if (fe->use_v2_blur)
-        vk_blur7_v2(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks,
-                    fe->n_blur_tasks, fe->taps, fe->blur_rows, nimg);
-    else
-        vk_blur7(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tiles,
-                 fe->n_blur_tiles, fe->taps, nimg);
+    vk_blur7_v2(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks,
+                fe->n_blur_tasks, fe->taps, fe->blur_rows, nimg);
 }
 
 /* quadtree on the host (fallback when the node list does not fit LDS, or VSLAM_FLAG_HOST_OCTREE) */
@@ -713,7 +699,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
-              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg, fe->octree_gen);
+              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
                   d_err, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
@@ -749,19 +735,35 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
                           int lap0, int lap1, bool want_host) {
     HIPCHK(hipSetDevice(fe->p.device));
-    if (!on_device) {
+    if (on_device == VSLAM_IMGS_HOST) {
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
      * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
-    const bool graphable = fe->use_graph && !on_device && fe->dev_octree && !fe->profiling;
+    const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
-    const long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
-                          (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24);
-    if (fe->graph_exec && fe->graph_key == key && fe->graph_lap0 == lap0 && fe->graph_lap1 == lap1) {
+    long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
+                    (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24);
+    if (on_device == VSLAM_IMGS_PINNED) {
+        /* the caller's pointers are kernel arguments of the captured pull: a different set of images is a different
+         * graph (a capture-card ring of a few buffers per context hits the cache every time) */
+        unsigned long long hsh = 0x9E3779B97F4A7C15ull ^ (unsigned long long)pitch;
+        for (int s = 0; s < nimg; s++) hsh = (hsh ^ (unsigned long long)(uintptr_t)imgs[s]) * 0x100000001B3ull;
+        key ^= (long long)(hsh | 2ull);
+    }
+    const bool same_imgs = on_device != VSLAM_IMGS_PINNED ||
+                           (fe->graph_pitch == pitch && !memcmp(fe->graph_imgs, imgs, (size_t)nimg * sizeof(imgs[0])));
+    if (fe->graph_exec && fe->graph_key == key && fe->graph_lap0 == lap0 && fe->graph_lap1 == lap1 && same_imgs) {
         fe->last_nimg = nimg;
         fe->cand_on_host = false;
+        /* what enqueue_front records on a plain pass: later NON-captured consumers (stereo refinement,
+         * vslam_fe_level_copy level 0) read fe->src, which a device-image pass in between may have pointed at the
+         * caller's (by now possibly freed) images */
+        for (int s = 0; s < nimg; s++) {
+            fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
+            fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
+        }
         HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
         return VSLAM_OK;
     }
@@ -786,6 +788,8 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     }
     hipGraphDestroy(graph);
     fe->graph_key = key;
+    fe->graph_pitch = pitch;
+    memcpy(fe->graph_imgs, imgs, (size_t)nimg * sizeof(imgs[0]));
     fe->graph_lap0 = lap0;
     fe->graph_lap1 = lap1;
     HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
@@ -889,7 +893,8 @@ int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* 
 extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                       int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
                                       uint8_t* const* desc, int cap, int* n, int* mono_index) {
-    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width) {
+    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width || imgs_on_device < 0 ||
+        imgs_on_device > VSLAM_IMGS_PINNED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
@@ -905,7 +910,8 @@ extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* con
 /* split form: enqueue everything (no host synchronisation in the device-quadtree path), collect later */
 extern "C" int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                             int imgs_on_device, int lap0, int lap1, int want_host) {
-    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width) {
+    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width || imgs_on_device < 0 ||
+        imgs_on_device > VSLAM_IMGS_PINNED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
@@ -977,6 +983,16 @@ extern "C" int vslam_fe_slot_buffers(vslam_fe* fe, int slot, const vslam_kp** de
 }
 
 extern "C" int vslam_fe_capacity(const vslam_fe* fe) { return fe ? fe->cap : VSLAM_ERR_INVALID; }
+
+extern "C" int vslam_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return VSLAM_OK;
+}
+extern "C" void vslam_host_free(void* p) {
+    if (p) hipHostFree(p);
+}
 
 extern "C" int vslam_fe_slot_host_views(vslam_fe* fe, int slot, const vslam_kp** host_kps,
                                         const uint8_t** host_desc) {

@@ -1,13 +1,15 @@
-/* vslam_kernels_v2.hip -- second-generation FAST and blur kernels (same results as v1, bit for bit).
+/* vslam_image_kernels.hip -- the image-streaming kernels of the extractor: pyramid, FAST cells, 7x7 blur.
  *
- * k_blur7_v2   marching-rows separable 7x7: one WAVE owns a 256-px-wide strip (64 lanes x 4 px, loaded as one
- *              dword per lane = 256 B coalesced), gets its neighbours' dwords with two wave shuffles, does
- *              the row pass with v_dot4_u32_u8 against packed tap constants (10 dot4 per 4 px, no byte
- *              extraction) and keeps a 7-row ring of row-pass results in VGPRs for the column pass.  No LDS,
- *              no barriers; every input byte is read once per strip (+6 halo rows per 32).
- * k_fast_cells_v2  same algorithm as k_fast_cells, but the LDS tiles have a compile-time pitch (ring offsets
- *              become ds_read immediates), pixel <-> thread mapping is 32x8 without any integer division,
- *              and the keep mask is 2 words per interior row.
+ * k_resize_level_v2  one thread = four consecutive output pixels of a row (cv::resize INTER_LINEAR 8u fixed point).
+ * k_fast_cells_v3    one workgroup per 30-px FAST cell: packed 4-pixel compass pre-test, survivor lists, one pass of the
+ *                    min3/max3 score networks on dense lanes, cell-local NMS, raster-ordered compaction.
+ * k_blur7_v2         marching-rows separable 7x7: one WAVE owns a 256-px-wide strip (64 lanes x 4 px, loaded as one
+ *                    dword per lane = 256 B coalesced), gets its neighbours' dwords with two wave shuffles, does
+ *                    the row pass with v_dot4_u32_u8 against packed tap constants (10 dot4 per 4 px, no byte
+ *                    extraction) and keeps a 7-row ring of row-pass results in VGPRs for the column pass.  No LDS,
+ *                    no barriers; every input byte is read once per strip (+6 halo rows per 32).
+ * (The kernel names keep their generation suffix so that profiles of different rounds line up; the first
+ * generations are in the git history only.)
  */
 #include "vslam_kernels.h"
 
@@ -166,7 +168,6 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
 /* ------------------------------------------------------------------------------------------------
  * FAST cells
  * ---------------------------------------------------------------------------------------------- */
-#define FP 72 /* LDS pitch in bytes; cell windows are at most 66 px wide (host checks) */
 
 /* hipcc splits min(a,min(b,c)) into shared two-input mins; the three-input forms halve the network */
 __device__ __forceinline__ int imin3v(int a, int b, int c) {
@@ -183,7 +184,7 @@ __device__ __forceinline__ int imax3v(int a, int b, int c) {
 /* One polarity of the FAST score: max over the 16 nine-pixel arcs of min_k d_k, with d_k = sign*(v - ring_k).
  * sign = +1 -> dark corners (cornerScore's a0), sign = -1 -> bright corners (its -b0).  The OpenCV score is
  * max(dark, bright) - 1. */
-template <int SIGN, int P = FP> /* P: LDS pitch of the window */
+template <int SIGN, int P> /* P: LDS pitch of the window */
 __device__ __forceinline__ int fast_half_score(const uint8_t* c) {
     const int v = c[0];
     int d[16];
@@ -204,211 +205,9 @@ __device__ __forceinline__ int fast_half_score(const uint8_t* c) {
     return A;
 }
 
-__global__ void __launch_bounds__(256)
-k_fast_cells_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
-                const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
-                int cand_cap, int iniTh, int minTh, int tile_rows) {
-    extern __shared__ __align__(16) uint8_t smem2[];
-    uint8_t* win = smem2;                        /* tile_rows x FP */
-    uint8_t* sc = win + tile_rows * FP;          /* (tile_rows-4) x FP, interior at (1..ih, 1..iw) */
-    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * FP); /* 2 words per interior row */
-    uint16_t* plist = (uint16_t*)(keep + (tile_rows - 6) * 2); /* pixels passing the dark compass pre-test */
-    uint16_t* plistB = plist + (tile_rows - 6) * 64;            /* ... the bright one */
-    __shared__ int s_npass[2];
-    __shared__ uint32_t s_wave_tot[4];
-    __shared__ int s_any_ini;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int slot = blockIdx.y;
-    /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2), so XCD k takes the k-th
-     * contiguous eighth of the cell list -- neighbouring cells, whose windows overlap by 6 px and share image
-     * rows, then hit the same L2 instead of being fetched by all eight. */
-    const int per_xcd = (ncells + 7) >> 3;
-    const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (cell >= ncells) return;
-    const CellDesc cd = cells[cell];
-    const int level = cd.level;
-    const LevelGeom lg = g.lv[level];
-    int pitch;
-    const uint8_t* img = level_base_v2(pyr, slot_stride, src, lg, level, slot, &pitch);
-    const int ww = cd.x1 - cd.x0, wh = cd.y1 - cd.y0;
-    const int iw = ww - 6, ih = wh - 6;
-    const int nwords = ih * 2;
-
-    /* stage the window with dword loads: 16 lanes x 4 bytes per row, 16 rows per sweep.  A lane's dword may
-     * run up to 3 bytes past the window, which is still inside the image row (windows end >= 16 px before it) */
-    {
-        const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0;
-        const int srow = tid >> 4, scol = (tid & 15) * 4;
-        for (int y = srow; y < wh; y += 16) {
-            if (scol < ww) *(uint32_t*)(win + y * FP + scol) = *(const uint32_t*)(gsrc + (size_t)y * pitch + scol);
-            if (scol + 64 < ww) win[y * FP + scol + 64] = gsrc[(size_t)y * pitch + scol + 64]; /* ww in 65..66 */
-            if (scol + 65 < ww && scol == 0) win[y * FP + 65] = gsrc[(size_t)y * pitch + 65];
-        }
-    }
-    /* zero frame of the score tile, keep mask */
-    if (tid < iw + 2) {
-        sc[tid] = 0;
-        sc[(ih + 1) * FP + tid] = 0;
-    }
-    if (tid < ih) {
-        sc[(tid + 1) * FP] = 0;
-        sc[(tid + 1) * FP + iw + 1] = 0;
-    }
-    if (tid < nwords) keep[tid] = 0;
-    if (tid == 0) {
-        s_any_ini = 0;
-        s_npass[0] = 0;
-        s_npass[1] = 0;
-    }
-    __syncthreads();
-
-    const int lx = tid & 31, lyb = tid >> 5; /* 32 columns x 8 rows per sweep */
-    /* Two stages, mirroring the reference's "FAST at iniThFAST; if the cell is empty, again at minThFAST"
-     * (fextractor.cpp:800-807): stage 0 works at T = iniThFAST and is final for every cell that yields a
-     * corner (the usual case) -- only ~1/3 of the pixels that pass the minThFAST pre-test pass it at 20.
-     *
-     * Pre-test (exact necessary condition): a nine-pixel arc always contains two compass-adjacent ring
-     * pixels (0,4,8,12), so a pixel whose score can reach T has two adjacent compass pixels darker than
-     * v - T or two brighter than v + T.  Everything else scores 0 -- which cannot change the NMS at T
-     * (a suppressing neighbour needs a score >= the candidate's >= T).  The test is made per polarity:
-     * a pixel that can only be a dark corner runs only the dark half of the network (and vice versa); both
-     * survivor lists are compacted so the min3/max3 networks run on dense lanes. */
-    int T = iniTh;
-    for (int stage = 0; stage < 2; stage++) {
-        for (int xb = 0; xb < iw; xb += 32) {
-            const int x = xb + lx;
-            for (int ly0 = 0; ly0 < ih; ly0 += 8) { /* uniform trip count: the ballots need whole waves */
-                const int ly = ly0 + lyb;
-                bool passD = false, passB = false;
-                if (x < iw && ly < ih) {
-                    const uint8_t* c = win + (ly + 3) * FP + x + 3;
-                    const int v = c[0];
-                    const int d0 = v - c[3 * FP], d4 = v - c[3], d8 = v - c[-3 * FP], d12 = v - c[-3];
-                    const bool k0 = d0 > T, k4 = d4 > T, k8 = d8 > T, k12 = d12 > T;
-                    const bool b0 = d0 < -T, b4 = d4 < -T, b8 = d8 < -T, b12 = d12 < -T;
-                    passD = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
-                    passB = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
-                    sc[(ly + 1) * FP + x + 1] = 0;
-                }
-                const uint16_t code = (uint16_t)(ly * 64 + x);
-                unsigned long long m = __ballot(passD);
-                if (m) {
-                    const int leader = __ffsll((long long)m) - 1;
-                    int base = 0;
-                    if (lane == leader) base = atomicAdd(&s_npass[0], __popcll(m));
-                    base = __shfl(base, leader, 64);
-                    if (passD) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
-                }
-                m = __ballot(passB);
-                if (m) {
-                    const int leader = __ffsll((long long)m) - 1;
-                    int base = 0;
-                    if (lane == leader) base = atomicAdd(&s_npass[1], __popcll(m));
-                    base = __shfl(base, leader, 64);
-                    if (passB) plistB[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
-                }
-            }
-        }
-        __syncthreads();
-        /* dark half on its list, then the bright half on its own (a pixel on both lists keeps the larger) */
-        const int nD = s_npass[0], nB = s_npass[1];
-        for (int i = tid; i < nD; i += 256) {
-            const int code = plist[i], ly = code >> 6, x = code & 63;
-            const int a = fast_half_score<1>(win + (ly + 3) * FP + x + 3) - 1;
-            sc[(ly + 1) * FP + x + 1] = (uint8_t)max(a, 0);
-        }
-        __syncthreads();
-        for (int i = tid; i < nB; i += 256) {
-            const int code = plistB[i], ly = code >> 6, x = code & 63;
-            const int a = fast_half_score<-1>(win + (ly + 3) * FP + x + 3) - 1;
-            uint8_t* q = sc + (ly + 1) * FP + x + 1;
-            if (a > (int)*q) *q = (uint8_t)a;
-        }
-        __syncthreads();
-        /* NMS at T only where a score exists: walk the two survivor lists (a pixel on both is visited twice) */
-        int any = 0;
-        for (int i = tid; i < nD + nB; i += 256) {
-            const int code = i < nD ? plist[i] : plistB[i - nD], ly = code >> 6, x = code & 63;
-            const uint8_t* q = sc + (ly + 1) * FP + x + 1;
-            const int s = q[0];
-            if (s >= T) {
-                const int mx = max(max(max((int)q[-FP - 1], (int)q[-FP]), max((int)q[-FP + 1], (int)q[-1])),
-                                   max(max((int)q[1], (int)q[FP - 1]), max((int)q[FP], (int)q[FP + 1])));
-                if (s > mx) {
-                    atomicOr(&keep[ly * 2 + (x >> 5)], 1u << (x & 31));
-                    any = 1;
-                }
-            }
-        }
-        if (any) s_any_ini = 1; /* "this stage found a corner"; benign race, all writers store 1 */
-        __syncthreads();
-        if (s_any_ini || stage == 1 || minTh == iniTh) break; /* block-uniform */
-        /* empty at iniThFAST: the whole cell again at minThFAST */
-        T = minTh;
-        if (tid == 0) {
-            s_npass[0] = 0;
-            s_npass[1] = 0;
-        }
-        __syncthreads();
-    }
-
-    /* ordered compaction: thread w owns keep word w = (row w>>1, columns (w&1)*32 ..); every kept bit already
-     * satisfies score >= T of the stage that produced it */
-    uint32_t bits = 0;
-    const int kly = tid >> 1, kxb = (tid & 1) * 32;
-    if (tid < nwords) bits = keep[tid];
-    const uint32_t cnt = __popc(bits);
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave_tot[wv] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k < wv) wave_off += s_wave_tot[k];
-        total += s_wave_tot[k];
-    }
-    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
-    CellOut* cout = (CellOut*)(hdr + 2);
-    uint32_t* cand = (uint32_t*)(cout + ncells);
-    if (tid == 0) {
-        cout[cell].base = cd.base;
-        cout[cell].count = total;
-    }
-    (void)cand_cap;
-    (void)hdr;
-    const uint32_t base = cd.base;
-    if (bits == 0) return;
-    uint32_t o = base + wave_off + incl - cnt;
-    const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
-    while (bits) {
-        const int k = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const uint32_t s = sc[(kly + 1) * FP + kxb + k + 1];
-        cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
-    }
-}
-
-void vk_fast_cells_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_rows, int nslots) {
-    const size_t shm = (size_t)tile_rows * FP + (size_t)(tile_rows - 4) * FP + (size_t)(tile_rows - 6) * 8 +
-                       (size_t)(tile_rows - 6) * 64 * 2 * 2 + 16;
-    hipLaunchKernelGGL(k_fast_cells_v2, dim3(((ncells + 7) / 8) * 8, nslots), dim3(256), shm, st, pyr, slot_stride, src, g, cells,
-                       cand_region, cand_stride, ncells, cand_cap, iniTh, minTh, tile_rows);
-}
-
-int vk_fast_v2_max_window() { return 66; } /* widest window the fixed LDS pitch supports (needs x+3 < FP-3) */
-int vk_fast_v2_max_rows() { return 128 + 6; } /* keep mask: 2 words per interior row, <= 256 threads */
-
 /* ------------------------------------------------------------------------------------------------
- * pyramid level, second generation: one thread = four consecutive output pixels of a row (same arithmetic as
- * k_resize_level, cv::resize INTER_LINEAR 8u).  All eight taps of a row lie in one 8-byte window of the source
+ * pyramid level: one thread = four consecutive output pixels of a row (same arithmetic as the generic
+ * one-pixel-per-thread k_resize_level in vslam_kernels.hip, cv::resize INTER_LINEAR 8u).  All eight taps of a row lie in one 8-byte window of the source
  * row (host table: window start per quad), so a thread issues two 8-byte loads instead of sixteen byte loads;
  * a v_perm_b32 per output picks its two taps as packed u16 and v_dot2_i32_i16 does the horizontal pass.
  * ---------------------------------------------------------------------------------------------- */
@@ -462,8 +261,7 @@ void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const 
 }
 
 /* ------------------------------------------------------------------------------------------------
- * FAST cells, third generation.  Same results as k_fast_cells / k_fast_cells_v2; the differences are all in
- * how many instructions the pre-test and the survivor bookkeeping cost:
+ * FAST cells.  What keeps the instruction count of the pre-test and the survivor bookkeeping down:
  *   - the window is staged one column to the left (LDS column = window column + 1), so the four interior
  *     pixels x = 4q..4q+3 of a row and their up/down compass pixels are aligned dwords and the left/right ones
  *     come out of two v_alignbyte_b32;
@@ -522,7 +320,10 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int slot = blockIdx.y;
-    const int per_xcd = (ncells + 7) >> 3; /* XCD-aware cell order, see k_fast_cells_v2 */
+    /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2), so XCD k takes the k-th contiguous
+     * eighth of the cell list -- neighbouring cells, whose windows overlap by 6 px and share image rows, then hit
+     * the same L2 instead of being fetched by all eight. */
+    const int per_xcd = (ncells + 7) >> 3;
     const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (cell >= ncells) return;
     const CellDesc cd = cells[cell];

@@ -131,6 +131,7 @@ k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, in
         c2 += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         __syncthreads();
     }
+    const int c2_raw = c2;
     c2 = min(c2, max_c2);
     int c1 = 0;
     for (int b = 0; b < n1; b += 256) {
@@ -158,10 +159,14 @@ k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, in
         c1 += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         __syncthreads();
     }
+    const int c1_raw = c1;
     c1 = min(c1, max_c2);
     if (blockIdx.x == 0 && tid == 0) {
         hdr[0] = c1;
         hdr[1] = c2;
+        /* more octave-0 keypoints than the LDS-resident lists hold (keypoints of a foreign extractor configuration):
+         * the result would be silently truncated, so k_si_replay reports the pair as failed instead */
+        hdr[2] = (c1_raw > max_c2 || c2_raw > max_c2) ? 1 : 0;
     }
 
     const float r = (float)window;
@@ -412,7 +417,7 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) nmatch_out[blockIdx.x] = cnt;
+    if (lane == 0) nmatch_out[blockIdx.x] = hdr[2] ? -1 : cnt; /* -1: capacity overflow (vslam_search_init_dev_wait) */
 }
 
 size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M) { return (size_t)npairs * si_pair_bytes(max_c2, M); }

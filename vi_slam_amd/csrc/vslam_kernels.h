@@ -1,4 +1,5 @@
-/* vslam_kernels.h -- launch wrappers implemented in vslam_kernels.hip / vslam_match_kernels.hip. */
+/* vslam_kernels.h -- launch wrappers implemented in the kernel files (vslam_image_kernels.hip, vslam_kernels.hip,
+ * vslam_octree_kernel.hip, vslam_match_kernels.hip, vslam_init_kernel.hip). */
 #ifndef VSLAM_KERNELS_H
 #define VSLAM_KERNELS_H
 
@@ -9,15 +10,6 @@ void vk_upload_disc(const int8_t* u, const int8_t* v, int n);
 void vk_resize_level(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                      const LevelGeom& sg, const LevelGeom& dg, int src_level, const uint16_t* xtab,
                      const int16_t* xa, const uint16_t* ytab, const int16_t* yb, int nslots);
-
-void vk_fast_cells(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-                   const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                   size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_pitch, int tile_rows,
-                   int max_px, int nslots);
-
-void vk_blur7(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-              const PyramidGeom& g, uint8_t* blur, const uint32_t* tiles, int ntiles, const int32_t taps[7],
-              int nslots);
 
 void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                         const BatchSrc& src, const PyramidGeom& g, const SelKp* sel, int nsel,
@@ -37,17 +29,11 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
 void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
                         const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,
                         const uint16_t* ytab, const int16_t* yb, int nslots);
-void vk_fast_cells_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-                      const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_rows, int nslots);
-int vk_fast_v2_max_window();
-int vk_fast_v2_max_rows();
-
 size_t vk_octree_lds_bytes(int maxNodes);
 int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int generation);
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
                    const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
                    int32_t* err_flag, int nslots);
@@ -89,6 +75,9 @@ void vk_fuse_search(hipStream_t st, const FuseArgsDev& A);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
 void vk_copy_ranges(hipStream_t st, const CopyRanges& R);
+/* host (pinned) images -> level 0 of the slots, one launch; src.l0 / src.pitch0 describe the host rows */
+void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
+                    int w, int h, int nimg);
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
                    int nslots, uint8_t* dst, size_t slot_bytes);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);

@@ -23,13 +23,6 @@ __device__ __forceinline__ const uint8_t* level_base(const uint8_t* pyr, size_t 
     return pyr + (size_t)slot * slot_stride + lg.off;
 }
 
-__device__ __forceinline__ int reflect101(int p, int len) {
-    /* BORDER_REFLECT_101 for |overshoot| < len (radius 3 vs len >= 7 always holds here) */
-    if (p < 0) p = -p;
-    if (p >= len) p = 2 * (len - 1) - p;
-    return p;
-}
-
 /* ------------------------------------------------------------------------------------------------
  * K1  pyramid level l from level l-1: cv::resize(INTER_LINEAR) 8u, fixed point 11 bits
  *     (FExtractor::ComputePyramid, fextractor.cpp:1135-1160 -> OpenCV resizeGeneric_ HResizeLinear /
@@ -57,233 +50,6 @@ k_resize_level(uint8_t* pyr, size_t slot_stride, BatchSrc src, LevelGeom sg, Lev
     const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
     uint8_t* D = pyr + (size_t)slot * slot_stride + dg.off;
     D[(size_t)dy * dg.pitch + dx] = (uint8_t)v;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * K2  FAST-9/16 per 30-px cell with threshold fallback and cell-local 3x3 NMS
- *     (FExtractor::ComputeKeyPointsOctTree cell loop, fextractor.cpp:780-819; cv::FAST + cornerScore).
- *
- * One workgroup per executed cell.  The cell window (interior + 3-px ring) is staged in LDS with
- * coalesced row reads; every interior pixel gets its FAST score S = max over the 16 nine-pixel arcs of
- * the Bresenham ring of min |diff| (both polarities) - 1, computed branch-free with min3/max3 networks.
- * "Corner at threshold T" == S >= T and OpenCV's response == S, so ONE score tile serves both the
- * iniThFAST pass and the minThFAST fallback.  NMS: a corner survives iff S is strictly greater than its
- * 8 neighbours, where positions outside the cell interior count 0 (cv::FAST runs on the cell
- * sub-image).  Survivors are emitted in raster order into a segment obtained with one global atomic per
- * cell; the host (or a later kernel) walks cells in index order, which reproduces vToDistributeKeys.
- * ---------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
-__device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
-
-/* ring offsets in OpenCV order (fast_score.cpp makeOffsets, patternSize 16): (dx,dy) */
-#define RING_AT(c, P, k)                                                                                   \
-    ((k) == 0 ? (c)[3 * (P)] : (k) == 1 ? (c)[3 * (P) + 1] : (k) == 2 ? (c)[2 * (P) + 2]                   \
-     : (k) == 3 ? (c)[(P) + 3] : (k) == 4 ? (c)[3] : (k) == 5 ? (c)[-(P) + 3]                              \
-     : (k) == 6 ? (c)[-2 * (P) + 2] : (k) == 7 ? (c)[-3 * (P) + 1] : (k) == 8 ? (c)[-3 * (P)]              \
-     : (k) == 9 ? (c)[-3 * (P) - 1] : (k) == 10 ? (c)[-2 * (P) - 2] : (k) == 11 ? (c)[-(P) - 3]            \
-     : (k) == 12 ? (c)[-3] : (k) == 13 ? (c)[(P) - 3] : (k) == 14 ? (c)[2 * (P) - 2] : (c)[3 * (P) - 1])
-
-__device__ __forceinline__ int fast_score(const uint8_t* c, const int P) {
-    const int v = c[0];
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)RING_AT(c, P, k);
-    int lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    }
-    int A = -256, B = 256; /* A = max_arcs min d (dark), B = min_arcs max d (bright = -B) */
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        A = max(A, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        B = min(B, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-    }
-    const int s = max(A, -B) - 1;
-    return s < 0 ? 0 : s; /* 0..254 */
-}
-
-__global__ void __launch_bounds__(256)
-k_fast_cells(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
-             const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
-             int cand_cap, int iniTh, int minTh, int tile_pitch, int tile_rows) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* win = smem;                                              /* tile_rows x tile_pitch */
-    uint8_t* sc = win + tile_rows * tile_pitch;                       /* (tile_rows-4) x tile_pitch */
-    uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * tile_pitch);  /* ceil(max_px/32) words */
-    __shared__ uint32_t s_wave_tot[4];
-    __shared__ int s_any_ini;
-
-    const int tid = threadIdx.x;
-    const int slot = blockIdx.y;
-    const CellDesc cd = cells[blockIdx.x];
-    const int level = cd.level;
-    const LevelGeom lg = g.lv[level];
-    int pitch;
-    const uint8_t* img = level_base(pyr, slot_stride, src, lg, level, slot, &pitch);
-    const int ww = cd.x1 - cd.x0, wh = cd.y1 - cd.y0; /* window */
-    const int iw = ww - 6, ih = wh - 6;               /* interior */
-    const int npx = iw * ih;
-    const int nwords = (npx + 31) >> 5;
-
-    /* stage the window: consecutive lanes read consecutive bytes of a row */
-    for (int i = tid; i < ww * wh; i += 256) {
-        const int y = i / ww, x = i - y * ww;
-        win[y * tile_pitch + x] = img[(size_t)(cd.y0 + y) * pitch + cd.x0 + x];
-    }
-    /* zero the score tile (its 1-px frame must read 0) and the keep mask */
-    for (int i = tid; i < (ih + 2) * tile_pitch; i += 256) sc[i] = 0;
-    for (int i = tid; i < nwords; i += 256) keep[i] = 0;
-    if (tid == 0) s_any_ini = 0;
-    __syncthreads();
-
-    /* scores of the interior */
-    {
-        int ly = tid / iw, lx = tid - ly * iw;
-        const int sy = 256 / iw, sx = 256 - sy * iw;
-        for (int p = tid; p < npx; p += 256) {
-            const uint8_t* c = win + (ly + 3) * tile_pitch + lx + 3;
-            sc[(ly + 1) * tile_pitch + lx + 1] = (uint8_t)fast_score(c, tile_pitch);
-            ly += sy;
-            lx += sx;
-            if (lx >= iw) { lx -= iw; ly++; }
-        }
-    }
-    __syncthreads();
-
-    /* strict local maxima with S >= minTh; note whether any of them reaches iniTh */
-    {
-        int ly = tid / iw, lx = tid - ly * iw;
-        const int sy = 256 / iw, sx = 256 - sy * iw;
-        int any_ini = 0;
-        for (int p = tid; p < npx; p += 256) {
-            const uint8_t* q = sc + (ly + 1) * tile_pitch + lx + 1;
-            const int s = q[0];
-            if (s >= minTh) {
-                const int P = tile_pitch;
-                const int m = max(max(max((int)q[-P - 1], (int)q[-P]), max((int)q[-P + 1], (int)q[-1])),
-                                  max(max((int)q[1], (int)q[P - 1]), max((int)q[P], (int)q[P + 1])));
-                if (s > m) {
-                    atomicOr(&keep[p >> 5], 1u << (p & 31));
-                    if (s >= iniTh) any_ini = 1;
-                }
-            }
-            ly += sy;
-            lx += sx;
-            if (lx >= iw) { lx -= iw; ly++; }
-        }
-        if (any_ini) s_any_ini = 1; /* benign race: all writers store 1 */
-    }
-    __syncthreads();
-    const int T = s_any_ini ? iniTh : minTh;
-
-    /* ordered compaction: thread w owns keep word w (nwords <= 256 is guaranteed by the host) */
-    uint32_t bits = 0;
-    if (tid < nwords) {
-        uint32_t b = keep[tid];
-        if (T != minTh) { /* drop survivors below iniTh */
-            uint32_t r = b;
-            while (r) {
-                const int k = __ffs(r) - 1;
-                r &= r - 1;
-                const int p = (tid << 5) + k;
-                const int ly = p / iw, lx = p - ly * iw;
-                if (sc[(ly + 1) * tile_pitch + lx + 1] < T) b &= ~(1u << k);
-            }
-        }
-        bits = b;
-    }
-    const uint32_t cnt = __popc(bits);
-    /* block exclusive scan of cnt */
-    uint32_t incl = cnt;
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave_tot[wv] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k < wv) wave_off += s_wave_tot[k];
-        total += s_wave_tot[k];
-    }
-    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
-    CellOut* cout = (CellOut*)(hdr + 2);
-    uint32_t* cand = (uint32_t*)(cout + ncells);
-    if (tid == 0) {
-        cout[blockIdx.x].base = cd.base;
-        cout[blockIdx.x].count = total;
-    }
-    (void)cand_cap;
-    (void)hdr;
-    const uint32_t base = cd.base;
-    if (bits == 0) return;
-    uint32_t o = base + wave_off + incl - cnt;
-    const int ox = cd.x0 + 3 - VSLAM_BORDER, oy = cd.y0 + 3 - VSLAM_BORDER;
-    while (bits) {
-        const int k = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const int p = (tid << 5) + k;
-        const int ly = p / iw, lx = p - ly * iw;
-        const uint32_t s = sc[(ly + 1) * tile_pitch + lx + 1];
-        cand[o++] = (s << 24) | ((uint32_t)(oy + ly) << 12) | (uint32_t)(ox + lx);
-    }
-}
-
-/* ------------------------------------------------------------------------------------------------
- * K3  GaussianBlur 7x7 sigma 2, CV_8U fixed point, BORDER_REFLECT_101 (fextractor.cpp:1085-1086 ->
- *     OpenCV GaussianBlurFixedPoint): row pass u8*u8.8 -> u16 exact, column pass -> (acc + 2^15) >> 16.
- *     64x16 output tile per workgroup, input tile + halo staged in LDS, row-pass result kept in LDS.
- * ---------------------------------------------------------------------------------------------- */
-#define BLUR_TW 64
-#define BLUR_TH 16
-struct BlurTaps { int32_t k[7]; };
-
-__global__ void __launch_bounds__(256)
-k_blur7(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
-        const uint32_t* __restrict__ tiles, BlurTaps taps) {
-    __shared__ uint8_t s_in[(BLUR_TH + 6) * (BLUR_TW + 8)];
-    __shared__ uint16_t s_h[(BLUR_TH + 6) * BLUR_TW];
-    const int tid = threadIdx.x;
-    const int slot = blockIdx.y;
-    const uint32_t td = tiles[blockIdx.x]; /* level << 24 | ty << 12 | tx */
-    const int level = td >> 24, ty = (td >> 12) & 0xFFF, tx = td & 0xFFF;
-    const LevelGeom lg = g.lv[level];
-    int pitch;
-    const uint8_t* img = level_base(pyr, slot_stride, src, lg, level, slot, &pitch);
-    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TH;
-    const int IW = BLUR_TW + 6, IP = BLUR_TW + 8, IH = BLUR_TH + 6;
-    for (int i = tid; i < IW * IH; i += 256) {
-        const int y = i / IW, x = i - y * IW;
-        /* positions past the image only feed outputs that are discarded: clamp keeps them in bounds */
-        const int gx = min(max(reflect101(x0 + x - 3, lg.w), 0), lg.w - 1);
-        const int gy = min(max(reflect101(y0 + y - 3, lg.h), 0), lg.h - 1);
-        s_in[y * IP + x] = img[(size_t)gy * pitch + gx];
-    }
-    __syncthreads();
-    for (int i = tid; i < BLUR_TW * IH; i += 256) {
-        const int y = i >> 6, x = i & 63;
-        const uint8_t* r = s_in + y * IP + x;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += (uint32_t)taps.k[k] * r[k];
-        s_h[y * BLUR_TW + x] = (uint16_t)min(acc, 0xFFFFu);
-    }
-    __syncthreads();
-    uint8_t* out = blur + (size_t)slot * slot_stride + lg.off;
-    for (int i = tid; i < BLUR_TW * BLUR_TH; i += 256) {
-        const int y = i >> 6, x = i & 63;
-        if (x0 + x >= lg.w || y0 + y >= lg.h) continue;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += (uint32_t)taps.k[k] * s_h[(y + k) * BLUR_TW + x];
-        const uint32_t v = (acc + 32768u) >> 16;
-        out[(size_t)(y0 + y) * lg.pitch + x0 + x] = (uint8_t)min(v, 255u);
-    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -556,24 +322,6 @@ void vk_resize_level(hipStream_t st, uint8_t* pyr, size_t slot_stride, const Bat
     dim3 grid((dg.w + 63) / 64, (dg.h + 3) / 4, nslots);
     hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, st, pyr, slot_stride, src, sg, dg, src_level, xtab,
                        xa, ytab, yb);
-}
-
-void vk_fast_cells(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-                   const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                   size_t cand_stride, int cand_cap, int iniTh, int minTh, int tile_pitch, int tile_rows,
-                   int max_px, int nslots) {
-    const size_t shm = (size_t)tile_rows * tile_pitch + (size_t)(tile_rows - 4) * tile_pitch +
-                       (size_t)((max_px + 31) / 32) * 4 + 16;
-    hipLaunchKernelGGL(k_fast_cells, dim3(ncells, nslots), dim3(256), shm, st, pyr, slot_stride, src, g, cells,
-                       cand_region, cand_stride, ncells, cand_cap, iniTh, minTh, tile_pitch, tile_rows);
-}
-
-void vk_blur7(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
-              const PyramidGeom& g, uint8_t* blur, const uint32_t* tiles, int ntiles, const int32_t taps[7],
-              int nslots) {
-    BlurTaps t;
-    for (int i = 0; i < 7; i++) t.k[i] = taps[i];
-    hipLaunchKernelGGL(k_blur7, dim3(ntiles, nslots), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tiles, t);
 }
 
 void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,

@@ -117,7 +117,7 @@ extern "C" int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, 
 extern "C" int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const uint8_t* const* imgs, size_t pitch,
                                               int imgs_on_device, float bf, float fx, int want_host) {
     if (!fe || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || 2 * npairs > fe->B || !imgs ||
-        pitch < (size_t)fe->p.width) {
+        pitch < (size_t)fe->p.width || imgs_on_device < 0 || imgs_on_device > VSLAM_IMGS_PINNED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
@@ -259,6 +259,12 @@ extern "C" int vslam_search_init_dev_wait(vslam_fe* fe, const int* n1, int32_t* 
         if (prev_matched && prev_matched[j] && n) memcpy(prev_matched[j], h_p + (size_t)j * fe->cap * 2, (size_t)n * 8);
         if (nmatches) nmatches[j] = h_n[j];
     }
+    for (int j = 0; j < npairs; j++)
+        if (h_n[j] < 0) { /* k_si_topm found more octave-0 keypoints than its lists hold: nothing was truncated silently */
+            g_err = "SearchForInitialization on the device: more octave-0 keypoints in a frame than the context's "
+                    "level-0 quota allows (use the host-keypoint entry point, which falls back to the host replay)";
+            return VSLAM_ERR_CAPACITY;
+        }
     return VSLAM_OK;
 }
 
@@ -289,6 +295,15 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
         bool fits = true;
         for (int j = 0; j < npairs; j++) fits = fits && n1[j] <= fe->cap && n2[j] <= fe->cap;
         fits = fits && fe->tab.quota[0] + 8 <= 4096 && nnratio >= 0.2f;
+        /* the device matcher keeps at most max_c2 octave-0 keypoints per frame (sized for THIS context's level-0
+         * quota); keypoints from another extractor configuration can exceed that while n <= cap: host replay then */
+        const int max_c2 = std::min(fe->cap, std::max(fe->tab.quota[0] + 8, 64));
+        for (int j = 0; j < npairs && fits; j++) {
+            int o1 = 0, o2 = 0;
+            for (int i = 0; i < n1[j]; i++) o1 += kps1[j][i].octave == 0;
+            for (int i = 0; i < n2[j]; i++) o2 += kps2[j][i].octave == 0;
+            fits = o1 <= max_c2 && o2 <= max_c2;
+        }
         if (!(mode && !strcmp(mode, "host")) && fits) {
             /* upload keypoints, counts and vbPrevMatched of every pair, run, download */
             size_t bytes = 0;

@@ -419,6 +419,36 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
 }
 
+/* Host images -> level 0 of the slots' pyramids, ONE launch per batch: a wave copies one image row, 16 bytes per lane
+ * and step, reading the caller's pinned memory (or the context's pinned staging) over PCIe and writing 16-byte
+ * aligned chunks of the 128-byte-pitched level-0 buffer.  Source rows may start at any address (KITTI rows are 1241
+ * bytes): the loads are unaligned dwordx4, only the last partial chunk of a row is read bytewise so that nothing past
+ * the caller's buffer is touched.  PCIe-bound (~0.47 MB per KITTI frame); the waves mostly wait, the CUs stay free
+ * for the other contexts' kernels. */
+__global__ void __launch_bounds__(256)
+k_pull_images(BatchSrc src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch, int w, int h) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), slot = blockIdx.y;
+    if (y >= h) return;
+    const uint8_t* srow = src.l0[slot] + (size_t)y * src.pitch0[slot];
+    uint8_t* drow = pyr + (size_t)slot * slot_stride + off0 + (size_t)y * dpitch;
+    for (int c = lane * 16; c < w; c += 64 * 16) {
+        uint4 v;
+        if (c + 16 <= w) v = *(const uint4*)(srow + c);
+        else {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; c + k < w; k++) t[k >> 2] |= (uint32_t)srow[c + k] << (8 * (k & 3));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        *(uint4*)(drow + c) = v; /* the padding up to the pitch may be written */
+    }
+}
+
+void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
+                    int w, int h, int nimg) {
+    hipLaunchKernelGGL(k_pull_images, dim3((h + 3) / 4, nimg), dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
+}
+
 /* zero the (total, overflow) header of every slot's candidate buffer and the quadtree's 16-byte error word */
 __global__ void k_reset_headers(uint8_t* d_cand, size_t stride, int nimg, int32_t* d_err) {
     const int t = threadIdx.x;

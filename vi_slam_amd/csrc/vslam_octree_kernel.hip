@@ -5,9 +5,9 @@
  * order-dependent facts are (a) the relative order of the keys inside a node (DivideNode keeps it),
  * (b) the order of the list and (c) the "largest node first, stop at N" rule.  All three are prefix sums:
  *
- *  - keys live in one array, each node owns a contiguous range; a split is a STABLE 4-way partition of
- *    the range, done for all nodes of a pass at once with one block-wide scan of packed 3x21-bit
- *    quadrant counters (rank of a key = scan value minus the scan value at its node's first key);
+ *  - keys stay where the gather put them and carry a node label; a split needs the per-child key COUNT of every
+ *    expandable node (a histogram) and then relabels each key; the relative order of the keys inside a node only
+ *    matters for the final "first key with the maximal response" = arg-max on (response, ~position);
  *  - children are push_front'ed in creation order and survivors keep their relative order, so after a
  *    pass   list = reverse(children in creation order) ++ survivors.  Nodes are stored IN LIST ORDER and
  *    rebuilt each pass from two scans (children created before me / survivors before me);
@@ -76,398 +76,14 @@ __device__ __forceinline__ int quadrant(uint32_t pt, const ONode& nd) {
     return (x < mx ? 0 : 1) | (y < my ? 0 : 2);
 }
 
-__global__ void __launch_bounds__(OT)
-k_octree(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
-         uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag) {
-    extern __shared__ __align__(16) uint8_t osm[];
-    const int MAXN = P.maxNodes;
-    ONode* cur = (ONode*)osm;
-    ONode* nxt = cur + MAXN;
-    u64* Sbeg = (u64*)(nxt + MAXN);
-    u64* Cnt = Sbeg + MAXN;               /* Send during a pass, then quadrant counts */
-    uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
-    uint16_t* newIdx = cb + MAXN;             /* list index of a survivor after the pass */
-    uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
-    uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
-    __shared__ u64 s_w64[OT / 64];
-    __shared__ uint32_t s_w32[OT / 64];
-    __shared__ int s_size, s_M, s_nexp, s_cut;
-
-    const int tid = threadIdx.x;
-    /* grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
-     * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
-    const int level = blockIdx.y, slot = blockIdx.x;
-#ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
-                           of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
-    int dbgn = 0;
-    unsigned long long* DBG = (unsigned long long*)P.dbg;
-#define STAMP() do { if (DBG && tid == 0 && level == 0 && slot == 0 && dbgn < 60) DBG[dbgn++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define STAMP() do { } while (0)
-#endif
-    STAMP();
-    const int N = P.N[level];
-    const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
-    const CellOut* cout = (const CellOut*)(hdr + 2);
-    const uint32_t* cand = (const uint32_t*)(cout + ncells);
-    uint32_t* pa = pts_a + (size_t)slot * pts_stride;
-    uint32_t* pb = pts_b + (size_t)slot * pts_stride;
-    uint16_t* na = nid_a + (size_t)slot * pts_stride;
-    uint16_t* nb = nid_b + (size_t)slot * pts_stride;
-    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
-    int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
-
-    /* ---- 0. gather this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817) */
-    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
-    uint32_t before = 0;
-    for (int c = tid; c < c0; c += OT) before += cout[c].count;
-    uint32_t off0;
-    {
-        uint32_t tot;
-        block_excl_scan<uint32_t>(before, s_w32, &tot);
-        off0 = tot;
-    }
-    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
-    uint32_t mine = 0;
-    for (int k = 0; k < K; k++) {
-        const int c = c0 + tid * K + k;
-        if (c < c1) mine += cout[c].count;
-    }
-    uint32_t ntot;
-    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
-    const int n = (int)ntot;
-    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
-        if (tid == 0) {
-            atomicOr(err_flag, 1);
-            *ocnt = 0;
-        }
-        return;
-    }
-    pa += off0; pb += off0; na += off0; nb += off0;
-    for (int k = 0; k < K; k++) {
-        const int c = c0 + tid * K + k;
-        if (c < c1) {
-            const uint32_t* q = cand + cout[c].base;
-            const uint32_t cnt = cout[c].count;
-            for (uint32_t e = 0; e < cnt; e++) pa[woff + e] = q[e];
-            woff += cnt;
-        }
-    }
-    if (n == 0) {
-        if (tid == 0) *ocnt = 0;
-        return;
-    }
-    __syncthreads();
-
-    STAMP();
-    const int C = (n + OT - 1) / OT;
-    const int i0 = min(tid * C, n), i1 = min(i0 + C, n);
-
-    /* ---- 1. initial nodes: stable bucketing by (int)(x / hX) (fextractor.cpp:534-576) */
-    const int nIni = P.nIni[level];
-    const float hX = P.hX[level];
-    const int Hh = P.H[level];
-    __shared__ uint32_t s_bcnt[64], s_bbeg[64], s_bidx[64];
-    if (tid < 64) s_bcnt[tid] = 0;
-    __syncthreads();
-    for (int g = 0; g * 3 < nIni; g++) {
-        u64 loc = 0;
-        for (int i = i0; i < i1; i++) {
-            int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
-            b = min(b, nIni - 1);
-            if (b / 3 == g) loc += 1ull << (FB * (b % 3));
-        }
-        u64 tot;
-        block_excl_scan<u64>(loc, s_w64, &tot);
-        if (tid < 3 && g * 3 + tid < nIni) s_bcnt[g * 3 + tid] = fld(tot, tid);
-        __syncthreads();
-    }
-    if (tid == 0) {
-        uint32_t acc = 0;
-        int li = 0;
-        for (int b = 0; b < nIni; b++) {
-            const uint32_t cb0 = s_bcnt[b];
-            s_bbeg[b] = acc;
-            s_bidx[b] = (uint32_t)li;
-            if (cb0) { /* empty initial nodes are erased (fextractor.cpp:572-573) */
-                ONode nd;
-                nd.x0 = (int16_t)(int)__fmul_rn(hX, (float)b);
-                nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
-                nd.y0 = 0;
-                nd.y1 = (int16_t)Hh;
-                nd.begin = acc;
-                nd.cf = (cb0 << 1) | (cb0 == 1 ? 1u : 0u);
-                cur[li++] = nd;
-            }
-            acc += cb0;
-        }
-        s_size = li;
-    }
-    __syncthreads();
-    for (int g = 0; g * 3 < nIni; g++) {
-        u64 loc = 0;
-        for (int i = i0; i < i1; i++) {
-            int b = (int)__fdiv_rn((float)(pa[i] & 0xFFF), hX);
-            b = min(b, nIni - 1);
-            if (b / 3 == g) loc += 1ull << (FB * (b % 3));
-        }
-        u64 tot;
-        u64 run = block_excl_scan<u64>(loc, s_w64, &tot);
-        for (int i = i0; i < i1; i++) {
-            const uint32_t pt = pa[i];
-            int b = (int)__fdiv_rn((float)(pt & 0xFFF), hX);
-            b = min(b, nIni - 1);
-            if (b / 3 == g) {
-                const uint32_t pos = s_bbeg[b] + fld(run, b % 3);
-                pb[pos] = pt;
-                nb[pos] = (uint16_t)s_bidx[b];
-                run += 1ull << (FB * (b % 3));
-            }
-        }
-        __syncthreads();
-    }
-    { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
-
-    STAMP();
-    /* ---- 2. split passes */
-    int phase = 1;
-    const int KN = (MAXN + OT - 1) / OT;
-    for (int iter = 0; iter < P.maxIter; iter++) {
-        const int size0 = s_size;
-        /* A. classify keys of expandable nodes, thread totals */
-        u64 loc = 0;
-#pragma unroll 8
-        for (int i = i0; i < i1; i++) {
-            const ONode nd = cur[na[i]];
-            if (!ND_NOMORE(nd)) loc += onehot(quadrant(pa[i], nd));
-        }
-        u64 tot64;
-        STAMP();
-        const u64 S0 = block_excl_scan<u64>(loc, s_w64, &tot64);
-        STAMP();
-        /* C. scan value at each node's first key and after its last key */
-        {
-            u64 run = S0;
-#pragma unroll 8
-            for (int i = i0; i < i1; i++) {
-                const int v = na[i];
-                const ONode nd = cur[v];
-                if (ND_NOMORE(nd)) continue;
-                if ((uint32_t)i == nd.begin) Sbeg[v] = run;
-                run += onehot(quadrant(pa[i], nd));
-                if ((uint32_t)i == nd.begin + ND_COUNT(nd) - 1) Cnt[v] = run;
-            }
-        }
-        __syncthreads();
-        STAMP();
-        /* D. node level */
-        for (int k = 0; k < KN; k++) {
-            const int v = tid * KN + k;
-            if (v < size0 && !ND_NOMORE(cur[v])) Cnt[v] -= Sbeg[v];
-        }
-        __syncthreads();
-        /* D1. processing rank of every expandable node */
-        uint32_t nexp_mine = 0;
-        for (int k = 0; k < KN; k++) {
-            const int v = tid * KN + k;
-            if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
-        }
-        uint32_t nexp;
-        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
-        if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
-        if (phase == 1) {
-            for (int k = 0; k < KN; k++) {
-                const int v = tid * KN + k;
-                if (v < size0 && !ND_NOMORE(cur[v])) {
-                    prank[v] = (uint16_t)rbase;
-                    ordv[rbase] = (uint16_t)v;
-                    rbase++;
-                }
-            }
-        } else {
-            /* descending (count, "created later" == smaller list index) */
-            for (int k = 0; k < KN; k++) {
-                const int v = tid * KN + k;
-                if (v < size0 && !ND_NOMORE(cur[v])) {
-                    const uint32_t cv = ND_COUNT(cur[v]);
-                    uint32_t r = 0;
-#pragma unroll 8
-                    for (int u = 0; u < size0; u++) {
-                        const uint32_t cfu = cur[u].cf; /* count << 1 | noMore */
-                        r += (!(cfu & 1u) && ((cfu >> 1) > cv || ((cfu >> 1) == cv && u < v))) ? 1u : 0u;
-                    }
-                    prank[v] = (uint16_t)r;
-                    ordv[r] = (uint16_t)v;
-                }
-            }
-        }
-        __syncthreads();
-        STAMP();
-        /* D2. in processing order: children created before me, running list size -> cut */
-        const int KE = ((int)nexp + OT - 1) / OT;
-        uint32_t chl = 0;
-        for (int k = 0; k < KE; k++) {
-            const int r = tid * KE + k;
-            if (r < (int)nexp) {
-                const int v = ordv[r];
-                chl += nchildren(Cnt[v], ND_COUNT(cur[v]));
-            }
-        }
-        uint32_t chtot;
-        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
-        if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
-        __syncthreads();
-        {
-            /* parent r is processed iff size0 + sum_{r'<r}(nch-1) < N (phase 2); phase 1: all */
-            uint32_t cb_run = chbase;
-            for (int k = 0; k < KE; k++) {
-                const int r = tid * KE + k;
-                if (r < (int)nexp) {
-                    const int v = ordv[r];
-                    const uint32_t nch = nchildren(Cnt[v], ND_COUNT(cur[v]));
-                    if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
-                    cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
-                    cb_run += nch;
-                }
-            }
-        }
-        __syncthreads();
-        const int ncut = s_cut;
-        /* M = children of processed parents; new size */
-        if (tid == 0) {
-            int M;
-            if (ncut >= (int)nexp) M = (int)chtot;
-            else M = cb[ordv[ncut]];
-            s_M = M;
-            s_size = size0 + M - ncut;
-            s_nexp = 0;
-        }
-        __syncthreads();
-        const int M = s_M;
-        STAMP();
-        /* D3. survivors: list index after the pass */
-        uint32_t sv = 0;
-        for (int k = 0; k < KN; k++) {
-            const int v = tid * KN + k;
-            if (v < size0) {
-                const bool processed = !ND_NOMORE(cur[v]) && prank[v] < ncut;
-                if (!processed) sv++;
-            }
-        }
-        uint32_t svtot;
-        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
-        int nexp_children = 0;
-        for (int k = 0; k < KN; k++) {
-            const int v = tid * KN + k;
-            if (v >= size0) continue;
-            const ONode nd = cur[v];
-            const bool processed = !ND_NOMORE(nd) && prank[v] < ncut;
-            if (!processed) {
-                newIdx[v] = (uint16_t)(M + svbase);
-                nxt[M + svbase] = nd;
-                svbase++;
-            } else {
-                const u64 c = Cnt[v];
-                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                int kq = 0;
-                uint32_t beg = nd.begin;
-                const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
-                const uint32_t c3 = ND_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t cq = q < 3 ? fld(c, q) : c3;
-                    if (!cq) continue;
-                    ONode ch;
-                    ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
-                    ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
-                    ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
-                    ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
-                    ch.begin = beg;
-                    ch.cf = (cq << 1) | (cq == 1 ? 1u : 0u);
-                    nxt[first - kq] = ch;
-                    if (cq > 1) nexp_children++;
-                    beg += cq;
-                    kq++;
-                }
-                cb[v] = (uint16_t)first;
-            }
-        }
-        if (nexp_children) atomicAdd(&s_nexp, nexp_children);
-        __syncthreads();
-        STAMP();
-        /* E. move the keys of processed parents (stable), relabel every key with its node's new index */
-        {
-            u64 run = S0;
-#pragma unroll 8
-            for (int i = i0; i < i1; i++) {
-                const uint32_t pt = pa[i];
-                const int v = na[i];
-                const ONode nd = cur[v];
-                if (ND_NOMORE(nd)) {
-                    pb[i] = pt;
-                    nb[i] = newIdx[v];
-                    continue;
-                }
-                const int q = quadrant(pt, nd);
-                if (prank[v] < ncut) {
-                    const u64 c = Cnt[v];
-                    const u64 rk = run - Sbeg[v]; /* keys of this node seen so far, quadrants 0..2 */
-                    const uint32_t r012 = fld(rk, 0) + fld(rk, 1) + fld(rk, 2);
-                    uint32_t pos = nd.begin + (q < 3 ? fld(rk, q) : ((uint32_t)i - nd.begin) - r012);
-                    int kq = 0;
-                    for (int q2 = 0; q2 < q; q2++) {
-                        const uint32_t cq = fld(c, q2);
-                        pos += cq;
-                        kq += cq != 0;
-                    }
-                    pb[pos] = pt;
-                    nb[pos] = (uint16_t)(cb[v] - kq);
-                } else {
-                    pb[i] = pt;
-                    nb[i] = newIdx[v];
-                }
-                run += onehot(q);
-            }
-        }
-        __syncthreads();
-        { uint32_t* t = pa; pa = pb; pb = t; uint16_t* u = na; na = nb; nb = u; }
-        { ONode* t = cur; cur = nxt; nxt = t; }
-        STAMP();
-        /* F. loop control (fextractor.cpp:658-729) */
-        const int size = s_size, nToExpand = s_nexp;
-        __syncthreads();
-        if (size >= N || size == size0) break;
-        if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
-    }
-
-    STAMP();
-    /* ---- 3. best response per node, first wins (fextractor.cpp:732-751); output in list order */
-    const int size = s_size;
-    for (int v = tid; v < size; v += OT) {
-        const ONode nd = cur[v];
-        uint32_t best = pa[nd.begin];
-        for (uint32_t k = 1; k < ND_COUNT(nd); k++) {
-            const uint32_t p = pa[nd.begin + k];
-            if ((p >> 24) > (best >> 24)) best = p;
-        }
-        out[v] = best;
-    }
-#ifdef VSLAM_OCT_STAMPS
-    __syncthreads();
-    STAMP();
-    if (DBG && tid == 0 && level == 0 && slot == 0) DBG[63] = dbgn;
-#endif
-    if (tid == 0) *ocnt = size;
-}
-
 /* ------------------------------------------------------------------------------------------------
- * Second generation: the same node logic, but the keys never move.  What a pass needs from the keys is only
+ * The keys never move.  What a pass needs from the keys is only
  * the per-child COUNT of every expandable node (which children exist, which can still be split, the sort key of
  * phase 2) -- a histogram (64-bit LDS atomics on the packed counters) -- and afterwards the keys' new node
  * labels.  The final "best response, first wins" is a segmented arg-max on (response, ~position).  All key
- * walks are strided by the workgroup size, i.e. coalesced; v1 gave each thread a contiguous chunk (needed by
- * its scan-based stable partition), which made every load of a wave hit 64 different cache lines -- 5.6 ms per
- * launch at 1080p / 100 k candidates.
+ * walks are strided by the workgroup size, i.e. coalesced (the first generation, a scan-based stable partition
+ * of the key array per pass, gave each thread a contiguous chunk -- 64 cache lines per wave load, 5.6 ms per
+ * launch at 1080p / 100 k candidates; it is in the git history).
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(OT)
 k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
@@ -922,14 +538,10 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int generation) {
-    if (generation >= 2)
-        hipLaunchKernelGGL(k_octree_v2, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st,
-                           cand_region, cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt,
-                           err_flag);
-    else
-        hipLaunchKernelGGL(k_octree, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region,
-                           cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag);
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots) {
+    hipLaunchKernelGGL(k_octree_v2, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st,
+                       cand_region, cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt,
+                       err_flag);
 }
 
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
@@ -940,7 +552,5 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, con
 }
 
 int vk_octree_set_max_lds(size_t bytes) {
-    int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc) return rc;
-    return (int)hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
