@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the ORB extract + match front-end on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W            # N=1, the driver's default call
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py                                   # N=1, all three workloads, a few minutes
+    python bench.py --gpus N --steps K --warmup W     # N>1 without a launcher: spawns torch.distributed.run itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W     # the driver's form
 
-A "step" = one pass of the hot path over one batch of synthetic frames per rank: `--batch` frames go
-through extraction (pyramid, FAST+NMS per cell, quadtree, orientation, blur, rBRIEF) and each frame is
-matched against its predecessor in video order (mono: FMatcher::SearchForInitialization, window 100;
-stereo: Frame::ComputeStereoMatches L<->R).  Frames are dealt round-robin over ranks; the only collective
-is one ring shift of packed result slots per step (mono workload, N>1; every predecessor lives on rank-1).  Input frames are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path over one batch of synthetic frames per rank: `--batch` images go through
+extraction (pyramid, FAST+NMS per cell, quadtree, orientation, blur, rBRIEF) and every frame is matched (mono:
+FMatcher::SearchForInitialization against its predecessor in video order, window 100; stereo:
+Frame::ComputeStereoMatches L<->R).  Keypoints, descriptors and matches are delivered to pinned host memory inside
+the step.  Frames are dealt round-robin over ranks; the only collective is one ring shift of packed result slots per
+step (mono workload, N>1: vslam_exchange_ring = ncclSend/ncclRecv on the extractor's stream, inside the library).
+
+Rank 0 prints ONE JSON line on stdout:
+  value                = headline workload (BASELINE configs[1], KITTI-00 mono 1241x376, 1000 features), input frames
+                         resident in HBM when the timed region starts (the contract's definition of `value`)
+  value_host_inputs    = the same workload with the frames in pinned HOST memory: H2D over PCIe inside the timed
+                         region (the span frame.cpp:103-116 + :124-132 starts from a host cv::Mat)
+  extra_workloads[]    = KITTI-00 stereo N=2000 (north_star's >=5x target) and 1920x1080 stereo N=4000, each with its
+                         own value / value_host_inputs / roofline / cpu_baseline
+The timed region is K steps repeated R times back to back (R chosen so that it lasts >= --min-seconds; `timed_repeats`).
+A second JSON line with per-stage details goes to STDERR.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,7 +43,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
     # BASELINE.json configs[1]: KITTI-00 mono, 8-level pyramid, 1000 features/frame
     "kitti00_mono_1241x376_n1000": dict(w=1241, h=376, nf=1000, stereo=False),
-    # configs[2]: KITTI-00 stereo (YAML: 2000 features), L<->R Hamming match
+    # config/KITTI00-Mono.yaml:20 says 2000 (config discrepancy)
+    "kitti00_mono_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=False),
+    # configs[2]: KITTI-00 stereo (YAML: 2000 features), L<->R Hamming match -- north_star's target workload
     "kitti00_stereo_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True),
     # configs[4]: synthetic 1920x1080 stream, 4000 features/frame
     "synthetic_stereo_1920x1080_n4000": dict(w=1920, h=1080, nf=4000, stereo=True),
@@ -38,9 +53,43 @@ WORKLOADS = {
     # UnprojectStereo + SearchByProjection(frame, previous frame); every rank follows its own sequence
     "kitti00_stereo_track_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True, track=True),
 }
+HEADLINE = "kitti00_mono_1241x376_n1000"
+EXTRAS = ["kitti00_stereo_1241x376_n2000", "synthetic_stereo_1920x1080_n4000"]
 BF, FX = 386.1448, 718.856  # config/KITTI00-Stereo.yaml Camera.bf, Camera.fx
 FY, CX, CY = 718.856, 607.1928, 185.2157
 TRACK_Z = 12.0  # the synthetic scene moves (+3,+1) px per frame; as a camera translation at this depth
+KERNEL_OF = {"pyramid": "k_pyramid", "fast": "k_fast_cells_v3", "blur": "k_blur7_v2", "describe": "k_orient_describe_dev"}
+PROF_KEY = {"pyramid": "pyramid_ms", "fast": "fast_ms", "blur": "blur_ms", "describe": "describe_ms"}
+
+
+def sig(x, n=5):
+    """round to n significant digits (keeps the one JSON line short enough for the driver's stdout tail)"""
+    if x is None or isinstance(x, (str, bool)) or x == 0 or not isinstance(x, (int, float)):
+        return x
+    if isinstance(x, int):
+        return x
+    return float("%.*g" % (n, x))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N worker processes through torch.distributed.run as a CHILD
+    process (nothing in this process has touched the GPU -- torch is not even imported yet) and exit with its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    if args.print_launch:
+        print(" ".join(cmd))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL / cross-process device memory)
+    return subprocess.call(cmd, env=env)
 
 
 def level_pixels(fe):
@@ -55,17 +104,14 @@ def algorithmic_bytes(fe, nf):
 
 
 def pmc_traffic(kernel, cfg, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/collect_pmc.sh,
-    separate FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of
-    a coalesced stream (MI355X_MICROARCH.md 'HBM'): calibrated here on the FAST kernel, whose unique input is
-    the pyramid pixels (1.44 MB per image) and whose raw FETCH_SIZE reads half of that -> the factor 2 is applied.
-    Only valid for the geometry/batch the profile was taken with; otherwise None."""
-    name = "r01g_pmc_traffic_kitti_b%d.json" % batch
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (tools/collect_pmc.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of a coalesced
+    stream (MI355X_MICROARCH.md 'HBM'); the factor 2 is applied here.  Only valid for the geometry / batch /
+    feature count the profile was taken with; otherwise None."""
+    name = "r02_pmc_traffic_%dx%d_n%d_b%d.json" % (cfg["w"], cfg["h"], cfg["nf"], batch)
     path = os.path.join(ROOT, "profiles", name)
-    if not (os.path.exists(path) and cfg["w"] == 1241 and cfg["h"] == 376):
+    if not os.path.exists(path):
         return None
-    if kernel.startswith("k_orient_describe") and cfg["nf"] != 1000:
-        return None  # the profile was taken with 1000 features; only this kernel's traffic depends on that
     k = json.load(open(path))["kernels"].get(kernel.split("(")[0])
     if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
         return None
@@ -73,24 +119,26 @@ def pmc_traffic(kernel, cfg, batch):
             "write_size_bytes": k["write_bytes"], "source": "profiles/" + name}
 
 
-def cpu_baseline(cfg, seconds=12.0):
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(cfg, seconds=12.0, all_seconds=8.0):
     """The oracle (a port of the reference's CPU path, oracle/) timed on this box's host cores: the same
     workload on a bounded sample of frames, reference-faithful threading (1 thread per image; the two
-    images of a stereo frame on 2 threads, frame.cpp:107-108)."""
+    images of a stereo frame on 2 threads, frame.cpp:107-108).  Test infrastructure used as the CHECKER/baseline
+    only, after the timed GPU region."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import orbo
     from vi_slam_amd import synth
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
-    nsample = 6
-    t_end = time.time() + seconds
+    nsample = 6 if w * h < 1000000 else 3
     frames = 0
-    t0 = time.time()
     if stereo:
         pairs = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
         eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
         pool = ThreadPoolExecutor(2)
         prev_track = None
         t0 = time.time()
+        t_end = t0 + seconds
         while time.time() < t_end:
             L, R = pairs[frames % nsample]
             fl = pool.submit(eL.compute, L)
@@ -115,6 +163,7 @@ def cpu_baseline(cfg, seconds=12.0):
         e = orbo.Extractor(nf)
         prev = None
         t0 = time.time()
+        t_end = t0 + seconds
         while time.time() < t_end:
             k, d, _ = e.compute(imgs[frames % nsample], lap=(0, 1000))
             if prev is not None:
@@ -126,7 +175,8 @@ def cpu_baseline(cfg, seconds=12.0):
             frames, w, h, nf)
     dt = time.time() - t0
     out = {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
-    out["all_cores"] = cpu_baseline_all_cores(cfg)
+    if all_seconds > 0:
+        out["all_cores"] = cpu_baseline_all_cores(cfg, all_seconds)
     return out
 
 
@@ -171,141 +221,119 @@ def cpu_baseline_all_cores(cfg, seconds=8.0):
             "sample": "%d frames on %d threads, one sequence per thread" % (total, ncores)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="kitti00_mono_1241x376_n1000", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=32, help="frames (mono) or images (stereo: L,R,L,R..) per rank per step")
-    ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
-    ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--exchange", default="shift", choices=["shift", "allgather"],
-                    help="N>1 exchange step: ring shift (all_to_all_single, one non-empty split) or all-gather")
-    ap.add_argument("--force-collective", action="store_true",
-                    help="rehearsal: take the N>1 code path (pack + ring shift on the extractor stream) at any world size")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ one workload
+class Pipeline:
+    """NCTX extractor contexts (HIP streams) kept in flight on one GPU; step t runs on context t % NCTX.  A step is
+    enqueued completely (H2D pull if the frames are in host memory, extraction, [N>1: pack + ring exchange],
+    matcher, D2H of results) with GPU-side events between contexts and collected by ONE host wait."""
 
-    import torch
-    import torch.distributed as dist
-    import vi_slam_amd as V
-    from vi_slam_amd import dist as vd
-    from vi_slam_amd import synth
+    def __init__(self, name, args, env):
+        import ctypes
+        import numpy as np
+        import torch
+        import vi_slam_amd as V
+        from vi_slam_amd import dist as vd
+        from vi_slam_amd import synth
+        self.np, self.torch, self.V, self.vd = np, torch, V, vd
+        self.name, self.args, self.env = name, args, env
+        rank, world = env["rank"], env["world"]
+        cfg = self.cfg = WORKLOADS[name]
+        w, h, nf = cfg["w"], cfg["h"], cfg["nf"]
+        self.stereo, self.track = cfg["stereo"], bool(cfg.get("track"))
+        B = args.batch
+        if self.stereo and B % 2:
+            B += 1
+        if self.track:
+            B = min(B, 32)  # one SearchByProjection pass takes up to 16 frame pairs
+        self.B = B
+        self.NCTX = max(3, args.inflight)
+        self.multi = (world > 1 or args.force_collective) and not self.stereo
+        self.ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=env["local_rank"], max_batch=B) for _ in range(self.NCTX)]
+        self.fe = self.ctxs[0]
+        self.matchers = [V.FMatcher(c, 0.9, True) for c in self.ctxs]
+        self.lap = (0, 0) if self.stereo else (0, 1000)  # frame.cpp:107-108 vs :289
+        # ---- synthetic frames (host copies kept for the pinned-input mode)
+        ndistinct = B if w * h < 1000000 else min(B, 16)  # 1080p frames are slow to synthesise; cycled
+        self.ndistinct = ndistinct
+        frames = []
+        for s in range(ndistinct):
+            if self.track:  # one contiguous sequence per rank
+                fr = synth.make_frame(w, h, seed=20250215 + rank, step=s // 2, right=bool(s & 1))
+            elif self.stereo:
+                fr = synth.make_frame(w, h, step=(s // 2) * world + rank, right=bool(s & 1))
+            else:
+                fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world))
+            frames.append(fr)
+        self.frames = [frames[s % ndistinct] for s in range(B)]
+        self.pitch = (w + 127) & ~127
+        self.dev_frames = torch.zeros((B, h, self.pitch), dtype=torch.uint8, device="cuda")
+        for s in range(B):
+            self.dev_frames[s, :, :w] = torch.from_numpy(self.frames[s]).cuda()
+        self.dev_ptrs = (ctypes.c_void_p * B)(*[self.dev_frames[s].data_ptr() for s in range(B)])
+        self.pinned = None
+        self.where = V.IMGS_DEVICE
+        self.slot_bytes = self.fe.slot_bytes
+        self.desc_off = 16 + self.fe.cap * 28
+        nb = self.NCTX if self.multi else 0
+        self.packed = [torch.zeros(B * self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        self.xchg = env.get("xchg")
+        recv_n = (world if (self.xchg and self.xchg.mode == "allgather") else 1) * B * self.slot_bytes
+        self.recv = [torch.zeros(recv_n, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        self.state = {"matches": 0}
+        self.job_cache = {}
+        self.track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
+        self.track_cam = (CX, CY, float(np.float32(1.0) / np.float32(FX)), float(np.float32(1.0) / np.float32(FY)))
+        self.track_Tcw = np.hstack([np.eye(3), np.array([[3.0 / FX * TRACK_Z], [1.0 / FY * TRACK_Z], [0.0]])]).astype(np.float32)
+        torch.cuda.synchronize()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if args.same_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_collective:
-        if world == 1:  # --force-collective without a launcher: a one-rank group
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # -------------------------------------------------------------------------------------------- inputs
+    def use_inputs(self, mode):
+        """'device': frames resident in HBM, zero-copy level 0.  'pinned': frames in pinned host memory (one ring of B
+        buffers per context, as a capture driver's DMA ring): every pass pulls them over PCIe itself."""
+        V = self.V
+        self.torch.cuda.synchronize()
+        if mode == "pinned":
+            if self.pinned is None:
+                self.pinned = []
+                for _ in range(self.NCTX):
+                    p = V.PinnedImages(self.B, self.cfg["h"], self.cfg["w"], self.cfg["w"])  # rows packed like cv::Mat
+                    for s in range(self.B):
+                        p.array[s][:] = self.frames[s]
+                    self.pinned.append(p)
+            self.where = V.IMGS_PINNED
         else:
-            dist.init_process_group("gloo")
+            self.where = V.IMGS_DEVICE
+        self.job_cache = {}
 
-    multi = world > 1 or (args.force_collective and dist.is_initialized())
-    cfg = WORKLOADS[args.workload]
-    w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
-    track = bool(cfg.get("track"))
-    B = args.batch
-    if stereo and B % 2:
-        B += 1
-    if track:
-        B = min(B, 32)  # one SearchByProjection pass takes up to 16 frame pairs
-    NCTX = max(3, args.inflight)  # extractor contexts (streams) kept in flight per GPU
-    ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=local_rank, max_batch=B) for _ in range(NCTX)]
-    fe = ctxs[0]
-    matchers = [V.FMatcher(c, 0.9, True) for c in ctxs]
-    lap = (0, 0) if stereo else (0, 1000)  # frame.cpp:107-108 vs :289
+    def _imgs(self, k):
+        if self.where == self.V.IMGS_PINNED:
+            return self.pinned[k].ptrs, self.pinned[k].pitch
+        return self.dev_ptrs, self.pitch
 
-    # ---- synthetic frames, resident in HBM before the timed region
-    pitch = (w + 127) & ~127
-    dev_frames = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
-    for s in range(B):
-        if track:  # one contiguous sequence per rank
-            fr = synth.make_frame(w, h, seed=20250215 + rank, step=s // 2, right=bool(s & 1))
-        elif stereo:
-            fr = synth.make_frame(w, h, step=(s // 2) * world + rank, right=bool(s & 1))
-        else:
-            fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world))
-        dev_frames[s, :, :w] = torch.from_numpy(fr).cuda()
-    import ctypes
-    ptrs = (ctypes.c_void_p * B)(*[dev_frames[s].data_ptr() for s in range(B)])
-    slot_bytes = fe.slot_bytes
-    desc_off = 16 + fe.cap * 28
-    packed = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if multi else 0)]
-    # packed slots of the LEFT neighbour (every predecessor lives there, vi_slam_amd/dist.py), one buffer per context
-    from_left = [torch.zeros(B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX if multi else 0)]
-    ring_in, ring_out = [0] * world, [0] * world
-    ring_in[(rank + 1) % world] = B * slot_bytes
-    ring_out[(rank - 1) % world] = B * slot_bytes
-    # Safety net: should this RCCL build reject the uneven all_to_all_single, the exchange falls back to an all-gather
-    # (world times the volume, same result); the left neighbour's block is then read out of the gathered buffer.
-    xchg = {"mode": args.exchange, "gathered": None}
-
-    def left_view(k):
-        """Tensor holding the left neighbour's packed slots of context k."""
-        if xchg["mode"] == "shift":
-            return from_left[k]
-        lo = ((rank - 1) % world) * B * slot_bytes
-        return xchg["gathered"][k][lo:lo + B * slot_bytes]
-
-    def exchange(k):
-        if xchg["mode"] == "shift":
-            try:
-                dist.all_to_all_single(from_left[k], packed[k], output_split_sizes=ring_out, input_split_sizes=ring_in)
-                return
-            except RuntimeError as e:  # pragma: no cover - depends on the collective library
-                if job_cache:
-                    raise
-                print("bench.py: all_to_all_single failed (%s); falling back to all_gather" % str(e).splitlines()[0],
-                      file=sys.stderr)
-                xchg["mode"] = "allgather"
-        if xchg["gathered"] is None:
-            xchg["gathered"] = [torch.zeros(world * B * slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(NCTX)]
-        dist.all_gather_into_tensor(xchg["gathered"][k], packed[k])
-    ext_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs] if multi else []
-    state = {"matches": 0}
-    torch.cuda.synchronize()
-
-    def slot_ptrs_in(buf, s):
+    # -------------------------------------------------------------------------------------------- one step
+    def _slot_ptrs_in(self, buf, s):
         """(kps, desc, count) device addresses of slot s inside a packed buffer."""
-        base = buf.data_ptr() + s * slot_bytes
-        return base + 16, base + desc_off, base
+        base = buf.data_ptr() + s * self.slot_bytes
+        return base + 16, base + self.desc_off, base
 
-    job_cache = {}
-    track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
-    track_cam = (CX, CY, float(np.float32(1.0) / np.float32(FX)), float(np.float32(1.0) / np.float32(FY)))
-    track_Tcw = np.hstack([np.eye(3), np.array([[3.0 / FX * TRACK_Z], [1.0 / FY * TRACK_Z], [0.0]])]).astype(np.float32)
-
-    def enqueue(t):
-        """Enqueue step t completely -- extraction, (N>1) pack + ring shift, matcher -- without waiting for
-        anything on the host: every pointer is a fixed device address and the counts stay in HBM."""
-        c, k = ctxs[t % NCTX], t % NCTX
-        nxt, prv = ctxs[(t + 1) % NCTX], ctxs[(t - 1) % NCTX]
-        if track:
+    def enqueue(self, t):
+        """Enqueue step t completely without waiting for anything on the host: every pointer is a fixed address and
+        the keypoint counts stay in HBM."""
+        V, vd = self.V, self.vd
+        NCTX, B, st = self.NCTX, self.B, self.state
+        rank, world = self.env["rank"], self.env["world"]
+        w, h = self.cfg["w"], self.cfg["h"]
+        c, k = self.ctxs[t % NCTX], t % NCTX
+        nxt, prv = self.ctxs[(t + 1) % NCTX], self.ctxs[(t - 1) % NCTX]
+        ptrs, pitch = self._imgs(k)
+        if self.track:
             npairs = B // 2
             c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last frame: it must finish first
-            c.frame_stereo_async(ptrs, pitch, BF, FX)
-            c.stereo_points_async(track_Twc, track_cam)  # UnprojectStereo of every left keypoint, own camera = world
+            c.frame_stereo_async(ptrs, pitch, BF, FX, where=self.where)
+            c.stereo_points_async(self.track_Twc, self.track_cam)  # UnprojectStereo of every left keypoint
             c.event_record(0)
             ck = (k, t == 0)
-            if ck not in job_cache:
+            if ck not in self.job_cache:
                 jobs = []
                 for j in range(npairs):
                     if j == 0 and t == 0:
@@ -315,36 +343,30 @@ def main():
                     x3, fl, _, _ = lc.stereo_points_buffers(lj, with_stereo=False)
                     ckp, cd, cn = c.slot_dev_ptrs(2 * j)
                     ur = c.stereo_points_buffers(j)[2]
-                    jobs.append(dict(Tcw=track_Tcw, cam=(FX, FY, CX, CY, BF), th=15, forward=0, backward=0, img=(w, h),
+                    jobs.append(dict(Tcw=self.track_Tcw, cam=(FX, FY, CX, CY, BF), th=15, forward=0, backward=0, img=(w, h),
                                      last_kps=lk, n_last=ln, last_flags=fl, last_x3dw=x3, mp_desc=ld, cur_kps=ckp,
                                      cur_desc=cd, n_cur=cn, cur_u_right=ur))
-                job_cache[ck] = (V.FMatcher.make_sbp_jobs(jobs, True), len(jobs))
-            arr, njobs = job_cache[ck]
+                self.job_cache[ck] = (V.FMatcher.make_sbp_jobs(jobs, True), len(jobs))
+            arr, njobs = self.job_cache[ck]
             if t > 0:
                 c.event_wait(prv, 0)
-            matchers[k].search_by_projection_dev_async(arr)
+            self.matchers[k].search_by_projection_dev_async(arr)
             c.event_record(1)
-            state.setdefault("njobs", {})[t] = njobs
+            st.setdefault("njobs", {})[t] = njobs
             return
-        if stereo:
-            c.frame_stereo_async(ptrs, pitch, BF, FX)
+        if self.stereo:
+            c.frame_stereo_async(ptrs, pitch, BF, FX, where=self.where)
             return
         c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
-        c.compute_batch_async(ptrs, pitch, lap)
-        if multi:
-            if args.dist_backend == "nccl":
-                c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=False)  # one kernel on c's stream
-                with torch.cuda.stream(ext_streams[k]):  # the ring shift is ordered on c's own stream
-                    exchange(k)
-            else:  # gloo rehearsal: staged through the host, fully synchronous
-                c.pack_slots(B, packed[k].data_ptr(), slot_bytes, sync=True)
-                vd.shift_slots(packed[k], from_left[k])
-                torch.cuda.synchronize()
+        c.compute_batch_async(ptrs, pitch, self.lap, where=self.where)
+        if self.multi:
+            c.pack_slots(B, self.packed[k].data_ptr(), self.slot_bytes, sync=False)  # one kernel on c's stream
+            self.xchg.exchange(c, self.packed[k], self.recv[k])  # RCCL: enqueued on c's own stream (no host sync)
         c.event_record(0)  # step t's results (own, and the left neighbour's) are complete
         # the device addresses are fixed per context, so the job array is built once (t == 0 has no predecessor
         # for slot 0 and is built separately)
         ck = (k, t == 0)
-        if ck not in job_cache:
+        if ck not in self.job_cache:
             jobs = []
             uses_prev_step = False
             for s in range(B):
@@ -352,55 +374,258 @@ def main():
                 if prev_step:
                     if t == 0:
                         continue
-                    p = slot_ptrs_in(left_view((t - 1) % NCTX), B - 1) if multi else prv.slot_dev_ptrs(B - 1)
+                    p = (self._slot_ptrs_in(self.xchg.left_block(self.recv[(t - 1) % NCTX]), B - 1) if self.multi
+                         else prv.slot_dev_ptrs(B - 1))
                     uses_prev_step = True
-                elif not multi:
+                elif not self.multi:
                     p = c.slot_dev_ptrs(ps)
                 else:
-                    p = slot_ptrs_in(left_view(k), ps)  # pr == (rank - 1) % world always
+                    p = self._slot_ptrs_in(self.xchg.left_block(self.recv[k]), ps)  # pr == (rank - 1) % world always
                 q = c.slot_dev_ptrs(s)
                 jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
-            job_cache[ck] = (V.FMatcher.make_init_jobs(jobs) if jobs else None, len(jobs), uses_prev_step)
-        arr, njobs, uses_prev_step = job_cache[ck]
+            self.job_cache[ck] = (V.FMatcher.make_init_jobs(jobs) if jobs else None, len(jobs), uses_prev_step)
+        arr, njobs, uses_prev_step = self.job_cache[ck]
         if uses_prev_step:
             c.event_wait(prv, 0)  # the previous step's results (not its matcher)
         if njobs:
-            matchers[k].search_init_dev_async(arr, 100, (w, h))
+            self.matchers[k].search_init_dev_async(arr, 100, (w, h))
         c.event_record(1)  # matcher(t) complete
-        state.setdefault("njobs", {})[t] = njobs
+        st.setdefault("njobs", {})[t] = njobs
 
-    def collect(t):
-        """One host wait per step delivers keypoints, descriptors and (mono) the matches."""
-        c = ctxs[t % NCTX]
+    def collect(self, t):
+        """One host wait per step delivers keypoints, descriptors and the matches."""
+        st, B = self.state, self.B
+        c = self.ctxs[t % self.NCTX]
         t_a = time.perf_counter()
-        if stereo:
-            feats, st = c.frame_stereo_wait()
-            state["matches"] = sum(int((u >= 0).sum()) for u, _ in st)
+        if self.stereo:
+            feats, stv = c.frame_stereo_wait()
+            st["matches"] = sum(int((u >= 0).sum()) for u, _ in stv)
             t_b = time.perf_counter()
-            if track:
-                nj = state["njobs"].pop(t)
+            if self.track:
+                nj = st["njobs"].pop(t)
                 ncur = [len(feats[2 * j][0]) for j in range(B // 2 - nj, B // 2)]
-                out = matchers[t % NCTX].search_by_projection_dev_wait(ncur)
-                state["track_matches"] = sum(o[0] for o in out)
+                out = self.matchers[t % self.NCTX].search_by_projection_dev_wait(ncur)
+                st["track_matches"] = sum(o[0] for o in out)
         else:
-            res = c.wait()
+            c.wait()
             t_b = time.perf_counter()
-            nj = state["njobs"].pop(t)
+            nj = st["njobs"].pop(t)
             if nj:
-                out = matchers[t % NCTX].search_init_dev_wait([fe.cap] * nj)
-                state["matches"] = sum(o[0] for o in out)
-        hs = state.setdefault("host_s", [0.0, 0.0])
+                out = self.matchers[t % self.NCTX].search_init_dev_wait([self.fe.cap] * nj)
+                st["matches"] = sum(o[0] for o in out)
+        hs = st.setdefault("host_s", [0.0, 0.0])
         hs[0] += t_b - t_a
         hs[1] += time.perf_counter() - t_b
 
-    def run(nsteps):
+    def run(self, nsteps):
+        NCTX = self.NCTX
         for t in range(nsteps + NCTX - 1):
             if t < nsteps:
                 t_e = time.perf_counter()
-                enqueue(t)
-                state["enq_s"] = state.get("enq_s", 0.0) + time.perf_counter() - t_e
+                self.enqueue(t)
+                self.state["enq_s"] = self.state.get("enq_s", 0.0) + time.perf_counter() - t_e
             if 0 <= t - (NCTX - 1) < nsteps:
-                collect(t - (NCTX - 1))
+                self.collect(t - (NCTX - 1))
+
+    # -------------------------------------------------------------------------------------------- timing
+    def timed(self, steps, warmup, min_seconds):
+        """W warmup steps, then R x K steps bracketed by barrier + synchronize; max over ranks.  R is agreed by all ranks
+        BEFORE the timed region (every rank must issue the same number of exchanges)."""
+        env = self.env
+        self.run(max(warmup, 1))
+        env["barrier"]()
+        t0 = time.perf_counter()
+        self.run(steps)  # calibration block, untimed
+        self.torch.cuda.synchronize()
+        block = env["max_over_ranks"](time.perf_counter() - t0)
+        reps = max(1, min(int(math.ceil(min_seconds / max(block, 1e-6))), 100000 // max(steps, 1) + 1))
+        for k in ("host_s", "enq_s"):
+            self.state.pop(k, None)
+        for c in self.ctxs:
+            c.set_profiling(True)
+        env["barrier"]()
+        t0 = time.perf_counter()
+        self.run(steps * reps)
+        env["barrier"]()
+        dt = env["max_over_ranks"](time.perf_counter() - t0)
+        prof = {}
+        for c in self.ctxs:
+            for k, v in c.get_profile().items():
+                prof[k] = prof.get(k, 0) + v
+            c.set_profiling(False)
+        frames_per_step = (self.B // 2 if self.stereo else self.B) * env["world"]
+        n = steps * reps
+        return {"value": frames_per_step * n / dt, "ms_per_step": dt / n * 1e3, "reps": reps, "seconds": dt, "prof": prof,
+                "host_ms_per_step": {k: v / n * 1e3 for k, v in zip(("enqueue", "wait_step", "fetch_matches"),
+                                                                   [self.state.get("enq_s", 0.0)] + self.state.get("host_s", [0, 0]))}}
+
+    def single_context_stage_ms(self, passes=30):
+        """The extraction pass alone on the GPU (one context, device-resident frames, no matcher, nothing else in flight):
+        per-stage HIP-event times whose spans contain no other stream's workgroups.  `passes` warm passes first so the
+        clocks are where a busy GPU holds them, then `passes` measured ones."""
+        self.torch.cuda.synchronize()
+        c0 = self.ctxs[0]
+        for i in range(2 * passes):
+            if i == passes:
+                c0.set_profiling(True)
+            if self.stereo:
+                c0.frame_stereo_async(self.dev_ptrs, self.pitch, BF, FX)
+                c0.frame_stereo_wait()
+            else:
+                c0.compute_batch_async(self.dev_ptrs, self.pitch, self.lap)
+                c0.wait()
+        alone = c0.get_profile()
+        c0.set_profiling(False)
+        nb = max(alone.get("batches", 0), 1)
+        return {k: alone[v] / nb for k, v in PROF_KEY.items()} | {"octree": alone["octree_ms"] / nb}
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        for c in self.ctxs:
+            c.close()
+        for p in self.pinned or []:
+            p.close()
+        self.dev_frames = None
+        self.packed = self.recv = None
+
+
+def roofline_of(pl, stage_alone, stage_pipe, res_dev):
+    """roofline object of one workload: the dominant image-streaming KERNEL (by its single-context launch time), its
+    algorithmic bytes per launch (SURVEY.md 8(d) x images per launch) over that time."""
+    ab = algorithmic_bytes(pl.fe, pl.cfg["nf"])
+    nlaunch = pl.fe.pyramid_launches() if hasattr(pl.fe, "pyramid_launches") else 7
+    per_launch = {k: (v / nlaunch if k == "pyramid" else v) for k, v in stage_alone.items() if k != "octree"}
+    dom = max(per_launch, key=per_launch.get)
+    kernel = KERNEL_OF[dom] if dom != "pyramid" else ("k_resize_level_v2(x%d)" % nlaunch if nlaunch > 2 else "k_pyramid")
+    bytes_per_launch = ab[dom] * pl.B / (nlaunch if dom == "pyramid" else 1.0)
+    ms = per_launch[dom]
+    achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    tr = pmc_traffic(kernel, pl.cfg, pl.B)
+    pipe_bytes = ab["pyramid"] + ab["fast"] + ab["blur"] + ab["describe"]
+    images_per_s = res_dev["value"] / pl.env["world"] * (2 if pl.stereo else 1)  # this rank's images per second
+    pipe_ms = stage_pipe.get(dom, 0.0) / (nlaunch if dom == "pyramid" else 1.0)
+    rl = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
+          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms,
+          "avg_launch_ms_note": "HIP events on the kernel's own stream, single context (nothing else on the GPU)",
+          # SURVEY.md 8(d): all extraction stages together, algorithmic bytes per image x images/s (per rank)
+          "pipeline_gbps_per_rank": pipe_bytes * images_per_s / 1e9,
+          "pipeline_frac": pipe_bytes * images_per_s / 1e9 / HBM_PEAK_GBS}
+    detail = {"traffic_detail": tr, "stage_ms_single_context": stage_alone, "stage_ms_pipelined_event_spans": stage_pipe,
+              "pipelined_event_span_ms_of_kernel": pipe_ms, "algorithmic_bytes_per_image": pipe_bytes}
+    return rl, detail
+
+
+def run_workload(name, args, env, want_cpu, cpu_seconds):
+    pl = Pipeline(name, args, env)
+    try:
+        inputs = args.inputs
+        res = {}
+        if inputs in ("device", "both"):
+            pl.use_inputs("device")
+            res["device"] = pl.timed(args.steps, args.warmup, args.min_seconds)
+        if inputs in ("pinned", "both"):
+            pl.use_inputs("pinned")
+            res["pinned"] = pl.timed(args.steps, args.warmup, args.min_seconds)
+        pl.use_inputs("device")
+        main = res.get("device") or res["pinned"]
+        out = {"workload": name, "value": main["value"] if "device" in res else None,
+               "value_host_inputs": res["pinned"]["value"] if "pinned" in res else None,
+               "ms_per_step": main["ms_per_step"], "timed_repeats": main["reps"], "timed_seconds": main["seconds"]}
+        detail = {"workload": name, "matches_last_step_rank0": pl.state["matches"],
+                  "track_matches_last_step_rank0": pl.state.get("track_matches"),
+                  "host_ms_per_step": main["host_ms_per_step"],
+                  "ms_per_step_host_inputs": res["pinned"]["ms_per_step"] if "pinned" in res else None}
+        if env["rank"] == 0:
+            prof = main["prof"]
+            nb = max(prof.get("batches", 0), 1)
+            stage_pipe = {k: prof[v] / nb for k, v in PROF_KEY.items()} | {"octree": prof["octree_ms"] / nb}
+            stage_alone = pl.single_context_stage_ms()
+            rl, rd = roofline_of(pl, stage_alone, stage_pipe, main)
+            out["roofline"] = rl
+            detail.update(rd)
+        out["config"] = {"workload": name, "frames_per_step_per_gpu": pl.B // 2 if pl.stereo else pl.B,
+                         "images_per_step_per_gpu": pl.B, "nfeatures": pl.cfg["nf"], "nlevels": 8, "scale_factor": 1.2,
+                         "contexts_in_flight": pl.NCTX, "distinct_frames": pl.ndistinct,
+                         "match": ("ComputeStereoMatches L<->R + UnprojectStereo + SearchByProjection(prev frame) th 15" if pl.track
+                                   else "ComputeStereoMatches L<->R") if pl.stereo else "SearchForInitialization(prev frame) window 100",
+                         "sharding": ("frames round-robin over ranks; one %s of packed result slots per step (%s)" %
+                                      (env["xchg"].mode if env.get("xchg") else "ring", env["xchg"].transport if env.get("xchg") else "none"))
+                         if not pl.stereo else "stereo frames independent per rank, no collective"}
+    finally:
+        pl.close()
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(WORKLOADS[name], cpu_seconds, min(cpu_seconds, 8.0))
+    return out, detail
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="all", choices=["all"] + sorted(WORKLOADS),
+                    help="'all' = the headline workload plus the two extra workloads in one line")
+    ap.add_argument("--inputs", default="both", choices=["device", "pinned", "both"],
+                    help="where the frames are when the timed region starts: HBM, pinned host memory, or both (two timed regions)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="minimum length of every timed region")
+    ap.add_argument("--batch", type=int, default=32, help="images (stereo: L,R,L,R..) per rank per step")
+    ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="ring", choices=["ring", "allgather"],
+                    help="N>1 exchange step: ring shift (ncclSend/ncclRecv pair) or the north_star-literal all-gather")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="take the N>1 code path (pack + exchange on the extractor stream) at world size 1")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N and no launcher: print the launch command, do not run")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="spawned ranks only rendezvous (gloo, no GPU touched), all-reduce and exit: tests the self-launch")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # before anything touches the GPU
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    if args.launch_check:
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": "ok", "world": world, "sum_of_ranks_plus_1": float(t.item())}))
+        dist.destroy_process_group()
+        return
+
+    import vi_slam_amd as V
+    from vi_slam_amd import dist as vd
+
+    if args.same_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    need_group = world > 1 or args.force_collective
+    if need_group:
+        if world == 1:  # --force-collective without a launcher: a one-rank group
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+
+    ctl_dev = "cuda" if (need_group and args.dist_backend == "nccl") else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -408,109 +633,82 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    state.pop("host_s", None)
-    state.pop("enq_s", None)
-    for c in ctxs:
-        c.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = {}
-    for c in ctxs:
-        for k, v in c.get_profile().items():
-            prof[k] = prof.get(k, 0) + v
-        c.set_profiling(False)
-    # After the timed region: the same extraction pass with NOTHING else on the GPU (one context, no matcher), so the
-    # dominant kernel's duration is also known without the other streams' workgroups inside its begin-to-end span.
-    alone = {}
-    if rank == 0:
-        torch.cuda.synchronize()
-        c0 = ctxs[0]
-        c0.set_profiling(True)
-        for _ in range(10):
-            if stereo:
-                c0.frame_stereo_async(ptrs, pitch, BF, FX)
-                c0.frame_stereo_wait()
-            else:
-                c0.compute_batch_async(ptrs, pitch, lap)
-                c0.wait()
-        alone = c0.get_profile()
-        c0.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
-    frames_per_step = (B // 2 if stereo else B) * world
-    value = frames_per_step * args.steps / dt
+    env = {"rank": rank, "world": world, "local_rank": local_rank, "barrier": barrier, "max_over_ranks": max_over_ranks}
+    if need_group:
+        # the exchange transport and mode are chosen ONCE, before any timed work, by a probe every rank agrees on
+        env["xchg"] = vd.SlotExchange.create(rank, world, local_rank, mode=args.exchange,
+                                             transport="rccl" if args.dist_backend == "nccl" else "gloo")
+
+    names = [HEADLINE] + ([] if args.no_extras else EXTRAS) if args.workload == "all" else [args.workload]
+    results, details = [], []
+    for i, name in enumerate(names):
+        want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+        out, det = run_workload(name, args, env, want_cpu, 12.0 if i == 0 else 8.0)
+        results.append(out)
+        details.append(det)
+        barrier()
 
     if rank == 0:
-        ab = algorithmic_bytes(fe, nf)
-        nb = max(prof["batches"], 1)
-        stage_ms = {"pyramid": prof["pyramid_ms"] / nb, "fast": prof["fast_ms"] / nb, "blur": prof["blur_ms"] / nb,
-                    "describe": prof["describe_ms"] / nb, "octree": prof["octree_ms"] / nb}
-        # dominant streaming KERNEL: per launch (the pyramid stage is 7 launches; the quadtree moves no image bytes)
-        per_launch = {k: (v / 7.0 if k == "pyramid" else v) for k, v in stage_ms.items() if k != "octree"}
-        dom = max(per_launch, key=per_launch.get)
-        kernel = {"pyramid": "k_resize_level_v2(x7)", "fast": "k_fast_cells_v3", "blur": "k_blur7_v2",
-                  "describe": "k_orient_describe_dev"}[dom]
-        tr = pmc_traffic(kernel, cfg, B)
-        bytes_per_launch = ab[dom] * B / (7.0 if dom == "pyramid" else 1.0)
-        achieved = bytes_per_launch / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
-        pipe_bytes = ab["pyramid"] + ab["fast"] + ab["blur"] + ab["describe"]
-        images_per_s = B * args.steps / dt  # this rank's images (stereo: two per frame)
-        uncontended = None
-        if alone.get("batches"):
-            a_ms = alone[{"pyramid": "pyramid_ms", "fast": "fast_ms", "blur": "blur_ms", "describe": "describe_ms"}[dom]]
-            a_ms = a_ms / alone["batches"] / (7.0 if dom == "pyramid" else 1.0)
-            if a_ms > 0:
-                a_gbs = bytes_per_launch / (a_ms * 1e-3) / 1e9
-                uncontended = {"note": "same kernel, same batch, nothing else on the GPU (10 launches after the timed region)",
-                               "avg_launch_ms": a_ms, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS}
-        out = {
+        head = results[0]
+        rl = {k: sig(v) for k, v in head.get("roofline", {}).items()}
+        line = {
             "metric": "frames/sec ORB extract+match",
-            "value": value,
+            "value": sig(head["value"] if head["value"] is not None else head["value_host_inputs"], 6),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": sig(head["ms_per_step"]),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": args.workload, "frames_per_step_per_gpu": B // 2 if stereo else B,
-                       "images_per_step_per_gpu": B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
-                       "match": ("ComputeStereoMatches L<->R + UnprojectStereo + SearchByProjection(frame, previous frame), th 15, on device"
-                                 if track else "ComputeStereoMatches L<->R") if stereo else "SearchForInitialization(prev frame), window 100, on device",
-                       "sharding": "frames round-robin over ranks; one ring shift of result slots per step (all_to_all_single, on the extractor stream)"
-                       if not stereo else ("one independent stereo sequence per rank, no collective" if track else
-                                           "stereo frames independent per rank, no collective"),
-                       "contexts_in_flight": NCTX, "matches_last_step_rank0": state["matches"],
-                       "track_matches_last_step_rank0": state.get("track_matches"),
-                       "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in
-                                            zip(("enqueue", "wait_step", "fetch_matches"),
-                                                [state.get("enq_s", 0.0)] + state.get("host_s", [0, 0]))}},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
-                         "traffic_detail": tr,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": per_launch[dom], "stage_ms_per_batch": stage_ms,
-                         "uncontended": uncontended,
-                         # all extraction stages together, algorithmic bytes per image x images/s
-                         "pipeline": {"algorithmic_bytes_per_image": pipe_bytes,
-                                      "achieved": pipe_bytes * images_per_s / 1e9,
-                                      "frac": pipe_bytes * images_per_s / 1e9 / HBM_PEAK_GBS}},
+            "inputs": "HBM-resident frames (value) and pinned host frames pulled over PCIe inside the step (value_host_inputs); "
+                      "keypoints+descriptors+matches delivered to pinned host memory inside the step in both",
+            "value_device_inputs": sig(head["value"], 6),
+            "value_host_inputs": sig(head["value_host_inputs"], 6),
+            "timed_repeats": head["timed_repeats"],
+            "timed_seconds": sig(head["timed_seconds"], 4),
+            "config": head["config"],
+            "roofline": rl,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
-    for c in ctxs:
-        c.close()
+        if "cpu_baseline" in head:
+            cb = head["cpu_baseline"]
+            line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": cb["sample"]}
+            if "all_cores" in cb:
+                line["cpu_baseline"]["all_cores"] = {"value": sig(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}
+        extras = []
+        for r in results[1:]:
+            e = {"workload": r["workload"], "value": sig(r["value"], 6), "value_host_inputs": sig(r["value_host_inputs"], 6),
+                 "unit": "frames/s", "ms_per_step": sig(r["ms_per_step"]),
+                 "frames_per_step_per_gpu": r["config"]["frames_per_step_per_gpu"]}
+            if "roofline" in r:
+                e["roofline"] = {k: sig(r["roofline"][k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                   "avg_launch_ms", "pipeline_gbps_per_rank")}
+            if "cpu_baseline" in r:
+                cb = r["cpu_baseline"]
+                e["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                     "sample": cb["sample"].split(":")[0]}
+                if "all_cores" in cb:
+                    e["cpu_baseline"]["all_cores"] = {"value": sig(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}
+                e["speedup_vs_cpu_port"] = sig((r["value_host_inputs"] or r["value"]) / cb["value"], 4)
+            extras.append(e)
+        if extras:
+            line["extra_workloads"] = extras
+        print(json.dumps(line))
+        sys.stdout.flush()
+        print(json.dumps({"bench_detail": details}), file=sys.stderr)
+    if env.get("xchg"):
+        env["xchg"].close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -1,6 +1,12 @@
-"""CPU: the N>1 path of bench.py (frame sharding + the one ring shift of result slots) on gloo, world_size 2/3."""
+"""CPU: the N>1 path (frame sharding + the one exchange of packed result slots) on gloo, world_size 2/3, driving the SAME
+object bench.py's RCCL branch drives (vi_slam_amd.dist.SlotExchange) with REAL packed slots: every rank extracts its
+frames with the oracle, packs them in the k_pack_slots layout, exchanges, matches each frame against its predecessor
+out of the received buffer, and the matches must equal a single process walking the whole sequence."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +15,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from vi_slam_amd import dist as vd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, NF, CAP = 320, 240, 300, 344
 
 
 def test_predecessor_is_video_order():
@@ -28,59 +37,121 @@ def test_predecessor_is_video_order():
                     assert not prev_step and (pr, ps) == frames[g - 1]
 
 
-def _worker(rank, world, port, batch, slot_bytes, q):
+def _extract(step_frame):
+    from oracle import orbo
+    from vi_slam_amd import synth
+    k, d, mono = orbo.Extractor(NF).compute(synth.make_frame(W, H, seed=77, step=step_frame), lap=(0, 1000))
+    return k, d, mono
+
+
+def _match(prev, cur):
+    from oracle import orbo
+    n, m12, _ = orbo.search_for_initialization(prev[0], prev[1], cur[0], cur[1], W, H, window=100, nnratio=0.9)
+    return n, m12
+
+
+def _single_process_reference(world, batch, steps):
+    feats = [_extract(g) for g in range(world * batch * steps)]
+    return {g: _match(feats[g - 1], feats[g]) for g in range(1, len(feats))}
+
+
+def _worker(rank, world, port, batch, steps, mode, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ok = True
-        prev_left = None
-        for step in range(2):  # two steps: slot 0 of rank 0 needs the previous step's buffer
-            local = torch.zeros(batch * slot_bytes, dtype=torch.uint8)
-            for s in range(batch):  # stamp every slot with its global frame id and a payload derived from it
-                g = step * world * batch + vd.global_frame(rank, s, world)
-                v = vd.slot_view(local, s, slot_bytes)
-                v[:4] = torch.from_numpy(np.array([g], np.int32).view(np.uint8))
-                v[4:] = (g * 7 + 3) % 251
-            left = torch.zeros(batch * slot_bytes, dtype=torch.uint8)
-            vd.shift_slots(local, left)
+        sb = vd.slot_bytes_for(CAP)
+        x = vd.SlotExchange.create(rank, world, 0, mode=mode, transport="gloo")
+        out = {}
+        prev_recv = None
+        for step in range(steps):  # two steps: slot 0 of rank 0 needs the previous step's buffer
+            own = []
+            send = torch.zeros(batch * sb, dtype=torch.uint8)
             for s in range(batch):
-                pr, ps, prev = vd.predecessor(rank, s, world, batch)
+                g = step * world * batch + vd.global_frame(rank, s, world)
+                k, d, mono = _extract(g)
+                own.append((k, d))
+                vd.slot_view(send, s, sb)[:] = torch.from_numpy(vd.pack_slot_host(k, d, mono, CAP, sb))
+            recv = torch.zeros(batch * sb * (world if mode == "allgather" else 1), dtype=torch.uint8)
+            x.exchange(None, send, recv)
+            for s in range(batch):
+                g = step * world * batch + vd.global_frame(rank, s, world)
+                pr, ps, from_prev = vd.predecessor(rank, s, world, batch)
                 assert pr == (rank - 1) % world  # every predecessor lives on the left neighbour
-                if prev:
-                    if prev_left is None:
+                if from_prev:
+                    if prev_recv is None:
                         continue
-                    v = vd.slot_view(prev_left, ps, slot_bytes)
+                    blk = x.left_block(prev_recv)
                 else:
-                    v = vd.slot_view(left, ps, slot_bytes)
-                g = int(v[:4].numpy().view(np.int32)[0])
-                ok &= g == step * world * batch + vd.global_frame(rank, s, world) - 1
-                ok &= bool((v[4:] == (g * 7 + 3) % 251).all())
-            prev_left = left
-        q.put((rank, ok))
+                    blk = x.left_block(recv)
+                pk, pd, _ = vd.unpack_slot_host(vd.slot_view(blk, ps, sb).numpy())
+                n, m12 = _match((pk, pd), own[s])
+                out[g] = (n, m12.tolist())
+            prev_recv = recv
+        q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ring_shift_delivers_predecessors_gloo(world):
+@pytest.mark.parametrize("world,mode", [(2, "ring"), (3, "ring"), (2, "allgather")])
+def test_exchange_delivers_predecessors_and_matches_equal_single_process(world, mode):
+    batch, steps = 2, 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 3, 512, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, steps, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    got = {}
+    for _ in procs:
+        _, out = q.get(timeout=240)
+        got.update(out)
     for p in procs:
         p.join(60)
-    assert res == [(r, True) for r in range(world)]
+    want = _single_process_reference(world, batch, steps)
+    assert sorted(got) == sorted(want)  # every frame but the very first found its predecessor
+    for g in want:
+        assert got[g][0] == want[g][0] and got[g][1] == want[g][1].tolist(), g
+    assert sum(v[0] for v in want.values()) > 20 * len(want)
 
 
-def test_world1_is_a_copy_without_process_group():
+def test_world1_exchange_is_a_copy_without_process_group():
+    x = vd.SlotExchange.create(0, 1, 0, mode="ring", transport="gloo")
     a = torch.arange(64, dtype=torch.uint8)
     b = torch.zeros(64, dtype=torch.uint8)
-    vd.shift_slots(a, b)
-    assert torch.equal(a, b)
+    x.exchange(None, a, b)
+    assert torch.equal(a, x.left_block(b))
+
+
+def test_pack_unpack_slot_roundtrip():
+    k, d, mono = _extract(0)
+    buf = vd.pack_slot_host(k, d, mono, CAP)
+    k2, d2, m2 = vd.unpack_slot_host(buf)
+    assert m2 == mono and np.array_equal(d, d2) and all(np.array_equal(k[f], k2[f]) for f in k.dtype.names)
+
+
+def test_bench_self_launches_n_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher spawns torch.distributed.run itself (VERDICT r1 item 3a);
+    --launch-check makes the spawned ranks only rendezvous (gloo) and all-reduce, so this runs without a GPU."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": "ok", "world": 2, "sum_of_ranks_plus_1": 3.0}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--print-launch"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "--nproc-per-node=4" in r.stdout and "torch.distributed.run" in r.stdout
+
+
+def test_bench_self_launch_propagates_failure():
+    """without a GPU the spawned ranks fail: the parent must exit non-zero, not hang and not print a number"""
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]

@@ -1,0 +1,221 @@
+"""GPU (-m gpu): round-2 additions -- pinned-image input, context re-use across input modes (graph replay),
+matcher overflow reporting, the in-library RCCL exchange at world size 1, and the BASELINE configs that round 1
+left without a parity test (stereo / init matcher at 1920x1080 N=4000, mono N=2000 = the YAML value)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import vi_slam_amd as V
+from oracle import orbo
+from vi_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BF, FX = 386.1448, 718.856
+
+
+def _same_feats(res, ref, tag=""):
+    k, d = res[0], res[1]
+    ko, do = ref[0], ref[1]
+    assert len(k) == len(ko), tag
+    for f in k.dtype.names:
+        assert np.array_equal(k[f], ko[f]), (tag, f)
+    assert np.array_equal(d, do), tag
+
+
+def _stereo_ref(L, R, nf):
+    eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
+    kL, dL, _ = eL.compute(L)
+    kR, dR, _ = eR.compute(R)
+    u, dep, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, BF, FX)
+    return (kL, dL), (kR, dR), u, dep
+
+
+@pytest.mark.parametrize("pitch", [1241, 1243, 1280])
+def test_pinned_host_images_equal_oracle(pitch):
+    """VSLAM_IMGS_PINNED: the pass pulls the caller's pinned rows over PCIe itself (k_pull_images); rows of 1241
+    bytes start at odd addresses (unaligned 16-byte loads, bytewise row tail)."""
+    fe = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=4)
+    pin = V.PinnedImages(4, 376, 1241, pitch)
+    try:
+        imgs = [synth.make_frame(1241, 376, step=s, right=bool(s & 1)) for s in range(4)]
+        for rep in range(2):  # second round: same pointers -> the captured graph is replayed; new content must be seen
+            for s in range(4):
+                pin.array[s][:] = imgs[(s + rep) % 4]
+            fe.compute_batch_async(pin.ptrs, pitch, (0, 0), where=V.IMGS_PINNED)
+            res = fe.wait(copy=True)
+            e = orbo.Extractor(2000)
+            for s in range(4):
+                _same_feats(res[s], e.compute(imgs[(s + rep) % 4]), "pinned %d/%d" % (rep, s))
+                assert np.array_equal(fe.mvImagePyramid(0, slot=s), imgs[(s + rep) % 4])
+        # pinned stereo frames through the one-enqueue frame path
+        fe.frame_stereo_async(pin.ptrs, pitch, BF, FX, where=V.IMGS_PINNED)
+        feats, st = fe.frame_stereo_wait()
+        for j in range(2):
+            (kL, dL), (kR, dR), wu, wd = _stereo_ref(np.array(pin.array[2 * j]), np.array(pin.array[2 * j + 1]), 2000)
+            _same_feats(feats[2 * j], (kL, dL))
+            _same_feats(feats[2 * j + 1], (kR, dR))
+            assert np.array_equal(st[j][0], wu) and np.array_equal(st[j][1], wd)
+    finally:
+        pin.close()
+        fe.close()
+
+
+def test_host_then_device_then_host_keeps_level0_sources():
+    """a host-image pass replays a captured graph; a device-image pass in between must not leave the
+    context's level-0 pointers on the caller's (then freed) device images when ComputeStereoMatches reads level 0."""
+    import torch
+    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 640, 360, max_batch=2)
+    try:
+        L, R = synth.make_stereo_pair(640, 360, seed=11)
+        L2, R2 = synth.make_stereo_pair(640, 360, seed=12)
+        fe.compute_batch([L, R])          # host pass: captures the graph
+        fe.compute_batch([L, R])          # host pass: replays it
+        dev = torch.zeros((2, 360, 640), dtype=torch.uint8, device="cuda")
+        dev[0] = torch.from_numpy(L2).cuda()
+        dev[1] = torch.from_numpy(R2).cuda()
+        torch.cuda.synchronize()
+        fe.compute_batch(None, device_ptrs=[dev[0].data_ptr(), dev[1].data_ptr()], pitch=640)
+        u, d = V.ComputeStereoMatches(fe, 0, fe, 1, 40.0, 435.2)
+        eL, eR = orbo.Extractor(1000), orbo.Extractor(1000)
+        kL, dL, _ = eL.compute(L2)
+        kR, dR, _ = eR.compute(R2)
+        wu, wd, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, 40.0, 435.2)
+        assert np.array_equal(u, wu) and np.array_equal(d, wd)
+        dev.fill_(0)                      # the caller recycles its device images ...
+        del dev
+        torch.cuda.synchronize()
+        res = fe.compute_batch([L, R])    # ... host pass again: graph replay
+        u, d = V.ComputeStereoMatches(fe, 0, fe, 1, 40.0, 435.2)
+        kL, dL, _ = eL.compute(L)
+        kR, dR, _ = eR.compute(R)
+        wu, wd, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, 40.0, 435.2)
+        _same_feats(res[0], (kL, dL))
+        assert np.array_equal(u, wu) and np.array_equal(d, wd) and (wu >= 0).sum() > 50
+        assert np.array_equal(fe.mvImagePyramid(0, slot=0), L)
+    finally:
+        fe.close()
+
+
+def test_search_init_more_octave0_keypoints_than_the_context_quota():
+    """keypoints of ANOTHER extractor configuration (2 levels: most points are octave 0) handed to a
+    matcher context sized for 8 levels.  Host-keypoint entry: falls back to the host replay, result == oracle.
+    Device-pointer entry: reports VSLAM_ERR_CAPACITY instead of silently truncating."""
+    a, b = synth.make_frame(1241, 376, seed=7, step=0), synth.make_frame(1241, 376, seed=7, step=1)
+    src = V.FExtractor(900, 1.2, 2, 20, 7, 1241, 376, max_batch=2)
+    dst = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    try:
+        (k1, d1, _), (k2, d2, _) = src.compute_batch([a, b], (0, 1000))
+        assert (k1["octave"] == 0).sum() > dst.features_per_level()[0] + 8 and len(k1) <= dst.cap
+        _, pd1, _ = src.slot_buffers(0)
+        _, pd2, _ = src.slot_buffers(1)
+        m = V.FMatcher(dst, 0.9, True)
+        nm, m12, pm = m.SearchForInitialization(k1, pd1, k2, pd2, np.stack([k1["x"], k1["y"]], 1), 100)
+        wn, wm, wp = orbo.search_for_initialization(k1, d1, k2, d2, 1241, 376, window=100, nnratio=0.9)
+        assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp) and nm > 50
+        p, c = src.slot_dev_ptrs(0), src.slot_dev_ptrs(1)
+        m.search_init_dev_async([(p[0], p[1], p[2], c[0], c[1], c[2], 0)], 100)
+        with pytest.raises(V.VslamError) as ei:
+            m.search_init_dev_wait([len(k1)])
+        assert ei.value.code == V.ERR_CAPACITY
+    finally:
+        src.close()
+        dst.close()
+
+
+def test_rccl_ring_and_allgather_world1_on_context_stream():
+    """vslam_comm / vslam_exchange_ring at world size 1: ncclSend/ncclRecv to self inside a group, enqueued on the
+    extractor's stream right behind k_pack_slots; the matcher then reads the RECEIVED buffer."""
+    import torch
+    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=4)
+    comm = None
+    try:
+        comm = V.Comm(0, 0, 1, V.Comm.unique_id())
+        frames = [synth.make_frame(1241, 376, step=s) for s in range(4)]
+        res = fe.compute_batch(frames, (0, 1000))
+        sb = fe.slot_bytes
+        send = torch.zeros(4 * sb, dtype=torch.uint8, device="cuda")
+        recv = torch.zeros(4 * sb, dtype=torch.uint8, device="cuda")
+        allg = torch.zeros(4 * sb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        fe.pack_slots(4, send.data_ptr(), sb, sync=False)
+        comm.ring(fe, send.data_ptr(), recv.data_ptr(), 4 * sb)
+        comm.allgather(fe, send.data_ptr(), allg.data_ptr(), 4 * sb)
+        # frame s-1 (from the received buffer) -> frame s (own slot), all on fe's stream, no host sync in between
+        jobs = []
+        for s in range(1, 4):
+            base = recv.data_ptr() + (s - 1) * sb
+            c = fe.slot_dev_ptrs(s)
+            jobs.append((base + 16, base + 16 + fe.cap * 28, base, c[0], c[1], c[2], 0))
+        m = V.FMatcher(fe, 0.9, True)
+        m.search_init_dev_async(jobs, 100)
+        out = m.search_init_dev_wait([len(res[s - 1][0]) for s in range(1, 4)])
+        for j, s in enumerate(range(1, 4)):
+            wn, wm, _ = orbo.search_for_initialization(res[s - 1][0], res[s - 1][1], res[s][0], res[s][1], 1241, 376,
+                                                       window=100, nnratio=0.9)
+            assert out[j][0] == wn and np.array_equal(out[j][1], wm) and wn > 50
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv) and torch.equal(send, allg)
+        assert int(send[:4].cpu().numpy().view(np.int32)[0]) == len(res[0][0])
+    finally:
+        if comm:
+            comm.close()
+        fe.close()
+
+
+def test_config5_stereo_1080p_n4000_matches_oracle():
+    """BASELINE configs[4]: 1920x1080, 4000 features -- extraction AND ComputeStereoMatches at full size."""
+    L, R = synth.make_stereo_pair(1920, 1080, seed=21)
+    fe = V.FExtractor(4000, 1.2, 8, 20, 7, 1920, 1080, max_batch=2)
+    try:
+        res = fe.compute_batch([L, R])
+        u, d = V.ComputeStereoMatches(fe, 0, fe, 1, BF, FX)
+        (kL, dL), (kR, dR), wu, wd = _stereo_ref(L, R, 4000)
+        _same_feats(res[0], (kL, dL), "L")
+        _same_feats(res[1], (kR, dR), "R")
+        assert np.array_equal(u, wu) and np.array_equal(d, wd) and (wu >= 0).sum() > 800
+    finally:
+        fe.close()
+
+
+def test_config5_search_for_initialization_1080p_n4000():
+    a, b = synth.make_frame(1920, 1080, seed=22, step=0), synth.make_frame(1920, 1080, seed=22, step=1)
+    fe = V.FExtractor(4000, 1.2, 8, 20, 7, 1920, 1080, max_batch=2)
+    try:
+        (k1, d1, _), (k2, d2, _) = fe.compute_batch([a, b], (0, 1000))
+        p, c = fe.slot_dev_ptrs(0), fe.slot_dev_ptrs(1)
+        m = V.FMatcher(fe, 0.9, True)
+        m.search_init_dev_async([(p[0], p[1], p[2], c[0], c[1], c[2], 0)], 100)
+        out = m.search_init_dev_wait([len(k1)], want_prev=True)
+        wn, wm, wp = orbo.search_for_initialization(k1, d1, k2, d2, 1920, 1080, window=100, nnratio=0.9)
+        assert out[0][0] == wn and np.array_equal(out[0][1], wm) and np.array_equal(out[0][2], wp) and wn > 100
+    finally:
+        fe.close()
+
+
+def test_kitti_mono_yaml_feature_count_n2000_pipeline():
+    """config/KITTI00-Mono.yaml:20 says ORBextractor.nFeatures: 2000 (BASELINE configs[1] says 1000): the mono path
+    (lapping area {0,1000}, frame.cpp:289) + SearchForInitialization at the YAML value, a chain of 4 frames."""
+    frames = [synth.make_frame(1241, 376, seed=31, step=s) for s in range(4)]
+    fe = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=4)
+    try:
+        res = fe.compute_batch(frames, (0, 1000))
+        e = orbo.Extractor(2000)
+        for s in range(4):
+            ko, do, mo = e.compute(frames[s], lap=(0, 1000))
+            _same_feats(res[s], (ko, do), "frame %d" % s)
+            assert res[s][2] == mo
+        jobs = []
+        for s in range(1, 4):
+            p, c = fe.slot_dev_ptrs(s - 1), fe.slot_dev_ptrs(s)
+            jobs.append((p[0], p[1], p[2], c[0], c[1], c[2], 0))
+        m = V.FMatcher(fe, 0.9, True)
+        m.search_init_dev_async(jobs, 100)
+        out = m.search_init_dev_wait([len(res[s - 1][0]) for s in range(1, 4)])
+        for j, s in enumerate(range(1, 4)):
+            wn, wm, _ = orbo.search_for_initialization(res[s - 1][0], res[s - 1][1], res[s][0], res[s][1], 1241, 376,
+                                                       window=100, nnratio=0.9)
+            assert out[j][0] == wn and np.array_equal(out[j][1], wm) and wn > 100
+    finally:
+        fe.close()

@@ -235,3 +235,29 @@ def test_worker_pool_stress_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe, "6000"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "pool_stress ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr
+
+
+@pytest.mark.parametrize("size,nlevels,scale", [((1241, 376), 8, 1.2), ((1920, 1080), 8, 1.2), ((752, 480), 8, 1.2),
+                                                ((321, 203), 6, 1.2), ((640, 480), 5, 1.1), ((1241, 376), 12, 1.1),
+                                                ((128, 128), 2, 1.2), ((500, 400), 4, 1.5)])
+def test_fused_pyramid_plan_emulation_equals_oracle_cascade(H, size, nlevels, scale):
+    """The tile plan of the fused pyramid kernel (k_pyramid_group: groups of levels computed in LDS with recomputed
+    halos) evaluated on the CPU with the kernel's own indexing: every level equals the oracle's cv::resize cascade,
+    no tile reads a byte that was neither staged nor computed, and the plan fits LDS."""
+    w, h = size
+    img = synth.make_frame(w, h, seed=w * 3 + nlevels)
+    e = orbo.Extractor(500, scale=scale, nlevels=nlevels)
+    e.pyramid_only(img)
+    sizes = [e.level(l).shape for l in range(nlevels)]
+    out = np.zeros(sum(a * b for a, b in sizes[1:]) + 16, np.uint8)
+    lds, ntiles = C.c_int(), C.c_int()
+    H.vslamh_pyramid_fused.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    ng = H.vslamh_pyramid_fused(_p(img), w, h, img.strides[0], 500, scale, nlevels, _p(out), C.byref(lds), C.byref(ntiles))
+    assert ng == (0 if nlevels == 1 else 1 + max(0, (nlevels - 1 - 3 + 3) // 4)), ng
+    assert 0 < lds.value <= 64 * 1024
+    o = 0
+    for l in range(1, nlevels):
+        hh, ww = sizes[l]
+        assert np.array_equal(out[o:o + hh * ww].reshape(hh, ww), e.level(l)), l
+        o += hh * ww

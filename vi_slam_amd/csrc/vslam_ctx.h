@@ -55,6 +55,13 @@ struct vslam_fe {
     int16_t* d_yb[VSLAM_MAX_LEVELS] = {};
     uint16_t* d_qbase[VSLAM_MAX_LEVELS] = {};    /* k_resize_level_v2 quad tables (nullptr: generic k_resize_level) */
     ResizeQuad* d_quads[VSLAM_MAX_LEVELS] = {};
+    /* fused pyramid: groups of levels per launch (k_pyramid_group); empty -> one launch per level */
+    struct PyrGroupCtx {
+        PyrGroupDev dev;
+        size_t lds_bytes;
+        PyrTileDev* d_tiles;
+    };
+    std::vector<PyrGroupCtx> pyr_groups;
     /* FAST cells */
     std::vector<vslam::HostCell> cells;
     int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};

@@ -108,6 +108,23 @@ struct ResizeQuad {
     uint32_t coef[4];
 };
 
+/* Fused pyramid (k_pyramid_group, vslam_image_kernels.hip): one entry per (tile, level of the group); same layout as
+ * vslam::PyrTileLevel (vslam_host.h), which the host planner fills. */
+struct PyrTileDev {
+    int16_t c0, nc, r0, nr, sq0, sq1, sr0, sr1;
+    uint32_t lds_off, pitch;
+};
+#define VSLAM_PYR_GROUP_LEVELS 4
+struct PyrGroupDev { /* by-value kernel argument */
+    int32_t l0, nl, ntiles, readable_w0; /* readable_w0: bytes of a source row that may be read (level 0: the image width) */
+    const PyrTileDev* tiles;             /* [ntiles][nl + 1] */
+    const uint16_t* qbase[VSLAM_PYR_GROUP_LEVELS];
+    const ResizeQuad* quads[VSLAM_PYR_GROUP_LEVELS];
+    const uint16_t* ytab[VSLAM_PYR_GROUP_LEVELS];
+    const int16_t* yb[VSLAM_PYR_GROUP_LEVELS];
+    LevelGeom lg[VSLAM_PYR_GROUP_LEVELS + 1]; /* lg[0] = source level */
+};
+
 /* vslam_mp_track: per MapPoint, what Frame::isInFrustum left in it */
 struct MpTrack {
     float projX, projY, projXR, viewCos;

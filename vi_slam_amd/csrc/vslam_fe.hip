@@ -35,6 +35,7 @@ static void free_ctx(vslam_fe* fe) {
         hipFree(fe->d_qbase[l]);
         hipFree(fe->d_quads[l]);
     }
+    for (auto& g : fe->pyr_groups) hipFree(g.d_tiles);
     hipFree(fe->d_cells);
     hipFree(fe->d_cand);
     if (fe->h_cand) hipHostFree(fe->h_cand);
@@ -159,22 +160,70 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     HIPCHK(hipMemset(fe->d_pyr, 0, fe->slot_stride * fe->B));
     HIPCHK(hipMemset(fe->d_blur, 0, fe->slot_stride * fe->B));
 
+    std::vector<vslam::PyrLevelTables> pyr_tabs(p.nlevels);
     for (int l = 1; l < p.nlevels; l++) {
-        vslam::ResizeTables r;
+        vslam::ResizeTables& r = pyr_tabs[l].r;
         const LevelGeom &s = fe->geom.lv[l - 1], &d = fe->geom.lv[l];
+        pyr_tabs[l].sw = s.w; pyr_tabs[l].sh = s.h; pyr_tabs[l].dw = d.w; pyr_tabs[l].dh = d.h;
         vslam::build_resize_tables(s.w, s.h, d.w, d.h, r);
         int rc;
         if ((rc = upload(&fe->d_xtab[l], r.xtab.data(), r.xtab.size() * 2))) return rc;
         if ((rc = upload(&fe->d_xa[l], r.xa.data(), r.xa.size() * 2))) return rc;
         if ((rc = upload(&fe->d_ytab[l], r.ytab.data(), r.ytab.size() * 2))) return rc;
         if ((rc = upload(&fe->d_yb[l], r.yb.data(), r.yb.size() * 2))) return rc;
-        std::vector<uint16_t> qbase;
-        std::vector<uint32_t> quads;
+        std::vector<uint16_t>& qbase = pyr_tabs[l].qbase;
+        std::vector<uint32_t>& quads = pyr_tabs[l].quads;
         /* four outputs whose eight taps do not fit one 8-byte source window (scale factors >~ 1.6): that level uses
          * the generic one-pixel-per-thread kernel */
         if (vslam::build_resize_quads(r, s.w, d.w, qbase, quads)) {
             if ((rc = upload(&fe->d_qbase[l], qbase.data(), qbase.size() * 2))) return rc;
             if ((rc = upload(&fe->d_quads[l], quads.data(), quads.size() * 4))) return rc;
+        } else {
+            qbase.clear(); /* marks "no quad table" for the fused-pyramid planner */
+            quads.clear();
+        }
+    }
+
+    /* fused pyramid plan: levels 1-3 from level 0, then groups of four (8 levels = 2 launches instead of 7).  Needs the
+     * quad table on every level; VSLAM_PYRAMID=levels keeps one launch per level (A/B runs). */
+    {
+        const char* pm = getenv("VSLAM_PYRAMID");
+        bool fused = !(pm && !strcmp(pm, "levels")) && p.nlevels > 1;
+        for (int l = 1; l < p.nlevels && fused; l++) fused = fe->d_quads[l] != nullptr;
+        static_assert(sizeof(PyrTileDev) == sizeof(vslam::PyrTileLevel), "planner and kernel share the tile record");
+        for (int l0 = 0; fused && l0 + 1 < p.nlevels;) {
+            const int nl = std::min(l0 == 0 ? 3 : VSLAM_PYR_GROUP_LEVELS, p.nlevels - 1 - l0);
+            std::vector<const vslam::PyrLevelTables*> gt;
+            for (int j = 1; j <= nl; j++) gt.push_back(&pyr_tabs[l0 + j]);
+            vslam::PyrGroupPlan plan;
+            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan)) {
+                fused = false;
+                break;
+            }
+            vslam_fe::PyrGroupCtx g;
+            memset(&g.dev, 0, sizeof(g.dev));
+            g.dev.l0 = l0;
+            g.dev.nl = nl;
+            g.dev.ntiles = plan.ntx * plan.nty;
+            g.dev.readable_w0 = p.width;
+            g.lds_bytes = plan.lds_bytes;
+            g.d_tiles = nullptr;
+            int rc;
+            if ((rc = upload(&g.d_tiles, plan.tiles.data(), plan.tiles.size() * sizeof(PyrTileDev)))) return rc;
+            g.dev.tiles = g.d_tiles;
+            for (int j = 0; j <= nl; j++) g.dev.lg[j] = fe->geom.lv[l0 + j];
+            for (int j = 1; j <= nl; j++) {
+                g.dev.qbase[j - 1] = fe->d_qbase[l0 + j];
+                g.dev.quads[j - 1] = fe->d_quads[l0 + j];
+                g.dev.ytab[j - 1] = fe->d_ytab[l0 + j];
+                g.dev.yb[j - 1] = fe->d_yb[l0 + j];
+            }
+            fe->pyr_groups.push_back(g);
+            l0 += nl;
+        }
+        if (!fused) {
+            for (auto& g : fe->pyr_groups) hipFree(g.d_tiles);
+            fe->pyr_groups.clear();
         }
     }
 
@@ -561,7 +610,9 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     vk_reset_headers(st, fe->d_cand, fe->cand_stride, nimg, fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr);
     const bool prof = fe->profiling;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
-    for (int l = 1; l < L; l++) {
+    for (const auto& g : fe->pyr_groups)
+        vk_pyramid_group(st, fe->d_pyr, fe->slot_stride, fe->src, g.dev, g.lds_bytes, nimg);
+    for (int l = 1; l < L && fe->pyr_groups.empty(); l++) {
         if (fe->d_quads[l])
             vk_resize_level_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
                                fe->d_qbase[l], fe->d_quads[l], fe->d_ytab[l], fe->d_yb[l], nimg);

@@ -137,6 +137,147 @@ bool build_resize_quads(const ResizeTables& r, int sw, int dw, std::vector<uint1
     return true;
 }
 
+
+/* ------------------------------------------------------------------ fused pyramid plan (k_pyramid_group) */
+static inline int div_floor4(int x) { return x >> 2; }
+
+static bool plan_with(const std::vector<const PyrLevelTables*>& tabs, int l0, int ntx, int nty, size_t max_lds,
+                      PyrGroupPlan& plan) {
+    const int nl = (int)tabs.size();
+    plan.l0 = l0;
+    plan.nl = nl;
+    plan.ntx = ntx;
+    plan.nty = nty;
+    plan.tiles.assign((size_t)ntx * nty * (nl + 1), PyrTileLevel{});
+    size_t lds_max = 0;
+    for (int ty = 0; ty < nty; ty++)
+        for (int tx = 0; tx < ntx; tx++) {
+            PyrTileLevel* T = &plan.tiles[((size_t)ty * ntx + tx) * (nl + 1)];
+            /* compute ranges, deepest level first: C_j = hull(own_j, need of level j+1) */
+            int cq0[VSLAM_MAX_LEVELS + 1], cq1[VSLAM_MAX_LEVELS + 1], cr0[VSLAM_MAX_LEVELS + 1], cr1[VSLAM_MAX_LEVELS + 1];
+            int nq0 = -1, nq1 = -1, nr0 = -1, nr1 = -1; /* need on the current level from the deeper one (empty: -1) */
+            for (int j = nl; j >= 0; j--) {
+                int oq0 = 0, oq1 = 0, or0 = 0, or1 = 0;
+                if (j >= 1) {
+                    const PyrLevelTables& t = *tabs[j - 1];
+                    const int nq = (t.dw + 3) / 4;
+                    oq0 = (int)((long long)tx * nq / ntx);
+                    oq1 = (int)((long long)(tx + 1) * nq / ntx);
+                    or0 = (int)((long long)ty * t.dh / nty);
+                    or1 = (int)((long long)(ty + 1) * t.dh / nty);
+                    T[j].sq0 = (int16_t)oq0; T[j].sq1 = (int16_t)oq1; T[j].sr0 = (int16_t)or0; T[j].sr1 = (int16_t)or1;
+                }
+                const bool own = j >= 1 && oq1 > oq0 && or1 > or0, need = nq1 > nq0 && nr1 > nr0;
+                if (!own && !need) { cq0[j] = cq1[j] = cr0[j] = cr1[j] = 0; }
+                else if (own && need) {
+                    cq0[j] = std::min(oq0, nq0); cq1[j] = std::max(oq1, nq1);
+                    cr0[j] = std::min(or0, nr0); cr1[j] = std::max(or1, nr1);
+                } else if (own) { cq0[j] = oq0; cq1[j] = oq1; cr0[j] = or0; cr1[j] = or1; }
+                else { cq0[j] = nq0; cq1[j] = nq1; cr0[j] = nr0; cr1[j] = nr1; }
+                nq0 = nq1 = nr0 = nr1 = -1;
+                if (j >= 1 && cq1[j] > cq0[j]) { /* what computing C_j reads of level j-1 */
+                    const PyrLevelTables& t = *tabs[j - 1];
+                    const int dxl = std::min(4 * cq1[j], t.dw) - 1;
+                    const int lo = t.qbase[cq0[j]];               /* windows start here (<= the first tap) */
+                    const int hi = t.r.xtab[2 * dxl + 1];          /* last tap column */
+                    nq0 = div_floor4(lo);
+                    nq1 = div_floor4(hi) + 1;
+                    nr0 = t.r.ytab[2 * cr0[j]];
+                    nr1 = t.r.ytab[2 * (cr1[j] - 1) + 1] + 1;
+                }
+            }
+            size_t off = 0;
+            for (int j = 0; j <= nl; j++) {
+                T[j].c0 = (int16_t)(4 * cq0[j]);
+                T[j].nc = (int16_t)(4 * (cq1[j] - cq0[j]));
+                T[j].r0 = (int16_t)cr0[j];
+                T[j].nr = (int16_t)(cr1[j] - cr0[j]);
+                T[j].pitch = (uint32_t)(T[j].nc + 8);
+                T[j].lds_off = (uint32_t)off;
+                off += ((size_t)T[j].pitch * T[j].nr + 15) & ~(size_t)15;
+                if (j >= 1 && T[j].nc / 4 > 64) return false; /* lane = quad */
+            }
+            lds_max = std::max(lds_max, off + 16);
+        }
+    plan.lds_bytes = lds_max;
+    return lds_max <= max_lds;
+}
+
+bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan) {
+    if (tabs.empty() || tabs.size() > VSLAM_MAX_LEVELS) return false;
+    for (const PyrLevelTables* t : tabs)
+        if (!t || t->qbase.empty()) return false; /* a level without the quad table: per-level launches */
+    const int nq1 = (tabs[0]->dw + 3) / 4, h1 = tabs[0]->dh;
+    const int nty = std::max(1, (h1 + 27) / 28);
+    for (int ntx = std::max(1, (nq1 + 51) / 52); ntx <= std::max(1, nq1 / 8); ntx++)
+        if (plan_with(tabs, l0, ntx, nty, max_lds, plan)) return true;
+    return false;
+}
+
+int emulate_pyramid_group(const PyrGroupPlan& plan, const std::vector<const PyrLevelTables*>& tabs,
+                          const uint8_t* src, int sstride, int readable_w, std::vector<uint8_t*>& dst,
+                          const std::vector<int>& dstride) {
+    const int nl = plan.nl;
+    std::vector<uint8_t> lds(plan.lds_bytes), ok(plan.lds_bytes);
+    for (int tile = 0; tile < plan.ntx * plan.nty; tile++) {
+        const PyrTileLevel* T = &plan.tiles[(size_t)tile * (nl + 1)];
+        std::fill(lds.begin(), lds.end(), (uint8_t)0xCD);
+        std::fill(ok.begin(), ok.end(), (uint8_t)0);
+        if (T[0].nr <= 0 || T[0].nc <= 0) continue;
+        /* stage the source tile: dwords of columns [c0, c0 + pitch), those inside the readable row width */
+        for (int r = 0; r < T[0].nr; r++)
+            for (int c = 0; c < (int)T[0].pitch; c++) {
+                const int col = T[0].c0 + c;
+                const size_t a = T[0].lds_off + (size_t)r * T[0].pitch + c;
+                if (a >= lds.size()) return -1;
+                if (col < readable_w) {
+                    lds[a] = src[(size_t)(T[0].r0 + r) * sstride + col];
+                    ok[a] = 1;
+                }
+            }
+        for (int j = 1; j <= nl; j++) {
+            const PyrLevelTables& t = *tabs[j - 1];
+            const PyrTileLevel &S = T[j - 1], &D = T[j];
+            for (int r = D.r0; r < D.r0 + D.nr; r++) {
+                const int sy0 = t.r.ytab[2 * r], sy1 = t.r.ytab[2 * r + 1], b0 = t.r.yb[2 * r], b1 = t.r.yb[2 * r + 1];
+                if (sy0 < S.r0 || sy1 >= S.r0 + S.nr) return -2;
+                for (int lane = 0; lane < D.nc / 4; lane++) {
+                    const int q = D.c0 / 4 + lane;
+                    const int loc = (int)t.qbase[q] - S.c0;
+                    if (loc < 0) return -3;
+                    const int dwb = loc & ~3, sh = loc & 3;
+                    if (dwb + 12 > (int)S.pitch) return -4;
+                    uint32_t out = 0;
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t sel = t.quads[(size_t)q * 8 + k], cf = t.quads[(size_t)q * 8 + 4 + k];
+                        const int o0 = sel & 0xFF, o1 = (sel >> 16) & 0xFF;
+                        const int a0 = (int16_t)(cf & 0xFFFF), a1 = (int16_t)(cf >> 16);
+                        int h[2];
+                        for (int rr = 0; rr < 2; rr++) {
+                            const size_t base = S.lds_off + (size_t)((rr ? sy1 : sy0) - S.r0) * S.pitch + dwb + sh;
+                            if (base + 8 > lds.size()) return -5;
+                            if (!ok[base + o0] || !ok[base + o1]) return -6; /* a tap that was never staged/computed */
+                            h[rr] = lds[base + o0] * a0 + lds[base + o1] * a1;
+                        }
+                        const int v = (((b0 * (h[0] >> 4)) >> 16) + ((b1 * (h[1] >> 4)) >> 16) + 2) >> 2;
+                        out |= (uint32_t)(v & 0xFF) << (8 * k);
+                    }
+                    const size_t da = D.lds_off + (size_t)(r - D.r0) * D.pitch + 4 * lane;
+                    if (da + 4 > lds.size()) return -7;
+                    for (int k = 0; k < 4; k++) {
+                        lds[da + k] = (uint8_t)(out >> (8 * k));
+                        ok[da + k] = 1;
+                    }
+                    if (q >= D.sq0 && q < D.sq1 && r >= D.sr0 && r < D.sr1)
+                        for (int k = 0; k < 4; k++)
+                            if (4 * q + k < dstride[j]) dst[j][(size_t)r * dstride[j] + 4 * q + k] = (uint8_t)(out >> (8 * k));
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 void build_cells(int level, int lw, int lh, std::vector<HostCell>& out) {
     /* fextractor.cpp:764-797 */
     const float W = 30;
@@ -533,6 +674,59 @@ int vslamh_resize_with_tables(const uint8_t* src, int sw, int sh, size_t sstride
             dst[(size_t)dy * dstride + dx] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
         }
     return 0;
+}
+
+/* The fused pyramid plan evaluated on the CPU: builds the tables and group plans exactly as vslam_fe_create does
+ * (groups of levels 1-3, 4-7, ...) and runs emulate_pyramid_group.  out = all levels >= 1 back to back, level l at
+ * offset sum of w*h of the levels before it, tightly packed.  Returns the number of groups, or a negative code. */
+int vslamh_pyramid_fused(const uint8_t* img, int w, int h, size_t stride, int nfeatures, float scale, int nlevels,
+                         uint8_t* out, int* lds_bytes_max, int* tiles_total) {
+    vslam::ExtractorTables t;
+    vslam::build_tables(nfeatures, scale, nlevels, t);
+    std::vector<vslam::PyrLevelTables> tabs(nlevels);
+    std::vector<int> lw(nlevels), lh(nlevels);
+    for (int l = 0; l < nlevels; l++) vslam::level_size(t, w, h, l, &lw[l], &lh[l]);
+    for (int l = 1; l < nlevels; l++) {
+        vslam::PyrLevelTables& T = tabs[l];
+        T.sw = lw[l - 1]; T.sh = lh[l - 1]; T.dw = lw[l]; T.dh = lh[l];
+        vslam::build_resize_tables(T.sw, T.sh, T.dw, T.dh, T.r);
+        if (!vslam::build_resize_quads(T.r, T.sw, T.dw, T.qbase, T.quads)) return -100;
+    }
+    /* level images with the product's pitch (multiple of 128) */
+    std::vector<std::vector<uint8_t>> lv(nlevels);
+    std::vector<int> pitch(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        pitch[l] = (lw[l] + 127) & ~127;
+        lv[l].assign((size_t)pitch[l] * lh[l], 0xEE);
+    }
+    for (int y = 0; y < h; y++) memcpy(&lv[0][(size_t)y * pitch[0]], img + (size_t)y * stride, w);
+    int ngroups = 0;
+    *lds_bytes_max = 0;
+    *tiles_total = 0;
+    for (int l0 = 0; l0 + 1 < nlevels;) {
+        const int nl = std::min(l0 == 0 ? 3 : 4, nlevels - 1 - l0);
+        std::vector<const vslam::PyrLevelTables*> gt;
+        for (int j = 1; j <= nl; j++) gt.push_back(&tabs[l0 + j]);
+        vslam::PyrGroupPlan plan;
+        if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan)) return -101;
+        std::vector<uint8_t*> dst(nl + 1, nullptr);
+        std::vector<int> ds(nl + 1, 0);
+        for (int j = 1; j <= nl; j++) { dst[j] = lv[l0 + j].data(); ds[j] = pitch[l0 + j]; }
+        /* level 0 may be the caller's image (readable up to w only); internal levels are readable up to their pitch */
+        const int rc = vslam::emulate_pyramid_group(plan, gt, lv[l0].data(), pitch[l0], l0 == 0 ? w : pitch[l0], dst, ds);
+        if (rc) return rc;
+        *lds_bytes_max = std::max(*lds_bytes_max, (int)plan.lds_bytes);
+        *tiles_total += plan.ntx * plan.nty;
+        ngroups++;
+        l0 += nl;
+    }
+    size_t o = 0;
+    for (int l = 1; l < nlevels; l++)
+        for (int y = 0; y < lh[l]; y++) {
+            memcpy(out + o, &lv[l][(size_t)y * pitch[l]], lw[l]);
+            o += lw[l];
+        }
+    return ngroups;
 }
 
 int vslamh_cells(int level, int lw, int lh, uint16_t* out5, int cap) {

@@ -43,6 +43,42 @@ void build_resize_tables(int sw, int sh, int dw, int dh, ResizeTables& r);
 bool build_resize_quads(const ResizeTables& r, int sw, int dw, std::vector<uint16_t>& qbase,
                         std::vector<uint32_t>& quads);
 
+/* ---- fused pyramid (k_pyramid_group): one workgroup computes a spatial tile of SEVERAL consecutive levels in LDS.
+ * Level l is resized from level l-1 (a cascade, fextractor.cpp:1148), so a tile of level l needs a slightly larger
+ * tile of level l-1: every (tile, level) gets a COMPUTE range (own range + what the deeper levels of the same tile
+ * need, recomputed instead of exchanged between workgroups) and a STORE range (a partition of the level: every
+ * pixel of a level is stored by exactly one tile).  Columns are counted in quads (4 output pixels, the unit of
+ * k_resize_level_v2's column table). */
+struct PyrTileLevel {     /* entry j of a tile: j = 0 is the group's source level (staged from HBM), j >= 1 computed */
+    int16_t c0, nc;       /* first column (multiple of 4) and number of columns (multiple of 4) held in LDS */
+    int16_t r0, nr;       /* first row, number of rows held in LDS */
+    int16_t sq0, sq1;     /* quads stored to HBM: [sq0, sq1) */
+    int16_t sr0, sr1;     /* rows stored to HBM: [sr0, sr1) */
+    uint32_t lds_off;     /* byte offset of this level's tile in the workgroup's LDS */
+    uint32_t pitch;       /* LDS row pitch in bytes = nc + 8 (the 8-byte tap window of the last quad may overrun nc) */
+};
+struct PyrGroupPlan {
+    int l0 = 0, nl = 0;        /* source level, number of computed levels (l0+1 .. l0+nl) */
+    int ntx = 0, nty = 0;      /* tiles per image */
+    size_t lds_bytes = 0;      /* dynamic LDS per workgroup */
+    std::vector<PyrTileLevel> tiles; /* [ntx*nty][nl+1] */
+};
+struct PyrLevelTables {   /* tables of destination level l (source l-1), as the per-level kernels use them */
+    int sw, sh, dw, dh;
+    ResizeTables r;
+    std::vector<uint16_t> qbase;
+    std::vector<uint32_t> quads;
+};
+/* Plan for levels l0+1 .. l0+nl (tabs[j-1] = tables of level l0+j).  Returns false if a tile would need more than 64
+ * quads per row (lane = quad) or more LDS than max_lds -- the caller then keeps the per-level launches. */
+bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan);
+/* CPU emulation of k_pyramid_group with the SAME plan and indexing (LDS tiles as arrays); used by the CPU tests to
+ * validate a plan before it ever runs on the GPU.  levels[j] = image of level l0+j (j = 0 input, j >= 1 output,
+ * pitch = stride[j]).  Returns 0, or a negative code if an access leaves a tile (the GPU would read garbage). */
+int emulate_pyramid_group(const PyrGroupPlan& plan, const std::vector<const PyrLevelTables*>& tabs,
+                          const uint8_t* src, int sstride, int readable_w, std::vector<uint8_t*>& dst,
+                          const std::vector<int>& dstride);
+
 /* FAST cell grid of one level (fextractor.cpp:764-797).  Cells are listed in the reference's visiting
  * order (row-major, skipped cells omitted). */
 struct HostCell {

@@ -261,6 +261,102 @@ void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused pyramid: levels l0+1 .. l0+nl in ONE launch (FExtractor::ComputePyramid, fextractor.cpp:1135-1160).
+ * Level l is resized from level l-1, so the seven per-level launches were a chain of dependent kernels whose small
+ * levels cannot fill 256 CUs.  Here a workgroup owns a spatial tile: it stages the tile of the source level (plus the
+ * halo the cascade needs) in LDS, computes its tile of level l0+1 into LDS, from that level l0+2, ... and stores the
+ * part of every level it owns to HBM.  Neighbouring tiles RECOMPUTE each other's halos (6-11 % more pixels) instead
+ * of exchanging them, so there is no inter-workgroup dependency.  The plan (compute / store range per tile and level,
+ * LDS offsets) comes from vslam::build_pyramid_group and is validated on the CPU by emulate_pyramid_group.
+ * Arithmetic = k_resize_level_v2: lane = quad of four output pixels, all eight taps of a source row inside one 8-byte
+ * window starting at qbase[q]; in LDS the window is cut out of three aligned dwords with v_alignbyte_b32.
+ * 8 levels = 2 launches (levels 1-3 from level 0, levels 4-7 from level 3).
+ * ---------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, int nslots) {
+    extern __shared__ __align__(16) uint8_t psm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    /* XCD-aware order: the (slot, tile) list is cut into 8 contiguous parts, one per XCD (workgroups b, b+8 share an L2),
+     * so the tiles of one image -- whose source halos overlap -- are fetched through one L2 */
+    const int nwork = G.ntiles * nslots, per_xcd = (nwork + 7) >> 3;
+    const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (wk >= nwork || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int slot = wk / G.ntiles, tile = wk - slot * G.ntiles;
+    const PyrTileDev* T = G.tiles + (size_t)tile * (G.nl + 1);
+    const PyrTileDev S0 = T[0];
+    if (S0.nr <= 0 || S0.nc <= 0) return; /* a tile that owns nothing (more tiles than quads on a tiny level) */
+    {   /* stage the source tile: a wave per row, a dword per lane and step */
+        int spitch;
+        const uint8_t* img = level_base_v2(pyr, slot_stride, src, G.lg[0], G.l0, slot, &spitch);
+        const int readable = G.l0 == 0 ? G.readable_w0 : spitch;
+        const int ndw = (int)S0.pitch >> 2;
+        for (int r = wave; r < S0.nr; r += 4) {
+            const uint8_t* grow = img + (size_t)(S0.r0 + r) * spitch + S0.c0;
+            uint32_t* lrow = (uint32_t*)(psm + S0.lds_off + (size_t)r * S0.pitch);
+            for (int d = lane; d < ndw; d += 64) {
+                const int col = S0.c0 + 4 * d;
+                uint32_t v = 0;
+                if (col + 4 <= readable) v = *(const uint32_t*)(grow + 4 * d);
+                else
+                    for (int k = 0; col + k < readable && k < 4; k++) v |= (uint32_t)grow[4 * d + k] << (8 * k);
+                lrow[d] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = 1; j <= G.nl; j++) {
+        const PyrTileDev S = T[j - 1], D = T[j];
+        const int nq = D.nc >> 2;
+        if (lane < nq && D.nr > 0) {
+            const int q = (D.c0 >> 2) + lane;
+            const int loc = (int)G.qbase[j - 1][q] - S.c0;
+            const uint32_t sh = (uint32_t)(loc & 3);
+            const uint4 sel = *(const uint4*)G.quads[j - 1][q].sel;
+            const uint4 cf = *(const uint4*)G.quads[j - 1][q].coef;
+            const uint8_t* scol = psm + S.lds_off + (loc & ~3);
+            uint8_t* dcol = psm + D.lds_off + 4 * lane;
+            const bool qstore = q >= D.sq0 && q < D.sq1;
+            uint8_t* gout = pyr + (size_t)slot * slot_stride + G.lg[j].off + 4 * (size_t)q;
+            const int gpitch = G.lg[j].pitch;
+            const uint16_t* ytab = G.ytab[j - 1];
+            const int16_t* yb = G.yb[j - 1];
+            for (int r = D.r0 + wave; r < D.r0 + D.nr; r += 4) {
+                const int ru = __builtin_amdgcn_readfirstlane(r); /* wave-uniform: the row tables are scalar loads */
+                const int sy0 = ytab[2 * ru], sy1 = ytab[2 * ru + 1];
+                const int b0 = yb[2 * ru], b1 = yb[2 * ru + 1];
+                const uint32_t* r0 = (const uint32_t*)(scol + (size_t)(sy0 - S.r0) * S.pitch);
+                const uint32_t* r1 = (const uint32_t*)(scol + (size_t)(sy1 - S.r0) * S.pitch);
+                const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], c0 = r1[0], c1 = r1[1], c2 = r1[2];
+                const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi0 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh);
+                uint32_t out = 0;
+#define RZ_ONE(k, SEL, CF)                                                                                 \
+    {                                                                                                      \
+        const int h0 = hdot2(__builtin_amdgcn_perm(hi0, lo0, SEL), CF);                                    \
+        const int h1 = hdot2(__builtin_amdgcn_perm(hi1, lo1, SEL), CF);                                    \
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;                     \
+        out |= (uint32_t)(v & 0xFF) << (8 * (k));                                                          \
+    }
+                RZ_ONE(0, sel.x, cf.x)
+                RZ_ONE(1, sel.y, cf.y)
+                RZ_ONE(2, sel.z, cf.z)
+                RZ_ONE(3, sel.w, cf.w)
+#undef RZ_ONE
+                *(uint32_t*)(dcol + (size_t)(r - D.r0) * D.pitch) = out;
+                if (qstore && r >= D.sr0 && r < D.sr1) *(uint32_t*)(gout + (size_t)r * gpitch) = out;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
+                      size_t lds_bytes, int nslots) {
+    const int nwork = G.ntiles * nslots;
+    hipLaunchKernelGGL(k_pyramid_group, dim3(((nwork + 7) / 8) * 8), dim3(256), lds_bytes, st, pyr, slot_stride, src, G, nslots);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * FAST cells.  What keeps the instruction count of the pre-test and the survivor bookkeeping down:
  *   - the window is staged one column to the left (LDS column = window column + 1), so the four interior
  *     pixels x = 4q..4q+3 of a row and their up/down compass pixels are aligned dwords and the left/right ones

@@ -23,6 +23,8 @@ void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t,
 void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                  uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int rows_per_task,
                  int nslots);
+void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
+                      size_t lds_bytes, int nslots);
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
                       size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots);
