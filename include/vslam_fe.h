@@ -38,6 +38,7 @@ extern "C" {
 #define VSLAM_IMGS_HOST 0
 #define VSLAM_IMGS_DEVICE 1
 #define VSLAM_IMGS_PINNED 2
+#define VSLAM_IMGS_STAGED 3 /* already in the slots' level 0: put there by vslam_fe_stage_images_async (imgs is ignored) */
 
 /* flags for vslam_fe_params.flags: OpenCV build-dependent arithmetic the reference inherits */
 #define VSLAM_FLAG_ATAN_FMA 1u /* cv::fastAtan2 Horner polynomial FMA-contracted (AVX2/FMA3 dispatch, aarch64) */
@@ -103,6 +104,13 @@ int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, int lap0, i
 int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                            int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
                            uint8_t* const* desc, int cap, int* n, int* mono_index);
+
+/* Upload only: pull nimg pinned (VSLAM_IMGS_PINNED) or pageable (VSLAM_IMGS_HOST) host images into level 0 of slots
+ * 0..nimg-1, enqueued on fe's stream, and return.  A following extraction with imgs_on_device == VSLAM_IMGS_STAGED uses
+ * them.  Splitting the upload from the extraction lets a pipelined caller start the PCIe transfer of the next pass
+ * before the GPU-side dependencies of the extraction itself (e.g. another context's matcher still reading this
+ * context's previous RESULTS -- the upload only overwrites level 0, which nothing outside the context reads). */
+int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int imgs_where);
 
 /* The same in two halves, so a caller can keep several contexts (streams) in flight: _async enqueues the
  * whole pass and returns without waiting for the GPU (with the device quadtree nothing in it touches the

@@ -219,3 +219,28 @@ def test_kitti_mono_yaml_feature_count_n2000_pipeline():
             assert out[j][0] == wn and np.array_equal(out[j][1], wm) and wn > 100
     finally:
         fe.close()
+
+
+def test_staged_upload_then_extract_equals_pinned_path():
+    """vslam_fe_stage_images_async + VSLAM_IMGS_STAGED: the upload split from the extraction (bench.py enqueues it ahead
+    of the cross-context waits); alternating with plain pinned passes on one context must not confuse the graph cache."""
+    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    pin = V.PinnedImages(2, 376, 1241, 1241)
+    try:
+        e = orbo.Extractor(1000)
+        for rep in range(3):
+            imgs = [synth.make_frame(1241, 376, seed=40 + rep, step=s) for s in range(2)]
+            for s in range(2):
+                pin.array[s][:] = imgs[s]
+            if rep == 1:
+                fe.compute_batch_async(pin.ptrs, 1241, (0, 1000), where=V.IMGS_PINNED)
+            else:
+                fe.stage_images_async(pin.ptrs, 1241, V.IMGS_PINNED)
+                fe.compute_batch_async(pin.ptrs, 1241, (0, 1000), where=V.IMGS_STAGED)
+            res = fe.wait(copy=True)
+            for s in range(2):
+                ko, do, mo = e.compute(imgs[s], lap=(0, 1000))
+                _same_feats(res[s], (ko, do), "staged %d/%d" % (rep, s))
+    finally:
+        pin.close()
+        fe.close()

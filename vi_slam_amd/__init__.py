@@ -18,7 +18,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libvslam_host.so")
 
 VSLAM_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
-IMGS_HOST, IMGS_DEVICE, IMGS_PINNED = 0, 1, 2  # where the input images live (vslam_fe.h VSLAM_IMGS_*)
+IMGS_HOST, IMGS_DEVICE, IMGS_PINNED, IMGS_STAGED = 0, 1, 2, 3  # where the input images live (vslam_fe.h VSLAM_IMGS_*)
 COMM_ID_BYTES = 128
 FLAG_ATAN_FMA = 1
 FLAG_HOST_OCTREE = 2
@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
+    "vslam_fe_stage_images_async",
 ]
 
 
@@ -200,6 +201,7 @@ def lib():
         L.vslam_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.vslam_host_free.argtypes = [vp]
         L.vslam_host_free.restype = None
+        L.vslam_fe_stage_images_async.argtypes = [vp, i, vp, C.c_size_t, i]
         _lib = L
     return _lib
 
@@ -377,6 +379,14 @@ class FExtractor:
         if not to_host:
             return [(n[i], mono[i]) for i in range(nimg)]
         return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy(), mono[i]) for i in range(nimg)]
+
+    def stage_images_async(self, ptrs, pitch, where=IMGS_PINNED):
+        """Upload only (vslam_fe_stage_images_async): pull the host images into level 0 of the slots on this context's
+        stream; follow with compute_batch_async / frame_stereo_async(..., where=IMGS_STAGED)."""
+        nimg = len(ptrs)
+        p = ptrs if isinstance(ptrs, C.Array) else (C.c_void_p * nimg)(*ptrs)
+        self._staged_n = nimg
+        _check(lib().vslam_fe_stage_images_async(self._h, nimg, p, pitch, where))
 
     def compute_batch_async(self, device_ptrs, pitch, vLappingArea=(0, 0), to_host=True, where=IMGS_DEVICE):
         """Enqueue one batched pass and return immediately (vslam_fe_extract_batch_async); collect with wait().

@@ -112,7 +112,7 @@ struct ResizeQuad {
  * vslam::PyrTileLevel (vslam_host.h), which the host planner fills. */
 struct PyrTileDev {
     int16_t c0, nc, r0, nr, sq0, sq1, sr0, sr1;
-    uint32_t lds_off, pitch;
+    uint32_t lds_off, pitch, rt_off;
 };
 #define VSLAM_PYR_GROUP_LEVELS 4
 struct PyrGroupDev { /* by-value kernel argument */

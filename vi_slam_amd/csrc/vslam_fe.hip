@@ -72,6 +72,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_mpflags);
     if (fe->h_proj) hipHostFree(fe->h_proj);
     if (fe->h_img) hipHostFree(fe->h_img);
+    hipFree(fe->d_stage);
     if (fe->graph_exec) hipGraphExecDestroy(fe->graph_exec);
     hipFree(fe->d_bow);
     if (fe->h_bow) hipHostFree(fe->h_bow);
@@ -270,7 +271,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         int rc;
         if ((rc = upload(&fe->d_pattern, VSLAM_ORB_PATTERN, 1024))) return rc;
     }
-    vk_upload_disc(fe->tab.disc_u.data(), fe->tab.disc_v.data(), (int)fe->tab.disc_u.size());
+    vk_upload_disc(fe->tab.umax);
     {
         /* marching-rows blur: one wave task per (level, row chunk, 248-column strip) */
         if (const char* e = getenv("VSLAM_BLUR_ROWS")) fe->blur_rows = std::min(512, std::max(8, atoi(e)));
@@ -568,6 +569,75 @@ static int stage_host_images(vslam_fe* fe, int nimg, const uint8_t* const* imgs,
     return VSLAM_OK;
 }
 
+static bool h2d_uses_sdma() { /* VSLAM_H2D = sdma (default) | pull */
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VSLAM_H2D");
+        v = !(e && !strcmp(e, "pull"));
+    }
+    return v != 0;
+}
+
+/* the device staging buffer of the sdma transport, allocated OUTSIDE stream capture (hipMalloc is not capturable) */
+static int ensure_stage(vslam_fe* fe, size_t spitch) {
+    if (!h2d_uses_sdma()) return VSLAM_OK;
+    const size_t one = (size_t)(fe->p.height - 1) * spitch + fe->p.width;
+    const size_t stride = (one + 255) & ~(size_t)255;
+    if (fe->d_stage_bytes >= stride * fe->B + 256) return VSLAM_OK;
+    HIPCHK(hipStreamSynchronize(fe->stream)); /* an earlier pass may still read the old buffer */
+    return vslam_ensure((void**)&fe->d_stage, &fe->d_stage_bytes, stride * fe->B + 256);
+}
+
+/* Host rows -> level 0 of slots 0..nimg-1, enqueued on fe's stream.  `where` = VSLAM_IMGS_PINNED (the caller's pinned
+ * images) or VSLAM_IMGS_HOST (rows already copied into the context's pinned staging by stage_host_images).
+ * Two transports (VSLAM_H2D = sdma | pull, default sdma):
+ *   sdma: hipMemcpyAsync (the DMA engines: no CU, no L2 miss-queue entries held for microseconds) copies every image
+ *         as one linear block into a device staging buffer -- ONE call when the images are equally spaced in memory, as
+ *         the buffers of a capture ring are -- and a kernel re-pitches from HBM into the 128-byte-pitched level 0.
+ *         Measured beside the other contexts' kernels: 102 k frames/s against 64-72 k with the pull kernel, whose host
+ *         reads (2-3 us each) sit in the L2's queues in front of everybody's HBM requests (describe 122 -> 274 us).
+ *   pull: one kernel reads the host rows over PCIe itself (55 GB/s alone on the GPU; kept for A/B runs). */
+static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where) {
+    const vslam_fe_params& p = fe->p;
+    hipStream_t st = fe->stream;
+    const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
+    const bool use_sdma = h2d_uses_sdma();
+    BatchSrc hs;
+    for (int s = 0; s < nimg; s++) {
+        if (where == VSLAM_IMGS_PINNED && !imgs[s]) {
+            g_err = "null image";
+            return VSLAM_ERR_INVALID;
+        }
+        hs.l0[s] = where == VSLAM_IMGS_PINNED ? imgs[s] : fe->h_img + img_bytes * s;
+        hs.pitch0[s] = where == VSLAM_IMGS_PINNED ? (uint32_t)pitch : (uint32_t)lp;
+    }
+    int from_host = 1;
+    if (use_sdma) {
+        const size_t spitch = hs.pitch0[0];
+        const size_t one = (size_t)(p.height - 1) * spitch + p.width; /* bytes of one image, first to last pixel */
+        const size_t stride = (one + 255) & ~(size_t)255;
+        if (fe->d_stage_bytes < stride * fe->B + 256) { /* ensure_stage() runs before any capture; cannot happen */
+            g_err = "internal: device staging buffer not allocated";
+            return VSLAM_ERR_HIP;
+        }
+        bool even = nimg > 1; /* equally spaced sources: one copy */
+        const ptrdiff_t d = nimg > 1 ? hs.l0[1] - hs.l0[0] : 0;
+        for (int s = 2; s < nimg && even; s++) even = hs.l0[s] - hs.l0[s - 1] == d;
+        if (even && d > 0 && (size_t)d >= one && (size_t)d * (nimg - 1) + one <= fe->d_stage_bytes) {
+            HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * (nimg - 1) + one, hipMemcpyHostToDevice, st));
+            for (int s = 0; s < nimg; s++) hs.l0[s] = fe->d_stage + (size_t)d * s;
+        } else {
+            for (int s = 0; s < nimg; s++) {
+                HIPCHK(hipMemcpyAsync(fe->d_stage + stride * s, hs.l0[s], one, hipMemcpyHostToDevice, st));
+                hs.l0[s] = fe->d_stage + stride * s;
+            }
+        }
+        from_host = 0;
+    }
+    vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg, from_host);
+    return VSLAM_OK;
+}
+
 static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device) {
     const vslam_fe_params& p = fe->p;
     const int L = p.nlevels;
@@ -581,27 +651,18 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
             fe->src.l0[s] = imgs[s];
             fe->src.pitch0[s] = (uint32_t)pitch;
         }
-    } else {
-        /* host rows (the caller's pinned images, or the pinned staging stage_host_images filled) are pulled into
-         * level 0 of the slots by one kernel */
-        BatchSrc hs;
-        const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
-        for (int s = 0; s < nimg; s++) {
-            if (on_device == VSLAM_IMGS_PINNED) {
-                if (!imgs[s]) {
-                    g_err = "null image";
-                    return VSLAM_ERR_INVALID;
-                }
-                hs.l0[s] = imgs[s];
-                hs.pitch0[s] = (uint32_t)pitch;
-            } else {
-                hs.l0[s] = fe->h_img + img_bytes * s;
-                hs.pitch0[s] = (uint32_t)lp;
-            }
+    } else if (on_device == VSLAM_IMGS_STAGED) {
+        for (int s = 0; s < nimg; s++) { /* vslam_fe_stage_images_async put them there */
             fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
-            fe->src.pitch0[s] = (uint32_t)lp;
+            fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
         }
-        vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg);
+    } else {
+        int rc = upload_host_rows(fe, nimg, imgs, pitch, on_device);
+        if (rc) return rc;
+        for (int s = 0; s < nimg; s++) {
+            fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
+            fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
+        }
     }
     fe->last_nimg = nimg;
     fe->cand_on_host = false;
@@ -790,12 +851,17 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
+    if (on_device == VSLAM_IMGS_HOST || on_device == VSLAM_IMGS_PINNED) {
+        int rc = ensure_stage(fe, on_device == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch);
+        if (rc) return rc;
+    }
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
      * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
     const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
-                    (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24);
+                    (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^
+                    ((long long)on_device << 56); /* host / pinned / staged passes capture different launches */
     if (on_device == VSLAM_IMGS_PINNED) {
         /* the caller's pointers are kernel arguments of the captured pull: a different set of images is a different
          * graph (a capture-card ring of a few buffers per context hits the cache every time) */
@@ -944,8 +1010,9 @@ int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* 
 extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                       int imgs_on_device, int lap0, int lap1, vslam_kp* const* kps,
                                       uint8_t* const* desc, int cap, int* n, int* mono_index) {
-    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width || imgs_on_device < 0 ||
-        imgs_on_device > VSLAM_IMGS_PINNED) {
+    if (!fe || (!imgs && imgs_on_device != VSLAM_IMGS_STAGED) || nimg < 1 || nimg > fe->B ||
+        (pitch < (size_t)fe->p.width && imgs_on_device != VSLAM_IMGS_STAGED) || imgs_on_device < 0 ||
+        imgs_on_device > VSLAM_IMGS_STAGED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
@@ -961,8 +1028,9 @@ extern "C" int vslam_fe_extract_batch(vslam_fe* fe, int nimg, const uint8_t* con
 /* split form: enqueue everything (no host synchronisation in the device-quadtree path), collect later */
 extern "C" int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                             int imgs_on_device, int lap0, int lap1, int want_host) {
-    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width || imgs_on_device < 0 ||
-        imgs_on_device > VSLAM_IMGS_PINNED) {
+    if (!fe || (!imgs && imgs_on_device != VSLAM_IMGS_STAGED) || nimg < 1 || nimg > fe->B ||
+        (pitch < (size_t)fe->p.width && imgs_on_device != VSLAM_IMGS_STAGED) || imgs_on_device < 0 ||
+        imgs_on_device > VSLAM_IMGS_STAGED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
@@ -993,6 +1061,27 @@ extern "C" int vslam_fe_extract(vslam_fe* fe, const uint8_t* img, size_t pitch, 
     vslam_kp* k[1] = {kps};
     uint8_t* d[1] = {desc};
     return vslam_fe_extract_batch(fe, 1, imgs, pitch, 0, lap0, lap1, k, d, cap, n, mono_index);
+}
+
+extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
+                                           int where) {
+    if (!fe || !imgs || nimg < 1 || nimg > fe->B || pitch < (size_t)fe->p.width ||
+        (where != VSLAM_IMGS_PINNED && where != VSLAM_IMGS_HOST)) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(fe->p.device));
+    if (where == VSLAM_IMGS_HOST) {
+        HIPCHK(hipStreamSynchronize(fe->stream)); /* the pinned staging may still be read by the previous pull */
+        int rc = stage_host_images(fe, nimg, imgs, pitch);
+        if (rc) return rc;
+    }
+    int rc2 = ensure_stage(fe, where == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch);
+    if (rc2) return rc2;
+    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where);
+    if (rc2) return rc2;
+    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
 }
 
 extern "C" int vslam_fe_candidates(vslam_fe* fe, int slot, int level, vslam_kp* out, int cap) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace vslam {
@@ -192,10 +193,15 @@ static bool plan_with(const std::vector<const PyrLevelTables*>& tabs, int l0, in
                 T[j].nc = (int16_t)(4 * (cq1[j] - cq0[j]));
                 T[j].r0 = (int16_t)cr0[j];
                 T[j].nr = (int16_t)(cr1[j] - cr0[j]);
-                T[j].pitch = (uint32_t)(T[j].nc + 8);
+                T[j].pitch = (uint32_t)((T[j].nc + 8 + 15) & ~15);
                 T[j].lds_off = (uint32_t)off;
-                off += ((size_t)T[j].pitch * T[j].nr + 15) & ~(size_t)15;
+                off += (size_t)T[j].pitch * T[j].nr;
                 if (j >= 1 && T[j].nc / 4 > 64) return false; /* lane = quad */
+                if (j == 0 && T[j].pitch / 16 > 64) return false; /* staging: lane = 16-byte chunk of a row */
+            }
+            for (int j = 1; j <= nl; j++) {
+                T[j].rt_off = (uint32_t)off;
+                off += ((size_t)T[j].nr * 8 + 15) & ~(size_t)15;
             }
             lds_max = std::max(lds_max, off + 16);
         }
@@ -208,7 +214,9 @@ bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0,
     for (const PyrLevelTables* t : tabs)
         if (!t || t->qbase.empty()) return false; /* a level without the quad table: per-level launches */
     const int nq1 = (tabs[0]->dw + 3) / 4, h1 = tabs[0]->dh;
-    const int nty = std::max(1, (h1 + 27) / 28);
+    int rows = 28; /* output rows of the first computed level per tile; VSLAM_PYR_ROWS for A/B runs */
+    if (const char* e = getenv("VSLAM_PYR_ROWS")) rows = std::min(64, std::max(4, atoi(e)));
+    const int nty = std::max(1, (h1 + rows - 1) / rows);
     for (int ntx = std::max(1, (nq1 + 51) / 52); ntx <= std::max(1, nq1 / 8); ntx++)
         if (plan_with(tabs, l0, ntx, nty, max_lds, plan)) return true;
     return false;

@@ -54,8 +54,10 @@ struct PyrTileLevel {     /* entry j of a tile: j = 0 is the group's source leve
     int16_t r0, nr;       /* first row, number of rows held in LDS */
     int16_t sq0, sq1;     /* quads stored to HBM: [sq0, sq1) */
     int16_t sr0, sr1;     /* rows stored to HBM: [sr0, sr1) */
-    uint32_t lds_off;     /* byte offset of this level's tile in the workgroup's LDS */
-    uint32_t pitch;       /* LDS row pitch in bytes = nc + 8 (the 8-byte tap window of the last quad may overrun nc) */
+    uint32_t lds_off;     /* byte offset of this level's tile in the workgroup's LDS (multiple of 16) */
+    uint32_t pitch;       /* LDS row pitch in bytes: nc + 8 (the 8-byte tap window of the last quad may overrun nc)
+                             rounded up to a multiple of 16 (rows are staged with 16-byte stores) */
+    uint32_t rt_off;      /* j >= 1: byte offset of the level's row table in LDS (nr entries of 8 bytes) */
 };
 struct PyrGroupPlan {
     int l0 = 0, nl = 0;        /* source level, number of computed levels (l0+1 .. l0+nl) */

@@ -239,7 +239,7 @@ k_resize_level_v2(uint8_t* pyr, size_t slot_stride, BatchSrc src, LevelGeom sg, 
     {                                                                                                      \
         const int h0 = hdot2(__builtin_amdgcn_perm(hi0, lo0, SEL), CF);                                    \
         const int h1 = hdot2(__builtin_amdgcn_perm(hi1, lo1, SEL), CF);                                    \
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;                     \
+        const int v = (((__mul24(b0, h0 >> 4)) >> 16) + ((__mul24(b1, h1 >> 4)) >> 16) + 2) >> 2;         \
         out |= (uint32_t)(v & 0xFF) << (8 * (j));                                                          \
     }
     RZ_ONE(0, sel.x, cf.x)
@@ -272,79 +272,155 @@ void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const 
  * window starting at qbase[q]; in LDS the window is cut out of three aligned dwords with v_alignbyte_b32.
  * 8 levels = 2 launches (levels 1-3 from level 0, levels 4-7 from level 3).
  * ---------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(256)
+/* 16 bytes of a source row starting at column `col`; only `nvalid` (< 16) of them may be read -- the last row of the
+ * caller's level-0 image may end with the buffer.  No loop: whole dwords, then at most three single bytes, all
+ * independent loads (one memory latency, not sixteen). */
+__device__ __forceinline__ uint4 pyr_load16_tail(const uint8_t* p, int nvalid) {
+    uint32_t t[4] = {0, 0, 0, 0};
+    const int nd = nvalid >> 2, nbyte = nvalid & 3;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < nd) t[i] = *(const uint32_t*)(p + 4 * i);
+        else if (i == nd) {
+            if (nbyte > 0) t[i] |= (uint32_t)p[4 * i];
+            if (nbyte > 1) t[i] |= (uint32_t)p[4 * i + 1] << 8;
+            if (nbyte > 2) t[i] |= (uint32_t)p[4 * i + 2] << 16;
+        }
+    }
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+template <int NT> /* threads per workgroup: NT / 64 waves share the rows of a tile */
+__global__ void __launch_bounds__(NT)
 k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, int nslots) {
     extern __shared__ __align__(16) uint8_t psm[];
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* XCD-aware order: the (slot, tile) list is cut into 8 contiguous parts, one per XCD (workgroups b, b+8 share an L2),
      * so the tiles of one image -- whose source halos overlap -- are fetched through one L2 */
     const int nwork = G.ntiles * nslots, per_xcd = (nwork + 7) >> 3;
     const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (wk >= nwork || (int)(blockIdx.x >> 3) >= per_xcd) return;
+    if (wk >= nwork) return;
     const int slot = wk / G.ntiles, tile = wk - slot * G.ntiles;
     const PyrTileDev* T = G.tiles + (size_t)tile * (G.nl + 1);
     const PyrTileDev S0 = T[0];
     if (S0.nr <= 0 || S0.nc <= 0) return; /* a tile that owns nothing (more tiles than quads on a tiny level) */
-    {   /* stage the source tile: a wave per row, a dword per lane and step */
+
+    /* Everything a level needs besides pixels is fetched NOW, so that no global-memory latency sits inside the per-level
+     * loops: the lane's quad record of every level (registers) and the row tables of every level (LDS). */
+    uint4 qsel[VSLAM_PYR_GROUP_LEVELS], qcf[VSLAM_PYR_GROUP_LEVELS];
+    int qloc[VSLAM_PYR_GROUP_LEVELS];
+#pragma unroll
+    for (int j = 1; j <= VSLAM_PYR_GROUP_LEVELS; j++) {
+        qsel[j - 1] = qcf[j - 1] = make_uint4(0, 0, 0, 0);
+        qloc[j - 1] = 0;
+        if (j <= G.nl) {
+            const PyrTileDev D = T[j];
+            if (lane < (D.nc >> 2)) {
+                const int q = (D.c0 >> 2) + lane;
+                qloc[j - 1] = (int)G.qbase[j - 1][q] - T[j - 1].c0;
+                qsel[j - 1] = *(const uint4*)G.quads[j - 1][q].sel;
+                qcf[j - 1] = *(const uint4*)G.quads[j - 1][q].coef;
+            }
+            uint2* rt = (uint2*)(psm + D.rt_off);
+            for (int i = threadIdx.x; i < D.nr; i += NT) {
+                const int r = D.r0 + i;
+                rt[i] = make_uint2(*(const uint32_t*)(G.ytab[j - 1] + 2 * r), *(const uint32_t*)(G.yb[j - 1] + 2 * r));
+            }
+        }
+    }
+    {   /* stage the source tile: lane = one 16-byte chunk of a row, several rows per wave instruction; the loads of
+         * four such instructions are issued before the first LDS store */
         int spitch;
         const uint8_t* img = level_base_v2(pyr, slot_stride, src, G.lg[0], G.l0, slot, &spitch);
+        /* bytes of a row that may be read: internal levels are padded to their pitch; of the caller's level-0 image
+         * only the LAST row ends with the buffer (reading a few bytes into the next row is harmless) */
         const int readable = G.l0 == 0 ? G.readable_w0 : spitch;
-        const int ndw = (int)S0.pitch >> 2;
-        for (int r = wave; r < S0.nr; r += 4) {
-            const uint8_t* grow = img + (size_t)(S0.r0 + r) * spitch + S0.c0;
-            uint32_t* lrow = (uint32_t*)(psm + S0.lds_off + (size_t)r * S0.pitch);
-            for (int d = lane; d < ndw; d += 64) {
-                const int col = S0.c0 + 4 * d;
-                uint32_t v = 0;
-                if (col + 4 <= readable) v = *(const uint32_t*)(grow + 4 * d);
-                else
-                    for (int k = 0; col + k < readable && k < 4; k++) v |= (uint32_t)grow[4 * d + k] << (8 * k);
-                lrow[d] = v;
+        const int last_row = G.lg[0].h - 1;
+        const int nch = (int)S0.pitch >> 4, rpi = 64 / nch;
+        const int rsub = lane / nch, ch = lane - rsub * nch;
+        const bool lact = rsub < rpi;
+        const int col = S0.c0 + 16 * ch;
+        for (int kb = 0; kb * NW * rpi < S0.nr; kb += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = ((kb + u) * NW + wave) * rpi + rsub;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (lact && row < S0.nr) {
+                    const uint8_t* gp = img + (size_t)(S0.r0 + row) * spitch + col;
+                    if (col + 16 <= readable || (G.l0 == 0 && S0.r0 + row < last_row)) v[u] = *(const uint4*)gp;
+                    else if (col < readable) v[u] = pyr_load16_tail(gp, readable - col);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = ((kb + u) * NW + wave) * rpi + rsub;
+                if (lact && row < S0.nr) *(uint4*)(psm + S0.lds_off + (size_t)row * S0.pitch + 16 * ch) = v[u];
             }
         }
     }
     __syncthreads();
-    for (int j = 1; j <= G.nl; j++) {
+#pragma unroll
+    for (int j = 1; j <= VSLAM_PYR_GROUP_LEVELS; j++) {
+        if (j > G.nl) break; /* uniform */
         const PyrTileDev S = T[j - 1], D = T[j];
-        const int nq = D.nc >> 2;
-        if (lane < nq && D.nr > 0) {
+        if (lane < (D.nc >> 2) && D.nr > 0) {
             const int q = (D.c0 >> 2) + lane;
-            const int loc = (int)G.qbase[j - 1][q] - S.c0;
+            const int loc = qloc[j - 1];
             const uint32_t sh = (uint32_t)(loc & 3);
-            const uint4 sel = *(const uint4*)G.quads[j - 1][q].sel;
-            const uint4 cf = *(const uint4*)G.quads[j - 1][q].coef;
-            const uint8_t* scol = psm + S.lds_off + (loc & ~3);
-            uint8_t* dcol = psm + D.lds_off + 4 * lane;
+            const uint4 sel = qsel[j - 1], cf = qcf[j - 1];
+            const int sp = (int)S.pitch, dp = (int)D.pitch;
+            const int sbase = (int)S.lds_off + (loc & ~3) - __mul24((int)S.r0, sp); /* + source row * sp */
+            const int dbase = (int)D.lds_off + 4 * lane - __mul24((int)D.r0, dp);   /* + row * dp */
             const bool qstore = q >= D.sq0 && q < D.sq1;
             uint8_t* gout = pyr + (size_t)slot * slot_stride + G.lg[j].off + 4 * (size_t)q;
             const int gpitch = G.lg[j].pitch;
-            const uint16_t* ytab = G.ytab[j - 1];
-            const int16_t* yb = G.yb[j - 1];
-            for (int r = D.r0 + wave; r < D.r0 + D.nr; r += 4) {
-                const int ru = __builtin_amdgcn_readfirstlane(r); /* wave-uniform: the row tables are scalar loads */
-                const int sy0 = ytab[2 * ru], sy1 = ytab[2 * ru + 1];
-                const int b0 = yb[2 * ru], b1 = yb[2 * ru + 1];
-                const uint32_t* r0 = (const uint32_t*)(scol + (size_t)(sy0 - S.r0) * S.pitch);
-                const uint32_t* r1 = (const uint32_t*)(scol + (size_t)(sy1 - S.r0) * S.pitch);
-                const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], c0 = r1[0], c1 = r1[1], c2 = r1[2];
-                const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi0 = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh);
-                uint32_t out = 0;
-#define RZ_ONE(k, SEL, CF)                                                                                 \
-    {                                                                                                      \
-        const int h0 = hdot2(__builtin_amdgcn_perm(hi0, lo0, SEL), CF);                                    \
-        const int h1 = hdot2(__builtin_amdgcn_perm(hi1, lo1, SEL), CF);                                    \
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;                     \
-        out |= (uint32_t)(v & 0xFF) << (8 * (k));                                                          \
+            const uint2* rt = (const uint2*)(psm + D.rt_off) - D.r0; /* indexed by the absolute row */
+            /* A wave owns a contiguous band of output rows and walks it top to bottom.  Consecutive output rows share a
+             * source row (sy1 of row r is sy0 of row r + 1 for 5 rows out of 6 at scale 1.2), so the horizontal pass
+             * of a source row -- (h >> 4) of the lane's four pixels -- is kept in registers and reused: 1.2 instead of
+             * 2 horizontal passes per output row. */
+            const int band = (D.nr + NW - 1) / NW;
+            const int rb = D.r0 + wave * band, re = min(rb + band, D.r0 + D.nr);
+            int prev_sy = -1;
+            int hp0 = 0, hp1 = 0, hp2 = 0, hp3 = 0;
+#define PYR_HPASS(SY, H0, H1, H2, H3)                                                                        \
+    {                                                                                                         \
+        const uint32_t* pr_ = (const uint32_t*)(psm + sbase + __mul24((int)(SY), sp));                        \
+        const uint32_t x0_ = pr_[0], x1_ = pr_[1], x2_ = pr_[2];                                             \
+        const uint32_t lo_ = __builtin_amdgcn_alignbyte(x1_, x0_, sh), hi_ = __builtin_amdgcn_alignbyte(x2_, x1_, sh); \
+        H0 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.x), cf.x) >> 4;                                        \
+        H1 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.y), cf.y) >> 4;                                        \
+        H2 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.z), cf.z) >> 4;                                        \
+        H3 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.w), cf.w) >> 4;                                        \
     }
-                RZ_ONE(0, sel.x, cf.x)
-                RZ_ONE(1, sel.y, cf.y)
-                RZ_ONE(2, sel.z, cf.z)
-                RZ_ONE(3, sel.w, cf.w)
-#undef RZ_ONE
-                *(uint32_t*)(dcol + (size_t)(r - D.r0) * D.pitch) = out;
+            for (int r = rb; r < re; r++) {
+                const uint2 e = rt[r];
+                /* wave-uniform by construction (LDS broadcast of the row table): scalar branches */
+                const int sy0 = __builtin_amdgcn_readfirstlane((int)(e.x & 0xFFFF));
+                const int sy1 = __builtin_amdgcn_readfirstlane((int)(e.x >> 16));
+                const int b0 = (int)(int16_t)(e.y & 0xFFFF), b1 = (int)e.y >> 16; /* 0 .. 2048 */
+                int g0, g1, g2, g3;
+                if (sy0 == prev_sy) {
+                    g0 = hp0; g1 = hp1; g2 = hp2; g3 = hp3;
+                } else
+                    PYR_HPASS(sy0, g0, g1, g2, g3)
+                if (sy1 != sy0) PYR_HPASS(sy1, hp0, hp1, hp2, hp3)
+                else {
+                    hp0 = g0; hp1 = g1; hp2 = g2; hp3 = g3;
+                }
+                prev_sy = sy1;
+                /* vertical pass: both factors fit 24 bits (b <= 2048, h >> 4 <= 32640): full-rate v_mul_i32_i24 */
+                const uint32_t v0 = (uint32_t)(((__mul24(b0, g0) >> 16) + (__mul24(b1, hp0) >> 16) + 2) >> 2);
+                const uint32_t v1 = (uint32_t)(((__mul24(b0, g1) >> 16) + (__mul24(b1, hp1) >> 16) + 2) >> 2);
+                const uint32_t v2 = (uint32_t)(((__mul24(b0, g2) >> 16) + (__mul24(b1, hp2) >> 16) + 2) >> 2);
+                const uint32_t v3 = (uint32_t)(((__mul24(b0, g3) >> 16) + (__mul24(b1, hp3) >> 16) + 2) >> 2);
+                const uint32_t out = (v0 & 0xFF) | ((v1 & 0xFF) << 8) | ((v2 & 0xFF) << 16) | (v3 << 24);
+                *(uint32_t*)(psm + dbase + __mul24(r, dp)) = out;
                 if (qstore && r >= D.sr0 && r < D.sr1) *(uint32_t*)(gout + (size_t)r * gpitch) = out;
             }
+#undef PYR_HPASS
         }
         __syncthreads();
     }
@@ -353,7 +429,15 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
 void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
                       size_t lds_bytes, int nslots) {
     const int nwork = G.ntiles * nslots;
-    hipLaunchKernelGGL(k_pyramid_group, dim3(((nwork + 7) / 8) * 8), dim3(256), lds_bytes, st, pyr, slot_stride, src, G, nslots);
+    static int nt = -1; /* VSLAM_PYR_NT = 256 | 512: waves per tile (A/B runs) */
+    if (nt < 0) {
+        const char* e = getenv("VSLAM_PYR_NT");
+        nt = (e && atoi(e) == 512) ? 512 : 256;
+    }
+    if (nt == 512)
+        hipLaunchKernelGGL(k_pyramid_group<512>, dim3(((nwork + 7) / 8) * 8), dim3(512), lds_bytes, st, pyr, slot_stride, src, G, nslots);
+    else
+        hipLaunchKernelGGL(k_pyramid_group<256>, dim3(((nwork + 7) / 8) * 8), dim3(256), lds_bytes, st, pyr, slot_stride, src, G, nslots);
 }
 
 /* ------------------------------------------------------------------------------------------------

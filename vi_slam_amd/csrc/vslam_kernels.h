@@ -5,7 +5,7 @@
 
 #include "vslam_device.h"
 
-void vk_upload_disc(const int8_t* u, const int8_t* v, int n);
+void vk_upload_disc(const int umax[16]); /* IC_Angle disc -> packed dword weights of the descriptor kernel */
 
 void vk_resize_level(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                      const LevelGeom& sg, const LevelGeom& dg, int src_level, const uint16_t* xtab,
@@ -79,7 +79,7 @@ void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes,
 void vk_copy_ranges(hipStream_t st, const CopyRanges& R);
 /* host (pinned) images -> level 0 of the slots, one launch; src.l0 / src.pitch0 describe the host rows */
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
-                    int w, int h, int nimg);
+                    int w, int h, int nimg, int from_host);
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
                    int nslots, uint8_t* dst, size_t slot_bytes);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);

@@ -59,14 +59,30 @@ k_resize_level(uint8_t* pyr, size_t slot_stride, BatchSrc src, LevelGeom sg, Lev
  *     pattern points with a=cosf, b=sinf (glibc-exact, vslam_trig.h), cvRound (round-half-even), sample
  *     the BLURRED level, 256 comparisons -> 4 wave ballots = 32 bytes.
  * ---------------------------------------------------------------------------------------------- */
-__constant__ int8_t c_disc_u[768];
-__constant__ int8_t c_disc_v[768];
-__constant__ int c_disc_n;
+/* IC_Angle weights for the dword form of the moment sum: the 31 x 31 patch is read as 31 rows x 8 unaligned dwords
+ * (columns u = -15 .. 16); item i = row * 8 + dword has two packed byte weights per pixel: wm = 1 inside the radius-15
+ * disc (|u| <= umax[|v|], fextractor.cpp:75-92), wu = (u + 15) inside, both 0 outside.  Then
+ *   m10 = sum u I = sum (u + 15) I - 15 sum I,   m01 = sum v I = sum_rows v * (sum_row I)      (exact int32). */
+__device__ uint32_t g_mom_wu[256];
+__device__ uint32_t g_mom_wm[256];
 
-void vk_upload_disc(const int8_t* u, const int8_t* v, int n) {
-    hipMemcpyToSymbol(HIP_SYMBOL(c_disc_u), u, n);
-    hipMemcpyToSymbol(HIP_SYMBOL(c_disc_v), v, n);
-    hipMemcpyToSymbol(HIP_SYMBOL(c_disc_n), &n, sizeof(int));
+void vk_upload_disc(const int umax[16]) {
+    uint32_t wu[256], wm[256];
+    for (int i = 0; i < 256; i++) {
+        const int row = i >> 3, dw = i & 7, v = row - 15;
+        wu[i] = wm[i] = 0;
+        if (row > 30) continue;
+        for (int j = 0; j < 4; j++) {
+            const int u = 4 * dw + j - 15;
+            const bool inside = u <= 15 && abs(u) <= umax[abs(v)];
+            if (inside) {
+                wu[i] |= (uint32_t)(u + 15) << (8 * j);
+                wm[i] |= 1u << (8 * j);
+            }
+        }
+    }
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mom_wu), wu, sizeof(wu));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mom_wm), wm, sizeof(wm));
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
@@ -96,22 +112,70 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
     return a;
 }
 
-__device__ __forceinline__ void orient_describe_one(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                    size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
-                                                    const SelKp s, const int8_t* __restrict__ pattern, vslam_kp* kps,
-                                                    uint8_t* desc, int cap, int atan_fma) {
-    const int lane = threadIdx.x & 63;
+/* One wave = one keypoint at a time, DESC_KPW keypoints one after the other, software-pipelined: the global loads of
+ * keypoint k+1 (its raw 31x31 patch as 4 dwords per lane, its blurred 37x37 support as 6 dwords per lane) are issued
+ * before keypoint k is computed, so the memory latency hides behind the trigonometry and the sampling of the previous
+ * keypoint.
+ *   moments   : v_dot4_u32_u8 of the raw dwords against the lane's packed disc weights (registers, fixed per lane).
+ *   descriptor: the blurred support goes to the wave's LDS tile (37 rows x 40 bytes, coalesced dword rows); the 512
+ *               rotated pattern points (|x|,|y| <= 13 -> radius <= 18 after rotation) are sampled from LDS.  The
+ *               previous version gathered 749 + 512 single bytes per keypoint from global memory: ~300 cache-line
+ *               accesses per keypoint against ~90 now.
+ * Keypoints are >= 19 px from the level border (EDGE_THRESHOLD), so every patch byte is inside the level; the dword
+ * rows may overrun the 37-px support by up to 3 bytes, still inside the row (or its padding). */
+#define DESC_KPW 4          /* keypoints per wave */
+#define DESC_TP 40          /* LDS tile pitch: 10 dwords cover 18 + 18 + 1 columns from a dword-aligned start */
+#define DESC_TROWS 37
+#define DESC_TILE_BYTES (DESC_TP * DESC_TROWS + 8)
+
+struct DescLoads {
+    uint32_t raw[4]; /* raw patch: item i = lane + 64 k -> row i >> 3, dword i & 7 (rows 0..30 of 31) */
+    uint32_t blr[6]; /* blurred support: item i = lane + 64 k -> row i / 10, dword i % 10 (370 items) */
+};
+
+__device__ __forceinline__ void desc_issue_loads(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                 size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                                                 const SelKp s, int lane, DescLoads& L) {
     const LevelGeom lg = g.lv[s.level];
     int pitch;
     const uint8_t* img = level_base(pyr, slot_stride, src, lg, s.level, s.slot, &pitch);
-    const uint8_t* center = img + (size_t)s.y * pitch + s.x;
+    const uint8_t* c = img + (size_t)((int)s.y - 15) * pitch + ((int)s.x - 15);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        L.raw[k] = 0;
+        if (i < 248) L.raw[k] = *(const uint32_t*)(c + (size_t)(i >> 3) * pitch + 4 * (i & 7)); /* unaligned dword */
+    }
+    const int xs = ((int)s.x - 18) & ~3;
+    const uint8_t* bc = blur + (size_t)s.slot * slot_stride + lg.off + (size_t)((int)s.y - 18) * lg.pitch + xs;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = lane + 64 * k;
+        const int row = (i * 205) >> 11; /* i / 10 for i < 1024 */
+        L.blr[k] = 0;
+        if (i < 370) L.blr[k] = *(const uint32_t*)(bc + (size_t)row * lg.pitch + 4 * (i - row * 10));
+    }
+}
 
+__device__ __forceinline__ void desc_compute(const PyramidGeom& g, const SelKp s, const DescLoads& L, uint8_t* tile,
+                                             const uint32_t wu[4], const uint32_t wm[4], const char4 pat[4],
+                                             vslam_kp* kps, uint8_t* desc, int cap, int atan_fma, int lane) {
+    const LevelGeom lg = g.lv[s.level];
+    /* blurred support -> LDS (LDS operations of one wave execute in order: no barrier between these stores and the
+     * sampling reads below, nor between the reads of one keypoint and the stores of the next) */
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = lane + 64 * k;
+        if (i < 370) ((uint32_t*)tile)[i] = L.blr[k];
+    }
+    /* IC_Angle */
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < c_disc_n; i += 64) {
-        const int u = c_disc_u[i], v = c_disc_v[i];
-        const int val = center[v * pitch + u];
-        m10 += u * val;
-        m01 += v * val;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = (lane + 64 * k) >> 3;
+        const int rs = (int)__builtin_amdgcn_udot4(L.raw[k], wm[k], 0u, false);
+        m10 += (int)__builtin_amdgcn_udot4(L.raw[k], wu[k], 0u, false) - 15 * rs;
+        m01 += (row - 15) * rs;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -119,23 +183,20 @@ __device__ __forceinline__ void orient_describe_one(const uint8_t* __restrict__ 
         m01 += __shfl_xor(m01, o, 64);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10, atan_fma);
-
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float rad = __fmul_rn(angle, factorPI);
     const float a = vslam_trig::glibc_cosf(rad), b = vslam_trig::glibc_sinf(rad);
-    const uint8_t* bc = blur + (size_t)s.slot * slot_stride + lg.off + (size_t)s.y * lg.pitch + s.x;
-    const int bp = lg.pitch;
+    const int xo = 18 + ((((int)s.x - 18) & 3)) + 18 * DESC_TP; /* tile byte of the keypoint centre */
     unsigned long long w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int pair = q * 64 + lane; /* descriptor bit index */
-        const char4 pt = ((const char4*)pattern)[pair];
+        const char4 pt = pat[q];
         const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * bp + c0], t1 = bc[r1 * bp + c1];
+        const int t0 = tile[xo + r0 * DESC_TP + c0], t1 = tile[xo + r1 * DESC_TP + c1];
         w[q] = __ballot(t0 < t1);
     }
     vslam_kp* okp = kps + (size_t)s.slot * cap + s.out;
@@ -156,14 +217,57 @@ __device__ __forceinline__ void orient_describe_one(const uint8_t* __restrict__ 
     }
 }
 
+/* the per-lane constants of a wave: disc weights of its four raw-patch items, its four pattern point pairs */
+__device__ __forceinline__ void desc_lane_tables(const int8_t* __restrict__ pattern, int lane, uint32_t wu[4],
+                                                 uint32_t wm[4], char4 pat[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        wu[k] = g_mom_wu[lane + 64 * k];
+        wm[k] = g_mom_wm[lane + 64 * k];
+        pat[k] = ((const char4*)pattern)[k * 64 + lane]; /* descriptor bit k*64 + lane */
+    }
+}
+
+/* keypoints sel[first .. first+n) of one list, DESC_KPW per wave */
+__device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                             size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                                             const SelKp* __restrict__ sel, int k0, int kend,
+                                             const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap,
+                                             int atan_fma, uint8_t* tile) {
+    const int lane = threadIdx.x & 63;
+    if (k0 >= kend) return; /* wave-uniform */
+    uint32_t wu[4], wm[4];
+    char4 pat[4];
+    desc_lane_tables(pattern, lane, wu, wm, pat);
+    SelKp s = sel[k0];
+    DescLoads L;
+    desc_issue_loads(pyr, blur, slot_stride, src, g, s, lane, L);
+    for (int k = k0; k < kend; k++) {
+        SelKp sn = s;
+        DescLoads Ln;
+        const bool more = k + 1 < kend; /* wave-uniform */
+        if (more) {
+            sn = sel[k + 1];
+            desc_issue_loads(pyr, blur, slot_stride, src, g, sn, lane, Ln);
+        }
+        desc_compute(g, s, L, tile, wu, wm, pat, kps, desc, cap, atan_fma, lane);
+        if (more) {
+            s = sn;
+            L = Ln;
+        }
+    }
+}
+
 /* host-selected keypoints (quadtree on the host): one flat list for the batch */
 __global__ void __launch_bounds__(256)
 k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
                   BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel, int nsel,
                   const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma) {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= nsel) return; /* wave-uniform */
-    orient_describe_one(pyr, blur, slot_stride, src, g, sel[k], pattern, kps, desc, cap, atan_fma);
+    __shared__ __align__(16) uint8_t s_tile[4][DESC_TILE_BYTES];
+    const int wave = threadIdx.x >> 6;
+    const int k0 = (blockIdx.x * 4 + wave) * DESC_KPW;
+    describe_run(pyr, blur, slot_stride, src, g, sel, k0, min(k0 + DESC_KPW, nsel), pattern, kps, desc, cap, atan_fma,
+                 s_tile[wave]);
 }
 
 /* device-selected keypoints (k_octree + k_assign_out): per-slot lists, counts read from HBM */
@@ -172,6 +276,7 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
                       BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
                       const int32_t* __restrict__ slot_counts, const int8_t* __restrict__ pattern, vslam_kp* kps,
                       uint8_t* desc, int cap, int atan_fma, int bps, int nwork) {
+    __shared__ __align__(16) uint8_t s_tile[4][DESC_TILE_BYTES];
     /* XCD-aware order: workgroups b and b+8 share an XCD/L2.  The (slot, keypoint-block) work list is
      * slot-major and level-major inside a slot, so handing XCD k the k-th contiguous eighth keeps one image
      * (or a few of its levels) per L2 instead of streaming every pyramid through all eight. */
@@ -179,10 +284,11 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
     const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (w >= nwork) return;
     const int slot = w / bps;
-    const int k = (w - slot * bps) * 4 + (threadIdx.x >> 6);
-    if (k >= slot_counts[slot * 4]) return; /* wave-uniform */
-    orient_describe_one(pyr, blur, slot_stride, src, g, sel[(size_t)slot * cap + k], pattern, kps, desc, cap,
-                        atan_fma);
+    const int wave = threadIdx.x >> 6;
+    const int k0 = ((w - slot * bps) * 4 + wave) * DESC_KPW;
+    const int n = slot_counts[slot * 4];
+    describe_run(pyr, blur, slot_stride, src, g, sel + (size_t)slot * cap, k0, min(k0 + DESC_KPW, n), pattern, kps, desc,
+                 cap, atan_fma, s_tile[wave]);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -328,7 +434,8 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
                         const BatchSrc& src, const PyramidGeom& g, const SelKp* sel, int nsel,
                         const int8_t* pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma) {
     if (nsel <= 0) return;
-    hipLaunchKernelGGL(k_orient_describe, dim3((nsel + 3) / 4), dim3(256), 0, st, pyr, blur, slot_stride, src, g,
+    const int per_wg = 4 * DESC_KPW;
+    hipLaunchKernelGGL(k_orient_describe, dim3((nsel + per_wg - 1) / per_wg), dim3(256), 0, st, pyr, blur, slot_stride, src, g,
                        sel, nsel, pattern, kps, desc, cap, atan_fma);
 }
 
@@ -336,7 +443,8 @@ void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* b
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
                             int cap, int atan_fma, int nslots) {
-    const int bps = (cap + 3) / 4, nwork = bps * nslots;
+    const int per_wg = 4 * DESC_KPW;
+    const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
     hipLaunchKernelGGL(k_orient_describe_dev, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
                        src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
 }

@@ -116,8 +116,9 @@ extern "C" int vslam_stereo_match(vslam_fe* feL, int sL, vslam_fe* feR, int sR, 
  * enqueue: images are L0,R0,L1,R1,...; slot 2j = left, 2j+1 = right of pair j. */
 extern "C" int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const uint8_t* const* imgs, size_t pitch,
                                               int imgs_on_device, float bf, float fx, int want_host) {
-    if (!fe || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || 2 * npairs > fe->B || !imgs ||
-        pitch < (size_t)fe->p.width || imgs_on_device < 0 || imgs_on_device > VSLAM_IMGS_PINNED) {
+    if (!fe || npairs < 1 || npairs > VSLAM_MAX_STEREO_JOBS || 2 * npairs > fe->B ||
+        (imgs_on_device != VSLAM_IMGS_STAGED && (!imgs || pitch < (size_t)fe->p.width)) || imgs_on_device < 0 ||
+        imgs_on_device > VSLAM_IMGS_STAGED) {
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }

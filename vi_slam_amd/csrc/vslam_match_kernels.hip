@@ -419,34 +419,70 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
 }
 
-/* Host images -> level 0 of the slots' pyramids, ONE launch per batch: a wave copies one image row, 16 bytes per lane
- * and step, reading the caller's pinned memory (or the context's pinned staging) over PCIe and writing 16-byte
- * aligned chunks of the 128-byte-pitched level-0 buffer.  Source rows may start at any address (KITTI rows are 1241
- * bytes): the loads are unaligned dwordx4, only the last partial chunk of a row is read bytewise so that nothing past
- * the caller's buffer is touched.  PCIe-bound (~0.47 MB per KITTI frame); the waves mostly wait, the CUs stay free
- * for the other contexts' kernels. */
+/* Host images -> level 0 of the slots' pyramids, ONE launch per batch, sized for PCIe and not for the GPU: a handful of
+ * workgroups (PULL_WG_PER_IMG per image) each keep PULL_DEPTH x 16 bytes per lane in flight -- ~1 MB in flight in
+ * all, several times the bandwidth-delay product of the link -- instead of thousands of short-lived workgroups whose
+ * waves would sit in every CU's wave slots waiting for the bus while the other contexts' kernels queue behind them.
+ * A wave copies whole rows: lane = 16-byte chunk, reading the caller's pinned memory (or the context's pinned staging)
+ * and writing 16-byte aligned chunks of the 128-byte-pitched level-0 buffer.  Source rows may start at any address
+ * (KITTI rows are 1241 bytes): the loads are unaligned dwordx4; only the last partial chunk of the image's LAST row is
+ * read bytewise, so nothing past the caller's buffer is touched. */
+#define PULL_WG_PER_IMG 2
+template <int PULL_DEPTH>
 __global__ void __launch_bounds__(256)
 k_pull_images(BatchSrc src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch, int w, int h) {
-    const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), slot = blockIdx.y;
-    if (y >= h) return;
-    const uint8_t* srow = src.l0[slot] + (size_t)y * src.pitch0[slot];
-    uint8_t* drow = pyr + (size_t)slot * slot_stride + off0 + (size_t)y * dpitch;
-    for (int c = lane * 16; c < w; c += 64 * 16) {
-        uint4 v;
-        if (c + 16 <= w) v = *(const uint4*)(srow + c);
-        else {
-            uint32_t t[4] = {0, 0, 0, 0};
-            for (int k = 0; c + k < w; k++) t[k >> 2] |= (uint32_t)srow[c + k] << (8 * (k & 3));
-            v = make_uint4(t[0], t[1], t[2], t[3]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.y;
+    const uint8_t* simg = src.l0[slot];
+    const size_t spitch = src.pitch0[slot];
+    uint8_t* dimg = pyr + (size_t)slot * slot_stride + off0;
+    const int nch = (w + 15) >> 4; /* 16-byte chunks per row */
+    const int nitems = h * nch;    /* (row, chunk) items of the image, dealt to the waves in blocks of 64 x PULL_DEPTH */
+    const int total_waves = PULL_WG_PER_IMG * 4, wid = blockIdx.x * 4 + wave;
+    for (int i0 = wid * 64 * PULL_DEPTH; i0 < nitems; i0 += total_waves * 64 * PULL_DEPTH) {
+        uint4 v[PULL_DEPTH];
+#pragma unroll
+        for (int u = 0; u < PULL_DEPTH; u++) {
+            const int i = i0 + u * 64 + lane;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (i < nitems) {
+                const int y = i / nch, ch = i - y * nch;
+                const uint8_t* p = simg + (size_t)y * spitch + 16 * ch;
+                if (16 * ch + 16 <= w || y < h - 1) v[u] = *(const uint4*)p; /* may run into the next row: harmless */
+                else {
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (int k = 0; 16 * ch + k < w; k++) t[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+                    v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+            }
         }
-        *(uint4*)(drow + c) = v; /* the padding up to the pitch may be written */
+#pragma unroll
+        for (int u = 0; u < PULL_DEPTH; u++) {
+            const int i = i0 + u * 64 + lane;
+            if (i < nitems) {
+                const int y = i / nch, ch = i - y * nch;
+                *(uint4*)(dimg + (size_t)y * dpitch + 16 * ch) = v[u]; /* the padding up to the pitch may be written */
+            }
+        }
     }
 }
 
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
-                    int w, int h, int nimg) {
-    hipLaunchKernelGGL(k_pull_images, dim3((h + 3) / 4, nimg), dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
+                    int w, int h, int nimg, int from_host) {
+    /* from_host: the rows come over PCIe.  Host reads stay in the L2's miss queues for microseconds; more of them in
+     * flight than the link needs (bandwidth x latency ~ 150 KB) only delays the HBM requests of the kernels that run
+     * beside the pull.  From device memory (the SDMA staging buffer) the deep variant simply finishes sooner. */
+    static int depth_host = -1;
+    if (depth_host < 0) {
+        const char* e = getenv("VSLAM_PULL_DEPTH");
+        depth_host = e ? atoi(e) : 1;
+    }
+    const dim3 grid(PULL_WG_PER_IMG, nimg);
+    const int depth = from_host ? depth_host : 8;
+    if (depth >= 8) hipLaunchKernelGGL(k_pull_images<8>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
+    else if (depth >= 4) hipLaunchKernelGGL(k_pull_images<4>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
+    else if (depth >= 2) hipLaunchKernelGGL(k_pull_images<2>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
+    else hipLaunchKernelGGL(k_pull_images<1>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
 }
 
 /* zero the (total, overflow) header of every slot's candidate buffer and the quadtree's 16-byte error word */
