@@ -10,9 +10,10 @@ stereo = len(sys.argv) > 1 and sys.argv[1] == "stereo"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 NF = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
-W, H = 1241, 376
+W = int(sys.argv[5]) if len(sys.argv) > 5 else 1241
+H = int(sys.argv[6]) if len(sys.argv) > 6 else 376
 fe = V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=B)
-pitch = 1280
+pitch = (W + 127) & ~127
 dev = torch.zeros((B, H, pitch), dtype=torch.uint8, device="cuda")
 for s in range(B):
     dev[s, :, :W] = torch.from_numpy(synth.make_frame(W, H, step=s // 2, right=bool(s & 1))).cuda()

@@ -11,7 +11,7 @@ import sys
 
 root = sys.argv[1]
 out = collections.defaultdict(dict)
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     files = glob.glob("%s/%s/*/*counter_collection.csv" % (root, sub))
     if not files:
         continue
@@ -28,7 +28,9 @@ for sub in ("fetch", "write", "sq"):
         out[k]["launches_" + sub] = len(v)
 B = sys.argv[2] if len(sys.argv) > 2 else "16"
 NF = sys.argv[3] if len(sys.argv) > 3 else "2000"
-res = {"workload": "run_extract_loop.py: 1241x376, %s features, %s images per launch, 5 launches" % (NF, B),
+W = sys.argv[4] if len(sys.argv) > 4 else "1241"
+H = sys.argv[5] if len(sys.argv) > 5 else "376"
+res = {"workload": "run_extract_loop.py: %sx%s, %s features, %s images per launch, 5 launches (single context)" % (W, H, NF, B),
        "kernels": {}}
 for k, d in sorted(out.items()):
     e = dict(d)

@@ -285,8 +285,9 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         fe->n_blur_tasks = (int)tasks.size();
         int rc;
         if ((rc = upload(&fe->d_blur_tasks, tasks.data(), tasks.size() * 4))) return rc;
-        /* limits of k_fast_cells_v3 (LDS pitch 72, 2 keep words per interior row) and k_blur7_v2 (8-byte row windows);
-         * cell windows are at most 59 + 6 px on a side and levels at least 40 px wide, so these never trigger */
+        /* limits of k_fast_cells_v3 (LDS pitch 72, 2 keep words per interior row) and
+         * k_blur7_v2 (8-byte row windows); cell windows are at most 59 + 6 px on a side and levels at least 40 px wide,
+         * so these never trigger */
         if (maxw > 66 || maxh > 134 || fe->geom.lv[p.nlevels - 1].w < 8) {
             g_err = "FAST cell window larger than 66 x 134 px";
             return VSLAM_ERR_UNSUPPORTED;
@@ -569,18 +570,22 @@ static int stage_host_images(vslam_fe* fe, int nimg, const uint8_t* const* imgs,
     return VSLAM_OK;
 }
 
-static bool h2d_uses_sdma() { /* VSLAM_H2D = sdma (default) | pull */
+/* VSLAM_H2D = sdma | pull forces one transport; default: the DMA engines for batches (they run beside the other
+ * contexts' kernels without disturbing them), the pull kernel for one or two images (a synchronous single-frame call
+ * has nothing to overlap with, and the hand-over between the DMA engine and the compute queue costs ~30 us) */
+static int h2d_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VSLAM_H2D");
-        v = !(e && !strcmp(e, "pull"));
+        v = !e ? 0 : !strcmp(e, "pull") ? 1 : !strcmp(e, "sdma") ? 2 : 0;
     }
-    return v != 0;
+    return v;
 }
+static bool h2d_uses_sdma(int nimg) { return h2d_mode() == 2 || (h2d_mode() == 0 && nimg > 2); }
 
 /* the device staging buffer of the sdma transport, allocated OUTSIDE stream capture (hipMalloc is not capturable) */
-static int ensure_stage(vslam_fe* fe, size_t spitch) {
-    if (!h2d_uses_sdma()) return VSLAM_OK;
+static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
+    if (!h2d_uses_sdma(nimg)) return VSLAM_OK;
     const size_t one = (size_t)(fe->p.height - 1) * spitch + fe->p.width;
     const size_t stride = (one + 255) & ~(size_t)255;
     if (fe->d_stage_bytes >= stride * fe->B + 256) return VSLAM_OK;
@@ -601,7 +606,7 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
     const vslam_fe_params& p = fe->p;
     hipStream_t st = fe->stream;
     const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
-    const bool use_sdma = h2d_uses_sdma();
+    const bool use_sdma = h2d_uses_sdma(nimg);
     BatchSrc hs;
     for (int s = 0; s < nimg; s++) {
         if (where == VSLAM_IMGS_PINNED && !imgs[s]) {
@@ -852,7 +857,7 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
         if (rc) return rc;
     }
     if (on_device == VSLAM_IMGS_HOST || on_device == VSLAM_IMGS_PINNED) {
-        int rc = ensure_stage(fe, on_device == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch);
+        int rc = ensure_stage(fe, on_device == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch, nimg);
         if (rc) return rc;
     }
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
@@ -1076,7 +1081,7 @@ extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
-    int rc2 = ensure_stage(fe, where == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch);
+    int rc2 = ensure_stage(fe, where == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch, nimg);
     if (rc2) return rc2;
     rc2 = upload_host_rows(fe, nimg, imgs, pitch, where);
     if (rc2) return rc2;

@@ -492,9 +492,11 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     uint8_t* win = smem3;                        /* tile_rows x P; window column c at LDS column c + 1 */
     uint8_t* sc = win + tile_rows * P;          /* (tile_rows-4) x P, interior at (1..ih, 1..iw) */
     uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * P); /* 2 words per interior row */
-    uint16_t* listD = (uint16_t*)(keep + (tile_rows - 6) * 2); /* dark-only up from 0, "both" down from lcap-1 */
-    uint16_t* listB = listD + lcap;                             /* bright-only */
-    __shared__ unsigned long long s_cnt; /* nD | nB << 21 | nX << 42 */
+    /* ONE survivor list: dark-only and "both polarities" pixels (bit 15 set) up from 0, bright-only down from lcap-1;
+     * the three sets are disjoint, so lcap = pixels of the largest cell interior always suffices */
+    uint16_t* list = (uint16_t*)(keep + (tile_rows - 6) * 2);
+    uint8_t* qmask = (uint8_t*)(list + lcap);   /* pre-test result per quad: dark bits | bright bits << 4; 8 or 16 B per row */
+    __shared__ uint32_t s_cnt; /* nD+nX | nB << 16 */
     __shared__ uint32_t s_wave_tot[NT / 64];
     __shared__ int s_any;
 
@@ -515,8 +517,10 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int iw = ww - 6, ih = wh - 6;
     const int nwords = ih * 2;
 
-    /* stage columns x0-1 .. (x0 >= 16; windows end >= 13 px before the row end): 9 lanes x 8 bytes per row
-     * (= the LDS pitch), 28 rows per sweep */
+    /* stage columns x0-1 .. (x0 >= 16; windows end >= 13 px before the row end): LPR lanes x 8 bytes per row
+     * (= the LDS pitch), RPS rows per sweep.  (A workgroup that walks several cells and prefetches the next window into
+     * registers while it works was tried: it costs 20 VGPRs = two of the eight waves per SIMD, and this kernel lives
+     * off its occupancy: 120-160 us against 111-114.) */
     {
         const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
         constexpr int LPR = P / 8, RPS = NT / LPR; /* 8-byte lanes per row, rows per sweep */
@@ -527,9 +531,10 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     }
     for (int i = tid; i < (ih + 2) * (P / 4); i += NT) ((uint32_t*)sc)[i] = 0;
     for (int i = tid; i < nwords; i += NT) keep[i] = 0;
+    for (int i = tid; i < ih * 4; i += NT) ((uint32_t*)qmask)[i] = 0; /* quads outside the interior stay 0 */
     if (tid == 0) {
         s_any = 0;
-        s_cnt = 0ull;
+        s_cnt = 0u;
     }
     __syncthreads();
 
@@ -575,70 +580,77 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
                 mD &= vmask;
                 mB &= vmask;
             }
-            const uint32_t mX = mD & mB;
-            mD &= ~mX;
-            mB &= ~mX;
-            const uint32_t cntp = __popc(mD) | (__popc(mB) << 10) | (__popc(mX) << 20);
-            const uint32_t incl = wave_incl_scan(cntp);
-            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (wtot) { /* wave-uniform */
-                unsigned long long base = 0;
-                if (lane == 0)
-                    base = atomicAdd(&s_cnt, (unsigned long long)(wtot & 0x3FFu) |
-                                                 ((unsigned long long)((wtot >> 10) & 0x3FFu) << 21) |
-                                                 ((unsigned long long)(wtot >> 20) << 42));
-                const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
-                const unsigned long long b64 = ((unsigned long long)bhi << 32) | blo;
-                const uint32_t excl = incl - cntp;
-                uint32_t oD = (uint32_t)(b64 & 0x1FFFFFu) + (excl & 0x3FFu);
-                uint32_t oB = (uint32_t)((b64 >> 21) & 0x1FFFFFu) + ((excl >> 10) & 0x3FFu);
-                uint32_t oX = (uint32_t)(b64 >> 42) + (excl >> 20);
-                const uint32_t code = (uint32_t)(ly * 64 + 4 * qx);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (mD & (1u << k)) listD[oD++] = (uint16_t)(code + k);
-                    if (mB & (1u << k)) listB[oB++] = (uint16_t)(code + k);
-                }
-                uint32_t mx = mX; /* rare */
-                while (mx) {
-                    const int k = __ffs(mx) - 1;
-                    mx &= mx - 1;
-                    listD[lcap - 1 - (int)(oX++)] = (uint16_t)(code + k);
+            /* the sweep only records the quad's result; survivors are compacted ONCE per stage below (the per-sweep
+             * wave scan + LDS atomic + eight masked list writes were ~100 of the ~170 instructions of a sweep) */
+            if (qx < QW && ly < ih) qmask[(ly << qsh) + qx] = (uint8_t)(mD | (mB << 4)); /* 8 or 16 bytes per row */
+        }
+        __syncthreads();
+        /* compaction: a lane takes one dword of the mask array = 4 quads = 16 pixels of a row */
+        int nD, nB;
+        {
+            const int dsh = qsh - 2, ndw = ih << dsh; /* 2 or 4 mask dwords per row */
+            for (int d0 = 0; d0 < ndw; d0 += NT) { /* block-uniform trip count */
+                const int di = d0 + tid;
+                uint32_t m = 0;
+                if (di < ndw) m = ((const uint32_t*)qmask)[di]; /* quads past QW were zeroed and never written */
+                const uint32_t lo = m & 0x0F0F0F0Fu, hi = (m >> 4) & 0x0F0F0F0Fu;
+                const uint32_t both = lo & hi;
+                uint32_t dbits = lo, bbits = hi & ~both; /* dbits keeps the "both" pixels, flagged below */
+                const uint32_t cntp = __popc(dbits) | (__popc(bbits) << 16);
+                const uint32_t incl = wave_incl_scan(cntp);
+                const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (wtot) { /* wave-uniform */
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_cnt, wtot);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t excl = incl - cntp;
+                    uint32_t oD = (base & 0xFFFFu) + (excl & 0xFFFFu);
+                    uint32_t oB = (uint32_t)lcap - 1u - ((base >> 16) + (excl >> 16));
+                    const uint32_t code0 = (uint32_t)((di >> dsh) * 64 + (di & ((1 << dsh) - 1)) * 16); /* row, first column */
+                    while (dbits) {
+                        const int j = __ffs(dbits) - 1; /* byte j >> 3 = quad, bit j & 7 = pixel of the quad */
+                        dbits &= dbits - 1;
+                        const uint32_t px = code0 + (uint32_t)((j >> 3) * 4 + (j & 7));
+                        list[oD++] = (uint16_t)(px | (((both >> j) & 1u) << 15));
+                    }
+                    while (bbits) {
+                        const int j = __ffs(bbits) - 1;
+                        bbits &= bbits - 1;
+                        list[oB--] = (uint16_t)(code0 + (uint32_t)((j >> 3) * 4 + (j & 7)));
+                    }
                 }
             }
         }
         __syncthreads();
-        const unsigned long long tot = s_cnt;
-        const int nD = (int)(tot & 0x1FFFFFu), nB = (int)((tot >> 21) & 0x1FFFFFu), nX = (int)(tot >> 42);
-        const int ntot = nD + nB + nX;
-        /* one pass of the networks over three disjoint lists (no two threads touch the same score byte).  Dark
-         * entries are handed out from thread 0 upwards, bright ones from thread 255 downwards, so with the usual
-         * ~110 + ~110 entries no wave has to run both networks */
+        {
+            const uint32_t tot = s_cnt;
+            nD = (int)(tot & 0xFFFFu);
+            nB = (int)(tot >> 16);
+        }
+        const int ntot = nD + nB;
+        /* one pass of the networks over the disjoint lists (no two threads touch the same score byte).  Dark entries
+         * are handed out from thread 0 upwards, bright ones from thread NT-1 downwards, so with the usual ~110 + ~110
+         * entries no wave has to run both networks; a flagged dark entry (both polarities possible, rare) runs both */
         for (int base = 0; base < max(nD, nB); base += NT) {
             const int iD = base + tid, iB = base + NT - 1 - tid;
             if (iD < nD) {
-                const int code = listD[iD];
-                const int a = fast_half_score<1, P>(win + ((code >> 6) + 3) * P + (code & 63) + 4);
+                const int e = list[iD], code = e & 0x7FFF;
+                const uint8_t* c = win + ((code >> 6) + 3) * P + (code & 63) + 4;
+                int a = fast_half_score<1, P>(c);
+                if (e & 0x8000) a = max(a, fast_half_score<-1, P>(c));
                 sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
             if (iB < nB) {
-                const int code = listB[iB];
+                const int code = list[lcap - 1 - iB];
                 const int a = fast_half_score<-1, P>(win + ((code >> 6) + 3) * P + (code & 63) + 4);
                 sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
-        }
-        for (int i = tid; i < nX; i += NT) { /* rare: both polarities possible */
-            const int code = listD[lcap - 1 - i];
-            const uint8_t* c = win + ((code >> 6) + 3) * P + (code & 63) + 4;
-            const int a = max(fast_half_score<1, P>(c), fast_half_score<-1, P>(c));
-            sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
         }
         __syncthreads();
         /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
         int any = 0;
         for (int i = tid; i < ntot; i += NT) {
-            const int code = i < nD ? listD[i] : i < nD + nB ? listB[i - nD] : listD[lcap - 1 - (i - nD - nB)];
+            const int code = (i < nD ? list[i] : list[lcap - 1 - (i - nD)]) & 0x7FFF;
             const int ly = code >> 6, x = code & 63;
             const uint8_t* q = sc + (ly + 1) * P + x + 1;
             const int s = q[0];
@@ -657,7 +669,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         /* empty at iniThFAST: the whole cell again at minThFAST (fextractor.cpp:800-807).  Scores already in
          * the tile belong to pixels that are listed again (the pre-test is monotone in T) and get rewritten. */
         T = minTh;
-        if (tid == 0) s_cnt = 0ull;
+        if (tid == 0) s_cnt = 0u;
         __syncthreads();
     }
 
@@ -685,19 +697,20 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         cout[cell].base = cd.base;
         cout[cell].count = total;
     }
-    if (cnt == 0) return;
-    uint32_t o = cd.base + wave_off + incl - cnt;
-    for (int j = 0; j < WPT; j++) {
-        const int w = tid * WPT + j;
-        if (w >= nwords) break;
-        uint32_t bits = keep[w];
-        const int kly = w >> 1, kxb = (w & 1) * 32;
-        const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
-        while (bits) {
-            const int k = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const uint32_t s = sc[(kly + 1) * P + kxb + k + 1];
-            cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+    if (cnt != 0) {
+        uint32_t o = cd.base + wave_off + incl - cnt;
+        for (int j = 0; j < WPT; j++) {
+            const int w = tid * WPT + j;
+            if (w >= nwords) break;
+            uint32_t bits = keep[w];
+            const int kly = w >> 1, kxb = (w & 1) * 32;
+            const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
+            while (bits) {
+                const int k = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t s = sc[(kly + 1) * P + kxb + k + 1];
+                cand[o++] = (s << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+            }
         }
     }
 }
@@ -731,7 +744,7 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
     }
     const int P = (max_window_w <= 42 && !force72) ? 48 : 72;
     const size_t shm = (size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 +
-                       (size_t)lcap * 2 * 2 + 16;
+                       (size_t)lcap * 2 + (size_t)(tile_rows - 6) * 16 + 16;
     const dim3 grid(((ncells + 7) / 8) * 8, nslots);
     const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
 #define FAST3_LAUNCH(NT_, P_)                                                                                              \

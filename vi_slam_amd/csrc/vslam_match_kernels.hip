@@ -472,13 +472,13 @@ void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t sl
     /* from_host: the rows come over PCIe.  Host reads stay in the L2's miss queues for microseconds; more of them in
      * flight than the link needs (bandwidth x latency ~ 150 KB) only delays the HBM requests of the kernels that run
      * beside the pull.  From device memory (the SDMA staging buffer) the deep variant simply finishes sooner. */
-    static int depth_host = -1;
+    static int depth_host = -1; /* VSLAM_PULL_DEPTH; default: shallow beside other work (batches), deep for one or two images */
     if (depth_host < 0) {
         const char* e = getenv("VSLAM_PULL_DEPTH");
-        depth_host = e ? atoi(e) : 1;
+        depth_host = e ? atoi(e) : 0;
     }
     const dim3 grid(PULL_WG_PER_IMG, nimg);
-    const int depth = from_host ? depth_host : 8;
+    const int depth = !from_host ? 8 : depth_host ? depth_host : nimg <= 2 ? 8 : 1;
     if (depth >= 8) hipLaunchKernelGGL(k_pull_images<8>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
     else if (depth >= 4) hipLaunchKernelGGL(k_pull_images<4>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
     else if (depth >= 2) hipLaunchKernelGGL(k_pull_images<2>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
