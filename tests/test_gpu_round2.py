@@ -244,3 +244,24 @@ def test_staged_upload_then_extract_equals_pinned_path():
     finally:
         pin.close()
         fe.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"VSLAM_OCT_FINE_D": "1"}, {"VSLAM_OCT_FINE_D": "3"}, {"VSLAM_OCTREE": "v2"}])
+@pytest.mark.parametrize("cfg", [(1241, 376, 1000), (640, 480, 3000), (1920, 1080, 4000)])
+def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(monkeypatch, env, cfg):
+    """k_octree_v3 counts keys once into a fine grid and never walks them per pass; when a split would need a finer
+    grid than it has (forced here with a depth of 1 or 3) it hands the (slot, level) problem to k_octree_v2.  Every
+    variant must give the oracle's keypoints."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, h, nf = cfg
+    imgs = [synth.make_frame(w, h, seed=50 + nf, step=s) for s in range(2)]
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=2)
+    try:
+        res = fe.compute_batch(imgs)
+        e = orbo.Extractor(nf)
+        for s in range(2):
+            ko, do, _ = e.compute(imgs[s])
+            _same_feats(res[s], (ko, do), "%s %s slot %d" % (env, cfg, s))
+    finally:
+        fe.close()

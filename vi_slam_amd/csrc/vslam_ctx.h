@@ -149,6 +149,8 @@ struct vslam_fe {
     OctParams oct;
     uint32_t* d_pts[2] = {nullptr, nullptr};  /* key ping-pong arrays, B x cand_cap */
     uint16_t* d_nid[2] = {nullptr, nullptr};  /* node (list index) of every key */
+    uint32_t* d_fine = nullptr;               /* k_octree_v3: fine-cell counts + prefix sums, B x oct.fineStride */
+    int32_t* d_oct_redo = nullptr;            /* k_octree_v3 -> k_octree_v2 hand-over flags, B x VSLAM_MAX_LEVELS */
     uint32_t* d_sel_xyr = nullptr;            /* per slot / level result lists */
     int32_t* d_sel_cnt = nullptr;
     int32_t* d_counts = nullptr;              /* [slot][4] = n, monoIndex, -, - ; then [B*4] = error flags */

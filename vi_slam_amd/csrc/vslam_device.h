@@ -68,6 +68,12 @@ struct OctParams {
     int32_t ptsCap;                   /* entries per slot in the key ping-pong arrays */
     int32_t maxIter;                  /* split passes allowed (64; lower only for timing experiments) */
     void* dbg;                        /* timing stamps (diagnostic builds only) */
+    /* k_octree_v3: keys are counted ONCE into the leaves of an implicit quadtree of depth fineD below the initial nodes
+     * (nIni << 2*fineD fine cells, <= 65536); a node of depth d is a run of 4^(fineD-d) fine cells, so the child
+     * counts of every split pass are differences of one prefix-sum array */
+    int32_t fineD[VSLAM_MAX_LEVELS];
+    int32_t fineOff[VSLAM_MAX_LEVELS]; /* uint32 offset of the level's two arrays (cells+1 each) in a slot's scratch */
+    int32_t fineStride;                /* uint32 entries of fine scratch per slot */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

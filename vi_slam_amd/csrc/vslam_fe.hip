@@ -59,6 +59,8 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_nid[0]);
     hipFree(fe->d_nid[1]);
     hipFree(fe->d_sel_xyr);
+    hipFree(fe->d_fine);
+    hipFree(fe->d_oct_redo);
     hipFree(fe->d_sel_cnt);
     hipFree(fe->d_counts);
     if (fe->h_counts) hipHostFree(fe->h_counts);
@@ -323,10 +325,29 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             selOff += cap_l;
             maxNodes = std::max(maxNodes, cap_l);
             /* k_octree_v2 parks a level's cell offsets (one u32 per cell) in the second node array (4 u32 per node) */
-            maxNodes = std::max(maxNodes, (fe->level_cell_first[l + 1] - fe->level_cell_first[l] + 3) / 4);
+            maxNodes = std::max(maxNodes, (fe->level_cell_first[l + 1] - fe->level_cell_first[l] + 1 + 3) / 4); /* + sentinel */
             if (nIni > 64) ok = false;
         }
         O.cellFirst[p.nlevels] = fe->level_cell_first[p.nlevels];
+        {
+            /* k_octree_v3's fine grid: deep enough that the split passes (which stop at N nodes) normally never reach
+             * a single fine cell -- a full quadtree has nIni * 4^d nodes at depth d -- plus two levels of slack for
+             * clustered keys; at most 65536 cells per level.  VSLAM_OCT_FINE_D forces a depth (tests: hand-over). */
+            const char* fd = getenv("VSLAM_OCT_FINE_D");
+            int fineOff = 0;
+            for (int l = 0; l < p.nlevels; l++) {
+                int D = 2;
+                while ((O.nIni[l] << (2 * D)) < O.N[l]) D++;
+                D += 2;
+                if (fd) D = atoi(fd);
+                D = std::max(1, std::min(D, 11));
+                while (D > 1 && ((long long)O.nIni[l] << (2 * D)) > 65536) D--;
+                O.fineD[l] = D;
+                O.fineOff[l] = fineOff;
+                fineOff += 2 * ((O.nIni[l] << (2 * D)) + 1) + 2;
+            }
+            O.fineStride = (fineOff + 3) & ~3;
+        }
         O.selStride = selOff;
         O.maxNodes = (maxNodes + 15) & ~15;
         O.ptsCap = fe->cand_cap;
@@ -350,6 +371,12 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             HIPCHK(hipMalloc((void**)&fe->d_nid[1], np * 2));
             HIPCHK(hipMalloc((void**)&fe->d_sel_xyr, (size_t)fe->B * O.selStride * 4));
             HIPCHK(hipMalloc((void**)&fe->d_sel_cnt, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
+            const char* og = getenv("VSLAM_OCTREE"); /* "v2": the walk-per-pass kernel only (A/B runs) */
+            if (!(og && !strcmp(og, "v2"))) {
+                HIPCHK(hipMalloc((void**)&fe->d_fine, (size_t)fe->B * O.fineStride * 4));
+                HIPCHK(hipMalloc((void**)&fe->d_oct_redo, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
+                HIPCHK(hipMemset(fe->d_oct_redo, 0, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
+            }
         }
         HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
         HIPCHK(hipHostMalloc((void**)&fe->h_counts, (size_t)(fe->B * 4 + 4) * 4, hipHostMallocDefault));
@@ -816,7 +843,8 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
-              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg);
+              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
+              fe->d_fine, fe->d_oct_redo);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
                   d_err, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));

@@ -35,7 +35,8 @@ size_t vk_octree_lds_bytes(int maxNodes);
 int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots);
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
+               int32_t* redo_flags);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
                    const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
                    int32_t* err_flag, int nslots);

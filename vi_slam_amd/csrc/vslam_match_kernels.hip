@@ -438,7 +438,7 @@ k_pull_images(BatchSrc src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int
     uint8_t* dimg = pyr + (size_t)slot * slot_stride + off0;
     const int nch = (w + 15) >> 4; /* 16-byte chunks per row */
     const int nitems = h * nch;    /* (row, chunk) items of the image, dealt to the waves in blocks of 64 x PULL_DEPTH */
-    const int total_waves = PULL_WG_PER_IMG * 4, wid = blockIdx.x * 4 + wave;
+    const int total_waves = (int)gridDim.x * 4, wid = blockIdx.x * 4 + wave;
     for (int i0 = wid * 64 * PULL_DEPTH; i0 < nitems; i0 += total_waves * 64 * PULL_DEPTH) {
         uint4 v[PULL_DEPTH];
 #pragma unroll
@@ -477,7 +477,8 @@ void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t sl
         const char* e = getenv("VSLAM_PULL_DEPTH");
         depth_host = e ? atoi(e) : 0;
     }
-    const dim3 grid(PULL_WG_PER_IMG, nimg);
+    /* a batch: 2 workgroups per image; one or two images (a synchronous single-frame call): spread each over 32 */
+    const dim3 grid(nimg <= 2 ? 32 : PULL_WG_PER_IMG, nimg);
     const int depth = !from_host ? 8 : depth_host ? depth_host : nimg <= 2 ? 8 : 1;
     if (depth >= 8) hipLaunchKernelGGL(k_pull_images<8>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);
     else if (depth >= 4) hipLaunchKernelGGL(k_pull_images<4>, grid, dim3(256), 0, st, src, pyr, slot_stride, off0, dpitch, w, h);

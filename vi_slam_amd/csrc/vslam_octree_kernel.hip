@@ -88,7 +88,7 @@ __device__ __forceinline__ int quadrant(uint32_t pt, const ONode& nd) {
 __global__ void __launch_bounds__(OT)
 k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
          uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag) {
+         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, const int32_t* redo_flags) {
     extern __shared__ __align__(16) uint8_t osm[];
     const int MAXN = P.maxNodes;
     ONode* cur = (ONode*)osm;
@@ -106,6 +106,8 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     /* grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
      * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
     const int level = blockIdx.y, slot = blockIdx.x;
+    /* behind k_octree_v3: only the (slot, level) problems it handed over (block-uniform early exit) */
+    if (redo_flags && !redo_flags[slot * VSLAM_MAX_LEVELS + level]) return;
 #ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
                            of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
     int dbgn = 0;
@@ -464,6 +466,541 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * k_octree_v3: the same distribution without a key walk per pass.
+ *
+ * DivideNode's boundaries depend on the node alone (midpoints, fextractor.cpp:474-475), never on the keys, so the
+ * quadtree below an initial node is a fixed implicit tree and a key's root-to-leaf path (one 2-bit quadrant per
+ * depth) can be computed once.  Keys are counted into the 4^D leaves ("fine cells", D = fineD[level]) of every
+ * initial node with ONE pass of atomics spread over thousands of addresses (k_octree_v2's per-pass histogram put
+ * every key of a pass on a handful of LDS counters: ~2 cycles per key, serialised), the counts are prefix-summed
+ * once, and from then on a node of depth d IS the run of 4^(D-d) fine cells under its path: the child counts a split
+ * pass needs are four differences of the prefix array, per NODE, not per key.  The node-level logic (list order,
+ * "largest first until N", creation ranks) is k_octree_v2's, unchanged.  The final "best response, first key wins"
+ * needs each key's final node: final nodes mark their first fine cell, a forward fill gives every fine cell its
+ * node, and one walk does the arg-max as before.  Key walks left: count, select (v2: two per pass + two).
+ * One workgroup per (slot, level) as before -- the quadtree stays a narrow kernel that hides behind the grid-filling
+ * ones.  A five-launch form with the two key walks as grid-wide kernels (wave-aggregated L2 atomics) was built and
+ * measured: 134 us per 32 KITTI frames against 82 here and 100 for v2 (454 / 448 / 650 at 1080p), the same batch-1
+ * latency, and its key kernels are wide -- they would compete with FAST and the blur for the CUs; dropped.
+ * If a pass would have to split a node that is already a single fine cell (keys clustered more densely than the
+ * fine grid resolves) the workgroup flags the problem and k_octree_v2, launched behind it, redoes exactly that
+ * (slot, level); VSLAM_OCT_FINE_D=<n> forces a shallow grid so that tests exercise the hand-over.
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ int oct_fine_cell(uint32_t key, float hX, int nIni, int Hh, int D) {
+    const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+    int b = (int)__fdiv_rn((float)x, hX); /* initial node, fextractor.cpp:557-561 */
+    b = min(b, nIni - 1);
+    int x0 = (int)__fmul_rn(hX, (float)b), x1 = (int)__fmul_rn(hX, (float)(b + 1)), y0 = 0, y1 = Hh;
+    int code = 0;
+    for (int d = 0; d < D; d++) { /* DivideNode: halfX = ceil((UR.x - UL.x) / 2); kp.x < n1.UR.x, kp.y < n1.BR.y */
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const int qx = x < mx ? 0 : 1, qy = y < my ? 0 : 1;
+        code = (code << 2) | qx | (qy << 1);
+        if (qx) x0 = mx; else x1 = mx;
+        if (qy) y0 = my; else y1 = my;
+    }
+    return (b << (2 * D)) | code;
+}
+
+/* inclusive scans over 64-cell tiles, lane = cell: a wave owns a contiguous run of tiles, loads are coalesced */
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) v = max(v, t);
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(OT)
+k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a,
+            uint16_t* fc_a, size_t pts_stride, uint32_t* fine, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
+            int32_t* redo_flags) {
+    extern __shared__ __align__(16) uint8_t osm[];
+    const int MAXN = P.maxNodes;
+    ONode* cur = (ONode*)osm;
+    ONode* nxt = cur + MAXN;
+    u64* Sbeg = (u64*)(nxt + MAXN);       /* arg-max array of the final selection */
+    u64* Cnt = Sbeg + MAXN;               /* packed per-quadrant key counts of a node */
+    uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
+    uint16_t* newIdx = cb + MAXN;
+    uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
+    uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
+    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ int s_size, s_M, s_nexp, s_cut, s_redo;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int level = blockIdx.y, slot = blockIdx.x;
+    int32_t* redo = redo_flags + slot * VSLAM_MAX_LEVELS + level;
+    const int N = P.N[level];
+    const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    const CellOut* cout = (const CellOut*)(hdr + 2);
+    const uint32_t* cand = (const uint32_t*)(cout + ncells);
+    uint32_t* pa = pts_a + (size_t)slot * pts_stride;
+    uint16_t* fca = fc_a + (size_t)slot * pts_stride; /* fine cell of every key (problems too large for registers) */
+    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
+    int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
+    if (tid == 0) {
+        *redo = 0;
+        s_redo = 0;
+    }
+#ifdef VSLAM_OCT_STAMPS
+    int dbgn3 = 0;
+    unsigned long long* DBG3 = (unsigned long long*)P.dbg;
+#define STAMP3() do { if (DBG3 && tid == 0 && level == 0 && slot == 0 && dbgn3 < 60) DBG3[dbgn3++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP3() do { } while (0)
+#endif
+    STAMP3();
+
+    /* ---- 0. this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817): a key's position in
+     * the gathered array IS its rank in the reference's key order.  Thread t takes the E consecutive positions
+     * [t*E, (t+1)*E): one binary search in the cells' offsets (LDS) for the first, then it walks on cell by cell. */
+    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
+    uint32_t before = 0;
+    for (int c = tid; c < c0; c += OT) before += cout[c].count;
+    uint32_t off0;
+    {
+        uint32_t tot;
+        block_excl_scan<uint32_t>(before, s_w32, &tot);
+        off0 = tot;
+    }
+    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
+    uint32_t mine = 0;
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) mine += cout[c].count;
+    }
+    uint32_t ntot;
+    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
+    const int n = (int)ntot;
+    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
+        if (tid == 0) {
+            atomicOr(err_flag, 1);
+            *ocnt = 0;
+        }
+        return;
+    }
+    pa += off0;
+    fca += off0;
+    /* cell offsets (+ sentinel) and the cells' segment bases, borrowed from the node arrays and Sbeg (2 * ncl + 1 words
+     * <= 4 * MAXN + 2 * MAXN): the gather below then needs ONE global round trip (the keys), not three */
+    uint32_t* coff = (uint32_t*)nxt;
+    uint32_t* cbas = coff + ncl + 1;
+    for (int k = 0; k < K; k++) {
+        const int c = c0 + tid * K + k;
+        if (c < c1) {
+            const CellOut co = cout[c];
+            coff[c - c0] = woff;
+            cbas[c - c0] = co.base;
+            woff += co.count;
+        }
+    }
+    if (tid == 0) coff[ncl] = ntot;
+    __syncthreads();
+    if (n == 0) {
+        if (tid == 0) *ocnt = 0;
+        return;
+    }
+    const int nIni = P.nIni[level];
+    const float hX = P.hX[level];
+    const int Hh = P.H[level];
+    const int D = P.fineD[level];
+    const int cells = nIni << (2 * D);
+    uint32_t* Hc = fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
+    uint32_t* PS = Hc + cells + 1;                                          /* exclusive prefix sums, later the owners */
+    for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+
+    /* keys of a problem of up to OKPT * 1024 keys (every KITTI-size level) and their fine cells stay in REGISTERS */
+    const bool inReg = n <= OKPT * OT;
+    const int E = (n + OT - 1) / OT; /* positions per thread */
+    uint32_t keyR[OKPT];
+    uint32_t cellR[OKPT / 2]; /* two 16-bit fine cells per register */
+#pragma unroll
+    for (int k = 0; k < OKPT; k++) keyR[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < OKPT / 2; k++) cellR[k] = 0u;
+    {
+        const int i0 = min(tid * E, n), i1 = min(i0 + E, n);
+        int c = 0;
+        if (i0 < i1) {
+            int lo = 0, hi = ncl - 1; /* last cell with coff <= i0 (empty cells share an offset: the last one holds it) */
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (coff[mid] <= (uint32_t)i0) lo = mid;
+                else hi = mid - 1;
+            }
+            c = lo;
+        }
+        uint32_t cbase = i0 < i1 ? cbas[c] : 0u, cfirst = i0 < i1 ? coff[c] : 0u, cnext = i0 < i1 ? coff[c + 1] : 0u;
+        if (inReg) {
+#pragma unroll
+            for (int k = 0; k < OKPT; k++) {
+                const int i = i0 + k;
+                if (i < i1) {
+                    while ((uint32_t)i >= cnext) { /* next non-empty cell */
+                        c++;
+                        cfirst = cnext;
+                        cnext = coff[c + 1];
+                        cbase = cbas[c];
+                    }
+                    keyR[k] = cand[cbase + ((uint32_t)i - cfirst)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < OKPT; k++)
+                if (i0 + k < i1) pa[i0 + k] = keyR[k];
+        } else {
+            for (int ib = i0; ib < i1; ib += OBATCH) { /* OBATCH loads in flight, then the stores */
+                uint32_t kk[OBATCH];
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++) {
+                    const int i = ib + j;
+                    kk[j] = 0u;
+                    if (i < i1) {
+                        while ((uint32_t)i >= cnext) {
+                            c++;
+                            cfirst = cnext;
+                            cnext = coff[c + 1];
+                            cbase = cbas[c];
+                        }
+                        kk[j] = cand[cbase + ((uint32_t)i - cfirst)];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++)
+                    if (ib + j < i1) pa[ib + j] = kk[j];
+            }
+        }
+    }
+    __syncthreads(); /* coff (in nxt) is free again; pa and the zeroed counters are complete */
+    STAMP3();
+
+    /* ---- 1. count the keys per fine cell */
+    if (inReg) {
+#pragma unroll
+        for (int k = 0; k < OKPT; k++) {
+            const int i = tid * E + k;
+            if (k < E && i < n) {
+                const int f = oct_fine_cell(keyR[k], hX, nIni, Hh, D);
+                cellR[k >> 1] |= (uint32_t)f << (16 * (k & 1));
+                atomicAdd(&Hc[f], 1u);
+            }
+        }
+    } else {
+        for (int base = tid; base < n; base += OBATCH * OT) {
+            uint32_t kk[OBATCH];
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) {
+                const int i = base + j * OT;
+                kk[j] = i < n ? pa[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++)
+                if (base + j * OT < n) {
+                    const int f = oct_fine_cell(kk[j], hX, nIni, Hh, D);
+                    fca[base + j * OT] = (uint16_t)f; /* the selection below reads it instead of walking the path again */
+                    atomicAdd(&Hc[f], 1u);
+                }
+        }
+    }
+    __syncthreads();
+    /* the counters were updated by atomics that execute in L2: drop whatever this CU's L1 holds of them (the zeroing
+     * stores may have allocated lines) before reading them with plain, coalesced loads */
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    STAMP3();
+    const int ntile = (cells + 63) >> 6, tpw = (ntile + OT / 64 - 1) / (OT / 64); /* tiles per wave */
+    {   /* exclusive prefix sums of the fine counts */
+        uint32_t carry = 0;
+        for (int t0 = wv * tpw; t0 < min((wv + 1) * tpw, ntile); t0 += 8) { /* 8 tiles in flight */
+            uint32_t h8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = (t0 + u) * 64 + lane;
+                h8[u] = (t0 + u < min((wv + 1) * tpw, ntile) && c < cells) ? Hc[c] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = (t0 + u) * 64 + lane;
+                const uint32_t inc = wave_incl_add(h8[u]);
+                if (t0 + u < min((wv + 1) * tpw, ntile) && c < cells) PS[c] = carry + inc - h8[u];
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
+        if (lane == 0) s_w32[wv] = carry;
+        __syncthreads();
+        uint32_t wo = 0;
+        for (int k = 0; k < wv; k++) wo += s_w32[k];
+        if (wo)
+            for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) {
+                const int c = t * 64 + lane;
+                if (c < cells) PS[c] += wo;
+            }
+        if (tid == 0) PS[cells] = (uint32_t)n;
+    }
+    __syncthreads();
+    STAMP3();
+    /* initial nodes; ONode.begin = first fine cell | depth << 24 */
+    if (tid == 0) {
+        int li = 0;
+        for (int b = 0; b < nIni; b++) {
+            const uint32_t cb0 = PS[(b + 1) << (2 * D)] - PS[b << (2 * D)];
+            if (cb0) { /* empty initial nodes are erased (fextractor.cpp:572-573) */
+                ONode nd;
+                nd.x0 = (int16_t)(int)__fmul_rn(hX, (float)b);
+                nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
+                nd.y0 = 0;
+                nd.y1 = (int16_t)Hh;
+                nd.begin = (uint32_t)(b << (2 * D));
+                nd.cf = (cb0 << 1) | (cb0 == 1 ? 1u : 0u);
+                cur[li++] = nd;
+            }
+        }
+        s_size = li;
+    }
+    __syncthreads();
+
+    /* ---- 2. split passes: k_octree_v2's node logic; the children's key counts come from the prefix sums */
+    int phase = 1;
+    const int KN = (MAXN + OT - 1) / OT;
+    for (int iter = 0; iter < P.maxIter; iter++) {
+        const int size0 = s_size;
+        /* A. children's key counts of every expandable node */
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0) {
+                const ONode nd = cur[v];
+                u64 c = 0ull;
+                if (!ND_NOMORE(nd)) {
+                    const int depth = (int)(nd.begin >> 24);
+                    if (depth >= D) s_redo = 1; /* finer than the grid resolves (benign race: all writers store 1) */
+                    else {
+                        const uint32_t cb0 = nd.begin & 0xFFFFFFu, q4 = 1u << (2 * (D - depth - 1));
+                        const uint32_t p0 = PS[cb0], p1 = PS[cb0 + q4], p2 = PS[cb0 + 2 * q4],
+                                       p3 = PS[cb0 + 3 * q4];
+                        c = (u64)(p1 - p0) | ((u64)(p2 - p1) << FB) | ((u64)(p3 - p2) << (2 * FB));
+                    }
+                }
+                Cnt[v] = c;
+            }
+        }
+        __syncthreads();
+        if (s_redo) { /* block-uniform: hand this (slot, level) to k_octree_v2 */
+            if (tid == 0) *redo = 1;
+            return;
+        }
+        /* D1. processing rank of every expandable node */
+        uint32_t nexp_mine = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
+        }
+        uint32_t nexp;
+        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
+        if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
+        if (phase == 1) {
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !ND_NOMORE(cur[v])) {
+                    prank[v] = (uint16_t)rbase;
+                    ordv[rbase] = (uint16_t)v;
+                    rbase++;
+                }
+            }
+        } else {
+            /* descending (count, "created later" == smaller list index) */
+            for (int k = 0; k < KN; k++) {
+                const int v = tid * KN + k;
+                if (v < size0 && !ND_NOMORE(cur[v])) {
+                    const uint32_t cv = ND_COUNT(cur[v]);
+                    uint32_t r = 0;
+#pragma unroll 8
+                    for (int u = 0; u < size0; u++) {
+                        const uint32_t cfu = cur[u].cf; /* count << 1 | noMore */
+                        r += (!(cfu & 1u) && ((cfu >> 1) > cv || ((cfu >> 1) == cv && u < v))) ? 1u : 0u;
+                    }
+                    prank[v] = (uint16_t)r;
+                    ordv[r] = (uint16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        /* D2. in processing order: children created before me, running list size -> cut */
+        const int KE = ((int)nexp + OT - 1) / OT;
+        uint32_t chl = 0;
+        for (int k = 0; k < KE; k++) {
+            const int r = tid * KE + k;
+            if (r < (int)nexp) {
+                const int v = ordv[r];
+                chl += nchildren(Cnt[v], ND_COUNT(cur[v]));
+            }
+        }
+        uint32_t chtot;
+        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
+        if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
+        __syncthreads();
+        {
+            /* parent r is processed iff size0 + sum_{r'<r}(nch-1) < N (phase 2); phase 1: all */
+            uint32_t cb_run = chbase;
+            for (int k = 0; k < KE; k++) {
+                const int r = tid * KE + k;
+                if (r < (int)nexp) {
+                    const int v = ordv[r];
+                    const uint32_t nch = nchildren(Cnt[v], ND_COUNT(cur[v]));
+                    if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
+                    cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
+                    cb_run += nch;
+                }
+            }
+        }
+        __syncthreads();
+        const int ncut = s_cut;
+        if (tid == 0) {
+            int M;
+            if (ncut >= (int)nexp) M = (int)chtot;
+            else M = cb[ordv[ncut]];
+            s_M = M;
+            s_size = size0 + M - ncut;
+            s_nexp = 0;
+        }
+        __syncthreads();
+        const int M = s_M;
+        /* D3. survivors keep their relative order behind the children (created in reverse) */
+        uint32_t sv = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v < size0) {
+                const bool processed = !ND_NOMORE(cur[v]) && prank[v] < ncut;
+                if (!processed) sv++;
+            }
+        }
+        uint32_t svtot;
+        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
+        int nexp_children = 0;
+        for (int k = 0; k < KN; k++) {
+            const int v = tid * KN + k;
+            if (v >= size0) continue;
+            const ONode nd = cur[v];
+            const bool processed = !ND_NOMORE(nd) && prank[v] < ncut;
+            if (!processed) {
+                nxt[M + svbase] = nd;
+                svbase++;
+            } else {
+                const u64 c = Cnt[v];
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                const int depth = (int)(nd.begin >> 24);
+                const uint32_t cb0 = nd.begin & 0xFFFFFFu, q4 = 1u << (2 * (D - depth - 1));
+                int kq = 0;
+                const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
+                const uint32_t c3 = ND_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cq = q < 3 ? fld(c, q) : c3;
+                    if (!cq) continue;
+                    ONode ch;
+                    ch.x0 = (q & 1) ? (int16_t)mx : nd.x0;
+                    ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
+                    ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
+                    ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
+                    ch.begin = (cb0 + (uint32_t)q * q4) | ((uint32_t)(depth + 1) << 24);
+                    ch.cf = (cq << 1) | (cq == 1 ? 1u : 0u);
+                    nxt[first - kq] = ch;
+                    if (cq > 1) nexp_children++;
+                    kq++;
+                }
+            }
+        }
+        if (nexp_children) atomicAdd(&s_nexp, nexp_children);
+        __syncthreads();
+        { ONode* t = cur; cur = nxt; nxt = t; }
+        /* F. loop control (fextractor.cpp:658-729) */
+        const int size = s_size, nToExpand = s_nexp;
+        __syncthreads();
+        if (size >= N || size == size0) break;
+        if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
+    }
+
+    STAMP3();
+    /* ---- 3. best response per node, first in key order wins (fextractor.cpp:732-751).  Every final node marks its
+     * first fine cell with (cell << 16 | list index + 1); a forward max-fill gives every cell the node it lies in. */
+    const int size = s_size;
+    u64* best = Sbeg;
+    for (int v = tid; v < size; v += OT) best[v] = 0ull;
+    for (int i = tid; i < cells; i += OT) Hc[i] = 0u;
+    __syncthreads();
+    for (int v = tid; v < size; v += OT) {
+        const uint32_t cb0 = cur[v].begin & 0xFFFFFFu;
+        Hc[cb0] = (cb0 << 16) | (uint32_t)(v + 1);
+    }
+    __syncthreads();
+    {
+        uint32_t carry = 0;
+        for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) { /* the wave's last marker, for the waves behind */
+            const int c = t * 64 + lane;
+            const uint32_t h = c < cells ? Hc[c] : 0u;
+            carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(h), 63));
+        }
+        if (lane == 0) s_w32[wv] = carry;
+        __syncthreads();
+        uint32_t run = 0;
+        for (int k = 0; k < wv; k++) run = max(run, s_w32[k]);
+        for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) {
+            const int c = t * 64 + lane;
+            const uint32_t h = c < cells ? Hc[c] : 0u;
+            const uint32_t inc = max(run, wave_incl_max(h));
+            if (c < cells) PS[c] = inc & 0xFFFFu; /* list index + 1 of the node this fine cell lies in */
+            run = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+    }
+    __syncthreads();
+    STAMP3();
+    if (inReg) {
+#pragma unroll
+        for (int k = 0; k < OKPT; k++) {
+            const int i = tid * E + k;
+            if (k < E && i < n) {
+                const uint32_t nid = PS[(cellR[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] - 1u;
+                atomicMax(&best[nid], ((u64)(keyR[k] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+            }
+        }
+    } else {
+        for (int base = tid; base < n; base += OBATCH * OT) {
+            uint32_t kk[OBATCH], ff[OBATCH];
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) {
+                const int i = base + j * OT;
+                kk[j] = i < n ? pa[i] : 0u;
+                ff[j] = i < n ? (uint32_t)fca[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) ff[j] = base + j * OT < n ? PS[ff[j]] : 1u;
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) {
+                const int i = base + j * OT;
+                if (i < n) atomicMax(&best[ff[j] - 1u], ((u64)(kk[j] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+            }
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < size; v += OT) /* every listed node holds at least one key */
+        out[v] = best[v] ? pa[0xFFFFFFFFu - (uint32_t)(best[v] & 0xFFFFFFFFull)] : 0u;
+#ifdef VSLAM_OCT_STAMPS
+    __syncthreads();
+    STAMP3();
+    if (DBG3 && tid == 0 && level == 0 && slot == 0) DBG3[63] = dbgn3;
+#endif
+    if (tid == 0) *ocnt = size;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * output order of a slot (fextractor.cpp:1071-1129): level-major; a keypoint whose scaled x lies in
  * [lap0, lap1] takes the next free index from the tail, the others from the head.  One workgroup per
  * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
@@ -538,10 +1075,18 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots) {
-    hipLaunchKernelGGL(k_octree_v2, dim3(nslots, nlevels), dim3(OT), vk_octree_lds_bytes(P.maxNodes), st,
-                       cand_region, cand_stride, ncells, P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt,
-                       err_flag);
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
+               int32_t* redo_flags) {
+    const dim3 grid(nslots, nlevels);
+    if (fine && redo_flags) { /* k_octree_v3, then k_octree_v2 for the problems it handed over (normally none) */
+        hipLaunchKernelGGL(k_octree_v3, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
+                           P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
+        hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
+                           P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag, (const int32_t*)redo_flags);
+        return;
+    }
+    hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
+                       pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag, (const int32_t*)nullptr);
 }
 
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
@@ -552,5 +1097,7 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, con
 }
 
 int vk_octree_set_max_lds(size_t bytes) {
-    return (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_octree_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
