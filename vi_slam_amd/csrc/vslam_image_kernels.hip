@@ -483,6 +483,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+#ifdef VSLAM_FAST_STAMPS /* diagnostic build: cycles per phase of wave 0 of every workgroup, summed (tools/fast_stamps.py) */
+__device__ unsigned long long g_fast_stamps[16];
+#define FSTAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_fast_stamps[k], t_ - fst_); fst_ = t_; } } while (0)
+extern "C" int vslam_dbg_fast_stamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fast_stamps), sizeof(g_fast_stamps)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamps), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
 template <int NT, int P> /* P: LDS pitch, 48 for windows up to 42 px, else 72 */
 __global__ void __launch_bounds__(NT)
 k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
@@ -501,6 +515,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     __shared__ int s_any;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef VSLAM_FAST_STAMPS
+    unsigned long long fst_ = __builtin_amdgcn_s_memtime();
+#endif
     const int slot = blockIdx.y;
     /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2), so XCD k takes the k-th contiguous
      * eighth of the cell list -- neighbouring cells, whose windows overlap by 6 px and share image rows, then hit
@@ -508,7 +525,19 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int per_xcd = (ncells + 7) >> 3;
     const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (cell >= ncells) return;
-    const CellDesc cd = cells[cell];
+    /* the cell record through the SCALAR cache: as four dwords (a 16-bit field alone becomes a vector load, i.e. one
+     * more full memory round trip in front of the window fetch -- the prologue's latency is half of a wave's life) */
+    CellDesc cd;
+    {
+        const uint4 raw = ((const uint4*)cells)[cell];
+        cd.level = (uint16_t)(raw.x & 0xFFFF);
+        cd.x0 = (uint16_t)(raw.x >> 16);
+        cd.y0 = (uint16_t)(raw.y & 0xFFFF);
+        cd.x1 = (uint16_t)(raw.y >> 16);
+        cd.y1 = (uint16_t)(raw.z & 0xFFFF);
+        cd.pad = 0;
+        cd.base = raw.w;
+    }
     const int level = cd.level;
     const LevelGeom lg = g.lv[level];
     int pitch;
@@ -518,16 +547,24 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int nwords = ih * 2;
 
     /* stage columns x0-1 .. (x0 >= 16; windows end >= 13 px before the row end): LPR lanes x 8 bytes per row
-     * (= the LDS pitch), RPS rows per sweep.  (A workgroup that walks several cells and prefetches the next window into
-     * registers while it works was tried: it costs 20 VGPRs = two of the eight waves per SIMD, and this kernel lives
-     * off its occupancy: 120-160 us against 111-114.) */
-    {
-        const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
-        constexpr int LPR = P / 8, RPS = NT / LPR; /* 8-byte lanes per row, rows per sweep */
-        const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
-        if (tid < RPS * LPR && scol < ww + 1)
-            for (int y = srow; y < wh; y += RPS)
-                *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
+     * (= the LDS pitch), RPS rows per sweep.  ALL loads of the window are issued before anything waits for one, and the
+     * tiles are zeroed while they are in flight.  In-kernel stamps (tools/fast_stamps.py, -DVSLAM_FAST_STAMPS) put 36 %
+     * of wave 0's life into this prologue, 27 % into the pre-test sweeps and 20 % into the six barriers -- but the
+     * waiting is hidden by the other seven waves of the SIMD: a workgroup that walks several cells and prefetches the
+     * next window while it works was built twice -- register staging (+20 VGPRs: 6 waves per SIMD) and LDS-DMA
+     * (global_load_lds_dwordx4 into a second tile, 7 waves per SIMD) -- and both were SLOWER (117-160 us against 111):
+     * what this kernel is short of is issue slots per instruction, not latency cover. */
+    constexpr int LPR = P / 8, RPS = NT / LPR;        /* 8-byte lanes per row, rows per sweep */
+    constexpr int NSW = (134 + RPS - 1) / RPS > 4 ? 4 : (134 + RPS - 1) / RPS; /* sweeps kept in registers at once */
+    const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
+    const bool stager = tid < RPS * LPR && scol < ww + 1;
+    const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
+    uint2 wreg[NSW];
+#pragma unroll
+    for (int u = 0; u < NSW; u++) {
+        const int y = srow + u * RPS;
+        wreg[u] = make_uint2(0u, 0u);
+        if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
     }
     for (int i = tid; i < (ih + 2) * (P / 4); i += NT) ((uint32_t*)sc)[i] = 0;
     for (int i = tid; i < nwords; i += NT) keep[i] = 0;
@@ -536,7 +573,17 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         s_any = 0;
         s_cnt = 0u;
     }
+#pragma unroll
+    for (int u = 0; u < NSW; u++) {
+        const int y = srow + u * RPS;
+        if (stager && y < wh) *(uint2*)(win + y * P + scol) = wreg[u];
+    }
+    if (stager) /* taller windows than NSW sweeps cover (cells of unusual geometries): the rest row by row */
+        for (int y = srow + NSW * RPS; y < wh; y += RPS)
+            *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
+    FSTAMP(0);
     __syncthreads();
+    FSTAMP(1);
 
     const int QW = (iw + 3) >> 2;               /* quads per interior row */
     const int qsh = QW > 8 ? 4 : 3;             /* 16 or 8 quad columns per sweep */
@@ -584,7 +631,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
              * wave scan + LDS atomic + eight masked list writes were ~100 of the ~170 instructions of a sweep) */
             if (qx < QW && ly < ih) qmask[(ly << qsh) + qx] = (uint8_t)(mD | (mB << 4)); /* 8 or 16 bytes per row */
         }
+        FSTAMP(2);
         __syncthreads();
+        FSTAMP(3);
         /* compaction: a lane takes one dword of the mask array = 4 quads = 16 pixels of a row */
         int nD, nB;
         {
@@ -621,7 +670,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
                 }
             }
         }
+        FSTAMP(4);
         __syncthreads();
+        FSTAMP(5);
         {
             const uint32_t tot = s_cnt;
             nD = (int)(tot & 0xFFFFu);
@@ -646,7 +697,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
                 sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
             }
         }
+        FSTAMP(6);
         __syncthreads();
+        FSTAMP(7);
         /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
         int any = 0;
         for (int i = tid; i < ntot; i += NT) {
@@ -664,7 +717,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
             }
         }
         if (any) s_any = 1; /* benign race, all writers store 1 */
+        FSTAMP(8);
         __syncthreads();
+        FSTAMP(9);
         if (s_any || stage == 1 || minTh == iniTh) break; /* block-uniform */
         /* empty at iniThFAST: the whole cell again at minThFAST (fextractor.cpp:800-807).  Scores already in
          * the tile belong to pixels that are listed again (the pre-test is monotone in T) and get rewritten. */
@@ -683,7 +738,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     }
     const uint32_t incl = wave_incl_scan(cnt);
     if (lane == 63) s_wave_tot[wv] = incl;
+    FSTAMP(10);
     __syncthreads();
+    FSTAMP(11);
     uint32_t wave_off = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < NT / 64; k++) {
@@ -713,6 +770,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
             }
         }
     }
+    FSTAMP(12);
 }
 
 /* threads per cell: a cell is 900 pixels, and ~150 of the ~420 instructions a thread executes do not depend on how many
