@@ -142,6 +142,7 @@ struct vslam_fe {
     float* h_stereo = nullptr; /* pinned: [uRight | depth] x pairs x cap */
     size_t h_stereo_bytes = 0;
     int stereo_pairs = 0;
+    int stereo_capR = 0; /* slot capacity of the right context of the last stereo enqueue (scratch carving) */
     int stereo_slotL[VSLAM_MAX_STEREO_JOBS] = {};
 
     /* GPU quadtree distribution */

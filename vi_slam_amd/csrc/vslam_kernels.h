@@ -52,7 +52,9 @@ void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma
 void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
                const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
                const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
-               int32_t* sad, int cap);
+               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch);
+/* bytes of rows_scratch: row table, bucket items and {uR, octave} records of njobs stereo pairs */
+size_t vk_stereo_rows_bytes(int njobs, int nrows, int max_band, int cap);
 void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
                              uint8_t* tmp, uint8_t* out);
 size_t vk_search_init_lds(int cap, int max_c2);

@@ -8,16 +8,22 @@ struct StereoScratch { /* carved out of fe->d_stereo */
     float* uRight;
     float* depth;
     int32_t* sad;
+    uint8_t* rows; /* row table of the right keypoints (vk_stereo_rows_bytes) */
+    int max_band;
 };
 
-static int stereo_scratch(vslam_fe* fe, int njobs, StereoScratch* s) {
+static int stereo_scratch(vslam_fe* fe, int njobs, int capR, StereoScratch* s) {
     const size_t n = (size_t)njobs * fe->cap;
-    int rc = vslam_ensure(&fe->d_stereo, &fe->stereo_bytes, n * 16);
+    /* rows of a right keypoint's band: floor(y - 2s) .. ceil(y + 2s), s <= the coarsest level's scale factor */
+    s->max_band = 2 * (int)std::ceil(2.0f * fe->tab.scale[fe->p.nlevels - 1]) + 3;
+    const size_t rows_bytes = vk_stereo_rows_bytes(njobs, fe->p.height, s->max_band, capR);
+    int rc = vslam_ensure(&fe->d_stereo, &fe->stereo_bytes, n * 16 + rows_bytes + 16);
     if (rc) return rc;
     s->best = (uint32_t*)fe->d_stereo;
     s->uRight = (float*)(s->best + n);
     s->depth = s->uRight + n;
     s->sad = (int32_t*)(s->depth + n);
+    s->rows = (uint8_t*)(s->sad + n);
     if (fe->h_stereo_bytes < n * 8) {
         if (fe->h_stereo) HIPCHK(hipHostFree(fe->h_stereo));
         fe->h_stereo = nullptr;
@@ -57,14 +63,15 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
     }
     if (feL != feR) HIPCHK(hipStreamSynchronize(feR->stream)); /* right results must be complete */
     StereoScratch sc;
-    int rc = stereo_scratch(feL, npairs, &sc);
+    int rc = stereo_scratch(feL, npairs, feR->cap, &sc);
+    feL->stereo_capR = feR->cap;
     if (rc) return rc;
     /* frame.cpp:853-855: mb = mbf/fx (frame.cpp:157), minZ = mb, maxD = mbf/minZ */
     const float mb = bf / fx;
     const float maxD = bf / mb;
     hipStream_t st = feL->stream;
     vk_stereo(st, jobs, npairs, feL->cap, feR->cap, feL->geom, feL->d_pyr, feL->slot_stride, feL->src, feR->d_pyr,
-              feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap);
+              feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap, sc.max_band, sc.rows);
     HIPCHK(hipGetLastError());
     const size_t n = (size_t)npairs * feL->cap;
     CopyRanges R;
@@ -839,7 +846,7 @@ extern "C" int vslam_stereo_points_dev_async(vslam_fe* fe, int npairs, const flo
         HIPCHK(hipMalloc((void**)&fe->d_mpflags, (size_t)fe->B * fe->cap));
     }
     StereoScratch sc;
-    int rc = stereo_scratch(fe, fe->stereo_pairs, &sc); /* same carving as the enqueue that filled it */
+    int rc = stereo_scratch(fe, fe->stereo_pairs, fe->stereo_capR, &sc); /* same carving as the enqueue that filled it */
     if (rc) return rc;
     UnprojJobs U;
     memset(&U, 0, sizeof(U));
@@ -876,7 +883,7 @@ extern "C" int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float**
             return VSLAM_ERR_INVALID;
         }
         StereoScratch sc;
-        int rc = stereo_scratch(fe, fe->stereo_pairs, &sc);
+        int rc = stereo_scratch(fe, fe->stereo_pairs, fe->stereo_capR, &sc);
         if (rc) return rc;
         if (dev_u_right) *dev_u_right = sc.uRight + (size_t)pair * fe->cap;
         if (dev_depth) *dev_depth = sc.depth + (size_t)pair * fe->cap;

@@ -27,79 +27,113 @@ __device__ __forceinline__ int refl101(int p, int len) {
 }
 
 /* ------------------------------------------------------------------------------------------------
- * S0  reset the per-left-keypoint best keys: bestDist = TH_HIGH (100), bestIdxR = 0 (frame.cpp:879-880)
+ * S1  the row table and the masked Hamming arg-min (frame.cpp:840-906).
+ *
+ * The reference buckets the right keypoints by image row -- keypoint iR is pushed onto vRowIndices[yi] for every row
+ * yi of its band [floor(yR - 2 s_R), ceil(yR + 2 s_R)] -- and a left keypoint only looks at the bucket of its own
+ * row: ~35 candidates out of 2000.  The first version of this kernel tested ALL pairs (4 M gates per KITTI stereo
+ * frame, 171 us per 16 frames under load); this one builds the same buckets:
+ *   k_stereo_rows  one workgroup per stereo pair: counting sort of (row, iR) entries in LDS -> rowStart[row], items[]
+ *                  (order inside a bucket is free: the arg-min key dist << 16 | iR picks the lowest iR on ties, which
+ *                  is what "first candidate wins" means for buckets filled in iR order), and a compact {uR, octave}
+ *                  record per right keypoint;
+ *   k_stereo_best  one WAVE per left keypoint, lane = candidate of its row bucket: gates |octR - octL| <= 1 and
+ *                  uL - maxD <= uR <= uL, 256-bit Hamming distance for the lanes that pass, wave minimum.
  * ---------------------------------------------------------------------------------------------- */
-__global__ void k_stereo_init(StereoJobs jobs, uint32_t* best, int cap) {
-    const int j = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < JNL(jobs.job[j])) best[(size_t)j * cap + i] = 100u << 16;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * S1  masked all-pairs Hamming arg-min (frame.cpp:861-906).  64 left keypoints per workgroup (one per
- *     lane, descriptor in 8 VGPRs); a 256-keypoint right tile with its row band [minr,maxr], octave and
- *     uR staged in LDS; every lane reads the same right entry (LDS broadcast).  Gate per pair:
- *     row(vL) in [floor(yR - 2 s_R), ceil(yR + 2 s_R)], |octR - octL| <= 1, uL - maxD <= uR <= uL.
- *     Tiles combine through atomicMin on key = dist << 16 | iR (first-wins == lowest iR on ties).
- * ---------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(256)
-k_stereo_best(StereoJobs jobs, PyramidGeom g, float maxD, uint32_t* best, int cap) {
-    __shared__ uint4 s_t[256 * 2];
-    __shared__ int s_minr[256], s_maxr[256], s_oct[256];
-    __shared__ float s_u[256];
-    const StereoJob jb = jobs.job[blockIdx.z];
+#define SROWS_T 1024
+__global__ void __launch_bounds__(SROWS_T)
+k_stereo_rows(StereoJobs jobs, PyramidGeom g, int nrows, int max_band, uint32_t* row_start /* [job][nrows + 1] */,
+              uint16_t* items /* [job][cap * max_band] */, float2* rattr /* [job][cap] */, int cap /* of the RIGHT context */) {
+    extern __shared__ uint32_t s_cnt[]; /* nrows + 1 */
+    __shared__ uint32_t s_w32[SROWS_T / 64];
+    const StereoJob jb = jobs.job[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int iL = blockIdx.x * 64 + lane;
-    const int t0 = blockIdx.y * 256;
-    if (blockIdx.x * 64 >= JNL(jb) || t0 >= JNR(jb)) return; /* block-uniform */
-    {
-        const int iR = t0 + tid;
-        if (iR < JNR(jb)) {
-            const vslam_kp k = jb.kpsR[iR];
-            const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
-            s_maxr[tid] = (int)ceilf(__fadd_rn(k.y, r));
-            s_minr[tid] = (int)floorf(__fsub_rn(k.y, r));
-            s_oct[tid] = k.octave;
-            s_u[tid] = k.x;
-            s_t[2 * tid] = ((const uint4*)jb.descR)[(size_t)iR * 2];
-            s_t[2 * tid + 1] = ((const uint4*)jb.descR)[(size_t)iR * 2 + 1];
-        } else {
-            s_minr[tid] = 1 << 30;
-            s_maxr[tid] = -(1 << 30);
-            s_oct[tid] = 1000;
-            s_u[tid] = 0.f;
-        }
-    }
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    int row = -(1 << 29), octL = -1000;
-    float minU = 1.f, maxU = 0.f;
-    if (iL < JNL(jb)) {
-        const vslam_kp k = jb.kpsL[iL];
-        qa = ((const uint4*)jb.descL)[(size_t)iL * 2];
-        qb = ((const uint4*)jb.descL)[(size_t)iL * 2 + 1];
-        row = (int)k.y; /* vRowIndices[vL]: float -> size_t truncation */
-        octL = k.octave;
-        minU = __fsub_rn(k.x, maxD);
-        maxU = __fsub_rn(k.x, 0.f);
-        if (maxU < 0) row = -(1 << 29); /* frame.cpp:876-877 */
+    const int nR = min(JNR(jb), cap);
+    uint32_t* rs = row_start + (size_t)blockIdx.x * (nrows + 1);
+    uint16_t* it = items + (size_t)blockIdx.x * cap * max_band;
+    float2* ra = rattr + (size_t)blockIdx.x * cap;
+    for (int r = tid; r <= nrows; r += SROWS_T) s_cnt[r] = 0;
+    __syncthreads();
+    for (int iR = tid; iR < nR; iR += SROWS_T) {
+        const vslam_kp k = jb.kpsR[iR];
+        const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), nrows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        for (int yi = minr; yi <= maxr; yi++) atomicAdd(&s_cnt[yi], 1u);
+        ra[iR] = make_float2(k.x, __int_as_float(k.octave));
     }
     __syncthreads();
-    uint32_t bestKey = 0xFFFFFFFFu;
-    for (int j = wv * 64; j < wv * 64 + 64; j++) {
-        const int oR = s_oct[j];
-        const float uR = s_u[j];
-        const bool gate = row >= s_minr[j] && row <= s_maxr[j] && oR >= octL - 1 && oR <= octL + 1 &&
-                          uR >= minU && uR <= maxU;
-        if (gate) {
-            const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
-            const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) +
-                               __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) +
-                               __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-            const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
-            bestKey = min(bestKey, key);
+    /* exclusive scan over the rows: thread t owns rows [t*E, (t+1)*E) */
+    const int E = (nrows + SROWS_T) / SROWS_T;
+    uint32_t sum = 0;
+    for (int j = 0; j < E; j++) {
+        const int r = tid * E + j;
+        if (r < nrows) sum += s_cnt[r];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w32[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int k = 0; k < wv; k++) run += s_w32[k];
+    for (int j = 0; j < E; j++) {
+        const int r = tid * E + j;
+        if (r < nrows) {
+            const uint32_t c = s_cnt[r];
+            rs[r] = run;
+            s_cnt[r] = run; /* becomes the fill cursor */
+            run += c;
         }
     }
-    if (iL < JNL(jb) && bestKey < (100u << 16)) atomicMin(&best[(size_t)blockIdx.z * cap + iL], bestKey);
+    if (tid == SROWS_T - 1) rs[nrows] = run;
+    __syncthreads();
+    for (int iR = tid; iR < nR; iR += SROWS_T) {
+        const vslam_kp k = jb.kpsR[iR];
+        const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), nrows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        for (int yi = minr; yi <= maxr; yi++) it[atomicAdd(&s_cnt[yi], 1u)] = (uint16_t)iR;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_stereo_best(StereoJobs jobs, float maxD, int nrows, int max_band, const uint32_t* __restrict__ row_start,
+              const uint16_t* __restrict__ items, const float2* __restrict__ rattr, uint32_t* best, int cap, int capR) {
+    const StereoJob jb = jobs.job[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= JNL(jb)) return; /* wave-uniform */
+    const uint32_t* rs = row_start + (size_t)blockIdx.y * (nrows + 1);
+    const uint16_t* it = items + (size_t)blockIdx.y * capR * max_band;
+    const float2* ra = rattr + (size_t)blockIdx.y * capR;
+    const vslam_kp k = jb.kpsL[iL];             /* wave-uniform: scalar loads */
+    const uint4 qa = ((const uint4*)jb.descL)[(size_t)iL * 2], qb = ((const uint4*)jb.descL)[(size_t)iL * 2 + 1];
+    const int row = (int)k.y;                   /* vRowIndices[vL]: float -> size_t truncation */
+    const float minU = __fsub_rn(k.x, maxD), maxU = __fsub_rn(k.x, 0.f);
+    uint32_t bestKey = 100u << 16;              /* bestDist = TH_HIGH, bestIdxR = 0 (frame.cpp:879-880) */
+    if (!(maxU < 0) && row >= 0 && row < nrows) { /* frame.cpp:876-877 */
+        const uint32_t s = rs[row], e = rs[row + 1];
+        for (uint32_t c0 = s; c0 < e; c0 += 64) { /* wave-uniform trip count: one turn for nearly every keypoint */
+            const uint32_t c = c0 + lane;
+            if (c < e) {
+                const int iR = it[c];
+                const float2 a = ra[iR];
+                const int oR = __float_as_int(a.y);
+                if (oR >= k.octave - 1 && oR <= k.octave + 1 && a.x >= minU && a.x <= maxU) {
+                    const uint4 ta = ((const uint4*)jb.descR)[(size_t)iR * 2], tb = ((const uint4*)jb.descR)[(size_t)iR * 2 + 1];
+                    const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) +
+                                       __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) +
+                                       __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                    bestKey = min(bestKey, (d << 16) | (uint32_t)iR); /* dist < bestDist, first (lowest) iR on ties */
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bestKey = min(bestKey, (uint32_t)__shfl_xor((int)bestKey, o, 64));
+    if (lane == 0) best[(size_t)blockIdx.y * cap + iL] = bestKey;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -136,25 +170,77 @@ k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t stri
         const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, 5.f), 5.f), 1.f);
         inside = !(iniu < 0 || endu >= (float)g.lv[oct].w);
     }
-    if (refine && inside && sub < 11) {
+    /* The two patches go through LDS: the 16 lanes of a keypoint stage its left 11x11 patch (rows of 12 bytes) and the
+     * right 11x21 strip (rows of 24 bytes) with unaligned dword loads -- 99 loads per keypoint instead of the 11 x 242
+     * single-byte gathers of the first version -- and lane s then sums |(l - cL) - (r - cR_s)| = |l - (r + k_s)|,
+     * k_s = cL - cR_s, over its shifted 11x11 window with v_sad_u16 on biased 16-bit pairs (+256 keeps r + k_s
+     * non-negative): one instruction per two pixels.  Patches that touch the image border (reflected by the
+     * reference's 19-px pyramid border) are staged pixel by pixel. */
+    __shared__ __align__(4) uint8_t s_pl[16][11 * 12];
+    __shared__ __align__(4) uint8_t s_pr[16][11 * 24];
+    const bool work = refine && inside;
+    if (work) {
         const LevelGeom lg = g.lv[oct];
         int pL, pR;
         const uint8_t* imL = level_base2(pyrL, strideL, srcL, lg, oct, jb.slotL, &pL);
         const uint8_t* imR = level_base2(pyrR, strideR, srcR, lg, oct, jb.slotR, &pR);
-        const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR = (int)scaleduR0 + sub - 5;
-        const int cL = imL[(size_t)refl101(cy, lg.h) * pL + refl101(cxL, lg.w)];
-        const int cR = imR[(size_t)refl101(cy, lg.h) * pR + refl101(cxR, lg.w)];
-        int acc = 0;
-        for (int dy = -5; dy <= 5; dy++) {
-            const int yy = refl101(cy + dy, lg.h);
-            const uint8_t* rl = imL + (size_t)yy * pL;
-            const uint8_t* rr = imR + (size_t)yy * pR;
-#pragma unroll
-            for (int dx = -5; dx <= 5; dx++) {
-                const int a = (int)rl[refl101(cxL + dx, lg.w)] - cL;
-                const int b = (int)rr[refl101(cxR + dx, lg.w)] - cR;
-                acc += abs(a - b);
+        const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR0 = (int)scaleduR0;
+        /* interior: every byte a dword row load touches lies inside the row (left 12 bytes from cxL-5, right 24 from cxR0-10) */
+        const bool interior = cy - 5 >= 0 && cy + 5 < lg.h && cxL - 5 >= 0 && cxL + 7 <= lg.w && cxR0 - 10 >= 0 && cxR0 + 14 <= lg.w;
+        if (interior) {
+            for (int i = sub; i < 99; i += 16) { /* 33 left dwords, then 66 right dwords */
+                if (i < 33) {
+                    const int row = i / 3, dw = i - row * 3;
+                    *(uint32_t*)&s_pl[grp][row * 12 + dw * 4] = *(const uint32_t*)(imL + (size_t)(cy - 5 + row) * pL + cxL - 5 + dw * 4);
+                } else {
+                    const int j = i - 33, row = j / 6, dw = j - row * 6;
+                    *(uint32_t*)&s_pr[grp][row * 24 + dw * 4] = *(const uint32_t*)(imR + (size_t)(cy - 5 + row) * pR + cxR0 - 10 + dw * 4);
+                }
             }
+        } else {
+            for (int i = sub; i < 11 * 11 + 11 * 21; i += 16) {
+                if (i < 121) {
+                    const int row = i / 11, c = i - row * 11;
+                    s_pl[grp][row * 12 + c] = imL[(size_t)refl101(cy - 5 + row, lg.h) * pL + refl101(cxL - 5 + c, lg.w)];
+                } else {
+                    const int j = i - 121, row = j / 21, c = j - row * 21;
+                    s_pr[grp][row * 24 + c] = imR[(size_t)refl101(cy - 5 + row, lg.h) * pR + refl101(cxR0 - 10 + c, lg.w)];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (work && sub < 11) {
+        const uint8_t* PLp = s_pl[grp];
+        const uint8_t* PRp = s_pr[grp];
+        const int k = (int)PLp[5 * 12 + 5] - (int)PRp[5 * 24 + sub + 5]; /* cL - cR of this shift */
+        const uint32_t kb = (uint32_t)(k + 256) * 0x00010001u, lb = 256u * 0x00010001u;
+        const uint32_t sh = (uint32_t)(sub & 3);
+        const int rdw = sub >> 2; /* first right dword of the lane's window */
+        uint32_t acc = 0;
+#pragma unroll
+        for (int row = 0; row < 11; row++) {
+            const uint32_t* lw = (const uint32_t*)(PLp + row * 12);
+            const uint32_t* rw = (const uint32_t*)(PRp + row * 24) + rdw;
+            const uint32_t l0 = lw[0], l1 = lw[1], l2 = lw[2];
+            const uint32_t a0 = rw[0], a1 = rw[1], a2 = rw[2], a3 = rw[3];
+            const uint32_t r0 = __builtin_amdgcn_alignbyte(a1, a0, sh), r1 = __builtin_amdgcn_alignbyte(a2, a1, sh),
+                           r2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
+            /* pixels 0..10 as u16 pairs: (0,1) (2,3) | (4,5) (6,7) | (8,9) (10,-); the eleventh pair repeats pixel 10 on
+             * BOTH sides with the same offset, and its second half is made equal on both sides -> contributes |l - r - k| once */
+#define SAD_PAIR(LW, RW, SEL)                                                                                  \
+    acc = __builtin_amdgcn_sad_u16(__builtin_amdgcn_perm(0u, (LW), (SEL)) + lb, __builtin_amdgcn_perm(0u, (RW), (SEL)) + kb, acc);
+            SAD_PAIR(l0, r0, 0x0c010c00u)
+            SAD_PAIR(l0, r0, 0x0c030c02u)
+            SAD_PAIR(l1, r1, 0x0c010c00u)
+            SAD_PAIR(l1, r1, 0x0c030c02u)
+            SAD_PAIR(l2, r2, 0x0c010c00u)
+            {   /* pixel 10 alone: low half = the pixel, high half = 0 on the left and -k_bias-compensated on the right */
+                const uint32_t lp = (__builtin_amdgcn_perm(0u, l2, 0x0c0c0c02u) + 256u);
+                const uint32_t rp = (__builtin_amdgcn_perm(0u, r2, 0x0c0c0c02u) + (uint32_t)(k + 256));
+                acc = __builtin_amdgcn_sad_u16(lp, rp, acc); /* high halves are both 0 */
+            }
+#undef SAD_PAIR
         }
         s_d[grp][sub] = (float)acc;
     }
@@ -273,15 +359,28 @@ __global__ void k_gather_rows32(const uint8_t* __restrict__ src, const int32_t* 
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+size_t vk_stereo_rows_bytes(int njobs, int nrows, int max_band, int cap) {
+    return (size_t)njobs * ((((size_t)nrows + 1) * 4 + 15) / 16 * 16 + (((size_t)cap * max_band * 2 + 15) & ~(size_t)15) + (size_t)cap * 8);
+}
+
 void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
                const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
                const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
-               int32_t* sad, int cap) {
+               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch) {
     if (njobs <= 0 || maxNL <= 0) return;
-    hipLaunchKernelGGL(k_stereo_init, dim3((maxNL + 255) / 256, njobs), dim3(256), 0, st, jobs, best, cap);
-    if (maxNR > 0)
-        hipLaunchKernelGGL(k_stereo_best, dim3((maxNL + 63) / 64, (maxNR + 255) / 256, njobs), dim3(256), 0, st,
-                           jobs, g, maxD, best, cap);
+    const int capR = maxNR; /* capacity of the right context's slots */
+    const int nrows = g.lv[0].h;
+    /* scratch: row_start[njobs][nrows + 1] | items[njobs][cap * max_band] | rattr[njobs][cap] */
+    uint32_t* row_start = (uint32_t*)rows_scratch;
+    size_t off = (size_t)njobs * ((((size_t)nrows + 1) * 4 + 15) / 16 * 16);
+    row_start = (uint32_t*)rows_scratch;
+    uint16_t* items = (uint16_t*)(rows_scratch + off);
+    off += (size_t)njobs * (((size_t)capR * max_band * 2 + 15) & ~(size_t)15);
+    float2* rattr = (float2*)(rows_scratch + off);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(njobs), dim3(SROWS_T), ((size_t)nrows + 1) * 4, st, jobs, g, nrows, max_band,
+                       row_start, items, rattr, capR);
+    hipLaunchKernelGGL(k_stereo_best, dim3((maxNL + 3) / 4, njobs), dim3(256), 0, st, jobs, maxD, nrows, max_band, row_start,
+                       items, rattr, best, cap, capR);
     hipLaunchKernelGGL(k_stereo_refine, dim3((maxNL + 15) / 16, njobs), dim3(256), 0, st, jobs, g, pyrL, strideL,
                        srcL, pyrR, strideR, srcR, mbf, maxD, best, uRight, depth, sad, cap);
     hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(1024), 0, st, jobs, uRight, depth, sad, cap);
