@@ -205,6 +205,63 @@ __device__ __forceinline__ int fast_half_score(const uint8_t* c) {
     return A;
 }
 
+/* The same for TWO pixels at once, in the halves of packed u16 registers (v_pk_sub_u16 clamp / v_pk_min_u16 /
+ * v_pk_max_u16), returned as max(score half, 0) per half.  A nine-pixel arc that starts in one half of the ring ends
+ * in the other one, so with suffix minima S and prefix minima Pm of the two ring halves
+ *     arc starting at element i of a half = min(S_thishalf[i], Pm_otherhalf[i]):
+ * 26 + 16 minima and 15 maxima for both pixels, against 2 x (32 three-input minima + 8 maxima) one by one.  Clamping
+ * the differences at 0 does not change max(score - 1, 0).
+ * (Unaligned LDS reads -- the ring rows as dwords / 8 bytes at x-1, x-2, x-3, 14 instead of 34 LDS instructions per pair --
+ * work on gfx950 but are served lane by lane: the kernel took 283 instead of 115 us.  Byte reads it is.) */
+__device__ __forceinline__ uint32_t pk_sub_sat16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int SIGN, int P>
+__device__ __forceinline__ uint32_t fast_pair_score(const uint8_t* ca, const uint8_t* cb) {
+#define RING(off) (SIGN > 0 ? pk_sub_sat16(v, (uint32_t)ca[off] | ((uint32_t)cb[off] << 16)) \
+                            : pk_sub_sat16((uint32_t)ca[off] | ((uint32_t)cb[off] << 16), v))
+    const uint32_t v = (uint32_t)ca[0] | ((uint32_t)cb[0] << 16);
+    uint32_t S1[8], P1[8], S2[8], P2[8];
+    /* ring 4..11: the centre row's right end, up the right side, the top, down the left side to row -1 */
+    S1[0] = RING(3);           S1[1] = RING(-P + 3);      S1[2] = RING(-2 * P + 2);  S1[3] = RING(-3 * P + 1);
+    S1[4] = RING(-3 * P);      S1[5] = RING(-3 * P - 1);  S1[6] = RING(-2 * P - 2);  S1[7] = RING(-P - 3);
+    P1[0] = S1[0];
+#pragma unroll
+    for (int i = 1; i < 7; i++) P1[i] = pk_min16(P1[i - 1], S1[i]);
+#pragma unroll
+    for (int i = 6; i >= 0; i--) S1[i] = pk_min16(S1[i], S1[i + 1]);
+    P1[7] = S1[0];
+    __builtin_amdgcn_sched_barrier(0); /* keeps the second half's loads below the first half's minima: <= 64 VGPRs */
+    /* ring 12..15, 0..3: down the left side from the centre row, the bottom, up the right side to row +1 */
+    S2[0] = RING(-3);          S2[1] = RING(P - 3);       S2[2] = RING(2 * P - 2);   S2[3] = RING(3 * P - 1);
+    S2[4] = RING(3 * P);       S2[5] = RING(3 * P + 1);   S2[6] = RING(2 * P + 2);   S2[7] = RING(P + 3);
+#undef RING
+    P2[0] = S2[0];
+#pragma unroll
+    for (int i = 1; i < 7; i++) P2[i] = pk_min16(P2[i - 1], S2[i]);
+#pragma unroll
+    for (int i = 6; i >= 0; i--) S2[i] = pk_min16(S2[i], S2[i + 1]);
+    P2[7] = S2[0];
+    uint32_t best = pk_min16(S1[0], P2[0]);
+#pragma unroll
+    for (int i = 1; i < 8; i++) best = pk_max16(best, pk_min16(S1[i], P2[i]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) best = pk_max16(best, pk_min16(S2[i], P1[i]));
+    return best;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * pyramid level: one thread = four consecutive output pixels of a row (same arithmetic as the generic
  * one-pixel-per-thread k_resize_level in vslam_kernels.hip, cv::resize INTER_LINEAR 8u).  All eight taps of a row lie in one 8-byte window of the source
@@ -469,6 +526,11 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_or0(uint32_t v) { /* lanes without a source read 0 */
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
@@ -483,6 +545,56 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+/* LDS byte address of a __shared__ object (the low half of its flat address) */
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+/* lane masks of "low / high u16 half != 0" straight into an SGPR pair (inactive lanes read 0) */
+__device__ __forceinline__ uint64_t half_lo_nonzero(uint32_t x) {
+    uint64_t m;
+    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(0u));
+    return m;
+}
+__device__ __forceinline__ uint64_t half_hi_nonzero(uint32_t x) {
+    uint64_t m;
+    asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "s"(0xFFFFu), "v"(x));
+    return m;
+}
+__device__ __forceinline__ uint32_t lane_select(uint64_t m, uint32_t a, uint32_t b) { /* a for the lanes of m, else b */
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) { /* set bits of m below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+/* ds_write_b16 of `code` by the lanes of `m` (a subset of exec) to per-lane addresses, then -- only if mX is not
+ * empty -- of codeX by the lanes of mX (a subset of m: same address, overwrites; LDS executes a wave's stores in order) */
+__device__ __forceinline__ void lds_store_b16_masked2(uint64_t m, uint64_t mX, uint32_t at, uint32_t code, uint32_t codeX) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\tds_write_b16 %3, %4\n\t"
+                 "s_cmp_eq_u64 %2, 0\n\ts_cbranch_scc1 1f\n\t"
+                 "s_mov_b64 exec, %2\n\tds_write_b16 %3, %5\n"
+                 "1:\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "s"(mX), "v"(at), "v"(code), "v"(codeX) : "memory", "scc");
+}
+/* LDS fetch-and-add without the compiler's wave-aggregation wrapper (the caller is a single lane already) */
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t addr, uint32_t v) {
+    uint32_t r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+
+#ifdef VSLAM_FAST_WGREC /* diagnostic build: one record per workgroup of the LAST launch: s_memtime at entry and exit,
+ * s_memrealtime (100 MHz) at entry, HW_ID (16 bits) | XCC_ID << 16 | (s_memrealtime at exit - entry) << 32 --
+ * tools/fast_occupancy.py turns them into workgroups in flight per CU over time */
+#define FAST_WG_RECORDS 65536
+__device__ unsigned long long g_fast_wg[FAST_WG_RECORDS * 4];
+extern "C" int vslam_dbg_fast_wg_records(unsigned long long* out, int n) {
+    if (n > FAST_WG_RECORDS) n = FAST_WG_RECORDS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_wg), sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess) return -3;
+    return n;
+}
+#endif
 #ifdef VSLAM_FAST_STAMPS /* diagnostic build: cycles per phase of wave 0 of every workgroup, summed (tools/fast_stamps.py) */
 __device__ unsigned long long g_fast_stamps[16];
 #define FSTAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_fast_stamps[k], t_ - fst_); fst_ = t_; } } while (0)
@@ -497,8 +609,9 @@ extern "C" int vslam_dbg_fast_stamps(unsigned long long* out16, int reset) {
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
+#define FAST_XCD_CHUNK 16
 template <int NT, int P> /* P: LDS pitch, 48 for windows up to 42 px, else 72 */
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
                 const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells,
                 int iniTh, int minTh, int tile_rows, int lcap) {
@@ -506,10 +619,10 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     uint8_t* win = smem3;                        /* tile_rows x P; window column c at LDS column c + 1 */
     uint8_t* sc = win + tile_rows * P;          /* (tile_rows-4) x P, interior at (1..ih, 1..iw) */
     uint32_t* keep = (uint32_t*)(sc + (tile_rows - 4) * P); /* 2 words per interior row */
-    /* ONE survivor list: dark-only and "both polarities" pixels (bit 15 set) up from 0, bright-only down from lcap-1;
-     * the three sets are disjoint, so lcap = pixels of the largest cell interior always suffices */
-    uint16_t* list = (uint16_t*)(keep + (tile_rows - 6) * 2);
-    uint8_t* qmask = (uint8_t*)(list + lcap);   /* pre-test result per quad: dark bits | bright bits << 4; 8 or 16 B per row */
+    /* survivor lists (codes ly << 6 | x): dark pixels, with bit 15 set where the bright polarity is possible too, and
+     * bright-only pixels; disjoint sets, each at most the pixels of the largest cell interior (lcap entries) */
+    uint16_t* listD = (uint16_t*)(keep + (tile_rows - 6) * 2);
+    uint16_t* listB = listD + lcap;
     __shared__ uint32_t s_cnt; /* nD+nX | nB << 16 */
     __shared__ uint32_t s_wave_tot[NT / 64];
     __shared__ int s_any;
@@ -518,12 +631,18 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
 #ifdef VSLAM_FAST_STAMPS
     unsigned long long fst_ = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef VSLAM_FAST_WGREC
+    const unsigned long long fst_entry_ = __builtin_amdgcn_s_memtime(), fst_real_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const int slot = blockIdx.y;
-    /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2), so XCD k takes the k-th contiguous
-     * eighth of the cell list -- neighbouring cells, whose windows overlap by 6 px and share image rows, then hit
-     * the same L2 instead of being fetched by all eight. */
-    const int per_xcd = (ncells + 7) >> 3;
-    const int cell = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    /* XCD-aware cell order: workgroups b and b+8 share an XCD (and its L2).  XCD k takes every eighth CHUNK of
+     * FAST_XCD_CHUNK consecutive cells -- neighbouring cells, whose windows overlap by 6 px and share image rows, hit
+     * the same L2 -- and the chunks are dealt round-robin, because the cost of a cell depends on its pyramid level and
+     * texture: with one contiguous eighth of the cell list per XCD the slowest XCD ran 122 us and the fastest 87
+     * (per-workgroup records, tools/fast_occupancy.py). */
+    const int xcd_i = (int)(blockIdx.x >> 3);
+    /* ... rotated by the image slot, so that the partial last round of chunks lands on a different XCD per image */
+    const int cell = ((xcd_i / FAST_XCD_CHUNK) * 8 + (int)((blockIdx.x + blockIdx.y) & 7)) * FAST_XCD_CHUNK + xcd_i % FAST_XCD_CHUNK;
     if (cell >= ncells) return;
     /* the cell record through the SCALAR cache: as four dwords (a 16-bit field alone becomes a vector load, i.e. one
      * more full memory round trip in front of the window fetch -- the prologue's latency is half of a wave's life) */
@@ -566,9 +685,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         wreg[u] = make_uint2(0u, 0u);
         if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
     }
-    for (int i = tid; i < (ih + 2) * (P / 4); i += NT) ((uint32_t*)sc)[i] = 0;
-    for (int i = tid; i < nwords; i += NT) keep[i] = 0;
-    for (int i = tid; i < ih * 4; i += NT) ((uint32_t*)qmask)[i] = 0; /* quads outside the interior stay 0 */
+    /* score tile and keep words are contiguous: zeroed in 16-byte stores (the tail may run into the lists, which
+     * are filled later) */
+    for (int i = tid; i < ((tile_rows - 4) * P + nwords * 4 + 15) / 16; i += NT) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) {
         s_any = 0;
         s_cnt = 0u;
@@ -588,113 +707,120 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int QW = (iw + 3) >> 2;               /* quads per interior row */
     const int qsh = QW > 8 ? 4 : 3;             /* 16 or 8 quad columns per sweep */
     const int qx = tid & ((1 << qsh) - 1), qly = tid >> qsh;
+    const int rem = iw - 4 * qx;                /* pixels of this lane's quad inside the interior (<= 0: none) */
+    uint64_t colm[4];                           /* lanes whose pixel j lies inside the interior */
+#pragma unroll
+    for (int j = 0; j < 4; j++) colm[j] = __builtin_amdgcn_ballot_w64(j < rem);
     const uint32_t* W32 = (const uint32_t*)win;
     int T = iniTh;
     for (int stage = 0; stage < 2; stage++) {
         const uint32_t TT = (uint32_t)T | ((uint32_t)T << 16);
         for (int ly0 = 0; ly0 < ih; ly0 += (NT >> qsh)) { /* block-uniform trip count */
             const int ly = ly0 + qly;
-            uint32_t mD = 0, mB = 0;
-            if (qx < QW && ly < ih) {
-                const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
-                const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
-                const uint32_t U = W32[ly * (P / 4) + qx + 1], Dn = W32[(ly + 6) * (P / 4) + qx + 1];
-                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, A0, 1); /* columns x-3 */
-                const uint32_t Rt = __builtin_amdgcn_alignbyte(E, C, 3);  /* columns x+3 */
+            /* every lane computes (rows past the interior and quads past QW read other parts of the LDS allocation;
+             * their results are dropped by rowok / rem below): no branch inside the sweep */
+            const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
+            const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
+            const uint32_t U = W32[ly * (P / 4) + qx + 1], Dn = W32[(ly + 6) * (P / 4) + qx + 1];
+            const uint32_t Lf = __builtin_amdgcn_alignbyte(C, A0, 1); /* columns x-3 */
+            const uint32_t Rt = __builtin_amdgcn_alignbyte(E, C, 3);  /* columns x+3 */
 #define EVN(x) __builtin_amdgcn_perm(0u, (x), 0x0c020c00u) /* pixels 0,2 as u16 halves */
 #define ODD(x) __builtin_amdgcn_perm(0u, (x), 0x0c030c01u) /* pixels 1,3 */
-                uint32_t passD[2], passB[2];
+            uint32_t passD[2], passB[2];
 #pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    const uint32_t v = par ? ODD(C) : EVN(C);
-                    const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
-                    const uint32_t u = par ? ODD(U) : EVN(U), d = par ? ODD(Dn) : EVN(Dn);
-                    const uint32_t l = par ? ODD(Lf) : EVN(Lf), r = par ? ODD(Rt) : EVN(Rt);
-                    /* dark: ring < v - T; bright: ring > v + T; (down|up) & (right|left) */
-                    passD[par] = pk_min(pk_sub_sat(vm, d) | pk_sub_sat(vm, u), pk_sub_sat(vm, r) | pk_sub_sat(vm, l));
-                    passB[par] = pk_min(pk_sub_sat(d, vp) | pk_sub_sat(u, vp), pk_sub_sat(r, vp) | pk_sub_sat(l, vp));
-                }
+            for (int par = 0; par < 2; par++) {
+                const uint32_t v = par ? ODD(C) : EVN(C);
+                const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
+                const uint32_t u = par ? ODD(U) : EVN(U), d = par ? ODD(Dn) : EVN(Dn);
+                const uint32_t l = par ? ODD(Lf) : EVN(Lf), r = par ? ODD(Rt) : EVN(Rt);
+                /* dark: (down|up) & (right|left) darker than v - T  <=>  max(min(d,u), min(r,l)) < v - T;
+                 * bright: min(max(d,u), max(r,l)) > v + T -- six min/max + two saturating subtractions per polarity
+                 * pair instead of eight subtractions, four ORs and two mins */
+                passD[par] = pk_sub_sat(vm, pk_max(pk_min(d, u), pk_min(r, l)));
+                passB[par] = pk_sub_sat(pk_min(pk_max(d, u), pk_max(r, l)), vp);
+            }
 #undef EVN
 #undef ODD
-                /* halves -> bit per pixel: bit0 px0, bit1 px1, bit2 px2, bit3 px3 */
-                const uint32_t one = 0x00010001u;
-                uint32_t t = pk_min(passD[0], one) | (pk_min(passD[1], one) << 1);
-                mD = (t & 3u) | ((t >> 14) & 0xCu);
-                t = pk_min(passB[0], one) | (pk_min(passB[1], one) << 1);
-                mB = (t & 3u) | ((t >> 14) & 0xCu);
-                const int rem = iw - 4 * qx; /* >= 1 */
-                const uint32_t vmask = rem >= 4 ? 0xFu : ((1u << rem) - 1u);
-                mD &= vmask;
-                mB &= vmask;
+            /* survivors go straight to the lists: per pixel column j of the quad one compare per polarity whose
+             * lane mask lands in an SGPR pair, the lane's rank from v_mbcnt, the wave's totals from s_bcnt1 on the
+             * scalar side, ONE LDS atomic per wave and sweep for the list space, stores under the lane mask.  (A
+             * per-stage compaction pass over a byte-per-quad mask array -- wave scan, per-lane bit loops -- was ~150
+             * instructions per wave on top of the bit extraction here; this is ~45 per sweep, and a barrier less.) */
+            const uint64_t rowm = __builtin_amdgcn_ballot_w64(ly < ih);
+            uint64_t mD[4], mB[4], mX[4];
+            uint32_t totD = 0, totB = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t ok = rowm & colm[j];
+                const uint64_t dk = ((j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1])) & ok;
+                const uint64_t br = ((j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1])) & ok;
+                mD[j] = dk;       /* dark, or both polarities possible: the latter are listed once, here, flagged */
+                mX[j] = dk & br;
+                mB[j] = br & ~dk;
+                totD += (uint32_t)__popcll(mD[j]);
+                totB += (uint32_t)__popcll(mB[j]);
             }
-            /* the sweep only records the quad's result; survivors are compacted ONCE per stage below (the per-sweep
-             * wave scan + LDS atomic + eight masked list writes were ~100 of the ~170 instructions of a sweep) */
-            if (qx < QW && ly < ih) qmask[(ly << qsh) + qx] = (uint8_t)(mD | (mB << 4)); /* 8 or 16 bytes per row */
-        }
-        FSTAMP(2);
-        __syncthreads();
-        FSTAMP(3);
-        /* compaction: a lane takes one dword of the mask array = 4 quads = 16 pixels of a row */
-        int nD, nB;
-        {
-            const int dsh = qsh - 2, ndw = ih << dsh; /* 2 or 4 mask dwords per row */
-            for (int d0 = 0; d0 < ndw; d0 += NT) { /* block-uniform trip count */
-                const int di = d0 + tid;
-                uint32_t m = 0;
-                if (di < ndw) m = ((const uint32_t*)qmask)[di]; /* quads past QW were zeroed and never written */
-                const uint32_t lo = m & 0x0F0F0F0Fu, hi = (m >> 4) & 0x0F0F0F0Fu;
-                const uint32_t both = lo & hi;
-                uint32_t dbits = lo, bbits = hi & ~both; /* dbits keeps the "both" pixels, flagged below */
-                const uint32_t cntp = __popc(dbits) | (__popc(bbits) << 16);
-                const uint32_t incl = wave_incl_scan(cntp);
-                const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (wtot) { /* wave-uniform */
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_cnt, wtot);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    const uint32_t excl = incl - cntp;
-                    uint32_t oD = (base & 0xFFFFu) + (excl & 0xFFFFu);
-                    uint32_t oB = (uint32_t)lcap - 1u - ((base >> 16) + (excl >> 16));
-                    const uint32_t code0 = (uint32_t)((di >> dsh) * 64 + (di & ((1 << dsh) - 1)) * 16); /* row, first column */
-                    while (dbits) {
-                        const int j = __ffs(dbits) - 1; /* byte j >> 3 = quad, bit j & 7 = pixel of the quad */
-                        dbits &= dbits - 1;
-                        const uint32_t px = code0 + (uint32_t)((j >> 3) * 4 + (j & 7));
-                        list[oD++] = (uint16_t)(px | (((both >> j) & 1u) << 15));
-                    }
-                    while (bbits) {
-                        const int j = __ffs(bbits) - 1;
-                        bbits &= bbits - 1;
-                        list[oB--] = (uint16_t)(code0 + (uint32_t)((j >> 3) * 4 + (j & 7)));
-                    }
+            if (totD | totB) { /* wave-uniform */
+                uint32_t base = 0;
+                if (lane == 0) base = lds_add_rtn(lds_addr(&s_cnt), totD | (totB << 16));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t aD = lds_addr(listD) + 2u * (base & 0xFFFFu), aB = lds_addr(listB) + 2u * (base >> 16);
+                const uint32_t code0 = (uint32_t)((ly << 6) + 4 * qx);
+                uint32_t pD = 0, pB = 0; /* entries of the pixel columns before j */
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t code = code0 + j;
+                    /* dark and bright-only lanes are disjoint: ONE store with a per-lane address */
+                    const uint32_t atD = aD + 2u * pD + 2u * lane_rank(mD[j]), atB = aB + 2u * pB + 2u * lane_rank(mB[j]);
+                    lds_store_b16_masked2(mD[j] | mB[j], mX[j], lane_select(mD[j], atD, atB), code, code | 0x8000u);
+                    pD += (uint32_t)__popcll(mD[j]);
+                    pB += (uint32_t)__popcll(mB[j]);
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the masked stores above are not tracked by the compiler */
+        FSTAMP(2);
+        FSTAMP(3);
         FSTAMP(4);
         __syncthreads();
         FSTAMP(5);
+        int nD, nB;
         {
             const uint32_t tot = s_cnt;
             nD = (int)(tot & 0xFFFFu);
             nB = (int)(tot >> 16);
         }
         const int ntot = nD + nB;
-        /* one pass of the networks over the disjoint lists (no two threads touch the same score byte).  Dark entries
-         * are handed out from thread 0 upwards, bright ones from thread NT-1 downwards, so with the usual ~110 + ~110
-         * entries no wave has to run both networks; a flagged dark entry (both polarities possible, rare) runs both */
-        for (int base = 0; base < max(nD, nB); base += NT) {
-            const int iD = base + tid, iB = base + NT - 1 - tid;
+        /* one pass of the networks over the disjoint lists (no two threads touch the same score byte), TWO list
+         * entries per thread in the halves of packed u16 registers.  Dark pairs are handed out from thread 0 upwards,
+         * bright ones from thread NT-1 downwards, so with the usual ~110 + ~110 entries each wave runs one network
+         * once; a flagged dark entry (both polarities possible, rare) makes its thread run both */
+        const int sc_off = tile_rows * P - 2 * P - 3; /* score byte of a pixel relative to its window byte */
+        for (int base = 0; base < max(nD, nB); base += 2 * NT) {
+            const int iD = base + 2 * tid, iB = base + 2 * (NT - 1 - tid);
             if (iD < nD) {
-                const int e = list[iD], code = e & 0x7FFF;
-                const uint8_t* c = win + ((code >> 6) + 3) * P + (code & 63) + 4;
-                int a = fast_half_score<1, P>(c);
-                if (e & 0x8000) a = max(a, fast_half_score<-1, P>(c));
-                sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+                const uint32_t e2 = *(const uint32_t*)(listD + iD);
+                const uint32_t eA = e2 & 0xFFFFu, eB = iD + 1 < nD ? e2 >> 16 : eA;
+                const uint8_t* cA = win + (((eA >> 6) & 0x1FFu) + 3) * P + (eA & 63u) + 4;
+                const uint8_t* cB = win + (((eB >> 6) & 0x1FFu) + 3) * P + (eB & 63u) + 4;
+                uint32_t a = fast_pair_score<1, P>(cA, cB);
+                if ((eA | eB) & 0x8000u) {
+                    const uint32_t b = fast_pair_score<-1, P>(cA, cB);
+                    const uint32_t m = ((eA & 0x8000u) ? 0xFFFFu : 0u) | ((eB & 0x8000u) ? 0xFFFF0000u : 0u);
+                    a = pk_max(a, b & m);
+                }
+                a = pk_sub_sat(a, 0x00010001u); /* OpenCV's score: max(dark, bright) - 1, not below 0 */
+                ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
             }
             if (iB < nB) {
-                const int code = list[lcap - 1 - iB];
-                const int a = fast_half_score<-1, P>(win + ((code >> 6) + 3) * P + (code & 63) + 4);
-                sc[((code >> 6) + 1) * P + (code & 63) + 1] = (uint8_t)max(a - 1, 0);
+                const uint32_t e2 = *(const uint32_t*)(listB + iB);
+                const uint32_t eA = e2 & 0xFFFFu, eB = iB + 1 < nB ? e2 >> 16 : eA;
+                const uint8_t* cA = win + ((eA >> 6) + 3) * P + (eA & 63u) + 4;
+                const uint8_t* cB = win + ((eB >> 6) + 3) * P + (eB & 63u) + 4;
+                const uint32_t a = pk_sub_sat(fast_pair_score<-1, P>(cA, cB), 0x00010001u);
+                ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
             }
         }
         FSTAMP(6);
@@ -703,7 +829,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         /* NMS at T only where a score exists (listed pixels with a score below T cannot suppress anything) */
         int any = 0;
         for (int i = tid; i < ntot; i += NT) {
-            const int code = (i < nD ? list[i] : list[lcap - 1 - (i - nD)]) & 0x7FFF;
+            const int code = (i < nD ? listD[i] : listB[i - nD]) & 0x7FFF;
             const int ly = code >> 6, x = code & 63;
             const uint8_t* q = sc + (ly + 1) * P + x + 1;
             const int s = q[0];
@@ -771,6 +897,21 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         }
     }
     FSTAMP(12);
+#ifdef VSLAM_FAST_WGREC
+    if (tid == 0) {
+        const unsigned rec = blockIdx.y * gridDim.x + blockIdx.x;
+        if (rec < FAST_WG_RECORDS) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_fast_wg[rec * 4 + 0] = fst_entry_;
+            g_fast_wg[rec * 4 + 1] = __builtin_amdgcn_s_memtime();
+            g_fast_wg[rec * 4 + 2] = fst_real_;
+            const unsigned long long dreal = __builtin_amdgcn_s_memrealtime() - fst_real_;
+            g_fast_wg[rec * 4 + 3] = (unsigned long long)(hw & 0xFFFFu) | ((unsigned long long)(xcc & 0xFu) << 16) | (dreal << 32);
+        }
+    }
+#endif
 }
 
 /* threads per cell: a cell is 900 pixels, and ~150 of the ~420 instructions a thread executes do not depend on how many
@@ -801,14 +942,22 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
         force72 = e && atoi(e) == 72;
     }
     const int P = (max_window_w <= 42 && !force72) ? 48 : 72;
-    const size_t shm = (size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 +
-                       (size_t)lcap * 2 + (size_t)(tile_rows - 6) * 16 + 16;
-    const dim3 grid(((ncells + 7) / 8) * 8, nslots);
+    const int nt = fast_v3_nt();
+    /* window + score tile + keep words + list; not less than what the pre-test sweep's idle lanes may READ (rows up
+     * to a sweep's height below the window, quads past the last one: results dropped, but the addresses stay inside
+     * the allocation) */
+    const size_t shm = std::max((size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 + (size_t)lcap * 4 + 16,
+                                (size_t)(tile_rows + nt / 8 + 1) * P + 128);
+    static int lds_pad = -1; /* VSLAM_FAST_LDS_PAD=bytes: extra LDS per workgroup (occupancy experiments) */
+    if (lds_pad < 0) {
+        const char* e = getenv("VSLAM_FAST_LDS_PAD");
+        lds_pad = e ? std::max(0, atoi(e)) : 0;
+    }
+    const dim3 grid((ncells + 8 * FAST_XCD_CHUNK - 1) / (8 * FAST_XCD_CHUNK) * (8 * FAST_XCD_CHUNK), nslots);
     const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
 #define FAST3_LAUNCH(NT_, P_)                                                                                              \
-    hipLaunchKernelGGL((k_fast_cells_v3<NT_, P_>), grid, dim3(NT_), shm, st, pyr, slot_stride, src, g, cells, cand_region, \
+    hipLaunchKernelGGL((k_fast_cells_v3<NT_, P_>), grid, dim3(NT_), shm + lds_pad, st, pyr, slot_stride, src, g, cells, cand_region, \
                        cand_stride, ncells, it, mt, tile_rows, lcap)
-    const int nt = fast_v3_nt();
     if (P == 48) {
         if (nt == 64) FAST3_LAUNCH(64, 48);
         else if (nt == 128) FAST3_LAUNCH(128, 48);
