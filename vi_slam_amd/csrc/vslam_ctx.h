@@ -151,6 +151,8 @@ struct vslam_fe {
     uint32_t* d_pts[2] = {nullptr, nullptr};  /* key ping-pong arrays, B x cand_cap */
     uint16_t* d_nid[2] = {nullptr, nullptr};  /* node (list index) of every key */
     uint32_t* d_fine = nullptr;               /* k_octree_v3: fine-cell counts + prefix sums, B x oct.fineStride */
+    uint8_t* d_walk = nullptr;                /* B x walk_stride: node arrays of the hand-over path in k_assign_out */
+    size_t walk_stride = 0;
     int32_t* d_oct_redo = nullptr;            /* k_octree_v3 -> k_octree_v2 hand-over flags, B x VSLAM_MAX_LEVELS */
     uint32_t* d_sel_xyr = nullptr;            /* per slot / level result lists */
     int32_t* d_sel_cnt = nullptr;

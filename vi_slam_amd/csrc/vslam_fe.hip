@@ -61,6 +61,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_sel_xyr);
     hipFree(fe->d_fine);
     hipFree(fe->d_oct_redo);
+    hipFree(fe->d_walk);
     hipFree(fe->d_sel_cnt);
     hipFree(fe->d_counts);
     if (fe->h_counts) hipHostFree(fe->h_counts);
@@ -376,6 +377,9 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 HIPCHK(hipMalloc((void**)&fe->d_fine, (size_t)fe->B * O.fineStride * 4));
                 HIPCHK(hipMalloc((void**)&fe->d_oct_redo, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
                 HIPCHK(hipMemset(fe->d_oct_redo, 0, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
+                /* node arrays of the walk-per-pass distribution for the problems k_octree_v3 hands over (k_assign_out) */
+                fe->walk_stride = (vk_octree_lds_bytes(O.maxNodes) + 255) & ~(size_t)255;
+                HIPCHK(hipMalloc((void**)&fe->d_walk, (size_t)fe->B * fe->walk_stride));
             }
         }
         HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
@@ -846,7 +850,8 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
               fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
               fe->d_fine, fe->d_oct_redo);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
-                  d_err, nimg);
+                  d_err, nimg, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->d_pts[0], fe->d_nid[0],
+                  (size_t)fe->cand_cap, fe->d_fine ? fe->d_oct_redo : nullptr, fe->d_walk, fe->walk_stride);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,

@@ -85,11 +85,33 @@ __device__ __forceinline__ int quadrant(uint32_t pt, const ONode& nd) {
  * of the key array per pass, gave each thread a contiguous chunk -- 64 cache lines per wave load, 5.6 ms per
  * launch at 1080p / 100 k candidates; it is in the git history).
  * ---------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(OT)
-k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P,
-         uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-         uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, const int32_t* redo_flags) {
-    extern __shared__ __align__(16) uint8_t osm[];
+/* what one (slot, level) problem of the walk-per-pass distribution needs from OctParams: plain values, so that the body
+ * can be shared by k_octree_v2 and the hand-over path of k_octree_v3 */
+struct OctWalkLevel {
+    int32_t N, H, nIni, c0, c1, selOff, selStride, maxNodes, ptsCap, maxIter;
+    float hX;
+    void* dbg;
+};
+__device__ __forceinline__ OctWalkLevel oct_walk_level(const OctParams& P, int level) {
+    OctWalkLevel L;
+    L.N = P.N[level]; L.H = P.H[level]; L.nIni = P.nIni[level]; L.hX = P.hX[level];
+    L.c0 = P.cellFirst[level]; L.c1 = P.cellFirst[level + 1];
+    L.selOff = P.selOff[level]; L.selStride = P.selStride; L.maxNodes = P.maxNodes; L.ptsCap = P.ptsCap;
+    L.maxIter = P.maxIter; L.dbg = P.dbg;
+    return L;
+}
+
+/* osm: the workgroup's dynamic LDS; s_w32[NT / 64] and s_ctl[4]: scratch words in LDS (scan partials; size, M, nexp, cut) */
+template <int NT, bool REGKEYS> /* threads of the workgroup; REGKEYS: problems up to OKPT * NT keys live in registers */
+__device__ __forceinline__ void
+oct_walk_body(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, const OctWalkLevel P, int level, int slot,
+              uint32_t* pts_a, uint16_t* nid_a, size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
+              uint8_t* osm, uint32_t* s_w32, int* s_ctl) {
+#define s_size s_ctl[0]
+#define s_M s_ctl[1]
+#define s_nexp s_ctl[2]
+#define s_cut s_ctl[3]
+    constexpr int WBATCH = REGKEYS ? OBATCH : 2; /* keys per thread and batch when streaming */
     const int MAXN = P.maxNodes;
     ONode* cur = (ONode*)osm;
     ONode* nxt = cur + MAXN;
@@ -99,15 +121,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint16_t* newIdx = cb + MAXN;             /* list index of a survivor after the pass */
     uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
     uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
-    __shared__ uint32_t s_w32[OT / 64];
-    __shared__ int s_size, s_M, s_nexp, s_cut;
-
     const int tid = threadIdx.x;
-    /* grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
-     * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
-    const int level = blockIdx.y, slot = blockIdx.x;
-    /* behind k_octree_v3: only the (slot, level) problems it handed over (block-uniform early exit) */
-    if (redo_flags && !redo_flags[slot * VSLAM_MAX_LEVELS + level]) return;
 #ifdef VSLAM_OCT_STAMPS /* diagnostic build (make EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS): where the level-0 workgroup
                            of slot 0 spends its time; read with vslam_dbg_octree_stamps / tools/octree_stamps.py */
     int dbgn = 0;
@@ -117,36 +131,34 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 #define STAMP() do { } while (0)
 #endif
     STAMP();
-    const int N = P.N[level];
+    const int N = P.N;
     const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
     const CellOut* cout = (const CellOut*)(hdr + 2);
     const uint32_t* cand = (const uint32_t*)(cout + ncells);
     uint32_t* pa = pts_a + (size_t)slot * pts_stride;
-    (void)pts_b;
-    (void)nid_b;
     uint16_t* na = nid_a + (size_t)slot * pts_stride;
-    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
+    uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff;
     int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
 
     /* ---- 0. gather this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817):
      * a wave per cell, coalesced.  A key's position in this array IS its rank in the reference's key order. */
-    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
+    const int c0 = P.c0, c1 = P.c1;
     uint32_t before = 0;
-    for (int c = tid; c < c0; c += OT) before += cout[c].count;
+    for (int c = tid; c < c0; c += NT) before += cout[c].count;
     uint32_t off0;
     {
         uint32_t tot;
-        block_excl_scan<uint32_t>(before, s_w32, &tot);
+        block_excl_scan<uint32_t, NT>(before, s_w32, &tot);
         off0 = tot;
     }
-    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
+    const int ncl = c1 - c0, K = (ncl + NT - 1) / NT;
     uint32_t mine = 0;
     for (int k = 0; k < K; k++) {
         const int c = c0 + tid * K + k;
         if (c < c1) mine += cout[c].count;
     }
     uint32_t ntot;
-    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
+    uint32_t woff = block_excl_scan<uint32_t, NT>(mine, s_w32, &ntot);
     const int n = (int)ntot;
     if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
         if (tid == 0) {
@@ -167,7 +179,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     __syncthreads();
     {
         const int lane = tid & 63, wv = tid >> 6;
-        for (int c = c0 + wv; c < c1; c += OT / 64) {
+        for (int c = c0 + wv; c < c1; c += NT / 64) {
             const uint32_t* q = cand + cout[c].base;
             const uint32_t cnt = cout[c].count, o = coff[c - c0];
             for (uint32_t e = lane; e < cnt; e += 64) pa[o + e] = q[e];
@@ -183,15 +195,15 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 
     /* Key walks.  A problem of up to OKPT * 1024 keys (every KITTI-size level) keeps its keys and their node labels in
      * REGISTERS for the whole kernel: after this one read the walks touch no global memory at all.  Larger problems
-     * (1080p level 0: ~100 k keys) stream keys and labels through registers in batches of OBATCH per thread, all
+     * (1080p level 0: ~100 k keys) stream keys and labels through registers in batches of WBATCH per thread, all
      * loads of a batch issued before the first use (one L2 round trip per batch instead of one per key). */
-    const bool inReg = n <= OKPT * OT;
+    const bool inReg = REGKEYS && n <= OKPT * NT;
     uint32_t keyR[OKPT];
     uint32_t nidR[OKPT];
     if (inReg) {
 #pragma unroll
         for (int k = 0; k < OKPT; k++) {
-            const int i = tid + k * OT;
+            const int i = tid + k * NT;
             keyR[k] = i < n ? pa[i] : 0u;
             nidR[k] = 0u;
         }
@@ -201,21 +213,21 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         if (inReg) {
 #pragma unroll
             for (int k = 0; k < OKPT; k++) {
-                const int i = tid + k * OT;
+                const int i = tid + k * NT;
                 if (i < n) body(i, keyR[k], nidR[k]);
             }
         } else {
-            for (int base = tid; base < n; base += OBATCH * OT) {
-                uint32_t kk[OBATCH], nn[OBATCH];
+            for (int base = tid; base < n; base += WBATCH * NT) {
+                uint32_t kk[WBATCH], nn[WBATCH];
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++) {
-                    const int i = base + j * OT;
+                for (int j = 0; j < WBATCH; j++) {
+                    const int i = base + j * NT;
                     kk[j] = i < n ? pa[i] : 0u;
                     nn[j] = i < n ? (uint32_t)na[i] : 0u;
                 }
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++) {
-                    const int i = base + j * OT;
+                for (int j = 0; j < WBATCH; j++) {
+                    const int i = base + j * NT;
                     if (i < n) {
                         const uint32_t before = nn[j];
                         body(i, kk[j], nn[j]);
@@ -227,9 +239,9 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     };
 
     /* ---- 1. initial nodes: stable bucketing by (int)(x / hX) (fextractor.cpp:534-576) */
-    const int nIni = P.nIni[level];
-    const float hX = P.hX[level];
-    const int Hh = P.H[level];
+    const int nIni = P.nIni;
+    const float hX = P.hX;
+    const int Hh = P.H;
     __shared__ uint32_t s_bcnt[64], s_bidx[64];
     if (tid < 64) s_bcnt[tid] = 0;
     __syncthreads();
@@ -274,7 +286,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     STAMP();
     /* ---- 2. split passes */
     int phase = 1;
-    const int KN = (MAXN + OT - 1) / OT;
+    const int KN = (MAXN + NT - 1) / NT;
     for (int iter = 0; iter < P.maxIter; iter++) {
         const int size0 = s_size;
         /* A. children's key counts of every expandable node: a histogram, no key moves */
@@ -301,7 +313,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
         }
         uint32_t nexp;
-        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
+        uint32_t rbase = block_excl_scan<uint32_t, NT>(nexp_mine, s_w32, &nexp);
         if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
         if (phase == 1) {
             for (int k = 0; k < KN; k++) {
@@ -332,7 +344,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         __syncthreads();
         STAMP();
         /* D2. in processing order: children created before me, running list size -> cut */
-        const int KE = ((int)nexp + OT - 1) / OT;
+        const int KE = ((int)nexp + NT - 1) / NT;
         uint32_t chl = 0;
         for (int k = 0; k < KE; k++) {
             const int r = tid * KE + k;
@@ -342,7 +354,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
         uint32_t chtot;
-        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
+        uint32_t chbase = block_excl_scan<uint32_t, NT>(chl, s_w32, &chtot);
         if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
         __syncthreads();
         {
@@ -383,7 +395,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
         uint32_t svtot;
-        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
+        uint32_t svbase = block_excl_scan<uint32_t, NT>(sv, s_w32, &svtot);
         int nexp_children = 0;
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
@@ -449,13 +461,13 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
      * key = response << 32 | ~position; output in list order */
     const int size = s_size;
     u64* best = Sbeg;
-    for (int v = tid; v < size; v += OT) best[v] = 0ull;
+    for (int v = tid; v < size; v += NT) best[v] = 0ull;
     __syncthreads();
     walk([&](int i, uint32_t key, uint32_t& nid) {
         atomicMax(&best[nid], ((u64)(key >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
     }, false);
     __syncthreads();
-    for (int v = tid; v < size; v += OT) /* every listed node holds at least one key */
+    for (int v = tid; v < size; v += NT) /* every listed node holds at least one key */
         out[v] = best[v] ? pa[0xFFFFFFFFu - (uint32_t)(best[v] & 0xFFFFFFFFull)] : 0u;
 #ifdef VSLAM_OCT_STAMPS
     __syncthreads();
@@ -463,6 +475,24 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     if (DBG && tid == 0 && level == 0 && slot == 0) DBG[63] = dbgn;
 #endif
     if (tid == 0) *ocnt = size;
+#undef s_size
+#undef s_M
+#undef s_nexp
+#undef s_cut
+}
+
+/* the distribution as a kernel of its own (VSLAM_OCTREE=v2, and contexts whose fine grid was not allocated): one workgroup
+ * per problem; grid (slots, levels): workgroups go to XCDs round-robin by linear id, so the heavy level-0 problems of a
+ * batch spread over all eight XCDs instead of piling onto XCD 0 (which grid (levels, slots) did) */
+__global__ void __launch_bounds__(OT)
+k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a, uint16_t* nid_a,
+            size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag) {
+    extern __shared__ __align__(16) uint8_t osm[];
+    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ int s_ctl[4];
+    const int level = blockIdx.y, slot = blockIdx.x;
+    oct_walk_body<OT, true>(cand_region, cand_stride, ncells, oct_walk_level(P, level), level, slot, pts_a, nid_a, pts_stride, sel_xyr,
+                      sel_cnt, err_flag, osm, s_w32, s_ctl);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -798,7 +828,9 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
         __syncthreads();
-        if (s_redo) { /* block-uniform: hand this (slot, level) to k_octree_v2 */
+        if (s_redo) { /* block-uniform: a node that is a single fine cell would have to be split.  k_assign_out, the next
+                         kernel of the pass, redoes this (slot, level) with the walk-per-pass distribution before it reads
+                         the level's result (see there for why not here and not in a launch of its own) */
             if (tid == 0) *redo = 1;
             return;
         }
@@ -1010,14 +1042,38 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
  * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
  * ---------------------------------------------------------------------------------------------- */
 #define AO_T 256 /* a small workgroup finds a free CU slot quickly next to the other streams' kernels */
+/* Hand-over from k_octree_v3 (walk != null): before anything else the slot's workgroup redoes the levels k_octree_v3
+ * flagged -- normally none -- with the walk-per-pass distribution in its streaming form, node arrays in GLOBAL scratch
+ * (walk) instead of LDS.  Why here: what the hand-over costs in the pipeline is the common case, in which nothing is
+ * handed over.  A launch of its own behind k_octree_v3 sits in the context's chain of kernels, and as a 1024-thread
+ * workgroup that needs every register of a CU it waits for a CU to drain of the other contexts' waves (53 us under
+ * load as a full grid of early-exit workgroups, 6 % of the mono rate; 3.5 % even as eight 256-thread workgroups, which
+ * still ask for 60 KB of LDS each).  Inlined into k_octree_v3 it takes that kernel from 104 to 128 allocated VGPRs, i.e.
+ * the last free registers of its CUs (5 %); called from it, it brings a stack, and a kernel with scratch memory ran
+ * 134 instead of 78 us.  This kernel is launched anyway, its 256-thread workgroups fit next to anything, and the
+ * registers the rare path adds cost one wave slot per SIMD. */
 __global__ void __launch_bounds__(AO_T)
-k_assign_out(OctParams P, PyramidGeom g, const uint32_t* __restrict__ sel_xyr, const int32_t* __restrict__ sel_cnt,
+k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
              int lap0, int lap1, SelKp* sel, int32_t* slot_counts /* [slot][4]: n, mono, 0, 0 */, int cap,
-             int32_t* err_flag) {
+             int32_t* err_flag, const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a,
+             size_t pts_stride, const int32_t* redo_flags, uint8_t* walk, size_t walk_stride) {
     __shared__ uint32_t s_w32[AO_T / 64];
     __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
     const int tid = threadIdx.x, slot = blockIdx.x;
     const int L = g.nlevels;
+    if (walk) {
+        __shared__ int s_walk_ctl[4];
+        int mine = 0;
+        if (tid < L) mine = redo_flags[slot * VSLAM_MAX_LEVELS + tid] != 0;
+        if (__syncthreads_or(mine)) { /* rare */
+            for (int lv = 0; lv < L; lv++) {
+                if (!redo_flags[slot * VSLAM_MAX_LEVELS + lv]) continue; /* block-uniform */
+                oct_walk_body<AO_T, false>(cand_region, cand_stride, ncells, oct_walk_level(P, lv), lv, slot, pts_a, nid_a, pts_stride,
+                                           sel_xyr, sel_cnt, err_flag, walk + (size_t)slot * walk_stride, s_w32, s_walk_ctl);
+                __syncthreads(); /* results (global memory) visible to the whole workgroup; scratch reused by the next level */
+            }
+        }
+    }
     if (tid == 0) {
         int acc = 0;
         for (int l = 0; l < L; l++) {
@@ -1081,23 +1137,24 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
                int32_t* redo_flags) {
+    (void)pts_b;
+    (void)nid_b;
     const dim3 grid(nslots, nlevels);
-    if (fine && redo_flags) { /* k_octree_v3, then k_octree_v2 for the problems it handed over (normally none) */
+    if (fine && redo_flags) /* k_octree_v3; problems its fine grid cannot resolve are flagged and redone by k_assign_out */
         hipLaunchKernelGGL(k_octree_v3, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
                            P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
-        hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
-                           P, pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag, (const int32_t*)redo_flags);
-        return;
-    }
-    hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
-                       pts_a, pts_b, nid_a, nid_b, pts_stride, sel_xyr, sel_cnt, err_flag, (const int32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
+                           pts_a, nid_a, pts_stride, sel_xyr, sel_cnt, err_flag);
 }
 
-void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, const uint32_t* sel_xyr,
-                   const int32_t* sel_cnt, int lap0, int lap1, SelKp* sel, int32_t* slot_counts, int cap,
-                   int32_t* err_flag, int nslots) {
+void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
+                   int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
+                   const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a, size_t pts_stride,
+                   const int32_t* redo_flags, uint8_t* walk, size_t walk_stride) {
     hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(AO_T), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
-                       slot_counts, cap, err_flag);
+                       slot_counts, cap, err_flag, cand_region, cand_stride, ncells, pts_a, nid_a, pts_stride, redo_flags,
+                       redo_flags ? walk : (uint8_t*)nullptr, walk_stride);
 }
 
 int vk_octree_set_max_lds(size_t bytes) {
