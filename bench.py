@@ -279,6 +279,9 @@ class Pipeline:
         self.xchg = env.get("xchg")
         recv_n = (world if (self.xchg and self.xchg.mode == "allgather") else 1) * B * self.slot_bytes
         self.recv = [torch.zeros(recv_n, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        # single GPU: the last frame of a step, which the NEXT step's first matcher job reads, is copied into a carry
+        # buffer of its own, so that a context may start its next extraction without waiting for that matcher
+        self.carry = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(0 if self.multi else self.NCTX)]
         self.state = {"matches": 0}
         self.job_cache = {}
         self.track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
@@ -364,12 +367,18 @@ class Pipeline:
         if self.stereo:
             c.frame_stereo_async(ptrs, pitch, BF, FX, where=where)
             return
-        c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last results: it must finish first
+        # The extraction overwrites only this context's own result slots, which nobody else reads: what the matcher of
+        # the NEXT step (context nxt, step t-NCTX+1) read from us is the carry / exchange buffer, so only the copy into
+        # that buffer has to wait for it -- not the extraction.  (With the wait in front of the extraction a context sat
+        # idle for a whole step between two of its passes: 353 us per 1140-us cycle in the kernel trace.)
         c.compute_batch_async(ptrs, pitch, self.lap, where=where)
+        c.event_wait(nxt, 1)
         if self.multi:
             c.pack_slots(B, self.packed[k].data_ptr(), self.slot_bytes, sync=False)  # one kernel on c's stream
             self.xchg.exchange(c, self.packed[k], self.recv[k])  # RCCL: enqueued on c's own stream (no host sync)
-        c.event_record(0)  # step t's results (own, and the left neighbour's) are complete
+        else:
+            c.pack_slots(1, self.carry[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
+        c.event_record(0)  # step t's results (own, and the left neighbour's / the carried last frame) are complete
         # the device addresses are fixed per context, so the job array is built once (t == 0 has no predecessor
         # for slot 0 and is built separately)
         ck = (k, t == 0)
@@ -382,7 +391,7 @@ class Pipeline:
                     if t == 0:
                         continue
                     p = (self._slot_ptrs_in(self.xchg.left_block(self.recv[(t - 1) % NCTX]), B - 1) if self.multi
-                         else prv.slot_dev_ptrs(B - 1))
+                         else self._slot_ptrs_in(self.carry[(t - 1) % NCTX], 0))
                     uses_prev_step = True
                 elif not self.multi:
                     p = c.slot_dev_ptrs(ps)
@@ -493,7 +502,7 @@ class Pipeline:
         for p in self.pinned or []:
             p.close()
         self.dev_frames = None
-        self.packed = self.recv = None
+        self.packed = self.recv = self.carry = None
 
 
 def roofline_of(pl, stage_alone, stage_pipe, res_dev):

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvslam_fe.so")
+LIB_PATH = os.environ.get("VSLAM_FE_LIB") or os.path.join(_HERE, "libvslam_fe.so")  # VSLAM_FE_LIB: a diagnostic build
 HOST_LIB_PATH = os.path.join(_HERE, "libvslam_host.so")
 
 VSLAM_OK = 0

@@ -180,4 +180,23 @@ int vslam_finish_extract(vslam_fe* fe, int nimg);
 int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
                   int* mono_index);
 
+
+/* Host wait for a stream.  hipStreamSynchronize blocks on an interrupt after a short spin; VSLAM_WAIT=spin polls
+ * hipStreamQuery instead (a core per waiting thread, lower wake-up latency). */
+static inline hipError_t vslam_stream_wait(hipStream_t st) {
+    static int spin = -1;
+    if (spin < 0) {
+        const char* e = getenv("VSLAM_WAIT");
+        spin = e && !strcmp(e, "spin");
+    }
+    if (!spin) return hipStreamSynchronize(st);
+    hipError_t r;
+    while ((r = hipStreamQuery(st)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return r;
+}
+
 #endif

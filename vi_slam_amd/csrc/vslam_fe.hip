@@ -521,7 +521,7 @@ static int pack_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t
     vk_pack_slots(fe->stream, fe->d_kps, fe->d_desc, fe->d_counts, fe->cap, first, nslots, (uint8_t*)dev_dst,
                   slot_bytes);
     HIPCHK(hipGetLastError());
-    if (sync) HIPCHK(hipStreamSynchronize(fe->stream));
+    if (sync) HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -553,7 +553,7 @@ extern "C" int vslam_fe_level_copy(vslam_fe* fe, int slot, int level, int blurre
         spitch = g.pitch;
     }
     HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, s, spitch, g.w, g.h, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -620,7 +620,7 @@ static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
     const size_t one = (size_t)(fe->p.height - 1) * spitch + fe->p.width;
     const size_t stride = (one + 255) & ~(size_t)255;
     if (fe->d_stage_bytes >= stride * fe->B + 256) return VSLAM_OK;
-    HIPCHK(hipStreamSynchronize(fe->stream)); /* an earlier pass may still read the old buffer */
+    HIPCHK(vslam_stream_wait(fe->stream)); /* an earlier pass may still read the old buffer */
     return vslam_ensure((void**)&fe->d_stage, &fe->d_stage_bytes, stride * fe->B + 256);
 }
 
@@ -992,7 +992,7 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
 int vslam_finish_extract(vslam_fe* fe, int nimg) {
     hipStream_t st = fe->stream;
     const double t_sync = hp_now();
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(vslam_stream_wait(st));
     g_hp[3] += hp_now() - t_sync;
     if (fe->dev_octree) {
         const int32_t* err = fe->h_counts + (size_t)fe->B * 4;
@@ -1110,7 +1110,7 @@ extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t
     }
     HIPCHK(hipSetDevice(fe->p.device));
     if (where == VSLAM_IMGS_HOST) {
-        HIPCHK(hipStreamSynchronize(fe->stream)); /* the pinned staging may still be read by the previous pull */
+        HIPCHK(vslam_stream_wait(fe->stream)); /* the pinned staging may still be read by the previous pull */
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
@@ -1226,7 +1226,7 @@ extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, co
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(idx2, fe->d_idx2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
     HIPCHK(hipMemcpyAsync(dist2, fe->d_dist2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -1243,7 +1243,7 @@ extern "C" int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, 
     vk_hamming_matrix(fe->stream, dev_q, nq, dev_t, nt, fe->d_dmat);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, fe->d_dmat, (size_t)nq * nt, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 

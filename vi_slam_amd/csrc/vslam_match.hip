@@ -61,7 +61,7 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
         jb.slotL = sL;
         jb.slotR = sR;
     }
-    if (feL != feR) HIPCHK(hipStreamSynchronize(feR->stream)); /* right results must be complete */
+    if (feL != feR) HIPCHK(vslam_stream_wait(feR->stream)); /* right results must be complete */
     StereoScratch sc;
     int rc = stereo_scratch(feL, npairs, feR->cap, &sc);
     feL->stereo_capR = feR->cap;
@@ -107,7 +107,7 @@ extern "C" int vslam_stereo_match_batch(vslam_fe* feL, vslam_fe* feR, int npairs
     HIPCHK(hipSetDevice(feL->p.device));
     int rc = enqueue_stereo(feL, feR, npairs, slotsL, slotsR, bf, fx);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(feL->stream));
+    HIPCHK(vslam_stream_wait(feL->stream));
     deliver_stereo(feL, u_right, depth);
     return VSLAM_OK;
 }
@@ -255,7 +255,7 @@ extern "C" int vslam_search_init_dev_wait(vslam_fe* fe, const int* n1, int32_t* 
         return VSLAM_ERR_INVALID;
     }
     HIPCHK(hipSetDevice(fe->p.device));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     const int npairs = fe->init_pairs;
     const size_t nm = (size_t)npairs * fe->cap;
     const int32_t* h_m = (const int32_t*)fe->h_init;
@@ -340,7 +340,7 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
                 off += (poff + (size_t)n1[j] * 8 + 63) & ~(size_t)63;
             }
             HIPCHK(hipMemcpyAsync(fe->d_tmp_desc[1], stage.data(), off, hipMemcpyHostToDevice, fe->stream));
-            HIPCHK(hipStreamSynchronize(fe->stream)); /* stage is pageable and goes out of scope */
+            HIPCHK(vslam_stream_wait(fe->stream)); /* stage is pageable and goes out of scope */
             rc = vslam_search_init_dev_async(fe, npairs, jobs.data(), img_w, img_h, window, nnratio, check_orientation);
             if (rc) return rc;
             return vslam_search_init_dev_wait(fe, n1, matches12, prev_matched, nmatches);
@@ -390,7 +390,7 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
         vk_hamming_matrix_batch(st, jobs, npairs, maxr, maxc, d_idx, d_rows, fe->d_dmat);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(dmat.data(), fe->d_dmat, out_total, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(vslam_stream_wait(st));
     }
     /* the stealing / ratio / rotation-histogram logic is order dependent: replayed on the host, one
      * pair per worker */
@@ -444,7 +444,7 @@ extern "C" int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_
     vk_dbg_sincos(fe->stream, dx, n, ds, dc);
     HIPCHK(hipMemcpyAsync(sin_out, ds, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
     HIPCHK(hipMemcpyAsync(cos_out, dc, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -458,7 +458,7 @@ extern "C" int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y) {
     HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, fe->stream));
     vk_dbg_logf(fe->stream, dx, n, dy);
     HIPCHK(hipMemcpyAsync(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -473,7 +473,7 @@ extern "C" int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x
     HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, fe->stream));
     vk_dbg_atan2(fe->stream, dy, dx, n, fma, da);
     HIPCHK(hipMemcpyAsync(deg, da, (size_t)n * 4, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
 }
 
@@ -482,7 +482,7 @@ extern "C" int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count) {
     *count = 0;
     if (!fe->d_init_fb) return VSLAM_OK;
     HIPCHK(hipSetDevice(fe->p.device));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     HIPCHK(hipMemcpy(count, fe->d_init_fb, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(fe->d_init_fb, 0, 4));
     return VSLAM_OK;
@@ -640,7 +640,7 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
     R.n = 1;
     vk_copy_ranges(st, R);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(vslam_stream_wait(st));
     memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
     *nmatches = *(const int32_t*)(h + o_n);
     return VSLAM_OK;
@@ -823,7 +823,7 @@ extern "C" int vslam_search_by_projection_dev_wait(vslam_fe* fe, const int* n_cu
         return VSLAM_ERR_INVALID;
     }
     HIPCHK(hipSetDevice(fe->p.device));
-    HIPCHK(hipStreamSynchronize(fe->stream));
+    HIPCHK(vslam_stream_wait(fe->stream));
     const int njobs = fe->sbp_jobs, cap = fe->cap;
     const int32_t* h_m = (const int32_t*)fe->h_sbp;
     const int32_t* h_n = h_m + (size_t)njobs * cap;
@@ -982,7 +982,7 @@ extern "C" int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp
     R.n = 1;
     vk_copy_ranges(st, R);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(vslam_stream_wait(st));
     memcpy(match_cur, h + o_m, (size_t)n_cur * 4);
     *nmatches = *(const int32_t*)(h + o_n);
     return VSLAM_OK;
@@ -1049,7 +1049,7 @@ extern "C" int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_h
     R.bytes[0] = (size_t)nsets * 4;
     vk_copy_ranges(st, R);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(vslam_stream_wait(st));
     memcpy(best, h + o_b, (size_t)nsets * 4);
     return VSLAM_OK;
 }
@@ -1127,7 +1127,7 @@ extern "C" int vslam_fuse_search(vslam_fe* fe, const vslam_fuse_params* p, const
     R.bytes[0] = total - o_bi;
     vk_copy_ranges(st, R);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(vslam_stream_wait(st));
     memcpy(best_idx, h + o_bi, (size_t)n_points * 4);
     memcpy(best_dist, h + o_bd, (size_t)n_points * 4);
     return VSLAM_OK;

@@ -554,6 +554,7 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
     return v;
 }
 
+template <bool REGKEYS> /* keys (and their fine cells) of problems up to OKPT * 1024 keys stay in registers between the two key walks */
 __global__ void __launch_bounds__(OT)
 k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a,
             uint16_t* fc_a, size_t pts_stride, uint32_t* fine, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
@@ -654,7 +655,7 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
 
     /* keys of a problem of up to OKPT * 1024 keys (every KITTI-size level) and their fine cells stay in REGISTERS */
-    const bool inReg = n <= OKPT * OT;
+    const bool inReg = REGKEYS && n <= OKPT * OT;
     const int E = (n + OT - 1) / OT; /* positions per thread */
     uint32_t keyR[OKPT];
     uint32_t cellR[OKPT / 2]; /* two 16-bit fine cells per register */
@@ -1141,8 +1142,24 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
     (void)nid_b;
     const dim3 grid(nslots, nlevels);
     if (fine && redo_flags) /* k_octree_v3; problems its fine grid cannot resolve are flagged and redone by k_assign_out */
-        hipLaunchKernelGGL(k_octree_v3, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
-                           P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
+    {
+        /* Keys in registers save the second key walk its re-read (46 KB per KITTI level, L2 hits), at 24 VGPRs per thread:
+         * 104 instead of 80 allocated, and a 1024-thread workgroup at 104 leaves room for ONE 64-register wave per SIMD
+         * next to it, at 80 for three.  With several contexts in flight the neighbours matter more than the re-read
+         * (VSLAM_OCT_REGKEYS=0|1 overrides; default: registers only for single images, where latency is what counts). */
+        static int regkeys = -1;
+        if (regkeys < 0) {
+            const char* e = getenv("VSLAM_OCT_REGKEYS");
+            regkeys = e ? (atoi(e) != 0 ? 1 : 0) : 2;
+        }
+        const bool rk = regkeys == 2 ? nslots <= 2 : regkeys == 1;
+        if (rk)
+            hipLaunchKernelGGL(k_octree_v3<true>, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
+                               P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
+        else
+            hipLaunchKernelGGL(k_octree_v3<false>, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
+                               P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
+    }
     else
         hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
                            pts_a, nid_a, pts_stride, sel_xyr, sel_cnt, err_flag);
@@ -1160,5 +1177,7 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uin
 int vk_octree_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
-    return (int)hipFuncSetAttribute((const void*)k_octree_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_octree_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
