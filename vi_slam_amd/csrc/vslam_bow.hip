@@ -149,7 +149,7 @@ static int bow_buffers(vslam_fe* fe, int nslots, int per) {
         if (fe->h_bow) HIPCHK(hipHostFree(fe->h_bow));
         fe->h_bow = nullptr;
         fe->h_bow_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_bow, bytes, hipHostMallocDefault));
+        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_bow, bytes));
         fe->h_bow_bytes = bytes;
     }
     return VSLAM_OK;

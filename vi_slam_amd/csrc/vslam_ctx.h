@@ -174,6 +174,7 @@ struct vslam_fe {
 
 int vslam_ensure(void** p, size_t* have, size_t want);
 int vslam_ensure_pinned(uint8_t** p, size_t* have, size_t want); /* grow-only pinned host buffer */
+int vslam_pinned_alloc(void** p, size_t bytes);                  /* hipHostMalloc on the device's NUMA node; returns a hipError_t */
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
                           int lap0, int lap1, bool want_host);
 int vslam_finish_extract(vslam_fe* fe, int nimg);

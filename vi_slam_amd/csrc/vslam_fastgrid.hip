@@ -370,10 +370,10 @@ extern "C" int vslam_fg_create(const vslam_fg_params* p, vslam_fg** out) {
     FG_TRY(hipStreamCreateWithFlags(&fg->stream, hipStreamNonBlocking));
     FG_TRY(hipMalloc((void**)&fg->d_pyr, fg->pyr_bytes));
     FG_TRY(hipMemset(fg->d_pyr, 0, fg->pyr_bytes));
-    FG_TRY(hipHostMalloc((void**)&fg->h_img, G.lv[0].bytes * p->max_batch, hipHostMallocDefault));
+    FG_TRY((hipError_t)vslam_pinned_alloc((void**)&fg->h_img, G.lv[0].bytes * p->max_batch));
     memset(fg->h_img, 0, G.lv[0].bytes * p->max_batch);
     FG_TRY(hipMalloc((void**)&fg->d_grid, (size_t)fg->cells * 16 * p->max_batch));
-    FG_TRY(hipHostMalloc((void**)&fg->h_grid, (size_t)fg->cells * 16 * p->max_batch, hipHostMallocDefault));
+    FG_TRY((hipError_t)vslam_pinned_alloc((void**)&fg->h_grid, (size_t)fg->cells * 16 * p->max_batch));
     FG_TRY(hipMalloc((void**)&fg->d_resp, (size_t)p->image_width * p->image_height * 4));
     FG_TRY(hipDeviceSynchronize());
 #undef FG_TRY

@@ -28,7 +28,7 @@ static int stereo_scratch(vslam_fe* fe, int njobs, int capR, StereoScratch* s) {
         if (fe->h_stereo) HIPCHK(hipHostFree(fe->h_stereo));
         fe->h_stereo = nullptr;
         fe->h_stereo_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_stereo, n * 8, hipHostMallocDefault));
+        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_stereo, n * 8));
         fe->h_stereo_bytes = n * 8;
     }
     return VSLAM_OK;
@@ -165,7 +165,7 @@ static int init_scratch(vslam_fe* fe, int npairs) {
         if (fe->h_init) HIPCHK(hipHostFree(fe->h_init));
         fe->h_init = nullptr;
         fe->h_init_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_init, per * npairs, hipHostMallocDefault));
+        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_init, per * npairs));
         fe->h_init_bytes = per * npairs;
     }
     return VSLAM_OK;
@@ -768,7 +768,7 @@ extern "C" int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, con
         if (fe->h_sbp) HIPCHK(hipHostFree(fe->h_sbp));
         fe->h_sbp = nullptr;
         fe->h_sbp_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_sbp, res_bytes, hipHostMallocDefault));
+        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_sbp, res_bytes));
         fe->h_sbp_bytes = res_bytes;
     }
     SbpJobs JS;
@@ -1024,7 +1024,7 @@ extern "C" int vslam_distinctive_descriptors(vslam_fe* fe, const uint8_t* desc_h
         if (fe->h_proj) HIPCHK(hipHostFree(fe->h_proj));
         fe->h_proj = nullptr;
         fe->h_proj_bytes = 0;
-        HIPCHK(hipHostMalloc((void**)&fe->h_proj, bytes, hipHostMallocDefault));
+        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_proj, bytes));
         fe->h_proj_bytes = bytes;
     }
     uint8_t *h = fe->h_proj, *d = fe->d_proj;
