@@ -30,13 +30,20 @@
 #define SI_HISTO 30
 #define SI_GRID_COLS 64 /* FRAME_GRID_COLS, frame.h:42 */
 #define SI_GRID_ROWS 48 /* FRAME_GRID_ROWS, frame.h:43 */
-#define SI_QPB 8        /* queries per k_si_topm workgroup (4 waves x 2) */
+#define SI_QPB_MAX 32   /* queries per k_si_topm workgroup: run-time (4 waves x 2..8), see vk_search_init */
 #define SI_MAX_M 16
 
 struct SiCand { /* one octave-0 keypoint of frame 2 */
     float x, y, angle;
     uint16_t cell; /* gridX * 64 + gridY (gridY < 48) */
     uint16_t idx;  /* index in frame 2 */
+};
+struct SiCandL { /* the same in k_si_topm's LDS list, which is sorted by grid column: the position c in the
+                   keypoint-ordered list (what the keys and k_si_replay refer to) instead of the angle */
+    float x, y;
+    uint32_t c;
+    uint16_t cell;
+    uint16_t idx;
 };
 struct SiQuery { /* one octave-0 keypoint of frame 1 */
     float px, py, angle; /* vbPrevMatched position, keypoint angle */
@@ -68,6 +75,12 @@ __device__ __forceinline__ bool si_in_window(const SiCand& cd, const SiWindow& w
     const float distx = __fsub_rn(cd.x, px), disty = __fsub_rn(cd.y, py);
     return fabsf(distx) < r && fabsf(disty) < r;
 }
+__device__ __forceinline__ bool si_in_window(const SiCandL& cd, const SiWindow& w, float px, float py, float r) {
+    const int gx = cd.cell >> 6, gy = cd.cell & 63;
+    if (gx < w.minX || gx > w.maxX || gy < w.minY || gy > w.maxY) return false;
+    const float distx = __fsub_rn(cd.x, px), disty = __fsub_rn(cd.y, py);
+    return fabsf(distx) < r && fabsf(disty) < r;
+}
 __device__ __forceinline__ uint32_t si_hamming(const uint4& da, const uint4& db, const uint4& ta, const uint4& tb) {
     return __popc(da.x ^ ta.x) + __popc(da.y ^ ta.y) + __popc(da.z ^ ta.z) + __popc(da.w ^ ta.w) +
            __popc(db.x ^ tb.x) + __popc(db.y ^ tb.y) + __popc(db.z ^ tb.z) + __popc(db.w ^ tb.w);
@@ -79,12 +92,18 @@ __device__ __forceinline__ uint32_t si_hamming(const uint4& da, const uint4& db,
  * candidates of its own queries.  Chunk 0 also publishes the compacted candidate list and the counts.
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
-k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, int M, uint8_t* scratch) {
+k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, int M, uint8_t* scratch, int SI_QPB) {
     extern __shared__ __align__(16) uint8_t sism[];
-    SiCand* cand = (SiCand*)sism;                    /* max_c2 */
+    SiCandL* cand = (SiCandL*)sism;                  /* max_c2, sorted by grid column */
     uint32_t* wkeys = (uint32_t*)(cand + max_c2);    /* 4 waves x max_c2: window keys of the current query */
-    __shared__ SiQuery s_q[SI_QPB];
+    SiCandL* tmpc = (SiCandL*)wkeys;                 /* ... and, before that, the list in keypoint order */
+    __shared__ SiQuery s_q[SI_QPB_MAX];
     __shared__ int s_wcnt[4];
+    __shared__ int s_col[SI_GRID_COLS + 1]; /* candidates per grid column, then the columns' first positions */
+    __shared__ int s_fill[SI_GRID_COLS];
+    if (threadIdx.x <= SI_GRID_COLS) s_col[threadIdx.x] = 0;
+    if (threadIdx.x < SI_GRID_COLS) s_fill[threadIdx.x] = 0;
+    __syncthreads();
     const InitJob jb = jobs.job[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = min(*jb.cnt1, cap), n2 = min(*jb.cnt2, cap);
@@ -125,14 +144,41 @@ k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, in
             cd.angle = k.angle;
             cd.cell = (uint16_t)(gx * 64 + gy);
             cd.idx = (uint16_t)i;
-            cand[pos] = cd;
             if (blockIdx.x == 0) gcand[pos] = cd;
+            SiCandL cl;
+            cl.x = k.x;
+            cl.y = k.y;
+            cl.c = (uint32_t)pos;
+            cl.cell = cd.cell;
+            cl.idx = cd.idx;
+            tmpc[pos] = cl;
+            atomicAdd(&s_col[gx], 1);
         }
         c2 += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         __syncthreads();
     }
     const int c2_raw = c2;
     c2 = min(c2, max_c2);
+    /* sort the list by grid column (order inside a column is irrelevant: keys are unique), so that a query only visits
+     * the columns of its window -- a sixth of the list at window 100 on a KITTI frame -- instead of testing all of it */
+    if (wave == 0) {
+        const int v = s_col[lane];
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        s_col[lane] = inc - v;
+        if (lane == 63) s_col[SI_GRID_COLS] = inc;
+    }
+    __syncthreads();
+    for (int i = tid; i < c2; i += 256) {
+        const SiCandL e = tmpc[i];
+        const int gx = e.cell >> 6;
+        cand[s_col[gx] + atomicAdd(&s_fill[gx], 1)] = e;
+    }
+    __syncthreads();
     int c1 = 0;
     for (int b = 0; b < n1; b += 256) {
         const int i = b + tid;
@@ -179,17 +225,18 @@ k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, in
             const uint4 da = ((const uint4*)jb.d1)[(size_t)qq.idx * 2];
             const uint4 db = ((const uint4*)jb.d1)[(size_t)qq.idx * 2 + 1];
             int nk = 0; /* window candidates, compacted (their order is irrelevant: keys are unique) */
-            for (int cb = 0; cb < c2; cb += 64) {
+            const int lo = s_col[win.minX], hi = s_col[win.maxX + 1]; /* 0 <= minX <= maxX <= 63 for a non-empty window */
+            for (int cb = lo; cb < hi; cb += 64) {
                 const int c = cb + lane;
                 bool in = false;
                 uint32_t key = 0;
-                if (c < c2) {
-                    const SiCand cd = cand[c];
+                if (c < hi) {
+                    const SiCandL cd = cand[c];
                     if (si_in_window(cd, win, qq.px, qq.py, r)) {
                         const uint4 ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
                         const uint4 tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
                         const uint32_t dist = si_hamming(da, db, ta, tb);
-                        key = (min(dist, 255u) << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
+                        key = (min(dist, 255u) << 24) | ((uint32_t)cd.cell << 12) | cd.c;
                         in = true;
                     }
                 }
@@ -439,9 +486,17 @@ void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, i
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
                     int max_c2, int M, uint8_t* scratch, int* fallbacks) {
     if (npairs <= 0) return;
-    const int chunks = (max_c2 + SI_QPB - 1) / SI_QPB;
+    /* queries per workgroup: every workgroup first rebuilds the pair's candidate list and finds its queries (a scan of
+     * both frames' keypoints), so fewer, longer workgroups repeat less of that; VSLAM_SI_QPB = 8 | 16 | 32 for A/B runs */
+    static int qpb = -1;
+    if (qpb < 0) {
+        const char* e = getenv("VSLAM_SI_QPB");
+        const int v = e ? atoi(e) : 0;
+        qpb = (v == 8 || v == 16 || v == 32) ? v : 16;
+    }
+    const int chunks = (max_c2 + qpb - 1) / qpb;
     hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
-                       window, max_c2, M, scratch);
+                       window, max_c2, M, scratch, qpb);
     hipLaunchKernelGGL(k_si_replay, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
                        window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
 }
