@@ -44,6 +44,13 @@ struct vslam_fe {
     hipStream_t stream = nullptr;
     hipEvent_t ev_cand = nullptr;
     hipEvent_t ev_x = nullptr; /* cross-context ordering (vslam_fe_wait_for) */
+    /* vslam_fe_stage_images_async: the DMA upload runs on a stream of its own, so that it can be issued passes ahead
+     * (it only needs the staging buffer, which the re-pitch kernel at the head of the previous pass has drained) */
+    hipStream_t copy_stream = nullptr;  /* shared by the device's contexts, never destroyed */
+    hipEvent_t ev_upload = nullptr;     /* recorded on copy_stream behind the upload */
+    hipEvent_t ev_stage_free = nullptr; /* recorded on stream behind the re-pitch that read d_stage */
+    bool stage_pending = false;         /* d_stage holds images the next IMGS_STAGED pass has to re-pitch */
+    BatchSrc stage_src;
     hipEvent_t ev_user[4] = {};  /* vslam_fe_event_record / _wait */
 
     uint8_t* d_pyr = nullptr;

@@ -23,6 +23,7 @@ extern "C" const char* vslam_last_error(void) { return vslam_err().c_str(); }
 
 static void free_ctx(vslam_fe* fe) {
     if (!fe) return;
+    if (fe->copy_stream) hipStreamSynchronize(fe->copy_stream);
     if (fe->stream) hipStreamSynchronize(fe->stream);
     delete fe->pool;
     hipFree(fe->d_pyr);
@@ -87,6 +88,8 @@ static void free_ctx(vslam_fe* fe) {
         if (fe->ev_user[i]) hipEventDestroy(fe->ev_user[i]);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
+    if (fe->ev_upload) hipEventDestroy(fe->ev_upload);
+    if (fe->ev_stage_free) hipEventDestroy(fe->ev_stage_free);
     if (fe->stream) hipStreamDestroy(fe->stream);
     delete fe;
 }
@@ -389,6 +392,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
 
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&fe->ev_upload, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&fe->ev_stage_free, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     {
         const char* e = getenv("VSLAM_GRAPH"); /* "0": never replay captured graphs */
@@ -633,7 +638,7 @@ static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
  *         Measured beside the other contexts' kernels: 102 k frames/s against 64-72 k with the pull kernel, whose host
  *         reads (2-3 us each) sit in the L2's queues in front of everybody's HBM requests (describe 122 -> 274 us).
  *   pull: one kernel reads the host rows over PCIe itself (55 GB/s alone on the GPU; kept for A/B runs). */
-static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where) {
+static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where, bool ahead = false) {
     const vslam_fe_params& p = fe->p;
     hipStream_t st = fe->stream;
     const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
@@ -656,21 +661,51 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
             g_err = "internal: device staging buffer not allocated";
             return VSLAM_ERR_HIP;
         }
+        /* ahead: the copy goes onto the context's copy stream behind the last re-pitch that read the staging buffer; the
+         * re-pitch into level 0 is left to the pass that uses the images (enqueue_front, IMGS_STAGED) */
+        if (ahead && !fe->copy_stream) { /* ONE upload stream per device, shared by its contexts and created on first use:
+                                           a stream per context doubles the HIP streams of a pipeline, and with eight
+                                           streams on the hardware queues the mono workload ran 87 k instead of 118 k
+                                           frames/s even when the extra streams were never used */
+            static std::mutex mu;
+            static hipStream_t shared[64][4] = {};
+            static int next[64] = {};
+            static int nshared = -1;
+            std::lock_guard<std::mutex> lk(mu);
+            if (nshared < 0) { /* VSLAM_COPY_STREAMS = 1..4 upload streams per device (contexts take them in turn) */
+                const char* e = getenv("VSLAM_COPY_STREAMS");
+                nshared = e ? std::min(4, std::max(1, atoi(e))) : 2;
+            }
+            const int dv = fe->p.device & 63, k = next[dv]++ % nshared;
+            if (!shared[dv][k]) HIPCHK(hipStreamCreateWithFlags(&shared[dv][k], hipStreamNonBlocking));
+            fe->copy_stream = shared[dv][k];
+        }
+        hipStream_t cs = ahead ? fe->copy_stream : st;
+        if (ahead) HIPCHK(hipStreamWaitEvent(cs, fe->ev_stage_free, 0));
+        else if (fe->stage_pending) HIPCHK(hipStreamWaitEvent(cs, fe->ev_upload, 0)); /* do not overtake an upload issued ahead */
         bool even = nimg > 1; /* equally spaced sources: one copy */
         const ptrdiff_t d = nimg > 1 ? hs.l0[1] - hs.l0[0] : 0;
         for (int s = 2; s < nimg && even; s++) even = hs.l0[s] - hs.l0[s - 1] == d;
         if (even && d > 0 && (size_t)d >= one && (size_t)d * (nimg - 1) + one <= fe->d_stage_bytes) {
-            HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * (nimg - 1) + one, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * (nimg - 1) + one, hipMemcpyHostToDevice, cs));
             for (int s = 0; s < nimg; s++) hs.l0[s] = fe->d_stage + (size_t)d * s;
         } else {
             for (int s = 0; s < nimg; s++) {
-                HIPCHK(hipMemcpyAsync(fe->d_stage + stride * s, hs.l0[s], one, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(fe->d_stage + stride * s, hs.l0[s], one, hipMemcpyHostToDevice, cs));
                 hs.l0[s] = fe->d_stage + stride * s;
             }
         }
         from_host = 0;
+        if (ahead) {
+            HIPCHK(hipEventRecord(fe->ev_upload, cs));
+            fe->stage_src = hs;
+            fe->stage_pending = true;
+            return VSLAM_OK;
+        }
+        fe->stage_pending = false;
     }
     vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg, from_host);
+    if (!from_host) HIPCHK(hipEventRecord(fe->ev_stage_free, st));
     return VSLAM_OK;
 }
 
@@ -688,6 +723,13 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
             fe->src.pitch0[s] = (uint32_t)pitch;
         }
     } else if (on_device == VSLAM_IMGS_STAGED) {
+        if (fe->stage_pending) { /* uploaded ahead into the staging buffer: re-pitch into level 0 now */
+            HIPCHK(hipStreamWaitEvent(st, fe->ev_upload, 0));
+            vk_pull_images(st, fe->stage_src, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)fe->geom.lv[0].pitch, p.width,
+                           p.height, nimg, 0);
+            HIPCHK(hipEventRecord(fe->ev_stage_free, st));
+            fe->stage_pending = false;
+        }
         for (int s = 0; s < nimg; s++) { /* vslam_fe_stage_images_async put them there */
             fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
             fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
@@ -1110,13 +1152,24 @@ extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t
     }
     HIPCHK(hipSetDevice(fe->p.device));
     if (where == VSLAM_IMGS_HOST) {
-        HIPCHK(vslam_stream_wait(fe->stream)); /* the pinned staging may still be read by the previous pull */
+        HIPCHK(vslam_stream_wait(fe->stream)); /* the pinned staging may still be read by the previous pull ... */
+        HIPCHK(hipEventSynchronize(fe->ev_upload)); /* ... or by an upload issued ahead */
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
     int rc2 = ensure_stage(fe, where == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch, nimg);
     if (rc2) return rc2;
-    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where);
+    /* VSLAM_STAGE_AHEAD=1: the DMA copy goes onto an upload stream shared by the device's contexts and may be issued
+     * passes ahead of its use (it waits only for the staging buffer); the pass re-pitches at its head.  Measured on the
+     * mono workload it is SLOWER than copy + re-pitch on the context's own stream at the head of the step (77-86 k against
+     * 85-103 k frames/s; one upload stream serialises copies that otherwise overlap on several DMA engines, and the
+     * host-input rate is bound by the link either way), so it is off by default. */
+    static int stage_ahead = -1;
+    if (stage_ahead < 0) {
+        const char* e = getenv("VSLAM_STAGE_AHEAD");
+        stage_ahead = e && atoi(e) != 0;
+    }
+    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where, /*ahead=*/stage_ahead && h2d_uses_sdma(nimg));
     if (rc2) return rc2;
     HIPCHK(hipGetLastError());
     return VSLAM_OK;

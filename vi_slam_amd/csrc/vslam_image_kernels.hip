@@ -683,7 +683,8 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     for (int u = 0; u < NSW; u++) {
         const int y = srow + u * RPS;
         wreg[u] = make_uint2(0u, 0u);
-        if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
+        /* uniform base + 32-bit lane offset: one v_mad_u32_u24 per load instead of a 64-bit multiply-add chain */
+        if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (uint32_t)(__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)scol));
     }
     /* score tile and keep words are contiguous: zeroed in 16-byte stores (the tail may run into the lists, which
      * are filled later) */
@@ -699,7 +700,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     }
     if (stager) /* taller windows than NSW sweeps cover (cells of unusual geometries): the rest row by row */
         for (int y = srow + NSW * RPS; y < wh; y += RPS)
-            *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (size_t)y * pitch + scol);
+            *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (uint32_t)(__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)scol));
     FSTAMP(0);
     __syncthreads();
     FSTAMP(1);
