@@ -265,3 +265,46 @@ def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(monkeypatch, env, cf
             _same_feats(res[s], (ko, do), "%s %s slot %d" % (env, cfg, s))
     finally:
         fe.close()
+
+
+@pytest.mark.parametrize("env", [{"VSLAM_OCT_FINE_D": "1"}, {"VSLAM_OCT_FINE_D": "3"}])
+def test_quadtree_handover_with_keys_in_global_memory(monkeypatch, env):
+    """batches of more than two images use the k_octree_v3 instantiation that re-reads its keys (80 VGPRs); the levels it
+    hands over are redone by k_assign_out with node arrays in global scratch"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    imgs = [synth.make_frame(1241, 376, seed=61, step=s) for s in range(4)]
+    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=4)
+    try:
+        res = fe.compute_batch(imgs)
+        e = orbo.Extractor(1000)
+        for s in range(4):
+            ko, do, _ = e.compute(imgs[s])
+            _same_feats(res[s], (ko, do), "%s slot %d" % (env, s))
+    finally:
+        fe.close()
+
+
+def _digest(extra_env):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(extra_env)
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "tools", "env_variant_check.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DIGEST ")]
+    assert lines, out.stdout[-1000:]
+    return lines[-1]
+
+
+def test_process_wide_switches_do_not_change_results():
+    """switches the library reads once per process (one child process each): every variant must deliver exactly what the
+    default does -- extraction from device and from staged pinned images, and the device-resident init matcher"""
+    ref = _digest({})
+    for env in ({"VSLAM_OCT_REGKEYS": "1"}, {"VSLAM_OCT_REGKEYS": "0"}, {"VSLAM_SI_QPB": "8"}, {"VSLAM_SI_QPB": "32"},
+                {"VSLAM_STAGE_AHEAD": "1"}, {"VSLAM_STAGE_AHEAD": "1", "VSLAM_COPY_STREAMS": "1"},
+                {"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0", "VSLAM_FAST_LDS_PAD": "4096"}, {"VSLAM_H2D": "pull"}):
+        assert _digest(env) == ref, env
