@@ -262,7 +262,7 @@ class Pipeline:
             elif self.stereo:
                 fr = synth.make_frame(w, h, step=(s // 2) * world + rank, right=bool(s & 1))
             else:
-                fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world))
+                fr = synth.make_frame(w, h, step=vd.global_frame(rank, s, world, B))
             frames.append(fr)
         self.frames = [frames[s % ndistinct] for s in range(B)]
         self.pitch = (w + 127) & ~127
@@ -275,9 +275,9 @@ class Pipeline:
         self.slot_bytes = self.fe.slot_bytes
         self.desc_off = 16 + self.fe.cap * 28
         nb = self.NCTX if self.multi else 0
-        self.packed = [torch.zeros(B * self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        self.packed = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(nb)]  # the rank's LAST frame
         self.xchg = env.get("xchg")
-        recv_n = (world if (self.xchg and self.xchg.mode == "allgather") else 1) * B * self.slot_bytes
+        recv_n = (world if (self.xchg and self.xchg.mode == "allgather") else 1) * self.slot_bytes
         self.recv = [torch.zeros(recv_n, dtype=torch.uint8, device="cuda") for _ in range(nb)]
         # single GPU: the last frame of a step, which the NEXT step's first matcher job reads, is copied into a carry
         # buffer of its own, so that a context may start its next extraction without waiting for that matcher
@@ -387,9 +387,9 @@ class Pipeline:
             c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)  # the same frames come round again on this context
             self.staged[k] = True
         c.event_wait(nxt, 1)
-        if self.multi:
-            c.pack_slots(B, self.packed[k].data_ptr(), self.slot_bytes, sync=False)  # one kernel on c's stream
-            self.xchg.exchange(c, self.packed[k], self.recv[k])  # RCCL: enqueued on c's own stream (no host sync)
+        if self.multi:  # the right neighbour needs this rank's last frame: pack it and shift it round the ring
+            c.pack_slots(1, self.packed[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
+            self.xchg.exchange(c, self.packed[k], self.recv[k], lane=k)  # RCCL: enqueued on c's own stream (no host sync)
         else:
             c.pack_slots(1, self.carry[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
         c.event_record(0)  # step t's results (own, and the left neighbour's / the carried last frame) are complete
@@ -401,16 +401,16 @@ class Pipeline:
             uses_prev_step = False
             for s in range(B):
                 pr, ps, prev_step = vd.predecessor(rank, s, world, B)
-                if prev_step:
-                    if t == 0:
-                        continue
-                    p = (self._slot_ptrs_in(self.xchg.left_block(self.recv[(t - 1) % NCTX]), B - 1) if self.multi
-                         else self._slot_ptrs_in(self.carry[(t - 1) % NCTX], 0))
-                    uses_prev_step = True
-                elif not self.multi:
-                    p = c.slot_dev_ptrs(ps)
-                else:
-                    p = self._slot_ptrs_in(self.xchg.left_block(self.recv[k]), ps)  # pr == (rank - 1) % world always
+                if s > 0:
+                    p = c.slot_dev_ptrs(ps)  # the rank's own previous slot
+                else:  # the left neighbour's last frame: out of the exchange buffer (single GPU: the carry buffer)
+                    if prev_step:
+                        if t == 0:
+                            continue
+                        uses_prev_step = True
+                    kk = (t - 1) % NCTX if prev_step else k
+                    p = (self._slot_ptrs_in(self.xchg.left_block(self.recv[kk]), 0) if self.multi
+                         else self._slot_ptrs_in(self.carry[kk], 0))
                 q = c.slot_dev_ptrs(s)
                 jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
             self.job_cache[ck] = (V.FMatcher.make_init_jobs(jobs) if jobs else None, len(jobs), uses_prev_step)
@@ -580,7 +580,7 @@ def run_workload(name, args, env, want_cpu, cpu_seconds):
                          "contexts_in_flight": pl.NCTX, "distinct_frames": pl.ndistinct,
                          "match": ("ComputeStereoMatches L<->R + UnprojectStereo + SearchByProjection(prev frame) th 15" if pl.track
                                    else "ComputeStereoMatches L<->R") if pl.stereo else "SearchForInitialization(prev frame) window 100",
-                         "sharding": ("frames round-robin over ranks; one %s of packed result slots per step (%s)" %
+                         "sharding": ("blocks of consecutive frames per rank; one %s shift of each rank's last packed result slot per step (%s)" %
                                       (env["xchg"].mode if env.get("xchg") else "ring", env["xchg"].transport if env.get("xchg") else "none"))
                          if not pl.stereo else "stereo frames independent per rank, no collective"}
     finally:
@@ -675,7 +675,8 @@ def main():
     if need_group:
         # the exchange transport and mode are chosen ONCE, before any timed work, by a probe every rank agrees on
         env["xchg"] = vd.SlotExchange.create(rank, world, local_rank, mode=args.exchange,
-                                             transport="rccl" if args.dist_backend == "nccl" else "gloo")
+                                             transport="rccl" if args.dist_backend == "nccl" else "gloo",
+                                             lanes=max(3, args.inflight))  # one communicator per context in flight
 
     names = [HEADLINE] + ([] if args.no_extras else EXTRAS) if args.workload == "all" else [args.workload]
     results, details = [], []

@@ -26,7 +26,7 @@ def test_predecessor_is_video_order():
             frames = {}
             for r in range(world):
                 for s in range(batch):
-                    frames[vd.global_frame(r, s, world)] = (r, s)
+                    frames[vd.global_frame(r, s, world, batch)] = (r, s)
             assert sorted(frames) == list(range(world * batch))
             for g in range(world * batch):
                 r, s = frames[g]
@@ -66,26 +66,32 @@ def _worker(rank, world, port, batch, steps, mode, q):
         prev_recv = None
         for step in range(steps):  # two steps: slot 0 of rank 0 needs the previous step's buffer
             own = []
-            send = torch.zeros(batch * sb, dtype=torch.uint8)
+            send = torch.zeros(sb, dtype=torch.uint8)  # the right neighbour needs this rank's LAST frame only
             for s in range(batch):
-                g = step * world * batch + vd.global_frame(rank, s, world)
+                g = step * world * batch + vd.global_frame(rank, s, world, batch)
                 k, d, mono = _extract(g)
                 own.append((k, d))
-                vd.slot_view(send, s, sb)[:] = torch.from_numpy(vd.pack_slot_host(k, d, mono, CAP, sb))
-            recv = torch.zeros(batch * sb * (world if mode == "allgather" else 1), dtype=torch.uint8)
+                if s == batch - 1:
+                    send[:] = torch.from_numpy(vd.pack_slot_host(k, d, mono, CAP, sb))
+            recv = torch.zeros(sb * (world if mode == "allgather" else 1), dtype=torch.uint8)
             x.exchange(None, send, recv)
             for s in range(batch):
-                g = step * world * batch + vd.global_frame(rank, s, world)
+                g = step * world * batch + vd.global_frame(rank, s, world, batch)
                 pr, ps, from_prev = vd.predecessor(rank, s, world, batch)
-                assert pr == (rank - 1) % world  # every predecessor lives on the left neighbour
-                if from_prev:
-                    if prev_recv is None:
-                        continue
-                    blk = x.left_block(prev_recv)
+                if s > 0:
+                    assert (pr, ps, from_prev) == (rank, s - 1, False)  # own previous slot
+                    prev = own[ps]
                 else:
-                    blk = x.left_block(recv)
-                pk, pd, _ = vd.unpack_slot_host(vd.slot_view(blk, ps, sb).numpy())
-                n, m12 = _match((pk, pd), own[s])
+                    assert pr == (rank - 1) % world and ps == batch - 1  # the left neighbour's last frame
+                    if from_prev:
+                        if prev_recv is None:
+                            continue
+                        blk = x.left_block(prev_recv)
+                    else:
+                        blk = x.left_block(recv)
+                    pk, pd, _ = vd.unpack_slot_host(vd.slot_view(blk, 0, sb).numpy())
+                    prev = (pk, pd)
+                n, m12 = _match(prev, own[s])
                 out[g] = (n, m12.tolist())
             prev_recv = recv
         q.put((rank, out))

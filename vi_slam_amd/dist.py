@@ -1,12 +1,15 @@
 """Frame sharding across GPUs and the one exchange step of the path.
 
-Extraction and stereo matching are independent per frame, so frames are dealt round-robin: global frame
-g of a step lives on rank g % world, slot g // world.  Cross-frame matching (mono initialisation,
-frame.cpp:289 + fmatcher.cpp:983) needs the predecessor frame's keypoints and descriptors.  With this dealing
-every predecessor lives on the LEFT neighbour (rank - 1 mod world: same slot, or for rank 0 the slot before),
-so the exchange is a ring shift of the fixed-size packed result slots: every rank sends its slots to
-rank + 1 and receives rank - 1's.  An all-gather (north_star's literal wording) moves world times as much for
-nothing; it is kept as `mode="allgather"`.  No other collective exists on this path.
+Extraction and stereo matching are independent per frame.  Cross-frame matching (mono initialisation, frame.cpp:289 +
+fmatcher.cpp:983) needs the predecessor frame's keypoints and descriptors, so the frames of a step are dealt in BLOCKS:
+rank r holds the `batch` consecutive frames r*batch .. (r+1)*batch - 1 of the step's world*batch.  Every predecessor
+but one is then the rank's own previous slot; only slot 0 needs a frame from elsewhere -- the LAST slot of the left
+neighbour (rank - 1 mod world; for rank 0 that is rank world-1's last frame of the PREVIOUS step).  The exchange is
+therefore a ring shift of ONE packed result slot per rank and step (62-125 KB): every rank sends its last slot to
+rank + 1 and receives rank - 1's.  (Round-robin dealing -- frame g on rank g % world -- put EVERY predecessor on the left
+neighbour: the same ring shift with batch times the payload, a 2-4 MB pack kernel in front of it, and 25 % of the
+single-GPU rate gone at world size 1; an all-gather, north_star's literal wording, moves world times as much again and is
+kept as `mode="allgather"`.)  No other collective exists on this path.
 
 `SlotExchange` is the ONE object bench.py, the GPU tests and the gloo CPU tests drive:
   transport "rccl": the library's own communicator (include/vslam_fe.h vslam_comm_*): vslam_exchange_ring =
@@ -20,18 +23,18 @@ import torch
 import torch.distributed as dist
 
 
-def global_frame(rank, slot, world):
+def global_frame(rank, slot, world, batch):
     """Index, inside one step, of the frame held by (rank, slot)."""
-    return slot * world + rank
+    return rank * batch + slot
 
 
 def predecessor(rank, slot, world, batch):
-    """(rank, slot, from_previous_step) of the frame preceding (rank, slot) in video order."""
-    g = global_frame(rank, slot, world)
-    if g == 0:
-        return world - 1, batch - 1, True
-    g -= 1
-    return g % world, g // world, False
+    """(rank, slot, from_previous_step) of the frame preceding (rank, slot) in video order.  slot > 0: the rank's own
+    previous slot.  slot 0: the last slot of the left neighbour, which arrives through the exchange (also at world
+    size 1, where the left neighbour is the rank itself one step earlier)."""
+    if slot > 0:
+        return rank, slot - 1, False
+    return (rank - 1) % world, batch - 1, rank == 0
 
 
 def slot_view(buf, slot, slot_bytes):
@@ -71,37 +74,47 @@ def unpack_slot_host(buf):
 
 
 class SlotExchange:
-    """The exchange step.  exchange(fe, send, recv): `send` = this rank's packed slots; afterwards left_block(recv)
-    holds the left neighbour's.  mode "ring": recv has send's size; "allgather": world x that."""
+    """The exchange step.  exchange(fe, send, recv): `send` = what this rank's right neighbour needs (its last packed
+    slot); afterwards left_block(recv) holds what the left neighbour sent.  mode "ring": recv has send's size;
+    "allgather": world x that."""
 
-    def __init__(self, rank, world, mode="ring", transport="gloo", comm=None):
+    def __init__(self, rank, world, mode="ring", transport="gloo", comms=None):
         assert mode in ("ring", "allgather") and transport in ("rccl", "gloo", "local")
-        self.rank, self.world, self.mode, self.transport, self.comm = rank, world, mode, transport, comm
+        self.rank, self.world, self.mode, self.transport = rank, world, mode, transport
+        self.comms = list(comms or [])  # rccl: one communicator per lane (extractor context in flight)
 
     @classmethod
-    def create(cls, rank, world, device, mode="ring", transport="rccl"):
-        """Collective constructor (every rank calls it).  transport "rccl": rank 0 makes the ncclUniqueId, it travels
-        through torch.distributed's broadcast, every rank builds the library's communicator, and ONE probe exchange
-        decides -- by an all-reduce every rank takes part in -- whether the transport works; a failed probe is fatal
-        (no collective is ever switched mid-run)."""
+    def create(cls, rank, world, device, mode="ring", transport="rccl", lanes=1):
+        """Collective constructor (every rank calls it).  transport "rccl": rank 0 makes the ncclUniqueIds, they travel
+        through torch.distributed's broadcast, every rank builds the library's communicators, and ONE probe exchange
+        per communicator decides -- by an all-reduce every rank takes part in -- whether the transport works; a failed
+        probe is fatal (no collective is ever switched mid-run).
+        lanes: communicators to build.  RCCL orders the operations of ONE communicator across streams (each launch
+        waits for the communicator's previous one), which couples extractor contexts that are otherwise independent:
+        with one communicator for four contexts in flight the mono workload lost a quarter of its rate at world size 1.
+        exchange(..., lane=k) uses communicator k % lanes; every rank must use the same lane for the same step."""
         if transport != "rccl":
             return cls(rank, world, mode, "gloo" if dist.is_initialized() else "local")
         import vi_slam_amd as V
         ctl = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        idt = torch.zeros(V.COMM_ID_BYTES, dtype=torch.uint8, device=ctl)
+        lanes = max(1, int(lanes))
+        idt = torch.zeros(lanes * V.COMM_ID_BYTES, dtype=torch.uint8, device=ctl)
         if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(V.Comm.unique_id()), dtype=torch.uint8))
+            ids = b"".join(bytes(V.Comm.unique_id()) for _ in range(lanes))
+            idt.copy_(torch.frombuffer(bytearray(ids), dtype=torch.uint8))
         if world > 1:
             dist.broadcast(idt, 0)
-        ok, comm, err = 1.0, None, ""
+        raw = bytes(idt.cpu().numpy().tobytes())
+        ok, comms, err = 1.0, [], ""
         try:
-            comm = V.Comm(device, rank, world, bytes(idt.cpu().numpy().tobytes()))
+            for k in range(lanes):
+                comms.append(V.Comm(device, rank, world, raw[k * V.COMM_ID_BYTES:(k + 1) * V.COMM_ID_BYTES]))
         except Exception as e:  # noqa: BLE001 - reported below, after every rank has voted
             ok, err = 0.0, str(e)
-        x = cls(rank, world, mode, "rccl", comm)
+        x = cls(rank, world, mode, "rccl", comms)
         if ok:
             try:
-                ok = 1.0 if x._probe(device) else 0.0
+                ok = 1.0 if all(x._probe(device, k) for k in range(lanes)) else 0.0
             except Exception as e:  # noqa: BLE001
                 ok, err = 0.0, str(e)
         if world > 1:
@@ -112,7 +125,7 @@ class SlotExchange:
             raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
         return x
 
-    def _probe(self, device):
+    def _probe(self, device, lane=0):
         """One exchange of a stamped buffer on a scratch stream context: the left neighbour's stamp must arrive."""
         import vi_slam_amd as V
         fe = V.FExtractor(100, 1.2, 2, 20, 7, 128, 128, device=device, max_batch=1)
@@ -121,7 +134,7 @@ class SlotExchange:
             send = torch.full((n,), self.rank + 1, dtype=torch.uint8, device="cuda")
             recv = torch.zeros(n * (self.world if self.mode == "allgather" else 1), dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()
-            self.exchange(fe, send, recv)
+            self.exchange(fe, send, recv, lane)
             torch.cuda.synchronize()  # the probe is the only place that waits for an exchange on the host
             want = (self.rank - 1) % self.world + 1
             return bool((self.left_block(recv) == want).all().item())
@@ -129,14 +142,15 @@ class SlotExchange:
             fe.close()
 
     # ------------------------------------------------------------------------------------------ the exchange
-    def exchange(self, fe, send, recv):
+    def exchange(self, fe, send, recv, lane=0):
         n = send.numel()
         if self.transport == "rccl":
             # enqueue-only, on fe's stream: ordered behind k_pack_slots, ahead of the matcher
+            comm = self.comms[lane % len(self.comms)]
             if self.mode == "ring":
-                self.comm.ring(fe, send.data_ptr(), recv.data_ptr(), n)
+                comm.ring(fe, send.data_ptr(), recv.data_ptr(), n)
             else:
-                self.comm.allgather(fe, send.data_ptr(), recv.data_ptr(), n)
+                comm.allgather(fe, send.data_ptr(), recv.data_ptr(), n)
             return recv
         if fe is not None and send.is_cuda:
             torch.cuda.synchronize()  # rehearsal path: gloo moves host memory only
@@ -167,6 +181,6 @@ class SlotExchange:
         return recv[lo:lo + n]
 
     def close(self):
-        if self.comm is not None:
-            self.comm.close()
-            self.comm = None
+        for c in self.comms:
+            c.close()
+        self.comms = []
