@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 # queues two of them end up behind each other on one queue (measured: 29k -> 38k frames/s with 8).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+VALU_NS_PER_WAVE_INST, NUM_SIMDS = 1.77, 1024  # measured issue time of a wave64 VALU instruction; 256 CUs x 4 SIMDs
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
@@ -116,7 +117,7 @@ def pmc_traffic(kernel, cfg, batch):
     if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
         return None
     return {"bytes": 2 * k["fetch_bytes_raw"] + k["write_bytes"], "fetch_size_raw_bytes": k["fetch_bytes_raw"],
-            "write_size_bytes": k["write_bytes"], "source": "profiles/" + name}
+            "write_size_bytes": k["write_bytes"], "valu_insts": k.get("SQ_INSTS_VALU"), "source": "profiles/" + name}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -540,6 +541,10 @@ def roofline_of(pl, stage_alone, stage_pipe, res_dev):
           # all extraction stages together, algorithmic bytes per image x images/s (per rank)
           "pipeline_gbps_per_rank": pipe_bytes * images_per_s / 1e9,
           "pipeline_frac": pipe_bytes * images_per_s / 1e9 / HBM_PEAK_GBS}
+    if tr and tr.get("valu_insts") and ms > 0:
+        # what actually bounds the kernel: wave64 VALU instructions per launch (committed SQ_INSTS_VALU) x 1.77 ns per
+        # instruction and SIMD (tools/issue_rate_probe.hip, 8 waves per SIMD) over 1024 SIMDs, against the launch time
+        rl["valu_issue_frac"] = tr["valu_insts"] * VALU_NS_PER_WAVE_INST / NUM_SIMDS / (ms * 1e6)
     detail = {"traffic_detail": tr, "stage_ms_single_context": stage_alone, "stage_ms_pipelined_event_spans": stage_pipe,
               "avg_launch_ms_note": "avg_launch_ms: HIP events on the kernel's own stream, single context (nothing else on the "
                                     "GPU); avg_launch_ms_pipelined: event span inside the timed region, other streams' workgroups included",
