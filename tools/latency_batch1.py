@@ -1,32 +1,50 @@
 #!/usr/bin/env python3
-"""Per-frame latency at batch 1 (SURVEY.md 8d 'reality check'): host image in -> keypoints/descriptors out."""
-import sys, time
-import numpy as np
+"""Per-frame latency at batch 1 (SURVEY.md 8d 'reality check'): host image in -> keypoints/descriptors out.
+Every figure is the MEDIAN of 7 windows of 100 calls: single windows are sometimes twice as slow on this pool (a mostly
+idle GPU changes its clocks; the slow windows hit any of the variants)."""
+import sys
+import time
+
 sys.path.insert(0, ".")
-import vi_slam_amd as V
-from vi_slam_amd import synth
+import vi_slam_amd as V  # noqa: E402
+from vi_slam_amd import synth  # noqa: E402
 
 W, H = 1241, 376
+
+
+def med(f, windows=7, n=100):
+    for _ in range(20):
+        f()
+    ts = []
+    for _ in range(windows):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        ts.append((time.perf_counter() - t0) / n * 1e3)
+    ts.sort()
+    return round(ts[len(ts) // 2], 4), round(ts[0], 4), round(ts[-1], 4)
+
+
 out = {}
 for nf in (1000, 2000):
     fe = V.FExtractor(nf, 1.2, 8, 20, 7, W, H, max_batch=2)
     img = synth.make_frame(W, H)
-    for _ in range(20):
-        fe.compute(img, (0, 1000))
-    t0 = time.perf_counter()
-    N = 300
-    for _ in range(N):
-        fe.compute(img, (0, 1000))
-    out["mono_extract_n%d_ms" % nf] = (time.perf_counter() - t0) / N * 1e3
+    out["mono_extract_n%d_ms_median_min_max" % nf] = med(lambda: fe.compute(img, (0, 1000)))
+    # the same from a caller-owned PINNED image (a capture driver's DMA buffer): no row copy into the context's staging
+    pin = V.PinnedImages(1, H, W, W)
+    pin.array[0][:] = img
+
+    def pinned():
+        fe.compute_batch_async(pin.ptrs, W, (0, 1000), where=V.IMGS_PINNED)
+        fe.wait()
+    out["mono_extract_n%d_pinned_image_ms_median_min_max" % nf] = med(pinned)
+    pin.close()
     if nf == 2000:
         L, R = synth.make_stereo_pair(W, H)
-        for _ in range(10):
+
+        def stereo():
             fe.compute_batch([L, R])
             V.ComputeStereoMatches(fe, 0, fe, 1, 386.1448, 718.856)
-        t0 = time.perf_counter()
-        for _ in range(N):
-            fe.compute_batch([L, R])
-            V.ComputeStereoMatches(fe, 0, fe, 1, 386.1448, 718.856)
-        out["stereo_frame_n2000_ms"] = (time.perf_counter() - t0) / N * 1e3
+        out["stereo_frame_n2000_ms_median_min_max"] = med(stereo)
     fe.close()
 print(out)
