@@ -383,7 +383,7 @@ class Pipeline:
         # the NEXT step (context nxt, step t-NCTX+1) read from us is the carry / exchange buffer, so only the copy into
         # that buffer has to wait for it -- not the extraction.  (With the wait in front of the extraction a context sat
         # idle for a whole step between two of its passes: 353 us per 1140-us cycle in the kernel trace.)
-        c.compute_batch_async(ptrs, pitch, self.lap, where=where)
+        c.compute_batch_async(ptrs, pitch, self.lap, where=where, to_host=os.environ.get("BENCH_NO_D2H") is None)
         if stage_next:
             c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)  # the same frames come round again on this context
             self.staged[k] = True

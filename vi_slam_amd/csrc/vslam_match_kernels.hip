@@ -3,6 +3,8 @@
  * depth) uses explicit round-to-nearest intrinsics, no fusion.
  */
 #include "vslam_kernels.h"
+#include <cstring>
+#include <cstdlib>
 
 __device__ __forceinline__ const uint8_t* level_base2(const uint8_t* pyr, size_t slot_stride,
                                                       const BatchSrc& src, const LevelGeom& lg, int level,
@@ -514,6 +516,22 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
     size_t total = 0;
     for (int r = 0; r < R.n; r++) total += R.bytes[r];
     if (!total) return;
+    /* Large transfers between HBM and pinned host memory go to the DMA engines (one hipMemcpyAsync per range on the same
+     * stream).  A kernel that stores 2 MB into pinned host memory holds a thousand waves on the CUs for the 36 us the
+     * link needs and sits in the memory pipeline of everything else that runs: with the keypoints and descriptors of a
+     * 32-frame step copied by this kernel the mono workload ran 118 k frames/s, through the DMA engines 131 k, without
+     * the copy 132 k.  Small ones (a single image's results, match lists: latency, captured graphs) stay one ~5-us
+     * kernel, cheaper to enqueue.  VSLAM_D2H=kernel|sdma forces one route. */
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("VSLAM_D2H");
+        mode = e && !strcmp(e, "kernel") ? 1 : (e && !strcmp(e, "sdma") ? 2 : 0);
+    }
+    if (mode == 2 || (mode == 0 && total >= (256u << 10))) {
+        for (int r = 0; r < R.n; r++)
+            if (R.bytes[r]) (void)hipMemcpyAsync(R.dst[r], R.src[r], R.bytes[r], hipMemcpyDefault, st);
+        return;
+    }
     const int blocks = (int)std::min<size_t>(256, (total / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
 }
