@@ -464,12 +464,14 @@ class Pipeline:
         BEFORE the timed region (every rank must issue the same number of exchanges)."""
         env = self.env
         self.run(max(warmup, 1))
+        self.run(steps)  # first calibration block: still warming up (first DMA copies, clocks) -- not used
+        self.torch.cuda.synchronize()
         env["barrier"]()
         t0 = time.perf_counter()
-        self.run(steps)  # calibration block, untimed
+        self.run(steps)  # second calibration block, untimed but clocked: how many repeats make min_seconds
         self.torch.cuda.synchronize()
         block = env["max_over_ranks"](time.perf_counter() - t0)
-        reps = max(1, min(int(math.ceil(min_seconds / max(block, 1e-6))), 100000 // max(steps, 1) + 1))
+        reps = max(1, min(int(math.ceil(1.25 * min_seconds / max(block, 1e-6))), 100000 // max(steps, 1) + 1))
         for k in ("host_s", "enq_s"):
             self.state.pop(k, None)
         for c in self.ctxs:

@@ -498,9 +498,17 @@ __global__ void __launch_bounds__(256) k_copy_ranges(CopyRanges R) {
         const uint8_t* src = (const uint8_t*)R.src[r];
         if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
             const size_t n16 = bytes >> 4;
-            if (src)
-                for (size_t i = tid; i < n16; i += nth) ((uint4*)dst)[i] = ((const uint4*)src)[i];
-            else
+            if (src) {
+                size_t i = tid;
+                for (; i + 7 * (size_t)nth < n16; i += 8 * (size_t)nth) { /* eight 16-byte loads in flight per lane */
+                    uint4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = ((const uint4*)src)[i + (size_t)u * nth];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ((uint4*)dst)[i + (size_t)u * nth] = v[u];
+                }
+                for (; i < n16; i += nth) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+            } else
                 for (size_t i = tid; i < n16; i += nth) ((uint4*)dst)[i] = make_uint4(0, 0, 0, 0);
             const size_t done = n16 << 4, tail = (bytes - done) >> 2;
             for (size_t i = tid; i < tail; i += nth)
@@ -516,12 +524,12 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
     size_t total = 0;
     for (int r = 0; r < R.n; r++) total += R.bytes[r];
     if (!total) return;
-    /* Large transfers between HBM and pinned host memory go to the DMA engines (one hipMemcpyAsync per range on the same
-     * stream).  A kernel that stores 2 MB into pinned host memory holds a thousand waves on the CUs for the 36 us the
-     * link needs and sits in the memory pipeline of everything else that runs: with the keypoints and descriptors of a
-     * 32-frame step copied by this kernel the mono workload ran 118 k frames/s, through the DMA engines 131 k, without
-     * the copy 132 k.  Small ones (a single image's results, match lists: latency, captured graphs) stay one ~5-us
-     * kernel, cheaper to enqueue.  VSLAM_D2H=kernel|sdma forces one route. */
+    /* Large transfers between HBM and pinned host memory are handed to the runtime (one hipMemcpyAsync per range on the
+     * same stream; in a kernel trace they appear as __amd_rocclr_copyBuffer, ~27 us per megabyte-sized copy).  With the
+     * keypoints and descriptors of a 32-frame step (2 MB) copied by the kernel below, the mono workload ran 117-124 k
+     * frames/s whatever its shape (8, 16, 32 or 256 workgroups, one or eight loads in flight per lane), through the runtime
+     * 131 k, without the copy 132 k.  Small ones (a single image's results, match lists: latency, captured graphs) stay
+     * one ~5-us kernel, cheaper to enqueue.  VSLAM_D2H=kernel|sdma forces one route. */
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("VSLAM_D2H");
@@ -532,7 +540,14 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
             if (R.bytes[r]) (void)hipMemcpyAsync(R.dst[r], R.src[r], R.bytes[r], hipMemcpyDefault, st);
         return;
     }
-    const int blocks = (int)std::min<size_t>(256, (total / 16 + 255) / 256 + 1);
+    /* a transfer to or from host memory is bound by the link, not by the GPU: a few workgroups with several loads in
+     * flight per lane keep it busy without parking waves on every CU (VSLAM_COPY_WGS overrides the cap of 16) */
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("VSLAM_COPY_WGS");
+        cap = e ? std::max(1, atoi(e)) : 16;
+    }
+    const int blocks = (int)std::min<size_t>((size_t)cap, (total / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
 }
 
