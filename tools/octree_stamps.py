@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""In-kernel stamps of k_octree_v2 (diagnostic build only:  make -C vi_slam_amd/csrc clean all EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS
-and VSLAM_OCT_DBG=1 in the environment): where the level-0 workgroup of slot 0 spends its time.
+"""In-kernel stamps of k_octree_v3 (diagnostic build only:  make -C vi_slam_amd/csrc EXTRA_HIPFLAGS=-DVSLAM_OCT_STAMPS after
+touching vslam_octree_kernel.hip, library copied aside and loaded with VSLAM_FE_LIB=..., and VSLAM_OCT_DBG=1 in the
+environment): where the level-0 workgroup of slot 0 spends its time.  Seven stamps: start, keys gathered, fine cells
+counted, prefix sums, split passes, owners filled, keys selected.
     octree_stamps.py [W H NF B]   -> microseconds since the kernel's first stamp"""
 import ctypes as C
 import os

@@ -709,9 +709,6 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const int qsh = QW > 8 ? 4 : 3;             /* 16 or 8 quad columns per sweep */
     const int qx = tid & ((1 << qsh) - 1), qly = tid >> qsh;
     const int rem = iw - 4 * qx;                /* pixels of this lane's quad inside the interior (<= 0: none) */
-    uint64_t colm[4];                           /* lanes whose pixel j lies inside the interior */
-#pragma unroll
-    for (int j = 0; j < 4; j++) colm[j] = __builtin_amdgcn_ballot_w64(j < rem);
     const uint32_t* W32 = (const uint32_t*)win;
     int T = iniTh;
     for (int stage = 0; stage < 2; stage++) {
@@ -752,7 +749,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
             uint32_t totD = 0, totB = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint64_t ok = rowm & colm[j];
+                /* lanes whose pixel j lies inside the interior: one compare here is cheaper than four lane masks kept in
+                 * SGPRs across the kernel (they spill: the kernel is capped at 80 SGPRs for 8 waves per SIMD) */
+                const uint64_t ok = rowm & __builtin_amdgcn_ballot_w64(j < rem);
                 const uint64_t dk = ((j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1])) & ok;
                 const uint64_t br = ((j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1])) & ok;
                 mD[j] = dk;       /* dark, or both polarities possible: the latter are listed once, here, flagged */
