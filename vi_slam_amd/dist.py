@@ -105,24 +105,29 @@ class SlotExchange:
         if world > 1:
             dist.broadcast(idt, 0)
         raw = bytes(idt.cpu().numpy().tobytes())
-        ok, comms, err = 1.0, [], ""
-        try:
-            for k in range(lanes):
-                comms.append(V.Comm(device, rank, world, raw[k * V.COMM_ID_BYTES:(k + 1) * V.COMM_ID_BYTES]))
-        except Exception as e:  # noqa: BLE001 - reported below, after every rank has voted
-            ok, err = 0.0, str(e)
-        x = cls(rank, world, mode, "rccl", comms)
-        if ok:
+        x = cls(rank, world, mode, "rccl", [])
+        for k in range(lanes):  # one communicator at a time, each followed by a vote: all ranks end up with the same number
+            ok, err, comm = 1.0, "", None
             try:
-                ok = 1.0 if all(x._probe(device, k) for k in range(lanes)) else 0.0
-            except Exception as e:  # noqa: BLE001
+                comm = V.Comm(device, rank, world, raw[k * V.COMM_ID_BYTES:(k + 1) * V.COMM_ID_BYTES])
+                x.comms.append(comm)
+                ok = 1.0 if x._probe(device, k) else 0.0
+            except Exception as e:  # noqa: BLE001 - reported below, after every rank has voted
                 ok, err = 0.0, str(e)
-        if world > 1:
-            t = torch.tensor([ok], dtype=torch.float64, device=ctl)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = float(t.item())
-        if not ok:
-            raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
+            if world > 1:
+                t = torch.tensor([ok], dtype=torch.float64, device=ctl)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = float(t.item())
+            if not ok:
+                if comm is not None:
+                    x.comms.pop()
+                    comm.close()
+                if k == 0:
+                    raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
+                if rank == 0:
+                    print("SlotExchange: communicator %d of %d could not be set up on every rank (%s); continuing with %d"
+                          % (k + 1, lanes, err or "another rank", k), flush=True)
+                break
         return x
 
     def _probe(self, device, lane=0):
