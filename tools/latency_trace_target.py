@@ -1,3 +1,5 @@
+"""Target for `rocprofv3 --kernel-trace`: 60 single-image extractions (the replayed HIP graph of the latency path); the last
+kernels of the trace are one steady-state iteration."""
 import sys
 sys.path.insert(0, "/root/repo")
 import vi_slam_amd as V

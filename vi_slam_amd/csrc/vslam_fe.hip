@@ -1223,6 +1223,8 @@ extern "C" int vslam_fe_capacity(const vslam_fe* fe) { return fe ? fe->cap : VSL
  * touch (sysfs: /sys/bus/pci/devices/<bus id>/local_cpulist), then back.  VSLAM_NUMA=0 disables. */
 #include <sched.h>
 static bool device_cpuset(cpu_set_t* out) {
+    static std::mutex mu; /* contexts may be created from several threads */
+    std::lock_guard<std::mutex> lk(mu);
     static int state = -1; /* -1 unknown, 0 unavailable, 1 cached */
     static cpu_set_t cached;
     if (state < 0) {
@@ -1240,7 +1242,8 @@ static bool device_cpuset(cpu_set_t* out) {
                 if (fgets(line, sizeof(line), fp)) {
                     CPU_ZERO(&cached);
                     int n = 0;
-                    for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+                    char* save = nullptr;
+                    for (char* tok = strtok_r(line, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
                         int a = 0, b = 0;
                         const int k = sscanf(tok, "%d-%d", &a, &b);
                         if (k == 1) b = a;
