@@ -232,6 +232,7 @@ def test_worker_pool_stress_under_thread_sanitizer(tmp_path):
     src = os.path.join(ROOT, "tests", "cpp", "pool_stress.cpp")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-o", exe, src])
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    env.pop("LD_PRELOAD", None)  # run_sanitizers.sh preloads ASan for the Python process; TSan cannot share a process with it
     r = subprocess.run([exe, "6000"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "pool_stress ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr
