@@ -128,53 +128,53 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
 #define DESC_TROWS 37
 #define DESC_TILE_BYTES (DESC_TP * DESC_TROWS + 8)
 
-struct DescLoads {
-    uint32_t raw[4]; /* raw patch: item i = lane + 64 k -> row i >> 3, dword i & 7 (rows 0..30 of 31) */
-    uint32_t blr[6]; /* blurred support: item i = lane + 64 k -> row i / 10, dword i % 10 (370 items) */
+/* everything a keypoint needs from the kernel-argument tables (level geometry, level-0 source of its slot), looked up
+ * ONCE and unconditionally per keypoint of the wave: look-ups under the `k < nk` conditions below make the compiler copy
+ * both argument structs to scratch memory (1.3 KB per lane) */
+struct DescAddr {
+    const uint8_t* raw; /* top-left of the raw 31x31 patch */
+    const uint8_t* blr; /* dword-aligned start of the blurred 37-row support */
+    int pitch, bpitch;
+    float scale;
 };
-
-__device__ __forceinline__ void desc_issue_loads(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                 size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
-                                                 const SelKp s, int lane, DescLoads& L) {
+__device__ __forceinline__ DescAddr desc_addr(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                              size_t slot_stride, const BatchSrc& src, const PyramidGeom& g, const SelKp s) {
     const LevelGeom lg = g.lv[s.level];
-    int pitch;
-    const uint8_t* img = level_base(pyr, slot_stride, src, lg, s.level, s.slot, &pitch);
-    const uint8_t* c = img + (size_t)((int)s.y - 15) * pitch + ((int)s.x - 15);
+    DescAddr A;
+    const uint8_t* img = level_base(pyr, slot_stride, src, lg, s.level, s.slot, &A.pitch);
+    A.raw = img + (size_t)((int)s.y - 15) * A.pitch + ((int)s.x - 15);
+    A.blr = blur + (size_t)s.slot * slot_stride + lg.off + (size_t)((int)s.y - 18) * lg.pitch + (((int)s.x - 18) & ~3);
+    A.bpitch = lg.pitch;
+    A.scale = lg.scale;
+    return A;
+}
+__device__ __forceinline__ void desc_issue_raw(const DescAddr& A, int lane, uint32_t raw[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4; k++) { /* item i = lane + 64 k -> row i >> 3, dword i & 7 (rows 0..30 of 31) */
         const int i = lane + 64 * k;
-        L.raw[k] = 0;
-        if (i < 248) L.raw[k] = *(const uint32_t*)(c + (size_t)(i >> 3) * pitch + 4 * (i & 7)); /* unaligned dword */
+        raw[k] = 0;
+        if (i < 248) raw[k] = *(const uint32_t*)(A.raw + (size_t)(i >> 3) * A.pitch + 4 * (i & 7)); /* unaligned dword */
     }
-    const int xs = ((int)s.x - 18) & ~3;
-    const uint8_t* bc = blur + (size_t)s.slot * slot_stride + lg.off + (size_t)((int)s.y - 18) * lg.pitch + xs;
+}
+__device__ __forceinline__ void desc_issue_blur(const DescAddr& A, int lane, uint32_t blr[6]) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 6; k++) { /* item i = lane + 64 k -> row i / 10, dword i % 10 (370 items) */
         const int i = lane + 64 * k;
         const int row = (i * 205) >> 11; /* i / 10 for i < 1024 */
-        L.blr[k] = 0;
-        if (i < 370) L.blr[k] = *(const uint32_t*)(bc + (size_t)row * lg.pitch + 4 * (i - row * 10));
+        blr[k] = 0;
+        if (i < 370) blr[k] = *(const uint32_t*)(A.blr + (size_t)row * A.bpitch + 4 * (i - row * 10));
     }
 }
 
-__device__ __forceinline__ void desc_compute(const PyramidGeom& g, const SelKp s, const DescLoads& L, uint8_t* tile,
-                                             const uint32_t wu[4], const uint32_t wm[4], const char4 pat[4],
-                                             vslam_kp* kps, uint8_t* desc, int cap, int atan_fma, int lane) {
-    const LevelGeom lg = g.lv[s.level];
-    /* blurred support -> LDS (LDS operations of one wave execute in order: no barrier between these stores and the
-     * sampling reads below, nor between the reads of one keypoint and the stores of the next) */
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int i = lane + 64 * k;
-        if (i < 370) ((uint32_t*)tile)[i] = L.blr[k];
-    }
-    /* IC_Angle */
+/* IC_Angle moments of one keypoint: every lane ends up with the wave's sums */
+__device__ __forceinline__ void desc_moments(const uint32_t raw[4], const uint32_t wu[4], const uint32_t wm[4], int lane,
+                                             int* m01_out, int* m10_out) {
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int row = (lane + 64 * k) >> 3;
-        const int rs = (int)__builtin_amdgcn_udot4(L.raw[k], wm[k], 0u, false);
-        m10 += (int)__builtin_amdgcn_udot4(L.raw[k], wu[k], 0u, false) - 15 * rs;
+        const int rs = (int)__builtin_amdgcn_udot4(raw[k], wm[k], 0u, false);
+        m10 += (int)__builtin_amdgcn_udot4(raw[k], wu[k], 0u, false) - 15 * rs;
         m01 += (row - 15) * rs;
     }
 #pragma unroll
@@ -182,10 +182,21 @@ __device__ __forceinline__ void desc_compute(const PyramidGeom& g, const SelKp s
         m10 += __shfl_xor(m10, o, 64);
         m01 += __shfl_xor(m01, o, 64);
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10, atan_fma);
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    const float a = vslam_trig::glibc_cosf(rad), b = vslam_trig::glibc_sinf(rad);
+    *m01_out = m01;
+    *m10_out = m10;
+}
+
+/* descriptor of one keypoint from its blurred support (already in registers) and its (angle, cos, sin) */
+__device__ __forceinline__ void desc_sample(const DescAddr& A, const SelKp s, const uint32_t blr[6], uint8_t* tile,
+                                            const char4 pat[4], float angle, float a, float b, vslam_kp* kps, uint8_t* desc,
+                                            int cap, int lane) {
+    /* blurred support -> LDS (LDS operations of one wave execute in order: no barrier between these stores and the
+     * sampling reads below, nor between the reads of one keypoint and the stores of the next) */
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = lane + 64 * k;
+        if (i < 370) ((uint32_t*)tile)[i] = blr[k];
+    }
     const int xo = 18 + ((((int)s.x - 18) & 3)) + 18 * DESC_TP; /* tile byte of the keypoint centre */
     unsigned long long w[4];
 #pragma unroll
@@ -202,9 +213,9 @@ __device__ __forceinline__ void desc_compute(const PyramidGeom& g, const SelKp s
     vslam_kp* okp = kps + (size_t)s.slot * cap + s.out;
     if (lane == 0) { /* fextractor.cpp:828-838 (octave, size), :1114-1116 (pt *= scale) */
         vslam_kp o;
-        o.x = s.level ? __fmul_rn((float)s.x, lg.scale) : (float)s.x;
-        o.y = s.level ? __fmul_rn((float)s.y, lg.scale) : (float)s.y;
-        o.size = (float)(int)__fmul_rn(31.f, lg.scale);
+        o.x = s.level ? __fmul_rn((float)s.x, A.scale) : (float)s.x;
+        o.y = s.level ? __fmul_rn((float)s.y, A.scale) : (float)s.y;
+        o.size = (float)(int)__fmul_rn(31.f, A.scale);
         o.angle = angle;
         o.response = (float)s.response;
         o.octave = s.level;
@@ -228,7 +239,13 @@ __device__ __forceinline__ void desc_lane_tables(const int8_t* __restrict__ patt
     }
 }
 
-/* keypoints sel[first .. first+n) of one list, DESC_KPW per wave */
+/* keypoints sel[k0 .. kend) of one list, at most DESC_KPW, on one wave -- in three phases:
+ *   A  the raw patches of ALL the wave's keypoints are loaded (4 dwords per lane each) and reduced to their moments;
+ *      lane k keeps keypoint k's (m01, m10);
+ *   B  fastAtan2 and the glibc-exact cosf/sinf -- 40 + 81 double-precision instructions, a third of this kernel's
+ *      issue time when they ran once per keypoint on 64 identical lanes -- run ONCE, lane k working on keypoint k;
+ *   C  per keypoint: blurred support -> LDS tile, 512 rotated samples, 4 ballots; the support of keypoint k+1 is loaded
+ *      while keypoint k is sampled. */
 __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                              size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                                              const SelKp* __restrict__ sel, int k0, int kend,
@@ -236,26 +253,51 @@ __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, co
                                              int atan_fma, uint8_t* tile) {
     const int lane = threadIdx.x & 63;
     if (k0 >= kend) return; /* wave-uniform */
+    const int nk = kend - k0; /* 1 .. DESC_KPW, wave-uniform */
     uint32_t wu[4], wm[4];
     char4 pat[4];
     desc_lane_tables(pattern, lane, wu, wm, pat);
-    SelKp s = sel[k0];
-    DescLoads L;
-    desc_issue_loads(pyr, blur, slot_stride, src, g, s, lane, L);
-    for (int k = k0; k < kend; k++) {
-        SelKp sn = s;
-        DescLoads Ln;
-        const bool more = k + 1 < kend; /* wave-uniform */
-        if (more) {
-            sn = sel[k + 1];
-            desc_issue_loads(pyr, blur, slot_stride, src, g, sn, lane, Ln);
-        }
-        desc_compute(g, s, L, tile, wu, wm, pat, kps, desc, cap, atan_fma, lane);
-        if (more) {
-            s = sn;
-            L = Ln;
-        }
+    SelKp s[DESC_KPW];
+    DescAddr A[DESC_KPW];
+    uint32_t raw[DESC_KPW][4];
+#pragma unroll
+    for (int k = 0; k < DESC_KPW; k++) { /* slots past the wave's last keypoint repeat it (looked up, never loaded) */
+        s[k] = sel[k0 + min(k, nk - 1)];
+        A[k] = desc_addr(pyr, blur, slot_stride, src, g, s[k]);
     }
+#pragma unroll
+    for (int k = 0; k < DESC_KPW; k++)
+        if (k < nk) desc_issue_raw(A[k], lane, raw[k]);
+    uint32_t blr[6], blrn[6];
+    desc_issue_blur(A[0], lane, blr);
+    int my01 = 0, my10 = 0;
+#pragma unroll
+    for (int k = 0; k < DESC_KPW; k++)
+        if (k < nk) {
+            int m01, m10;
+            desc_moments(raw[k], wu, wm, lane, &m01, &m10);
+            if (lane == k) {
+                my01 = m01;
+                my10 = m10;
+            }
+        }
+    const float angle = fast_atan2_deg((float)my01, (float)my10, atan_fma);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    const float ca = vslam_trig::glibc_cosf(rad), sb = vslam_trig::glibc_sinf(rad);
+#pragma unroll
+    for (int k = 0; k < DESC_KPW; k++)
+        if (k < nk) {
+            if (k + 1 < nk) desc_issue_blur(A[min(k + 1, DESC_KPW - 1)], lane, blrn);
+            const float ang_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle), k));
+            const float a_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), k));
+            const float b_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), k));
+            desc_sample(A[k], s[k], blr, tile, pat, ang_k, a_k, b_k, kps, desc, cap, lane);
+            if (k + 1 < nk) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) blr[j] = blrn[j];
+            }
+        }
 }
 
 /* host-selected keypoints (quadtree on the host): one flat list for the batch */
