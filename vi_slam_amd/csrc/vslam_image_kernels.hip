@@ -1,8 +1,9 @@
 /* vslam_image_kernels.hip -- the image-streaming kernels of the extractor: pyramid, FAST cells, 7x7 blur.
  *
  * k_resize_level_v2  one thread = four consecutive output pixels of a row (cv::resize INTER_LINEAR 8u fixed point).
- * k_fast_cells_v3    one workgroup per 30-px FAST cell: packed 4-pixel compass pre-test, survivor lists, one pass of the
- *                    min3/max3 score networks on dense lanes, cell-local NMS, raster-ordered compaction.
+ * k_fast_cells_v3    one workgroup per 30-px FAST cell: packed 4-pixel compass pre-test that writes its survivor lists
+ *                    as it goes, one pass of packed two-pixel score networks on dense lanes, cell-local NMS,
+ *                    raster-ordered compaction.
  * k_blur7_v2         marching-rows separable 7x7: one WAVE owns a 256-px-wide strip (64 lanes x 4 px, loaded as one
  *                    dword per lane = 256 B coalesced), gets its neighbours' dwords with two wave shuffles, does
  *                    the row pass with v_dot4_u32_u8 against packed tap constants (10 dot4 per 4 px, no byte
@@ -502,13 +503,14 @@ void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const Ba
  *   - the window is staged one column to the left (LDS column = window column + 1), so the four interior
  *     pixels x = 4q..4q+3 of a row and their up/down compass pixels are aligned dwords and the left/right ones
  *     come out of two v_alignbyte_b32;
- *   - the compass pre-test runs on FOUR pixels per thread in packed u16 arithmetic: "ring pixel darker than
- *     v - T" is v_pk_sub_u16 clamp(v - T, c) != 0, "brighter than v + T" is v_pk_sub_u16 clamp(c, v + T) != 0,
- *     and the four adjacent-pair terms fold into (down|up) & (right|left) = two v_or + one v_pk_min_u16;
- *   - survivors are counted per thread, placed by ONE wave scan (DPP) and ONE LDS atomic per wave for all
- *     three lists, instead of two ballots + two atomics per pixel column;
- *   - the lists are disjoint (dark-only, bright-only, both), so a single pass of the min3/max3 networks
- *     covers them without a barrier in between.
+ *   - the compass pre-test runs on FOUR pixels per thread in packed u16 arithmetic: "(down|up) & (right|left) darker
+ *     than v - T" is max(min(d,u), min(r,l)) < v - T, the bright case min(max(d,u), max(r,l)) > v + T: six
+ *     v_pk_min/max_u16 and two v_pk_sub_u16 clamp per polarity pair and pixel pair;
+ *   - survivors are written to the lists inside the sweep: per pixel column one compare per polarity straight into an
+ *     SGPR lane mask, ranks from v_mbcnt, totals from s_bcnt1, ONE LDS atomic per wave and sweep, one store under the
+ *     lane mask for the dark and the bright-only lanes together (they are disjoint);
+ *   - the lists are disjoint (dark incl. the flagged "both polarities possible", bright-only), a thread takes TWO
+ *     entries in the halves of packed registers, and with the usual list lengths each wave runs one network once.
  * ---------------------------------------------------------------------------------------------- */
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { /* per u16 half: max(a - b, 0) */
