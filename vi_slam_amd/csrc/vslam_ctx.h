@@ -160,7 +160,7 @@ struct vslam_fe {
     uint32_t* d_fine = nullptr;               /* k_octree_v3: fine-cell counts + prefix sums, B x oct.fineStride */
     uint8_t* d_walk = nullptr;                /* B x walk_stride: node arrays of the hand-over path in k_assign_out */
     size_t walk_stride = 0;
-    int32_t* d_oct_redo = nullptr;            /* k_octree_v3 -> k_octree_v2 hand-over flags, B x VSLAM_MAX_LEVELS */
+    int32_t* d_oct_redo = nullptr;            /* k_octree_v3 -> k_assign_out hand-over flags, B x VSLAM_MAX_LEVELS */
     uint32_t* d_sel_xyr = nullptr;            /* per slot / level result lists */
     int32_t* d_sel_cnt = nullptr;
     int32_t* d_counts = nullptr;              /* [slot][4] = n, monoIndex, -, - ; then [B*4] = error flags */

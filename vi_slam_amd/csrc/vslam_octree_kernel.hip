@@ -513,12 +513,9 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
  * measured: 134 us per 32 KITTI frames against 82 here and 100 for v2 (454 / 448 / 650 at 1080p), the same batch-1
  * latency, and its key kernels are wide -- they would compete with FAST and the blur for the CUs; dropped.
  * If a pass would have to split a node that is already a single fine cell (keys clustered more densely than the
- * fine grid resolves) the workgroup flags the problem and k_octree_v2, launched behind it, redoes exactly that
- * (slot, level); VSLAM_OCT_FINE_D=<n> forces a shallow grid so that tests exercise the hand-over.  (Normally every
- * workgroup of that second launch exits at once; beside the other contexts' kernels it still shows 54 us in a trace,
- * waiting for 1024 thread slots + LDS per workgroup just to exit.  Two cheaper-looking forms lost: the walk body
- * inlined into this kernel -> 128 VGPRs and spills, 77 -> 86 us; a 4-workgroup "redo" kernel looping over the flags
- * -> its run-time level index put the parameter block into scratch memory, 77 -> 95 us alone.)
+ * fine grid resolves) the workgroup flags the problem and k_assign_out, the next kernel of the pass, redoes exactly that
+ * (slot, level) with the walk-per-pass body (oct_walk_body) before it reads the level's result; VSLAM_OCT_FINE_D=<n> forces
+ * a shallow grid so that tests exercise the hand-over.  (Normally every level of every image is resolved here.)
  * ---------------------------------------------------------------------------------------------- */
 __device__ __forceinline__ int oct_fine_cell(uint32_t key, float hX, int nIni, int Hh, int D) {
     const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
