@@ -74,6 +74,8 @@ struct OctParams {
     int32_t fineD[VSLAM_MAX_LEVELS];
     int32_t fineOff[VSLAM_MAX_LEVELS]; /* uint32 offset of the level's two arrays (cells+1 each) in a slot's scratch */
     int32_t fineStride;                /* uint32 entries of fine scratch per slot */
+    int32_t fineLdsOff;                /* != 0: the fine arrays live in LDS at this byte offset of the dynamic allocation ... */
+    int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays) */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

@@ -351,9 +351,20 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 fineOff += 2 * ((O.nIni[l] << (2 * D)) + 1) + 2;
             }
             O.fineStride = (fineOff + 3) & ~3;
+
         }
         O.selStride = selOff;
         O.maxNodes = (maxNodes + 15) & ~15;
+        {   /* fine arrays in LDS when the largest level's pair fits next to the node arrays (VSLAM_OCT_FINE_LDS=0: never) */
+            int maxcells = 0;
+            for (int l = 0; l < p.nlevels; l++) maxcells = std::max(maxcells, O.nIni[l] << (2 * O.fineD[l]));
+            const size_t fb = 2 * ((size_t)maxcells + 1) * 4 + 16, nb = (vk_octree_lds_bytes(O.maxNodes) + 15) & ~(size_t)15;
+            const char* fl = getenv("VSLAM_OCT_FINE_LDS");
+            if (!(fl && atoi(fl) == 0) && nb + fb <= 64 * 1024) {
+                O.fineLdsOff = (int32_t)nb;
+                O.fineLdsBytes = (int32_t)fb;
+            }
+        }
         O.ptsCap = fe->cand_cap;
         O.dbg = nullptr;
         if (getenv("VSLAM_OCT_DBG")) {
@@ -364,7 +375,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if (vk_octree_lds_bytes(O.maxNodes) > 150 * 1024) ok = false; /* list does not fit LDS: host quadtree */
         fe->dev_octree = ok;
         if (ok) {
-            if (vk_octree_set_max_lds(vk_octree_lds_bytes(O.maxNodes)) != 0) {
+            if (vk_octree_set_max_lds(vk_octree_lds_bytes(O.maxNodes) + (O.fineLdsOff ? (size_t)O.fineLdsBytes + 16 : 0)) != 0) {
                 g_err = "hipFuncSetAttribute(k_octree, max dynamic LDS) failed";
                 return VSLAM_ERR_HIP;
             }

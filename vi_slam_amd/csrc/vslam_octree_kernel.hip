@@ -551,7 +551,11 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
     return v;
 }
 
-template <bool REGKEYS> /* keys (and their fine cells) of problems up to OKPT * 1024 keys stay in registers between the two key walks */
+/* REGKEYS: keys (and their fine cells) of problems up to OKPT * 1024 keys stay in registers between the two key walks.
+ * FINE_LDS: the two fine-cell arrays (counts -> prefix sums, later owner markers -> owners) live in LDS behind the node
+ * arrays instead of in a slot's global scratch: LDS atomics instead of 11.5 k L2 atomics from one CU, and every later
+ * look-up a ds_read (vk_octree chooses it when the largest level's arrays fit: KITTI at 1000 features, 33 KB). */
+template <bool REGKEYS, bool FINE_LDS>
 __global__ void __launch_bounds__(OT)
 k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a,
             uint16_t* fc_a, size_t pts_stride, uint32_t* fine, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
@@ -647,7 +651,8 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     const int Hh = P.H[level];
     const int D = P.fineD[level];
     const int cells = nIni << (2 * D);
-    uint32_t* Hc = fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
+    uint32_t* Hc = FINE_LDS ? (uint32_t*)(osm + P.fineLdsOff)
+                            : fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
     uint32_t* PS = Hc + cells + 1;                                          /* exclusive prefix sums, later the owners */
     for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
 
@@ -752,8 +757,10 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     __syncthreads();
     /* the counters were updated by atomics that execute in L2: drop whatever this CU's L1 holds of them (the zeroing
      * stores may have allocated lines) before reading them with plain, coalesced loads */
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    if (!FINE_LDS) {
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    }
     STAMP3();
     const int ntile = (cells + 63) >> 6, tpw = (ntile + OT / 64 - 1) / (OT / 64); /* tiles per wave */
     {   /* exclusive prefix sums of the fine counts */
@@ -1155,12 +1162,18 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
             regkeys = e ? (atoi(e) != 0 ? 1 : 0) : 2;
         }
         const bool rk = regkeys == 2 ? nslots <= 2 : regkeys == 1;
-        if (rk)
-            hipLaunchKernelGGL(k_octree_v3<true>, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
-                               P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
-        else
-            hipLaunchKernelGGL(k_octree_v3<false>, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells,
-                               P, pts_a, nid_a, pts_stride, fine, sel_xyr, sel_cnt, err_flag, redo_flags);
+        const size_t lds = P.fineLdsOff ? (size_t)P.fineLdsOff + (size_t)P.fineLdsBytes : vk_octree_lds_bytes(P.maxNodes);
+#define OCT3_LAUNCH(RK_, FL_)                                                                                                   \
+    hipLaunchKernelGGL((k_octree_v3<RK_, FL_>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, pts_a, nid_a, pts_stride, \
+                       fine, sel_xyr, sel_cnt, err_flag, redo_flags)
+        if (P.fineLdsOff) {
+            if (rk) OCT3_LAUNCH(true, true);
+            else OCT3_LAUNCH(false, true);
+        } else {
+            if (rk) OCT3_LAUNCH(true, false);
+            else OCT3_LAUNCH(false, false);
+        }
+#undef OCT3_LAUNCH
     }
     else
         hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
@@ -1179,7 +1192,11 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uin
 int vk_octree_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
-    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
-    return (int)hipFuncSetAttribute((const void*)k_octree_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_octree_v3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
