@@ -306,5 +306,7 @@ def test_process_wide_switches_do_not_change_results():
     ref = _digest({})
     for env in ({"VSLAM_OCT_REGKEYS": "1"}, {"VSLAM_OCT_REGKEYS": "0"}, {"VSLAM_SI_QPB": "8"}, {"VSLAM_SI_QPB": "32"},
                 {"VSLAM_STAGE_AHEAD": "1"}, {"VSLAM_STAGE_AHEAD": "1", "VSLAM_COPY_STREAMS": "1"},
-                {"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0", "VSLAM_FAST_LDS_PAD": "4096"}, {"VSLAM_H2D": "pull"}):
+                {"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0", "VSLAM_FAST_LDS_PAD": "4096"}, {"VSLAM_H2D": "pull"},
+                {"VSLAM_OCT_FINE_LDS": "0"}, {"VSLAM_OCT_FINE_LDS": "0", "VSLAM_OCT_REGKEYS": "1"}, {"VSLAM_D2H": "kernel"},
+                {"VSLAM_D2H": "sdma"}):
         assert _digest(env) == ref, env
