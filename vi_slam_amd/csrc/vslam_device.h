@@ -75,7 +75,8 @@ struct OctParams {
     int32_t fineOff[VSLAM_MAX_LEVELS]; /* uint32 offset of the level's two arrays (cells+1 each) in a slot's scratch */
     int32_t fineStride;                /* uint32 entries of fine scratch per slot */
     int32_t fineLdsOff;                /* != 0: the fine arrays live in LDS at this byte offset of the dynamic allocation ... */
-    int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays) */
+    int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays / its 16-bit counters) */
+    int32_t fineLdsMode;               /* 1: both arrays in LDS; 2: only the counters, as packed 16-bit pairs */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

@@ -360,9 +360,22 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             for (int l = 0; l < p.nlevels; l++) maxcells = std::max(maxcells, O.nIni[l] << (2 * O.fineD[l]));
             const size_t fb = 2 * ((size_t)maxcells + 1) * 4 + 16, nb = (vk_octree_lds_bytes(O.maxNodes) + 15) & ~(size_t)15;
             const char* fl = getenv("VSLAM_OCT_FINE_LDS");
-            if (!(fl && atoi(fl) == 0) && nb + fb <= 64 * 1024) {
+            /* a fine cell holds at most as many keys as it has pixels: 16-bit counters are safe below 65536 pixels */
+            bool small_cells = true;
+            for (int l = 0; l < p.nlevels; l++) {
+                const long long px = (long long)(fe->geom.lv[l].w) * fe->geom.lv[l].h;
+                if (px / std::max(1, O.nIni[l] << (2 * O.fineD[l])) + 64 >= 65536) small_cells = false;
+            }
+            const size_t fb16 = ((size_t)maxcells / 2 + 1) * 4 + 16;
+            const int flv = fl ? atoi(fl) : -1; /* VSLAM_OCT_FINE_LDS = 0 never, 1 full arrays only, 2 counters only */
+            if (flv != 0 && flv != 2 && nb + fb <= 64 * 1024) {
                 O.fineLdsOff = (int32_t)nb;
                 O.fineLdsBytes = (int32_t)fb;
+                O.fineLdsMode = 1;
+            } else if (flv != 0 && flv != 1 && small_cells && nb + fb16 <= 64 * 1024) {
+                O.fineLdsOff = (int32_t)nb;
+                O.fineLdsBytes = (int32_t)fb16;
+                O.fineLdsMode = 2;
             }
         }
         O.ptsCap = fe->cand_cap;

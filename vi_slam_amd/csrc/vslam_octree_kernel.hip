@@ -552,10 +552,13 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
 }
 
 /* REGKEYS: keys (and their fine cells) of problems up to OKPT * 1024 keys stay in registers between the two key walks.
- * FINE_LDS: the two fine-cell arrays (counts -> prefix sums, later owner markers -> owners) live in LDS behind the node
+ * FINE = 1: the two fine-cell arrays (counts -> prefix sums, later owner markers -> owners) live in LDS behind the node
  * arrays instead of in a slot's global scratch: LDS atomics instead of 11.5 k L2 atomics from one CU, and every later
- * look-up a ds_read (vk_octree chooses it when the largest level's arrays fit: KITTI at 1000 features, 33 KB). */
-template <bool REGKEYS, bool FINE_LDS>
+ * look-up a ds_read (vk_octree chooses it when the largest level's arrays fit: KITTI at 1000 features, 33 KB).
+ * FINE = 2: the arrays do not fit, but the COUNTERS do as packed 16-bit pairs (a fine cell cannot hold more keys than it
+ * has pixels; the host checks that this is < 65536): the count walk's atomics go to LDS, the prefix sums read them there
+ * and write the (global) prefix array; everything after that is plain loads and stores as with FINE = 0. */
+template <bool REGKEYS, int FINE> /* FINE: 0 global arrays, 1 both arrays in LDS, 2 only 16-bit COUNTERS in LDS (see above) */
 __global__ void __launch_bounds__(OT)
 k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a,
             uint16_t* fc_a, size_t pts_stride, uint32_t* fine, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
@@ -651,10 +654,15 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     const int Hh = P.H[level];
     const int D = P.fineD[level];
     const int cells = nIni << (2 * D);
-    uint32_t* Hc = FINE_LDS ? (uint32_t*)(osm + P.fineLdsOff)
-                            : fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
+    uint32_t* Hc = FINE == 1 ? (uint32_t*)(osm + P.fineLdsOff)
+                             : fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
+    uint32_t* Hc16 = (uint32_t*)(osm + P.fineLdsOff); /* FINE == 2: packed 16-bit counters, cell c in half c & 1 of word c >> 1 */
     uint32_t* PS = Hc + cells + 1;                                          /* exclusive prefix sums, later the owners */
-    for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+    if (FINE == 2) {
+        for (int i = tid; i <= cells >> 1; i += OT) Hc16[i] = 0u;
+    } else {
+        for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+    }
 
     /* keys of a problem of up to OKPT * 1024 keys (every KITTI-size level) and their fine cells stay in REGISTERS */
     const bool inReg = REGKEYS && n <= OKPT * OT;
@@ -734,7 +742,8 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (k < KW && i < n) {
                 const int f = oct_fine_cell(keyR[k], hX, nIni, Hh, D);
                 cellR[k >> 1] |= (uint32_t)f << (16 * (k & 1));
-                atomicAdd(&Hc[f], 1u);
+                if (FINE == 2) atomicAdd(&Hc16[f >> 1], 1u << (16 * (f & 1)));
+                else atomicAdd(&Hc[f], 1u);
             }
         }
     } else {
@@ -750,14 +759,15 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                 if (base + j * OT < n) {
                     const int f = oct_fine_cell(kk[j], hX, nIni, Hh, D);
                     fca[base + j * OT] = (uint16_t)f; /* the selection below reads it instead of walking the path again */
-                    atomicAdd(&Hc[f], 1u);
+                    if (FINE == 2) atomicAdd(&Hc16[f >> 1], 1u << (16 * (f & 1)));
+                    else atomicAdd(&Hc[f], 1u);
                 }
         }
     }
     __syncthreads();
     /* the counters were updated by atomics that execute in L2: drop whatever this CU's L1 holds of them (the zeroing
      * stores may have allocated lines) before reading them with plain, coalesced loads */
-    if (!FINE_LDS) {
+    if (FINE == 0) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
     }
@@ -770,7 +780,8 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int c = (t0 + u) * 64 + lane;
-                h8[u] = (t0 + u < min((wv + 1) * tpw, ntile) && c < cells) ? Hc[c] : 0u;
+                h8[u] = (t0 + u < min((wv + 1) * tpw, ntile) && c < cells)
+                            ? (FINE == 2 ? (Hc16[c >> 1] >> (16 * (c & 1))) & 0xFFFFu : Hc[c]) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -1166,12 +1177,15 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
 #define OCT3_LAUNCH(RK_, FL_)                                                                                                   \
     hipLaunchKernelGGL((k_octree_v3<RK_, FL_>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, pts_a, nid_a, pts_stride, \
                        fine, sel_xyr, sel_cnt, err_flag, redo_flags)
-        if (P.fineLdsOff) {
-            if (rk) OCT3_LAUNCH(true, true);
-            else OCT3_LAUNCH(false, true);
+        if (P.fineLdsOff && P.fineLdsMode == 1) {
+            if (rk) OCT3_LAUNCH(true, 1);
+            else OCT3_LAUNCH(false, 1);
+        } else if (P.fineLdsOff && P.fineLdsMode == 2) {
+            if (rk) OCT3_LAUNCH(true, 2);
+            else OCT3_LAUNCH(false, 2);
         } else {
-            if (rk) OCT3_LAUNCH(true, false);
-            else OCT3_LAUNCH(false, false);
+            if (rk) OCT3_LAUNCH(true, 0);
+            else OCT3_LAUNCH(false, 0);
         }
 #undef OCT3_LAUNCH
     }
@@ -1192,11 +1206,11 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uin
 int vk_octree_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
-    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc) return rc;
-    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc) return rc;
-    rc = (int)hipFuncSetAttribute((const void*)k_octree_v3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc) return rc;
-    return (int)hipFuncSetAttribute((const void*)k_octree_v3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const void* fns[6] = {(const void*)k_octree_v3<true, 0>, (const void*)k_octree_v3<false, 0>, (const void*)k_octree_v3<true, 1>,
+                          (const void*)k_octree_v3<false, 1>, (const void*)k_octree_v3<true, 2>, (const void*)k_octree_v3<false, 2>};
+    for (int i = 0; i < 6; i++) {
+        rc = (int)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (rc) return rc;
+    }
+    return 0;
 }
