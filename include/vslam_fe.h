@@ -53,6 +53,46 @@ typedef struct vslam_kp {
     int32_t octave, class_id;
 } vslam_kp;
 
+/* Behaviour switches of a context.  Every field: -1 = library default (vslam_tuning_init sets all of them to -1).
+ * vslam_fe_create resolves them ONCE: a field the caller set wins, then the process default, which is read from the
+ * environment variable named in the comment a single time per process (under std::call_once; documented for A/B runs of
+ * whole programs), then the built-in default.  Nothing reads the environment after that, and no switch is cached in
+ * unsynchronised statics, so two threads creating and using two contexts (frame.cpp:107-108) share no mutable state. */
+typedef struct vslam_tuning {
+    int32_t pyramid_per_level;    /* VSLAM_PYRAMID=levels: 1 = one launch per pyramid level instead of the fused groups */
+    int32_t pyr_rows;             /* VSLAM_PYR_ROWS: rows of the first computed level per fused-pyramid tile (4..64, default 28) */
+    int32_t pyr_threads;          /* VSLAM_PYR_NT: 256 | 512 threads per fused-pyramid tile (default 256) */
+    int32_t blur_rows;            /* VSLAM_BLUR_ROWS: output rows per wave task of the blur (8..512, default 32) */
+    int32_t fast_threads;         /* VSLAM_FAST_NT: 64 | 128 | 256 threads per FAST cell (default 128) */
+    int32_t fast_pitch;           /* VSLAM_FAST_PITCH: 72 forces the wide LDS pitch of the FAST window */
+    int32_t fast_lds_pad;         /* VSLAM_FAST_LDS_PAD: extra LDS bytes per FAST workgroup (occupancy experiments) */
+    int32_t octree_walk_kernel;   /* VSLAM_OCTREE=v2: 1 = the walk-per-pass quadtree kernel only */
+    int32_t oct_fine_depth;       /* VSLAM_OCT_FINE_D: depth of the one-walk kernel's fine grid (tests force 1 or 3) */
+    int32_t oct_fine_lds;         /* VSLAM_OCT_FINE_LDS: 0 never in LDS, 1 full arrays only, 2 counters only */
+    int32_t oct_lds_budget_kb;    /* VSLAM_OCT_LDS_BUDGET_KB: LDS a quadtree workgroup may take (16..150, default 128) */
+    int32_t oct_regkeys;          /* VSLAM_OCT_REGKEYS: 0 | 1 keys in registers between the key walks (default: batches <= 2) */
+    int32_t oct_max_iter;         /* VSLAM_OCT_MAXITER: split-pass limit (default 64) */
+    int32_t oct_debug;            /* VSLAM_OCT_DBG: 1 = allocate the stamp buffer of diagnostic builds */
+    int32_t graphs;               /* VSLAM_GRAPH: 0 = never capture / replay HIP graphs */
+    int32_t h2d_route;            /* VSLAM_H2D=pull|sdma: 1 = kernel reads pinned memory, 2 = DMA engines (default by batch size) */
+    int32_t copy_streams;         /* VSLAM_COPY_STREAMS: upload streams per device for staged-ahead uploads (1..4, default 2) */
+    int32_t stage_ahead;          /* VSLAM_STAGE_AHEAD: 1 = vslam_fe_stage_images_async uploads on a copy stream */
+    int32_t d2h_route;            /* VSLAM_D2H=kernel|sdma: 1 = copy kernel, 2 = hipMemcpyAsync for every result transfer */
+    int32_t copy_wgs;             /* VSLAM_COPY_WGS: workgroup cap of the copy kernel (default 16) */
+    int32_t pull_depth;           /* VSLAM_PULL_DEPTH: loads in flight per lane of the pull kernel */
+    int32_t init_topm;            /* VSLAM_INIT_TOPM: sorted candidate prefix per query of SearchForInitialization (1..16, default 8) */
+    int32_t init_match_host;      /* VSLAM_INIT_MATCH=host: 1 = order-dependent replay on the host (cross-check path) */
+    int32_t sbp_topm;             /* VSLAM_SBP_TOPM: the same for SearchByProjection */
+    int32_t sbp_sequential;       /* VSLAM_SBP_MODE=seq: 1 = skip the parallel resolution (cross-check path) */
+    int32_t si_queries_per_block; /* VSLAM_SI_QPB: 8 | 16 | 32 queries per k_si_topm workgroup (default 16) */
+    int32_t fg_threads;           /* VSLAM_FG_NT: 64 | 128 | 256 threads per grid-detector cell (default 128) */
+    int32_t wait_spin;            /* VSLAM_WAIT=spin: 1 = host waits poll hipStreamQuery instead of blocking */
+    int32_t numa;                 /* VSLAM_NUMA: 0 = do not allocate pinned memory from the CPUs next to the device */
+    int32_t host_prof;            /* VSLAM_HOST_PROF: 1 = host-side wall time per API phase, printed at destroy */
+    int32_t reserved[6];
+} vslam_tuning;
+void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
+
 typedef struct vslam_fe_params {
     int32_t width, height;   /* level-0 image size (reference: image.cols/rows at compute()) */
     int32_t nfeatures;       /* ORBextractor.nFeatures   (tracking.cpp:1021-1085) */
@@ -64,6 +104,7 @@ typedef struct vslam_fe_params {
     int32_t max_batch;       /* image slots processed per batched call, 1..VSLAM_MAX_BATCH */
     uint32_t flags;          /* VSLAM_FLAG_* */
     int32_t gauss_taps[7];   /* all zero -> OpenCV 4.2 taps {18,34,48,56,48,34,18} */
+    const vslam_tuning* tuning; /* NULL: library defaults; copied by vslam_fe_create */
 } vslam_fe_params;
 
 typedef struct vslam_fe vslam_fe;
@@ -73,6 +114,12 @@ typedef struct vslam_fe vslam_fe;
 /* FExtractor::FExtractor (fextractor.cpp:401-461): allocates pyramids for max_batch image slots, builds
  * scale tables, per-level quotas, resize coefficient tables and the FAST cell list. */
 int vslam_fe_create(const vslam_fe_params* params, vslam_fe** out);
+/* Change switches of an existing context between calls (fields >= 0 of *t overwrite the context's; like every other
+ * call on a context this is not re-entrant).  Takes effect for what is consulted per call -- the transport routes
+ * (h2d_route, d2h_route, stage_ahead, pull_depth, copy_wgs), the matcher switches (init_topm, init_match_host, sbp_topm,
+ * sbp_sequential, si_queries_per_block), oct_regkeys, the FAST / pyramid launch shapes, graphs = 0; switches that shaped
+ * the context's buffers at creation (pyramid plan, blur rows, quadtree grid depth and LDS placement) stay as created. */
+int vslam_fe_set_tuning(vslam_fe* fe, const vslam_tuning* t);
 void vslam_fe_destroy(vslam_fe* fe);
 const char* vslam_last_error(void);
 
@@ -514,6 +561,12 @@ int vslam_dbg_sincos(vslam_fe* fe, const float* x, int n, float* sin_out, float*
 int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, int fma, float* deg);
 /* glibc logf as MapPoint::PredictScale uses it (mappoint.cpp:514); normal positive inputs, NaN otherwise */
 int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y);
+/* Quadtree statistics of a context: how many (slot, level) DistributeOctTree problems (fextractor.cpp:530-754) ran on the
+ * device so far, how many of them the one-walk kernel could not finish on its own (keys clustered more finely than its
+ * grid resolves: handed over to the walk-per-pass code, same result), and -- last_level_masks, max_batch words or NULL --
+ * bit l of word s set if level l of slot s was handed over in the last pass.  Updated when a pass's results are collected. */
+int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* handed_over,
+                          uint32_t* last_level_masks);
 /* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
  * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */
 int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);

@@ -121,9 +121,70 @@ def make_fastgrid():
     print("wrote fastgrid.npz:", len(out), "arrays")
 
 
+REAL_STEREO = (822.5 * 0.4, 822.5)  # (bf, fx): hut_stereo.json's fx; the baseline is a test parameter, not a calibration
+REAL_CASES = [  # (image, nfeatures, lapping area): Frame's stereo ctor passes {0,0}, the mono ctor {0,1000} (frame.cpp:107,289)
+    ("hut1", 1200, (0, 0)), ("hut2", 1200, (0, 0)), ("hut3", 2000, (0, 0)), ("hut4", 2000, (0, 0)), ("hut5", 2000, (0, 0)),
+    ("lenna", 1200, (0, 0)), ("lenna", 2000, (0, 1000)), ("chess", 1200, (0, 0)), ("chess", 2000, (0, 1000)),
+    ("hut1", 5000, (0, 1000)), ("hut2", 5000, (0, 1000)), ("hut4", 5000, (0, 1000)), ("hut5", 5000, (0, 1000)),
+]
+REAL_STEREO_PAIRS = [("hut1", "hut2", 1200), ("hut3", "hut4", 2000), ("hut4", "hut5", 2000)]
+REAL_INIT_PAIRS = [("hut1", "hut2", 5000), ("hut4", "hut5", 5000)]  # mono initialisation extracts 5 x nFeatures (tracking.cpp:1093)
+
+
+def real_case_key(name, nf, lap):
+    return "%s_n%d_lap%d_%d" % (name, nf, lap[0], lap[1])
+
+
+def real_images():
+    """The reference's own test images at FULL size as gray arrays (fixed-point BGR2GRAY): hut_stereo/01-05.png 752x480,
+    lenna.png 512x512, chessboard_798_798.png (the tie-heavy one)."""
+    ims = {"hut%d" % i: gray(os.path.join(IMG, "scenery/hut_stereo/%02d.png" % i)) for i in range(1, 6)}
+    ims["lenna"] = gray(os.path.join(IMG, "lenna.png"))
+    ims["chess"] = gray("/root/reference/test/images/chessboard_798_798.png")
+    return ims
+
+
+def make_real_fullsize():
+    """tests/golden/real_images.npz (inputs) + real_expected.npz (oracle outputs: keypoints in full, descriptors as
+    SHA-256, stereo uRight/depth and init matches in full).  These pin the oracle on real pixels at full size; they are
+    oracle outputs, not reference outputs (the reference needs OpenCV 4.2)."""
+    import hashlib
+    ims = real_images()
+    np.savez_compressed(os.path.join(OUT, "real_images.npz"), **ims)
+    out = {}
+    for name, nf, lap in REAL_CASES:
+        e = orbo.Extractor(nf)
+        k, d, m = e.compute(ims[name], lap=lap)
+        key = real_case_key(name, nf, lap)
+        out[key + "_kps"] = k
+        out[key + "_desc_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8)
+        out[key + "_mono"] = np.int32(m)
+        out[key + "_ncand"] = np.asarray([len(e.candidates(l)) for l in range(8)], np.int32)
+    for a, b, nf in REAL_STEREO_PAIRS:
+        eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
+        kL, dL, _ = eL.compute(ims[a])
+        kR, dR, _ = eR.compute(ims[b])
+        u, dep, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, *REAL_STEREO)
+        out["stereo_%s_%s_n%d_uRight" % (a, b, nf)] = u
+        out["stereo_%s_%s_n%d_depth" % (a, b, nf)] = dep
+    for a, b, nf in REAL_INIT_PAIRS:
+        e = orbo.Extractor(nf)
+        k1, d1, _ = e.compute(ims[a], lap=(0, 1000))
+        k2, d2, _ = e.compute(ims[b], lap=(0, 1000))
+        h, w = ims[a].shape
+        nm, m12, pm = orbo.search_for_initialization(k1, d1, k2, d2, w, h, window=100)
+        out["init_%s_%s_n%d_matches" % (a, b, nf)] = m12
+        out["init_%s_%s_n%d_nmatches" % (a, b, nf)] = np.int32(nm)
+    np.savez_compressed(os.path.join(OUT, "real_expected.npz"), **out)
+    print("wrote real_images.npz (%d images), real_expected.npz (%d arrays)" % (len(ims), len(out)))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fastgrid":
         make_fastgrid()
+    elif len(sys.argv) > 1 and sys.argv[1] == "real":
+        make_real_fullsize()
     else:
         main()
         make_fastgrid()
+        make_real_fullsize()

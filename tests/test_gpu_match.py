@@ -210,11 +210,10 @@ def test_frame_stereo_async_pipeline(fe):
         assert (wu >= 0).sum() > 300
 
 
-def test_search_init_host_replay_path_agrees(monkeypatch):
-    """VSLAM_INIT_MATCH=host: distance matrices on the GPU, order-dependent replay on the host."""
-    monkeypatch.setenv("VSLAM_INIT_MATCH", "host")
+def test_search_init_host_replay_path_agrees():
+    """init_match_host: distance matrices on the GPU, order-dependent replay on the host."""
     a, b = synth.make_frame(1241, 376, step=3), synth.make_frame(1241, 376, step=4)
-    f = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2)
+    f = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=2, tuning=dict(init_match_host=1))
     try:
         (k1, d1, _), (k2, d2, _) = f.compute_batch([a, b], (0, 1000))
         _, pd1, _ = f.slot_buffers(0)
@@ -254,12 +253,11 @@ def test_search_init_device_jobs_async(fe):
 
 
 @pytest.mark.parametrize("topm", ["1", "2", "8"])
-def test_search_init_sorted_prefix_and_rescan_path(monkeypatch, topm):
-    """k_si_replay works from a sorted prefix of VSLAM_INIT_TOPM candidates per query and re-scans the whole
+def test_search_init_sorted_prefix_and_rescan_path(topm):
+    """k_si_replay works from a sorted prefix of init_topm candidates per query and re-scans the whole
     window when the prefix is exhausted: a prefix of 1 or 2 forces that path, the result must not change."""
-    monkeypatch.setenv("VSLAM_INIT_TOPM", topm)
     frames = [synth.make_frame(1241, 376, seed=11, step=s) for s in range(3)]
-    f = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=3)
+    f = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=3, tuning=dict(init_topm=int(topm)))
     try:
         res = f.compute_batch(frames, (0, 1000))
         jobs = []

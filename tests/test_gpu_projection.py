@@ -68,9 +68,16 @@ def test_projection_matches_with_stereo_gate(scene):
     _run(scene, Tcw, 15, flags, gemm_float=True)
 
 
-def test_sequential_replay_path_agrees(scene, monkeypatch):
-    """VSLAM_SBP_MODE=seq skips the parallel (deferred-acceptance) resolution: one wave walks the queries in order."""
-    monkeypatch.setenv("VSLAM_SBP_MODE", "seq")
+@pytest.fixture
+def tune(scene):
+    """per-call switches of the shared context (vslam_fe_set_tuning), restored to the defaults afterwards"""
+    yield scene["fe"].set_tuning
+    scene["fe"].set_tuning(sbp_sequential=0, sbp_topm=8)
+
+
+def test_sequential_replay_path_agrees(scene, tune):
+    """sbp_sequential skips the parallel (deferred-acceptance) resolution: one wave walks the queries in order."""
+    tune(sbp_sequential=1)
     rng = np.random.default_rng(3)
     flags = rng.integers(0, 4, len(scene["k0"])).astype(np.uint8)
     zmed = float(np.median(scene["z"][scene["has_depth"]]))
@@ -104,8 +111,8 @@ def test_mappoint_flags_observations_and_initial_occupancy(scene):
 
 
 @pytest.mark.parametrize("topm", ["1", "2"])
-def test_sorted_prefix_exhaustion_rescans(scene, monkeypatch, topm):
-    monkeypatch.setenv("VSLAM_SBP_TOPM", topm)
+def test_sorted_prefix_exhaustion_rescans(scene, tune, topm):
+    tune(sbp_topm=int(topm))
     flags = np.full(len(scene["k0"]), 3, np.uint8)
     zmed = float(np.median(scene["z"][scene["has_depth"]]))
     m = V.FMatcher(scene["fe"], 0.9, True)
@@ -241,10 +248,9 @@ def test_local_map_matcher_equals_oracle(scene, th, nnratio, seed):
         assert m.search_init_fallbacks() == 0  # tracking's usual window: resolved by the parallel fixpoint alone
 
 
-@pytest.mark.parametrize("env", [{"VSLAM_SBP_MODE": "seq"}, {"VSLAM_SBP_TOPM": "2"}, {"VSLAM_SBP_TOPM": "1"}])
-def test_local_map_matcher_sequential_and_short_prefix(scene, monkeypatch, env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+@pytest.mark.parametrize("env", [{"sbp_sequential": 1}, {"sbp_topm": 2}, {"sbp_topm": 1}])
+def test_local_map_matcher_sequential_and_short_prefix(scene, tune, env):
+    tune(**env)
     mps = _local_map(scene, 9, jitter=4.0)
     mps["flags"] |= np.uint32(1)
     m = V.FMatcher(scene["fe"], 0.8, True)
@@ -338,8 +344,8 @@ def test_search_by_projection_keyframe_equals_oracle(scene):
     _run_kf(scene, _pose(tx=0.5, yaw=0.1, tz=-3.0), 10, 100, flags, mn, mx)
 
 
-def test_search_by_projection_keyframe_sequential_path(scene, monkeypatch):
-    monkeypatch.setenv("VSLAM_SBP_MODE", "seq")
+def test_search_by_projection_keyframe_sequential_path(scene, tune):
+    tune(sbp_sequential=1)
     mn, mx = _kf_points(scene)
     zmed = float(np.median(scene["z"][scene["has_depth"]]))
     flags = np.ones(len(scene["k0"]), np.uint8)

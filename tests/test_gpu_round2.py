@@ -246,17 +246,15 @@ def test_staged_upload_then_extract_equals_pinned_path():
         fe.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"VSLAM_OCT_FINE_D": "1"}, {"VSLAM_OCT_FINE_D": "3"}, {"VSLAM_OCTREE": "v2"}])
+@pytest.mark.parametrize("env", [{}, {"oct_fine_depth": 1}, {"oct_fine_depth": 3}, {"octree_walk_kernel": 1}])
 @pytest.mark.parametrize("cfg", [(1241, 376, 1000), (640, 480, 3000), (1920, 1080, 4000)])
-def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(monkeypatch, env, cfg):
+def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(env, cfg):
     """k_octree_v3 counts keys once into a fine grid and never walks them per pass; when a split would need a finer
     grid than it has (forced here with a depth of 1 or 3) it hands the (slot, level) problem to k_octree_v2.  Every
     variant must give the oracle's keypoints."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     w, h, nf = cfg
     imgs = [synth.make_frame(w, h, seed=50 + nf, step=s) for s in range(2)]
-    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=2)
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=2, tuning=env)
     try:
         res = fe.compute_batch(imgs)
         e = orbo.Extractor(nf)
@@ -267,14 +265,12 @@ def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(monkeypatch, env, cf
         fe.close()
 
 
-@pytest.mark.parametrize("env", [{"VSLAM_OCT_FINE_D": "1"}, {"VSLAM_OCT_FINE_D": "3"}])
-def test_quadtree_handover_with_keys_in_global_memory(monkeypatch, env):
+@pytest.mark.parametrize("env", [{"oct_fine_depth": 1}, {"oct_fine_depth": 3}])
+def test_quadtree_handover_with_keys_in_global_memory(env):
     """batches of more than two images use the k_octree_v3 instantiation that re-reads its keys (80 VGPRs); the levels it
     hands over are redone by k_assign_out with node arrays in global scratch"""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     imgs = [synth.make_frame(1241, 376, seed=61, step=s) for s in range(4)]
-    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=4)
+    fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=4, tuning=env)
     try:
         res = fe.compute_batch(imgs)
         e = orbo.Extractor(1000)
@@ -300,13 +296,23 @@ def _digest(extra_env):
     return lines[-1]
 
 
-def test_process_wide_switches_do_not_change_results():
-    """switches the library reads once per process (one child process each): every variant must deliver exactly what the
-    default does -- extraction from device and from staged pinned images, and the device-resident init matcher"""
-    ref = _digest({})
-    for env in ({"VSLAM_OCT_REGKEYS": "1"}, {"VSLAM_OCT_REGKEYS": "0"}, {"VSLAM_SI_QPB": "8"}, {"VSLAM_SI_QPB": "32"},
-                {"VSLAM_STAGE_AHEAD": "1"}, {"VSLAM_STAGE_AHEAD": "1", "VSLAM_COPY_STREAMS": "1"},
-                {"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0", "VSLAM_FAST_LDS_PAD": "4096"}, {"VSLAM_H2D": "pull"},
-                {"VSLAM_OCT_FINE_LDS": "0"}, {"VSLAM_OCT_FINE_LDS": "0", "VSLAM_OCT_REGKEYS": "1"}, {"VSLAM_D2H": "kernel"},
-                {"VSLAM_D2H": "sdma"}):
-        assert _digest(env) == ref, env
+def test_switches_do_not_change_results():
+    """Every A/B switch must deliver exactly what the default does -- extraction from device and from staged pinned
+    images, and the device-resident init matcher.  Per-context switches go through vslam_fe_params.tuning in THIS process
+    (several contexts with different settings side by side: nothing is cached process-wide any more); the environment
+    defaults and the process-wide switches (wait mode, NUMA placement, upload streams) get one child process each."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("env_variant_check", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                                                                                  "env_variant_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = mod.digest()
+    for tuning in ({"oct_regkeys": 1}, {"oct_regkeys": 0}, {"si_queries_per_block": 8}, {"si_queries_per_block": 32},
+                   {"stage_ahead": 1}, {"fast_lds_pad": 4096}, {"h2d_route": 1}, {"h2d_route": 2}, {"oct_fine_lds": 0},
+                   {"oct_fine_lds": 0, "oct_regkeys": 1}, {"d2h_route": 1}, {"d2h_route": 2}, {"graphs": 0},
+                   {"pyramid_per_level": 1}, {"fast_threads": 256}, {"pyr_threads": 512}, {"blur_rows": 16}):
+        assert mod.digest(tuning) == ref, tuning
+    for env in ({"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0"}, {"VSLAM_STAGE_AHEAD": "1", "VSLAM_COPY_STREAMS": "1"},
+                {"VSLAM_D2H": "kernel", "VSLAM_OCT_REGKEYS": "1", "VSLAM_PYRAMID": "levels"}):
+        assert _digest(env).split()[-1] == ref, env

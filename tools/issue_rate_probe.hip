@@ -1,107 +1,217 @@
-// Issue-rate probe for gfx950: how many cycles does a SIMD need per wave64 VALU / SALU / LDS instruction when 8 waves
-// per SIMD keep it busy, and do the instruction classes overlap?      hipcc --offload-arch=gfx950 -O3 -o tools/bin/issue_rate_probe tools/issue_rate_probe.hip
+// Issue-rate probe for gfx950 (round 3 rewrite).  Question: how many shader cycles does one SIMD need per wave64
+// instruction of a given kind when 1, 2, 4 or 8 waves per SIMD keep it busy -- and do plain 32-bit VALU operations issue
+// faster than packed 16-bit ones (which would decide the arithmetic of the FAST score network)?
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/issue_rate_probe tools/issue_rate_probe.hip && tools/bin/issue_rate_probe
+//
+// Every row is ONE instruction kind: a block of 32 of them over EIGHT independent destination registers (a register is
+// rewritten every 8th instruction), ITERS blocks per wave.  The clock is read INSIDE the kernel: s_memtime (shader cycles)
+// around the loop of every wave, s_memrealtime (100 MHz) beside it, so the row shows cycles and the clock the chip ran at;
+// the host checks hipGetLastError after every launch and prints the event time as a cross-check.  Workgroups are 256
+// threads (one wave per SIMD), wps workgroups per CU; HW_ID is recorded and the waves per (CU, SIMD) are counted to confirm
+// the placement the arithmetic assumes.
 #include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdint>
-#include <vector>
 #include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
 
-#define REP8(x) x x x x x x x x
-#define VALU8 REP8("v_pk_min_u16 %0, %0, %1\n\t" "v_pk_max_u16 %2, %2, %1\n\t" "v_and_b32 %3, %3, %1\n\t" "v_or_b32 %4, %4, %1\n\t")
-#define SALU8 REP8("s_add_u32 %0, %0, %1\n\t" "s_and_b32 %2, %2, %1\n\t" "s_or_b32 %3, %3, %1\n\t" "s_xor_b32 %4, %4, %1\n\t")
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-__global__ void k_valu(uint32_t* out, int iters) {
-    uint32_t a = threadIdx.x, b = 3, c = 5, d = 7, e = 9;
-    for (int i = 0; i < iters; i++) asm volatile(VALU8 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-    if (a + c + d + e == 0x12345) out[0] = a;
-}
-__global__ void k_valu_perm(uint32_t* out, int iters) { /* v_perm + pk_sub clamp + mbcnt + alignbyte mix */
-    uint32_t a = threadIdx.x, b = 3, c = 5, d = 7, e = 9;
+struct WaveRec { unsigned long long cyc, rt; unsigned hwid, pad; };
+
+#define R4(x) x x x x
+/* 8 independent destinations %0..%7, one shared source %8 (and %9 where three inputs are needed) */
+#define BLK8(OP, TAIL) \
+    OP " %0, %0, %8" TAIL "\n\t" OP " %1, %1, %8" TAIL "\n\t" OP " %2, %2, %8" TAIL "\n\t" OP " %3, %3, %8" TAIL "\n\t" \
+    OP " %4, %4, %8" TAIL "\n\t" OP " %5, %5, %8" TAIL "\n\t" OP " %6, %6, %8" TAIL "\n\t" OP " %7, %7, %8" TAIL "\n\t"
+#define BLK8_3(OP, TAIL) \
+    OP " %0, %0, %8, %9" TAIL "\n\t" OP " %1, %1, %8, %9" TAIL "\n\t" OP " %2, %2, %8, %9" TAIL "\n\t" OP " %3, %3, %8, %9" TAIL "\n\t" \
+    OP " %4, %4, %8, %9" TAIL "\n\t" OP " %5, %5, %8, %9" TAIL "\n\t" OP " %6, %6, %8, %9" TAIL "\n\t" OP " %7, %7, %8, %9" TAIL "\n\t"
+
+#define PROLOGUE()                                                                                          \
+    unsigned long long t0, t1, r0, r1;                                                                      \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) : : "memory")
+#define EPILOGUE(sink)                                                                                      \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : : "memory"); \
+    if ((threadIdx.x & 63) == 0) {                                                                          \
+        unsigned hw;                                                                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                    \
+        WaveRec w; w.cyc = t1 - t0; w.rt = r1 - r0; w.hwid = hw; w.pad = 0;                                 \
+        rec[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;                                       \
+    }                                                                                                       \
+    if ((sink) == 0x12345u) out[0] = (sink)
+
+#define VKERNEL(NAME, BODY)                                                                                 \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, WaveRec* rec, int iters) {                   \
+        uint32_t a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7; \
+        uint32_t s = 0x00030005u, s2 = 0x07060504u;                                                         \
+        PROLOGUE();                                                                                         \
+        for (int i = 0; i < iters; i++)                                                                     \
+            asm volatile(R4(BODY) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s), "v"(s2)); \
+        EPILOGUE(a + b + c + d + e + f + g + h);                                                            \
+    }
+
+VKERNEL(k_add_u32, BLK8("v_add_u32", ""))
+VKERNEL(k_and_b32, BLK8("v_and_b32", ""))
+VKERNEL(k_xor_b32, BLK8("v_xor_b32", ""))
+VKERNEL(k_min_u32, BLK8("v_min_u32", ""))
+VKERNEL(k_min3_i32, BLK8_3("v_min3_i32", ""))
+VKERNEL(k_max3_u32, BLK8_3("v_max3_u32", ""))
+VKERNEL(k_pk_min_u16, BLK8("v_pk_min_u16", ""))
+VKERNEL(k_pk_max_u16, BLK8("v_pk_max_u16", ""))
+VKERNEL(k_pk_sub_u16c, BLK8("v_pk_sub_u16", " clamp"))
+VKERNEL(k_pk_add_u16, BLK8("v_pk_add_u16", ""))
+VKERNEL(k_perm_b32, BLK8_3("v_perm_b32", ""))
+VKERNEL(k_alignbyte, BLK8_3("v_alignbyte_b32", ""))
+VKERNEL(k_bfe_u32, BLK8_3("v_bfe_u32", ""))
+VKERNEL(k_lshl_or, BLK8_3("v_lshl_or_b32", ""))
+VKERNEL(k_and_or, BLK8_3("v_and_or_b32", ""))
+VKERNEL(k_add3, BLK8_3("v_add3_u32", ""))
+VKERNEL(k_mad_u32_u24, BLK8_3("v_mad_u32_u24", ""))
+VKERNEL(k_fma_f32, BLK8_3("v_fma_f32", ""))
+VKERNEL(k_add_f32, BLK8("v_add_f32", ""))
+VKERNEL(k_bcnt, BLK8("v_bcnt_u32_b32", ""))
+VKERNEL(k_mbcnt, BLK8("v_mbcnt_lo_u32_b32", ""))
+VKERNEL(k_sad_u16, BLK8_3("v_sad_u16", ""))
+VKERNEL(k_sad_u8, BLK8_3("v_sad_u8", ""))
+VKERNEL(k_dot4_u8, BLK8_3("v_dot4_u32_u8", ""))
+VKERNEL(k_mul_lo, BLK8("v_mul_lo_u32", ""))
+VKERNEL(k_mul_u24, BLK8("v_mul_u32_u24", ""))
+VKERNEL(k_min_u16, BLK8("v_min_u16", ""))
+/* DPP / SDWA forms as the FAST kernel uses them */
+VKERNEL(k_add_dpp, BLK8("v_add_u32_dpp", " row_shr:1 row_mask:0xf bank_mask:0xf"))
+VKERNEL(k_min_sdwa, BLK8("v_min_u16_sdwa", " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"))
+
+/* v_cmp into SGPR pairs: 8 independent destinations */
+__global__ void __launch_bounds__(256) k_cmp_sgpr(uint32_t* out, WaveRec* rec, int iters) {
+    uint32_t a = threadIdx.x, s = 77;
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+    PROLOGUE();
     for (int i = 0; i < iters; i++)
-        asm volatile(REP8("v_perm_b32 %0, %0, %1, %1\n\t" "v_pk_sub_u16 %2, %2, %1 clamp\n\t" "v_alignbyte_b32 %3, %3, %1, 1\n\t" "v_mbcnt_lo_u32_b32 %4, %1, %4\n\t")
-                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-    if (a + c + d + e == 0x12345) out[0] = a;
+        asm volatile(R4("v_cmp_lt_u32 %0, %8, %9\n\tv_cmp_gt_u32 %1, %8, %9\n\tv_cmp_lt_u32 %2, %8, %9\n\tv_cmp_gt_u32 %3, %8, %9\n\t"
+                        "v_cmp_lt_u32 %4, %8, %9\n\tv_cmp_gt_u32 %5, %8, %9\n\tv_cmp_lt_u32 %6, %8, %9\n\tv_cmp_gt_u32 %7, %8, %9\n\t")
+                     : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3), "+s"(m4), "+s"(m5), "+s"(m6), "+s"(m7) : "v"(a), "v"(s));
+    EPILOGUE((uint32_t)(m0 + m1 + m2 + m3 + m4 + m5 + m6 + m7));
 }
-__global__ void k_salu(uint32_t* out, int iters) {
-    uint32_t a = blockIdx.x, b = 3, c = 5, d = 7, e = 9;
-    for (int i = 0; i < iters; i++) asm volatile(SALU8 : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e));
-    if (a + c + d + e == 0x12345) out[0] = a;
-}
-__global__ void k_mix(uint32_t* out, int iters) { /* 32 VALU + 32 SALU per iteration, independent */
-    uint32_t a = threadIdx.x, b = 3, c = 5, d = 7, e = 9;
-    uint32_t sa = blockIdx.x, sb = 3, sc = 5, sd = 7, se = 9;
+
+/* packed f32: 64-bit register pairs */
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_pk_fma_f32(uint32_t* out, WaveRec* rec, int iters) {
+    f2 a = {1.f, 2.f}, b = a, c = a, d = a, e = a, f = a, g = a, h = a, s = {1.0001f, 0.9999f}, s2 = {0.5f, 0.25f};
+    a.x = (float)threadIdx.x;
+    PROLOGUE();
     for (int i = 0; i < iters; i++)
-        asm volatile(REP8("v_pk_min_u16 %0, %0, %1\n\t" "s_add_u32 %5, %5, %6\n\t" "v_pk_max_u16 %2, %2, %1\n\t" "s_and_b32 %7, %7, %6\n\t"
-                          "v_and_b32 %3, %3, %1\n\t" "s_or_b32 %8, %8, %6\n\t" "v_or_b32 %4, %4, %1\n\t" "s_xor_b32 %9, %9, %6\n\t")
-                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+s"(sa), "+s"(sb), "+s"(sc), "+s"(sd), "+s"(se));
-    if (a + c + d + e + sa + sc + sd + se == 0x12345) out[0] = a;
+        asm volatile(R4(BLK8_3("v_pk_fma_f32", "")) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s), "v"(s2));
+    EPILOGUE((uint32_t)(a.x + b.x + c.x + d.x + e.x + f.x + g.x + h.x));
 }
-__global__ void k_lds_u8(uint32_t* out, int iters, int stride) { /* 32 ds_read_u8 per iteration */
-    __shared__ uint8_t sm[8192];
-    for (int i = threadIdx.x; i < 8192; i += 64) sm[i] = (uint8_t)i;
+
+/* SALU: 8 independent SGPR chains */
+__global__ void __launch_bounds__(256) k_salu(uint32_t* out, WaveRec* rec, int iters) {
+    uint32_t a = blockIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7, s = 3;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4("s_add_u32 %0, %0, %8\n\ts_and_b32 %1, %1, %8\n\ts_or_b32 %2, %2, %8\n\ts_xor_b32 %3, %3, %8\n\t"
+                        "s_add_u32 %4, %4, %8\n\ts_and_b32 %5, %5, %8\n\ts_or_b32 %6, %6, %8\n\ts_xor_b32 %7, %7, %8\n\t")
+                     : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g), "+s"(h) : "s"(s) : "scc");
+    EPILOGUE(a + b + c + d + e + f + g + h);
+}
+/* 32 VALU (v_add_u32) + 32 SALU per block, interleaved one to one, all independent */
+__global__ void __launch_bounds__(256) k_valu_salu(uint32_t* out, WaveRec* rec, int iters) {
+    uint32_t a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, s = 5;
+    uint32_t sa = blockIdx.x, sb = sa + 1, sc = sa + 2, sd = sa + 3, ss = 3;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4(R4("v_add_u32 %0, %0, %8\n\ts_add_u32 %4, %4, %9\n\tv_add_u32 %1, %1, %8\n\ts_and_b32 %5, %5, %9\n\t"
+                        "v_add_u32 %2, %2, %8\n\ts_or_b32 %6, %6, %9\n\tv_add_u32 %3, %3, %8\n\ts_xor_b32 %7, %7, %9\n\t") "")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(sa), "+s"(sb), "+s"(sc), "+s"(sd) : "v"(s), "s"(ss) : "scc");
+    EPILOGUE(a + b + c + d + sa + sb + sc + sd);
+}
+/* the mix of round 2's row: two packed + two plain per four instructions */
+VKERNEL(k_mix_r02, "v_pk_min_u16 %0, %0, %8\n\tv_pk_max_u16 %1, %1, %8\n\tv_and_b32 %2, %2, %8\n\tv_or_b32 %3, %3, %8\n\t"
+                   "v_pk_min_u16 %4, %4, %8\n\tv_pk_max_u16 %5, %5, %8\n\tv_and_b32 %6, %6, %8\n\tv_or_b32 %7, %7, %8\n\t")
+
+/* LDS byte reads beside VALU, as in FAST: 32 ds_read_u8 (+ 32 v_add_u32) per block */
+template <bool WITH_VALU>
+__global__ void __launch_bounds__(256) k_lds_u8(uint32_t* out, WaveRec* rec, int iters, int stride) {
+    __shared__ uint8_t sm[4 * 8192];
+    uint8_t* my = sm + (threadIdx.x >> 6) * 8192;
+    for (int i = threadIdx.x & 63; i < 8192; i += 64) my[i] = (uint8_t)i;
     __syncthreads();
-    uint32_t addr = (threadIdx.x * stride) & 4095, acc = 0;
-    const uint8_t* p = sm + addr;
+    const uint32_t addr = (uint32_t)(my - sm) + (((threadIdx.x & 63) * stride) & 4095);
+    uint32_t acc = 0, a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, s = 5;
+    PROLOGUE();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
-        for (int k = 0; k < 32; k++) acc += p[(k * 53) & 4095];
-        asm volatile("" : "+v"(acc));
-    }
-    if (acc == 0x12345) out[0] = acc;
-}
-__global__ void k_mix_lds(uint32_t* out, int iters, int stride) { /* 32 ds_read_u8 + 32 VALU pk ops per iteration */
-    __shared__ uint8_t sm[8192];
-    for (int i = threadIdx.x; i < 8192; i += 64) sm[i] = (uint8_t)i;
-    __syncthreads();
-    uint32_t addr = (threadIdx.x * stride) & 4095, acc = 0;
-    uint32_t a = threadIdx.x, b = 3, c = 5, d = 7, e = 9;
-    const uint8_t* p = sm + addr;
-    for (int i = 0; i < iters; i++) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) acc += p[(k * 53) & 4095];
-        asm volatile(REP8("v_pk_min_u16 %0, %0, %1\n\t" "v_pk_max_u16 %2, %2, %1\n\t" "v_and_b32 %3, %3, %1\n\t") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-        asm volatile("" : "+v"(acc));
-    }
-    if (acc + a + c + d == 0x12345) out[0] = acc;
-}
-
-template <class F>
-static double time_ms(F launch) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    launch(); hipDeviceSynchronize();
-    std::vector<float> t;
-    for (int r = 0; r < 5; r++) {
-        hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms);
-    }
-    std::sort(t.begin(), t.end());
-    return t[2];
-}
-
-int main() {
-    uint32_t* out; hipMalloc(&out, 64);
-    int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-    printf("reported clock %d kHz\n", clk);
-    const int iters = 4000;
-    for (int wps = 1; wps <= 8; wps *= 2) { /* waves per SIMD */
-        const int nwg = 256 * 4 * wps;
-        const double per_simd_instr = (double)wps * iters * 32;
-        double t;
-        t = time_ms([&] { hipLaunchKernelGGL(k_valu, dim3(nwg), dim3(64), 0, 0, out, iters); });
-        printf("wps %d  valu      : %.3f ms  -> %.2f ns per wave-instr per SIMD\n", wps, t, t * 1e6 / per_simd_instr);
-        t = time_ms([&] { hipLaunchKernelGGL(k_valu_perm, dim3(nwg), dim3(64), 0, 0, out, iters); });
-        printf("wps %d  valu perm : %.3f ms  -> %.2f ns per wave-instr per SIMD\n", wps, t, t * 1e6 / per_simd_instr);
-        t = time_ms([&] { hipLaunchKernelGGL(k_salu, dim3(nwg), dim3(64), 0, 0, out, iters); });
-        printf("wps %d  salu      : %.3f ms  -> %.2f ns per instr per SIMD\n", wps, t, t * 1e6 / per_simd_instr);
-        t = time_ms([&] { hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(64), 0, 0, out, iters); });
-        printf("wps %d  valu+salu : %.3f ms  -> %.2f ns per (valu+salu) pair per SIMD\n", wps, t, t * 1e6 / per_simd_instr);
-        for (int stride : {1, 4, 48, 67}) {
-            t = time_ms([&] { hipLaunchKernelGGL(k_lds_u8, dim3(nwg), dim3(64), 0, 0, out, iters / 4, stride); });
-            printf("wps %d  lds u8 stride %2d : %.3f ms -> %.2f ns per ds_read per SIMD\n", wps, stride, t, t * 1e6 / (per_simd_instr / 4));
+        for (int k = 0; k < 32; k++) {
+            uint32_t v;
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"((k * 53) & 4095));
+            if (WITH_VALU) asm volatile("v_add_u32 %0, %0, %1" : "+v"((k & 3) == 0 ? a : (k & 3) == 1 ? b : (k & 3) == 2 ? c : d) : "v"(s));
+            asm volatile("s_waitcnt lgkmcnt(15)");
+            acc ^= v;
         }
-        t = time_ms([&] { hipLaunchKernelGGL(k_mix_lds, dim3(nwg), dim3(64), 0, 0, out, iters / 4, 67); });
-        printf("wps %d  lds u8(67)+24 valu: %.3f ms -> %.2f ns per ds_read per SIMD\n", wps, t, t * 1e6 / (per_simd_instr / 4));
     }
+    EPILOGUE(acc + a + b + c + d);
+}
+
+struct Row { const char* name; void (*fn)(uint32_t*, WaveRec*, int); int per_block; };
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    uint32_t* out; CHECK(hipMalloc(&out, 64));
+    const int maxw = 256 * 4 * 8;
+    WaveRec* rec; CHECK(hipMalloc(&rec, sizeof(WaveRec) * maxw));
+    std::vector<WaveRec> h(maxw);
+    hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
+    printf("device %s, %d CUs, reported clock %d kHz; iters %d x 32 instructions per wave\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, iters);
+    printf("cyc/instr = median over waves of (wave's s_memtime cycles) / (instructions per wave x waves per SIMD); MHz from s_memrealtime (100 MHz)\n");
+    const Row rows[] = {
+        {"v_add_u32", k_add_u32, 32}, {"v_and_b32", k_and_b32, 32}, {"v_xor_b32", k_xor_b32, 32}, {"v_min_u32", k_min_u32, 32},
+        {"v_min3_i32", k_min3_i32, 32}, {"v_max3_u32", k_max3_u32, 32}, {"v_pk_min_u16", k_pk_min_u16, 32}, {"v_pk_max_u16", k_pk_max_u16, 32},
+        {"v_pk_sub_u16 clamp", k_pk_sub_u16c, 32}, {"v_pk_add_u16", k_pk_add_u16, 32}, {"v_min_u16", k_min_u16, 32},
+        {"v_min_u16 sdwa", k_min_sdwa, 32}, {"v_add_u32 dpp row_shr", k_add_dpp, 32}, {"v_perm_b32", k_perm_b32, 32},
+        {"v_alignbyte_b32", k_alignbyte, 32}, {"v_bfe_u32", k_bfe_u32, 32}, {"v_lshl_or_b32", k_lshl_or, 32}, {"v_and_or_b32", k_and_or, 32},
+        {"v_add3_u32", k_add3, 32}, {"v_mad_u32_u24", k_mad_u32_u24, 32}, {"v_mul_u32_u24", k_mul_u24, 32}, {"v_mul_lo_u32", k_mul_lo, 32},
+        {"v_bcnt_u32_b32", k_bcnt, 32}, {"v_mbcnt_lo", k_mbcnt, 32}, {"v_sad_u16", k_sad_u16, 32}, {"v_sad_u8", k_sad_u8, 32},
+        {"v_dot4_u32_u8", k_dot4_u8, 32}, {"v_cmp -> sgpr pair", k_cmp_sgpr, 32}, {"v_add_f32", k_add_f32, 32}, {"v_fma_f32", k_fma_f32, 32},
+        {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"mix r02 (2 pk + 2 plain)", k_mix_r02, 32}, {"s_add/and/or/xor", k_salu, 32},
+        {"v_add_u32 + salu 1:1 (pairs)", k_valu_salu, 64},
+    };
+    auto run = [&](const char* name, int wps, int per_block, int iters, auto launch) {
+        const int nwg = 256 * wps, nw = nwg * 4;
+        CHECK(hipMemset(rec, 0, sizeof(WaveRec) * maxw));
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        launch(nwg); CHECK(hipGetLastError()); CHECK(hipDeviceSynchronize()); /* warm-up */
+        CHECK(hipEventRecord(e0)); launch(nwg); CHECK(hipGetLastError()); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipMemcpy(h.data(), rec, sizeof(WaveRec) * nw, hipMemcpyDeviceToHost));
+        std::vector<double> cyc, mhz; std::map<unsigned, int> per_simd;
+        for (int i = 0; i < nw; i++) {
+            if (!h[i].cyc) continue;
+            cyc.push_back((double)h[i].cyc);
+            if (h[i].rt) mhz.push_back((double)h[i].cyc / (double)h[i].rt * 100.0);
+            /* HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13] (+ xcc from the dispatch: unknown here, counted modulo) */
+            per_simd[(h[i].hwid >> 4) & 0xFFF]++;
+        }
+        if (cyc.empty()) { printf("%-30s wps %d: NO WAVE RECORDS (kernel did not run)\n", name, wps); return; }
+        std::sort(cyc.begin(), cyc.end()); std::sort(mhz.begin(), mhz.end());
+        const double per = cyc[cyc.size() / 2] / ((double)iters * 32 * wps);
+        printf("%-30s wps %d: %6.2f cyc/%s  (min %.2f max %.2f)  clock %4.0f MHz  event %.3f ms  waves %zu\n", name, wps, per,
+               per_block == 64 ? "pair " : "instr", cyc.front() / ((double)iters * 32 * wps), cyc.back() / ((double)iters * 32 * wps),
+               mhz.empty() ? 0.0 : mhz[mhz.size() / 2], ms, cyc.size());
+    };
+    for (const Row& r : rows)
+        for (int wps : {1, 2, 4, 8})
+            run(r.name, wps, r.per_block, iters, [&](int nwg) { hipLaunchKernelGGL(r.fn, dim3(nwg), dim3(256), 0, 0, out, rec, iters); });
+    for (int stride : {1, 4, 48, 67})
+        for (int wps : {1, 2, 4}) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "ds_read_u8 stride %d", stride);
+            run(nm, wps, 32, iters / 4, [&](int nwg) { hipLaunchKernelGGL(k_lds_u8<false>, dim3(nwg), dim3(256), 0, 0, out, rec, iters / 4, stride); });
+            snprintf(nm, sizeof nm, "ds_read_u8 s%d + v_add 1:1", stride);
+            run(nm, wps, 32, iters / 4, [&](int nwg) { hipLaunchKernelGGL(k_lds_u8<true>, dim3(nwg), dim3(256), 0, 0, out, rec, iters / 4, stride); });
+        }
     return 0;
 }

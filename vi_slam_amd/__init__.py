@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_tuning_init", "vslam_fe_set_tuning",
 ]
 
 
@@ -93,11 +93,34 @@ class VslamError(RuntimeError):
         self.code = code
 
 
+#: vslam_tuning field names, in declaration order (include/vslam_fe.h); every field -1 = library default
+TUNING_FIELDS = ["pyramid_per_level", "pyr_rows", "pyr_threads", "blur_rows", "fast_threads", "fast_pitch", "fast_lds_pad",
+                 "octree_walk_kernel", "oct_fine_depth", "oct_fine_lds", "oct_lds_budget_kb", "oct_regkeys", "oct_max_iter",
+                 "oct_debug", "graphs", "h2d_route", "copy_streams", "stage_ahead", "d2h_route", "copy_wgs", "pull_depth",
+                 "init_topm", "init_match_host", "sbp_topm", "sbp_sequential", "si_queries_per_block", "fg_threads",
+                 "wait_spin", "numa", "host_prof"]
+
+
+class _Tuning(C.Structure):  # vslam_tuning
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 6)]
+
+
+def make_tuning(**kw):
+    """vslam_tuning with every field at its default (-1) except the given ones, e.g. make_tuning(oct_fine_depth=1)"""
+    t = _Tuning()
+    lib().vslam_tuning_init(C.byref(t))
+    for k, v in kw.items():
+        if k not in TUNING_FIELDS:
+            raise KeyError("unknown tuning field %r" % k)
+        setattr(t, k, int(v))
+    return t
+
+
 class _Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("nfeatures", C.c_int32),
                 ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
                 ("min_th_fast", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),
-                ("flags", C.c_uint32), ("gauss_taps", C.c_int32 * 7)]
+                ("flags", C.c_uint32), ("gauss_taps", C.c_int32 * 7), ("tuning", C.POINTER(_Tuning))]
 
 
 class _InitJob(C.Structure):  # vslam_init_job
@@ -281,10 +304,12 @@ class FExtractor:
     """
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, device=0,
-                 max_batch=1, flags=0, gauss_taps=None):
+                 max_batch=1, flags=0, gauss_taps=None, tuning=None):
+        """tuning: dict of vslam_tuning fields (TUNING_FIELDS) that override the library defaults for THIS context"""
         L = lib()
+        tn = make_tuning(**tuning) if tuning else None
         p = _Params(width, height, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, max_batch,
-                    flags, (C.c_int32 * 7)(*(gauss_taps or [0] * 7)))
+                    flags, (C.c_int32 * 7)(*(gauss_taps or [0] * 7)), C.pointer(tn) if tn is not None else None)
         h = C.c_void_p()
         _check(L.vslam_fe_create(C.byref(p), C.byref(h)))
         self._h = h
@@ -534,6 +559,21 @@ class FExtractor:
                                                  C.byref(u) if with_stereo else None,
                                                  C.byref(d) if with_stereo else None))
         return x.value, f.value, u.value, d.value
+
+    def set_tuning(self, **kw):
+        """change per-call switches of this context (vslam_fe_set_tuning), e.g. set_tuning(sbp_sequential=1)"""
+        t = make_tuning(**kw)
+        lib().vslam_fe_set_tuning.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib().vslam_fe_set_tuning(self._h, C.byref(t)))
+
+    def octree_stats(self):
+        """(problems, handed_over, last_level_masks): (slot, level) quadtree problems distributed on the device so far, how
+        many of them k_octree_v3 handed over to the walk-per-pass code, and the level bit masks of the last pass's slots"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        m = (C.c_uint32 * MAX_BATCH)()
+        lib().vslam_fe_octree_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib().vslam_fe_octree_stats(self._h, C.byref(a), C.byref(b), m))
+        return a.value, b.value, [int(v) for v in m]
 
     def set_profiling(self, on=True):
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))

@@ -20,6 +20,7 @@
 #include "vslam_host.h"
 #include "vslam_pool.h"
 #include "vslam_kernels.h"
+#include "vslam_tuning.h"
 
 std::string& vslam_err();
 #define g_err (vslam_err())
@@ -36,6 +37,7 @@ std::string& vslam_err();
 /* ------------------------------------------------------------------ context */
 struct vslam_fe {
     vslam_fe_params p;
+    vslam_tuning tune; /* the context's behaviour switches, resolved once by vslam_fe_create (vslam_tuning.h) */
     vslam::ExtractorTables tab;
     PyramidGeom geom;
     size_t slot_stride = 0; /* bytes per slot in d_pyr / d_blur */
@@ -94,6 +96,10 @@ struct vslam_fe {
     BatchSrc src;
     int n_out[VSLAM_MAX_BATCH] = {};
     int mono_out[VSLAM_MAX_BATCH] = {};
+    /* quadtree statistics (vslam_fe_octree_stats): (slot, level) problems distributed on the device so far, how many of
+     * them k_octree_v3 could not finish on its own, and the per-slot level masks of the last pass */
+    unsigned long long oct_problems = 0, oct_handed_over = 0;
+    uint32_t oct_last_mask[VSLAM_MAX_BATCH] = {};
     int32_t pack_hdr[VSLAM_MAX_BATCH][4] = {}; /* headers of vslam_fe_pack_slots while the copy is in flight */
     std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
     std::vector<std::vector<vslam::Cand>> cand_level;
@@ -192,11 +198,7 @@ int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* 
 /* Host wait for a stream.  hipStreamSynchronize blocks on an interrupt after a short spin; VSLAM_WAIT=spin polls
  * hipStreamQuery instead (a core per waiting thread, lower wake-up latency). */
 static inline hipError_t vslam_stream_wait(hipStream_t st) {
-    static int spin = -1;
-    if (spin < 0) {
-        const char* e = getenv("VSLAM_WAIT");
-        spin = e && !strcmp(e, "spin");
-    }
+    const bool spin = vslam_process_tuning().wait_spin == 1; /* process-wide switch, resolved once (vslam_tuning.h) */
     if (!spin) return hipStreamSynchronize(st);
     hipError_t r;
     while ((r = hipStreamQuery(st)) == hipErrorNotReady) {

@@ -402,15 +402,8 @@ extern "C" int vslam_fg_grid(const vslam_fg* fg, int* n_cols, int* n_rows) {
 }
 
 static int fg_nt() { /* threads per cell, see vk_fast_cells_v3; VSLAM_FG_NT = 64 | 128 | 256 for A/B runs */
-    static int nt = -1;
-    if (nt < 0) {
-        nt = 128;
-        if (const char* e = getenv("VSLAM_FG_NT")) {
-            const int v = atoi(e);
-            if (v == 64 || v == 128 || v == 256) nt = v;
-        }
-    }
-    return nt;
+    const int v = vslam_process_tuning().fg_threads; /* process-wide */
+    return (v == 64 || v == 128 || v == 256) ? v : 128;
 }
 
 static void fg_launch_detect(vslam_fg* fg, int n, float* resp_out, int resp_level, int resp_slot) {

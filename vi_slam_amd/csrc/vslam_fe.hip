@@ -194,8 +194,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     /* fused pyramid plan: levels 1-3 from level 0, then groups of four (8 levels = 2 launches instead of 7).  Needs the
      * quad table on every level; VSLAM_PYRAMID=levels keeps one launch per level (A/B runs). */
     {
-        const char* pm = getenv("VSLAM_PYRAMID");
-        bool fused = !(pm && !strcmp(pm, "levels")) && p.nlevels > 1;
+        bool fused = fe->tune.pyramid_per_level != 1 && p.nlevels > 1;
         for (int l = 1; l < p.nlevels && fused; l++) fused = fe->d_quads[l] != nullptr;
         static_assert(sizeof(PyrTileDev) == sizeof(vslam::PyrTileLevel), "planner and kernel share the tile record");
         for (int l0 = 0; fused && l0 + 1 < p.nlevels;) {
@@ -203,7 +202,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             std::vector<const vslam::PyrLevelTables*> gt;
             for (int j = 1; j <= nl; j++) gt.push_back(&pyr_tabs[l0 + j]);
             vslam::PyrGroupPlan plan;
-            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan)) {
+            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan, fe->tune.pyr_rows)) {
                 fused = false;
                 break;
             }
@@ -280,7 +279,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     vk_upload_disc(fe->tab.umax);
     {
         /* marching-rows blur: one wave task per (level, row chunk, 248-column strip) */
-        if (const char* e = getenv("VSLAM_BLUR_ROWS")) fe->blur_rows = std::min(512, std::max(8, atoi(e)));
+        if (fe->tune.blur_rows >= 0) fe->blur_rows = std::min(512, std::max(8, (int)fe->tune.blur_rows));
         std::vector<uint32_t> tasks;
         for (int l = 0; l < p.nlevels; l++) {
             const int br = fe->blur_rows;
@@ -337,13 +336,13 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             /* k_octree_v3's fine grid: deep enough that the split passes (which stop at N nodes) normally never reach
              * a single fine cell -- a full quadtree has nIni * 4^d nodes at depth d -- plus two levels of slack for
              * clustered keys; at most 65536 cells per level.  VSLAM_OCT_FINE_D forces a depth (tests: hand-over). */
-            const char* fd = getenv("VSLAM_OCT_FINE_D");
+            const int fd = fe->tune.oct_fine_depth; /* -1: by the level's quota */
             int fineOff = 0;
             for (int l = 0; l < p.nlevels; l++) {
                 int D = 2;
                 while ((O.nIni[l] << (2 * D)) < O.N[l]) D++;
                 D += 2;
-                if (fd) D = atoi(fd);
+                if (fd >= 0) D = fd;
                 D = std::max(1, std::min(D, 11));
                 while (D > 1 && ((long long)O.nIni[l] << (2 * D)) > 65536) D--;
                 O.fineD[l] = D;
@@ -359,7 +358,6 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             int maxcells = 0;
             for (int l = 0; l < p.nlevels; l++) maxcells = std::max(maxcells, O.nIni[l] << (2 * O.fineD[l]));
             const size_t fb = 2 * ((size_t)maxcells + 1) * 4 + 16, nb = (vk_octree_lds_bytes(O.maxNodes) + 15) & ~(size_t)15;
-            const char* fl = getenv("VSLAM_OCT_FINE_LDS");
             /* a fine cell holds at most as many keys as it has pixels: 16-bit counters are safe below 65536 pixels */
             bool small_cells = true;
             for (int l = 0; l < p.nlevels; l++) {
@@ -367,9 +365,9 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 if (px / std::max(1, O.nIni[l] << (2 * O.fineD[l])) + 64 >= 65536) small_cells = false;
             }
             const size_t fb16 = ((size_t)maxcells / 2 + 1) * 4 + 16;
-            const int flv = fl ? atoi(fl) : -1; /* VSLAM_OCT_FINE_LDS = 0 never, 1 full arrays only, 2 counters only */
-            const char* bk = getenv("VSLAM_OCT_LDS_BUDGET_KB"); /* LDS a quadtree workgroup may take in all (default 128: at 1080p the 64 KB of counters next to 49 KB of nodes are worth +3.4 %) */
-            const size_t budget = (size_t)(bk ? std::min(150, std::max(16, atoi(bk))) : 128) * 1024;
+            const int flv = fe->tune.oct_fine_lds; /* 0 never, 1 full arrays only, 2 counters only */
+            /* LDS a quadtree workgroup may take in all (default 128: at 1080p the 64 KB of counters next to 49 KB of nodes are worth +3.4 %) */
+            const size_t budget = (size_t)std::min(150, std::max(16, tune_or(fe->tune.oct_lds_budget_kb, 128))) * 1024;
             if (flv != 0 && flv != 2 && nb + fb <= budget) {
                 O.fineLdsOff = (int32_t)nb;
                 O.fineLdsBytes = (int32_t)fb;
@@ -382,11 +380,11 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         }
         O.ptsCap = fe->cand_cap;
         O.dbg = nullptr;
-        if (getenv("VSLAM_OCT_DBG")) {
+        if (fe->tune.oct_debug == 1) {
             HIPCHK(hipMalloc(&O.dbg, 64 * 8));
             HIPCHK(hipMemset(O.dbg, 0, 64 * 8));
         }
-        O.maxIter = getenv("VSLAM_OCT_MAXITER") ? atoi(getenv("VSLAM_OCT_MAXITER")) : 64;
+        O.maxIter = tune_or(fe->tune.oct_max_iter, 64);
         if (vk_octree_lds_bytes(O.maxNodes) > 150 * 1024) ok = false; /* list does not fit LDS: host quadtree */
         fe->dev_octree = ok;
         if (ok) {
@@ -401,8 +399,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             HIPCHK(hipMalloc((void**)&fe->d_nid[1], np * 2));
             HIPCHK(hipMalloc((void**)&fe->d_sel_xyr, (size_t)fe->B * O.selStride * 4));
             HIPCHK(hipMalloc((void**)&fe->d_sel_cnt, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
-            const char* og = getenv("VSLAM_OCTREE"); /* "v2": the walk-per-pass kernel only (A/B runs) */
-            if (!(og && !strcmp(og, "v2"))) {
+            if (fe->tune.octree_walk_kernel != 1) { /* 1: the walk-per-pass kernel only (A/B runs) */
                 HIPCHK(hipMalloc((void**)&fe->d_fine, (size_t)fe->B * O.fineStride * 4));
                 HIPCHK(hipMalloc((void**)&fe->d_oct_redo, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
                 HIPCHK(hipMemset(fe->d_oct_redo, 0, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
@@ -421,10 +418,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     HIPCHK(hipEventCreateWithFlags(&fe->ev_upload, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_stage_free, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
-    {
-        const char* e = getenv("VSLAM_GRAPH"); /* "0": never replay captured graphs */
-        fe->use_graph = !(e && !strcmp(e, "0"));
-    }
+    fe->use_graph = fe->tune.graphs != 0; /* 0: never replay captured graphs */
     fe->sel_level.resize((size_t)fe->B * p.nlevels);
     fe->cand_level.resize((size_t)fe->B * p.nlevels);
     unsigned hw = std::thread::hardware_concurrency();
@@ -447,6 +441,8 @@ extern "C" int vslam_fe_create(const vslam_fe_params* p, vslam_fe** out) {
     }
     vslam_fe* fe = new vslam_fe();
     fe->p = *p;
+    fe->tune = vslam_resolve_tuning(p->tuning);
+    fe->p.tuning = nullptr; /* the caller's struct need not outlive the call */
     int rc = create_impl(p, fe);
     if (rc != VSLAM_OK) {
         std::string keep = g_err;
@@ -455,6 +451,13 @@ extern "C" int vslam_fe_create(const vslam_fe_params* p, vslam_fe** out) {
         return rc;
     }
     *out = fe;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_set_tuning(vslam_fe* fe, const vslam_tuning* t) {
+    if (!fe || !t) return VSLAM_ERR_INVALID;
+    vslam_apply_tuning(fe->tune, t);
+    fe->use_graph = fe->use_graph && fe->tune.graphs != 0;
     return VSLAM_OK;
 }
 
@@ -469,6 +472,16 @@ extern "C" int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scal
         if (quota) quota[i] = fe->tab.quota[i];
     }
     return fe->p.nlevels;
+}
+
+extern "C" int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* handed_over,
+                                     uint32_t* last_level_masks) {
+    if (!fe) return VSLAM_ERR_INVALID;
+    if (problems) *problems = fe->oct_problems;
+    if (handed_over) *handed_over = fe->oct_handed_over;
+    if (last_level_masks)
+        for (int s = 0; s < fe->B; s++) last_level_masks[s] = s < fe->last_nimg ? fe->oct_last_mask[s] : 0u;
+    return VSLAM_OK;
 }
 
 extern "C" int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64) {
@@ -635,19 +648,14 @@ static int stage_host_images(vslam_fe* fe, int nimg, const uint8_t* const* imgs,
 /* VSLAM_H2D = sdma | pull forces one transport; default: the DMA engines for batches (they run beside the other
  * contexts' kernels without disturbing them), the pull kernel for one or two images (a synchronous single-frame call
  * has nothing to overlap with, and the hand-over between the DMA engine and the compute queue costs ~30 us) */
-static int h2d_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VSLAM_H2D");
-        v = !e ? 0 : !strcmp(e, "pull") ? 1 : !strcmp(e, "sdma") ? 2 : 0;
-    }
-    return v;
+static bool h2d_uses_sdma(const vslam_fe* fe, int nimg) {
+    const int mode = fe->tune.h2d_route; /* 1 pull, 2 sdma, else by batch size */
+    return mode == 2 || (mode != 1 && nimg > 2);
 }
-static bool h2d_uses_sdma(int nimg) { return h2d_mode() == 2 || (h2d_mode() == 0 && nimg > 2); }
 
 /* the device staging buffer of the sdma transport, allocated OUTSIDE stream capture (hipMalloc is not capturable) */
 static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
-    if (!h2d_uses_sdma(nimg)) return VSLAM_OK;
+    if (!h2d_uses_sdma(fe, nimg)) return VSLAM_OK;
     const size_t one = (size_t)(fe->p.height - 1) * spitch + fe->p.width;
     const size_t stride = (one + 255) & ~(size_t)255;
     if (fe->d_stage_bytes >= stride * fe->B + 256) return VSLAM_OK;
@@ -668,7 +676,7 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
     const vslam_fe_params& p = fe->p;
     hipStream_t st = fe->stream;
     const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
-    const bool use_sdma = h2d_uses_sdma(nimg);
+    const bool use_sdma = h2d_uses_sdma(fe, nimg);
     BatchSrc hs;
     for (int s = 0; s < nimg; s++) {
         if (where == VSLAM_IMGS_PINNED && !imgs[s]) {
@@ -696,12 +704,10 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
             static std::mutex mu;
             static hipStream_t shared[64][4] = {};
             static int next[64] = {};
-            static int nshared = -1;
+            static int nshared = 0; /* guarded by mu */
             std::lock_guard<std::mutex> lk(mu);
-            if (nshared < 0) { /* VSLAM_COPY_STREAMS = 1..4 upload streams per device (contexts take them in turn) */
-                const char* e = getenv("VSLAM_COPY_STREAMS");
-                nshared = e ? std::min(4, std::max(1, atoi(e))) : 2;
-            }
+            if (nshared == 0) /* copy_streams = 1..4 upload streams per device (contexts take them in turn); process-wide */
+                nshared = std::min(4, std::max(1, tune_or(vslam_process_tuning().copy_streams, 2)));
             const int dv = fe->p.device & 63, k = next[dv]++ % nshared;
             if (!shared[dv][k]) HIPCHK(hipStreamCreateWithFlags(&shared[dv][k], hipStreamNonBlocking));
             fe->copy_stream = shared[dv][k];
@@ -730,7 +736,7 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
         }
         fe->stage_pending = false;
     }
-    vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg, from_host);
+    vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg, from_host, fe->tune);
     if (!from_host) HIPCHK(hipEventRecord(fe->ev_stage_free, st));
     return VSLAM_OK;
 }
@@ -752,7 +758,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
         if (fe->stage_pending) { /* uploaded ahead into the staging buffer: re-pitch into level 0 now */
             HIPCHK(hipStreamWaitEvent(st, fe->ev_upload, 0));
             vk_pull_images(st, fe->stage_src, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)fe->geom.lv[0].pitch, p.width,
-                           p.height, nimg, 0);
+                           p.height, nimg, 0, fe->tune);
             HIPCHK(hipEventRecord(fe->ev_stage_free, st));
             fe->stage_pending = false;
         }
@@ -776,7 +782,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     const bool prof = fe->profiling;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
     for (const auto& g : fe->pyr_groups)
-        vk_pyramid_group(st, fe->d_pyr, fe->slot_stride, fe->src, g.dev, g.lds_bytes, nimg);
+        vk_pyramid_group(st, fe->d_pyr, fe->slot_stride, fe->src, g.dev, g.lds_bytes, nimg, fe->tune);
     for (int l = 1; l < L && fe->pyr_groups.empty(); l++) {
         if (fe->d_quads[l])
             vk_resize_level_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,
@@ -787,7 +793,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
     vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
-                     fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg);
+                     fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg, fe->tune);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     return VSLAM_OK;
 }
@@ -916,7 +922,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
               fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
-              fe->d_fine, fe->d_oct_redo);
+              fe->d_fine, fe->d_oct_redo, fe->tune.oct_regkeys);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
                   d_err, nimg, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->d_pts[0], fe->d_nid[0],
                   (size_t)fe->cand_cap, fe->d_fine ? fe->d_oct_redo : nullptr, fe->d_walk, fe->walk_stride);
@@ -933,7 +939,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
 /* VSLAM_HOST_PROF=1: host-side wall time per API phase, printed by vslam_fe_destroy (diagnostics only) */
 static double g_hp[6];
 static long g_hp_n;
-static const bool g_hp_on = getenv("VSLAM_HOST_PROF") != nullptr;
+static const bool g_hp_on = vslam_process_tuning().host_prof == 1; /* process-wide */
 static inline double hp_now() {
     return g_hp_on ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch())
                          .count()
@@ -963,7 +969,11 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     }
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
      * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
-    const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
+    /* a STAGED pass whose upload was issued ahead on a copy stream (stage_pending) waits for that upload and re-pitches at
+     * its head: an event recorded outside a capture is no dependency of the captured graph, so such a pass is never
+     * captured or replayed */
+    const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling &&
+                           !(on_device == VSLAM_IMGS_STAGED && fe->stage_pending);
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
                     (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^
@@ -1012,7 +1022,9 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     hipGraphDestroy(graph);
     fe->graph_key = key;
     fe->graph_pitch = pitch;
-    memcpy(fe->graph_imgs, imgs, (size_t)nimg * sizeof(imgs[0]));
+    /* only a pinned pass bakes the caller's pointers into the graph; STAGED passes may come with imgs == NULL */
+    if (on_device == VSLAM_IMGS_PINNED) memcpy(fe->graph_imgs, imgs, (size_t)nimg * sizeof(imgs[0]));
+    else memset(fe->graph_imgs, 0, sizeof(fe->graph_imgs));
     fe->graph_lap0 = lap0;
     fe->graph_lap1 = lap1;
     HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
@@ -1052,7 +1064,7 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
         R.src[R.n] = fe->d_desc;
         R.bytes[R.n++] = (size_t)nimg * fe->cap * 32;
     }
-    vk_copy_ranges(st, R);
+    vk_copy_ranges(st, R, fe->tune);
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
 }
@@ -1075,7 +1087,10 @@ int vslam_finish_extract(vslam_fe* fe, int nimg) {
         for (int s = 0; s < nimg; s++) {
             fe->n_out[s] = fe->h_counts[s * 4];
             fe->mono_out[s] = fe->h_counts[s * 4 + 1];
+            fe->oct_last_mask[s] = (uint32_t)fe->h_counts[s * 4 + 2];
+            fe->oct_handed_over += (unsigned)__builtin_popcount(fe->oct_last_mask[s]);
         }
+        fe->oct_problems += (unsigned long long)nimg * fe->p.nlevels;
     }
     if (fe->profiling) {
         float ms;
@@ -1190,12 +1205,8 @@ extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t
      * mono workload it is SLOWER than copy + re-pitch on the context's own stream at the head of the step (77-86 k against
      * 85-103 k frames/s; one upload stream serialises copies that otherwise overlap on several DMA engines, and the
      * host-input rate is bound by the link either way), so it is off by default. */
-    static int stage_ahead = -1;
-    if (stage_ahead < 0) {
-        const char* e = getenv("VSLAM_STAGE_AHEAD");
-        stage_ahead = e && atoi(e) != 0;
-    }
-    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where, /*ahead=*/stage_ahead && h2d_uses_sdma(nimg));
+    const bool stage_ahead = fe->tune.stage_ahead == 1;
+    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where, /*ahead=*/stage_ahead && h2d_uses_sdma(fe, nimg));
     if (rc2) return rc2;
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
@@ -1251,15 +1262,21 @@ extern "C" int vslam_fe_capacity(const vslam_fe* fe) { return fe ? fe->cap : VSL
 static bool device_cpuset(cpu_set_t* out) {
     static std::mutex mu; /* contexts may be created from several threads */
     std::lock_guard<std::mutex> lk(mu);
-    static int state = -1; /* -1 unknown, 0 unavailable, 1 cached */
-    static cpu_set_t cached;
-    if (state < 0) {
-        state = 0;
-        const char* e = getenv("VSLAM_NUMA");
-        int dev = 0;
+    /* one entry per device (the current one): a process with contexts on several GPUs gets each device's own CPUs */
+    struct PerDevice {
+        int state = 0; /* 0 unknown, 1 unavailable, 2 cached */
+        cpu_set_t set;
+    };
+    static PerDevice per_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int& state = per_device[dev].state;
+    cpu_set_t& cached = per_device[dev].set;
+    if (state == 0) {
+        state = 1;
+        const bool off = vslam_process_tuning().numa == 0; /* process-wide */
         char bus[64] = {0};
-        if (!(e && atoi(e) == 0) && hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
+        if (!off && hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) {
             for (char* c = bus; *c; c++) *c = (char)tolower(*c);
             char path[160];
             snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
@@ -1279,14 +1296,14 @@ static bool device_cpuset(cpu_set_t* out) {
                                 n++;
                             }
                     }
-                    if (n > 0) state = 1;
+                    if (n > 0) state = 2;
                 }
                 fclose(fp);
             }
         }
     }
-    if (state == 1) *out = cached;
-    return state == 1;
+    if (state == 2) *out = cached;
+    return state == 2;
 }
 int vslam_pinned_alloc(void** p, size_t bytes) {
     cpu_set_t near, saved;

@@ -209,13 +209,13 @@ static bool plan_with(const std::vector<const PyrLevelTables*>& tabs, int l0, in
     return lds_max <= max_lds;
 }
 
-bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan) {
+bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan, int rows_override) {
     if (tabs.empty() || tabs.size() > VSLAM_MAX_LEVELS) return false;
     for (const PyrLevelTables* t : tabs)
         if (!t || t->qbase.empty()) return false; /* a level without the quad table: per-level launches */
     const int nq1 = (tabs[0]->dw + 3) / 4, h1 = tabs[0]->dh;
-    int rows = 28; /* output rows of the first computed level per tile; VSLAM_PYR_ROWS for A/B runs */
-    if (const char* e = getenv("VSLAM_PYR_ROWS")) rows = std::min(64, std::max(4, atoi(e)));
+    int rows = 28; /* output rows of the first computed level per tile (vslam_tuning.pyr_rows for A/B runs) */
+    if (rows_override >= 0) rows = std::min(64, std::max(4, rows_override));
     const int nty = std::max(1, (h1 + rows - 1) / rows);
     for (int ntx = std::max(1, (nq1 + 51) / 52); ntx <= std::max(1, nq1 / 8); ntx++)
         if (plan_with(tabs, l0, ntx, nty, max_lds, plan)) return true;

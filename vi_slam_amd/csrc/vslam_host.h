@@ -73,7 +73,8 @@ struct PyrLevelTables {   /* tables of destination level l (source l-1), as the 
 };
 /* Plan for levels l0+1 .. l0+nl (tabs[j-1] = tables of level l0+j).  Returns false if a tile would need more than 64
  * quads per row (lane = quad) or more LDS than max_lds -- the caller then keeps the per-level launches. */
-bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan);
+bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0, size_t max_lds, PyrGroupPlan& plan,
+                         int rows_override = -1 /* vslam_tuning.pyr_rows */);
 /* CPU emulation of k_pyramid_group with the SAME plan and indexing (LDS tiles as arrays); used by the CPU tests to
  * validate a plan before it ever runs on the GPU.  levels[j] = image of level l0+j (j = 0 input, j >= 1 output,
  * pitch = stride[j]).  Returns 0, or a negative code if an access leaves a tile (the GPU would read garbage). */

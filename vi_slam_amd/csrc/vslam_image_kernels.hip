@@ -485,13 +485,9 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
 }
 
 void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
-                      size_t lds_bytes, int nslots) {
+                      size_t lds_bytes, int nslots, const vslam_tuning& T) {
     const int nwork = G.ntiles * nslots;
-    static int nt = -1; /* VSLAM_PYR_NT = 256 | 512: waves per tile (A/B runs) */
-    if (nt < 0) {
-        const char* e = getenv("VSLAM_PYR_NT");
-        nt = (e && atoi(e) == 512) ? 512 : 256;
-    }
+    const int nt = T.pyr_threads == 512 ? 512 : 256; /* waves per tile (A/B runs) */
     if (nt == 512)
         hipLaunchKernelGGL(k_pyramid_group<512>, dim3(((nwork + 7) / 8) * 8), dim3(512), lds_bytes, st, pyr, slot_stride, src, G, nslots);
     else
@@ -919,42 +915,28 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
 /* threads per cell: a cell is 900 pixels, and ~150 of the ~420 instructions a thread executes do not depend on how many
  * pixels it owns (prologue, NMS bookkeeping, compaction), so fewer, busier threads per cell cost fewer instructions in
  * total; VSLAM_FAST_NT = 64 | 128 | 256 selects the variant for A/B runs */
-static int fast_v3_nt() {
-    static int nt = -1;
-    if (nt < 0) {
-        nt = 128;
-        if (const char* e = getenv("VSLAM_FAST_NT")) {
-            const int v = atoi(e);
-            if (v == 64 || v == 128 || v == 256) nt = v;
-        }
-    }
-    return nt;
+static int fast_v3_nt(const vslam_tuning& T) {
+    const int v = T.fast_threads;
+    return (v == 64 || v == 128 || v == 256) ? v : 128;
 }
 
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots) {
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots,
+                      const vslam_tuning& T) {
     /* survivor lists: dark-only + "both" share one list (from both ends), bright-only the other; neither can hold
      * more entries than the largest cell interior has pixels.  Windows up to 42 px wide (KITTI, 1080p: 38) fit an
      * LDS pitch of 48 bytes instead of 72: 9.7 KB per cell, 16 cells resident per CU. */
     const int lcap = (max_px + 7) & ~3;
-    static int force72 = -1; /* VSLAM_FAST_PITCH=72: the wider pitch everywhere, for A/B runs */
-    if (force72 < 0) {
-        const char* e = getenv("VSLAM_FAST_PITCH");
-        force72 = e && atoi(e) == 72;
-    }
+    const bool force72 = T.fast_pitch == 72; /* the wider pitch everywhere, for A/B runs */
     const int P = (max_window_w <= 42 && !force72) ? 48 : 72;
-    const int nt = fast_v3_nt();
+    const int nt = fast_v3_nt(T);
     /* window + score tile + keep words + list; not less than what the pre-test sweep's idle lanes may READ (rows up
      * to a sweep's height below the window, quads past the last one: results dropped, but the addresses stay inside
      * the allocation) */
     const size_t shm = std::max((size_t)tile_rows * P + (size_t)(tile_rows - 4) * P + (size_t)(tile_rows - 6) * 8 + (size_t)lcap * 4 + 16,
                                 (size_t)(tile_rows + nt / 8 + 1) * P + 128);
-    static int lds_pad = -1; /* VSLAM_FAST_LDS_PAD=bytes: extra LDS per workgroup (occupancy experiments) */
-    if (lds_pad < 0) {
-        const char* e = getenv("VSLAM_FAST_LDS_PAD");
-        lds_pad = e ? std::max(0, atoi(e)) : 0;
-    }
+    const int lds_pad = std::max(0, tune_or(T.fast_lds_pad, 0)); /* extra LDS per workgroup (occupancy experiments) */
     const dim3 grid((ncells + 8 * FAST_XCD_CHUNK - 1) / (8 * FAST_XCD_CHUNK) * (8 * FAST_XCD_CHUNK), nslots);
     const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
 #define FAST3_LAUNCH(NT_, P_)                                                                                              \

@@ -484,16 +484,12 @@ int vk_search_init_set_max_lds(size_t bytes) {
 
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2, int M, uint8_t* scratch, int* fallbacks) {
+                    int max_c2, int M, uint8_t* scratch, int* fallbacks, const vslam_tuning& T) {
     if (npairs <= 0) return;
     /* queries per workgroup: every workgroup first rebuilds the pair's candidate list and finds its queries (a scan of
      * both frames' keypoints), so fewer, longer workgroups repeat less of that; VSLAM_SI_QPB = 8 | 16 | 32 for A/B runs */
-    static int qpb = -1;
-    if (qpb < 0) {
-        const char* e = getenv("VSLAM_SI_QPB");
-        const int v = e ? atoi(e) : 0;
-        qpb = (v == 8 || v == 16 || v == 32) ? v : 16;
-    }
+    const int qv = T.si_queries_per_block;
+    const int qpb = (qv == 8 || qv == 16 || qv == 32) ? qv : 16;
     const int chunks = (max_c2 + qpb - 1) / qpb;
     hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
                        window, max_c2, M, scratch, qpb);

@@ -3,6 +3,7 @@
 #ifndef VSLAM_KERNELS_H
 #define VSLAM_KERNELS_H
 
+#include "vslam_tuning.h"
 #include "vslam_device.h"
 
 void vk_upload_disc(const int umax[16]); /* IC_Angle disc -> packed dword weights of the descriptor kernel */
@@ -23,11 +24,13 @@ void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t,
 void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                  uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int rows_per_task,
                  int nslots);
+/* T: the context's resolved switches (vslam_tuning.h); the launchers read their A/B knobs from it, never from the environment */
 void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
-                      size_t lds_bytes, int nslots);
+                      size_t lds_bytes, int nslots, const vslam_tuning& T);
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots);
+                      size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots,
+                      const vslam_tuning& T);
 void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
                         const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,
                         const uint16_t* ytab, const int16_t* yb, int nslots);
@@ -36,7 +39,7 @@ int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
-               int32_t* redo_flags);
+               int32_t* redo_flags, int regkeys);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
                    const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a, size_t pts_stride,
@@ -64,7 +67,7 @@ int vk_search_init_set_max_lds(size_t bytes);
 /* k_si_topm + k_si_replay; scratch = vk_search_init_scratch_bytes(); fallbacks (nullable) counts full re-scans */
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
                     float nnratio, int checkOri, int32_t* matches_out, float* prev_out, int32_t* nmatch_out,
-                    int max_c2, int M, uint8_t* scratch, int* fallbacks);
+                    int max_c2, int M, uint8_t* scratch, int* fallbacks, const vslam_tuning& T);
 /* FMatcher::SearchByProjection(CurrentFrame, LastFrame): k_sbp_rank + k_sbp_replay over up to
  * VSLAM_MAX_SBP_JOBS problems; maxLast / maxCur size the grid and the LDS (capacities) */
 size_t vk_sbp_rank_lds(int nCur);
@@ -80,10 +83,10 @@ void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs);
 void vk_fuse_search(hipStream_t st, const FuseArgsDev& A);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
-void vk_copy_ranges(hipStream_t st, const CopyRanges& R);
+void vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T = vslam_process_tuning());
 /* host (pinned) images -> level 0 of the slots, one launch; src.l0 / src.pitch0 describe the host rows */
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
-                    int w, int h, int nimg, int from_host);
+                    int w, int h, int nimg, int from_host, const vslam_tuning& T);
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
                    int nslots, uint8_t* dst, size_t slot_bytes);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);

@@ -220,8 +220,7 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
         fe->init_lds_set = true;
     }
     /* sorted candidate prefix per query; VSLAM_INIT_TOPM=<1..16> (tests force the re-scan path with 2) */
-    int M = 8;
-    if (const char* e = getenv("VSLAM_INIT_TOPM")) M = std::min(16, std::max(1, atoi(e)));
+    const int M = std::min(16, std::max(1, tune_or(fe->tune.init_topm, 8)));
     rc = vslam_ensure((void**)&fe->d_init_scratch, &fe->init_scratch_bytes,
                       vk_search_init_scratch_bytes(npairs, max_c2, M) + 16);
     if (rc) return rc;
@@ -234,7 +233,7 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
     float* d_p = (float*)(d_m + nm);
     int32_t* d_n = (int32_t*)(d_p + 2 * nm);
     vk_search_init(fe->stream, J, npairs, fe->cap, img_w, img_h, window, nnratio, check_orientation, d_m, d_p, d_n,
-                   max_c2, M, fe->d_init_scratch, fe->d_init_fb);
+                   max_c2, M, fe->d_init_scratch, fe->d_init_fb, fe->tune);
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -299,7 +298,7 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
     {
         /* default: the whole matcher on the GPU (k_si_topm + k_si_replay).  VSLAM_INIT_MATCH=host keeps the distance
          * matrices on the GPU and replays the order-dependent part on the host (cross-check path). */
-        const char* mode = getenv("VSLAM_INIT_MATCH");
+        const bool host_mode = fe->tune.init_match_host == 1;
         bool fits = true;
         for (int j = 0; j < npairs; j++) fits = fits && n1[j] <= fe->cap && n2[j] <= fe->cap;
         fits = fits && fe->tab.quota[0] + 8 <= 4096 && nnratio >= 0.2f;
@@ -312,7 +311,7 @@ extern "C" int vslam_search_for_initialization_batch(vslam_fe* fe, int npairs, c
             for (int i = 0; i < n2[j]; i++) o2 += kps2[j][i].octave == 0;
             fits = o1 <= max_c2 && o2 <= max_c2;
         }
-        if (!(mode && !strcmp(mode, "host")) && fits) {
+        if (!host_mode && fits) {
             /* upload keypoints, counts and vbPrevMatched of every pair, run, download */
             size_t bytes = 0;
             for (int j = 0; j < npairs; j++) bytes += ((size_t)(n1[j] + n2[j]) * sizeof(vslam_kp) + (size_t)n1[j] * 8 + 16 + 63) & ~(size_t)63;
@@ -548,8 +547,7 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
         return VSLAM_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(fe->p.device));
-    int M = 8;
-    if (const char* e = getenv("VSLAM_SBP_TOPM")) M = std::min(16, std::max(1, atoi(e)));
+    const int M = std::min(16, std::max(1, tune_or(fe->tune.sbp_topm, 8)));
     const size_t lds = std::max(vk_sbp_rank_lds(n_cur), vk_sbp_replay_lds(n_cur, n_last));
     if (lds > 150 * 1024) {
         g_err = "SearchByProjection: frame too large for the LDS-resident matcher";
@@ -629,8 +627,8 @@ static int sbp_frame_impl(vslam_fe* fe, const vslam_proj_params* p, const vslam_
         JS.kf.maxDist = (const float*)(d + o_mx);
         for (int i = 0; i < 3; i++) JS.kf.ow[i] = kf->ow[i];
     }
-    const char* mode = getenv("VSLAM_SBP_MODE"); /* "seq": skip the parallel resolution (cross-check path) */
-    vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb, mode && !strcmp(mode, "seq"));
+    const bool seq_mode = fe->tune.sbp_sequential == 1; /* skip the parallel resolution (cross-check path) */
+    vk_search_by_projection(st, JS, 1, n_last, n_cur, fe->d_init_fb, seq_mode);
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -723,9 +721,7 @@ extern "C" int vslam_search_by_projection_keyframe(vslam_fe* fe, const vslam_pro
 }
 
 static int sbp_prepare(vslam_fe* fe, int* M_out) {
-    int M = 8;
-    if (const char* e = getenv("VSLAM_SBP_TOPM")) M = std::min(16, std::max(1, atoi(e)));
-    *M_out = M;
+    *M_out = std::min(16, std::max(1, tune_or(fe->tune.sbp_topm, 8)));
     if (!fe->proj_lds_set) {
         if (vk_sbp_set_max_lds(150 * 1024) != 0) {
             g_err = "hipFuncSetAttribute(k_sbp_*) failed";
@@ -801,8 +797,8 @@ extern "C" int vslam_search_by_projection_dev_async(vslam_fe* fe, int njobs, con
         J.nmatches = d_nm + j;
         J.needSeq = d_nm + njobs + j;
     }
-    const char* mode = getenv("VSLAM_SBP_MODE");
-    vk_search_by_projection(fe->stream, JS, njobs, cap, cap, fe->d_init_fb, mode && !strcmp(mode, "seq"));
+    const bool seq_mode = fe->tune.sbp_sequential == 1;
+    vk_search_by_projection(fe->stream, JS, njobs, cap, cap, fe->d_init_fb, seq_mode);
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
@@ -971,8 +967,8 @@ extern "C" int vslam_search_by_projection_mappoints(vslam_fe* fe, const vslam_mp
     J.matchCur = (int32_t*)(d + o_m);
     J.nmatches = (int32_t*)(d + o_n);
     J.needSeq = (int32_t*)(d + o_n) + 1;
-    const char* mode = getenv("VSLAM_SBP_MODE");
-    vk_search_by_projection(st, JS, 1, n_mp, n_cur, fe->d_init_fb, mode && !strcmp(mode, "seq"));
+    const bool seq_mode = fe->tune.sbp_sequential == 1;
+    vk_search_by_projection(st, JS, 1, n_mp, n_cur, fe->d_init_fb, seq_mode);
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));

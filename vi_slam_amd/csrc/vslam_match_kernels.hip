@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) k_copy_ranges(CopyRanges R) {
     }
 }
 
-void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
+void vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T) {
     size_t total = 0;
     for (int r = 0; r < R.n; r++) total += R.bytes[r];
     if (!total) return;
@@ -530,11 +530,7 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
      * frames/s whatever its shape (8, 16, 32 or 256 workgroups, one or eight loads in flight per lane), through the runtime
      * 131 k, without the copy 132 k.  Small ones (a single image's results, match lists: latency, captured graphs) stay
      * one ~5-us kernel, cheaper to enqueue.  VSLAM_D2H=kernel|sdma forces one route. */
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("VSLAM_D2H");
-        mode = e && !strcmp(e, "kernel") ? 1 : (e && !strcmp(e, "sdma") ? 2 : 0);
-    }
+    const int mode = T.d2h_route == 1 ? 1 : T.d2h_route == 2 ? 2 : 0; /* 1 copy kernel, 2 runtime copy, 0 by size */
     if (mode == 2 || (mode == 0 && total >= (256u << 10))) {
         for (int r = 0; r < R.n; r++)
             if (R.bytes[r]) (void)hipMemcpyAsync(R.dst[r], R.src[r], R.bytes[r], hipMemcpyDefault, st);
@@ -542,11 +538,7 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R) {
     }
     /* a transfer to or from host memory is bound by the link, not by the GPU: a few workgroups with several loads in
      * flight per lane keep it busy without parking waves on every CU (VSLAM_COPY_WGS overrides the cap of 16) */
-    static int cap = -1;
-    if (cap < 0) {
-        const char* e = getenv("VSLAM_COPY_WGS");
-        cap = e ? std::max(1, atoi(e)) : 16;
-    }
+    const int cap = std::max(1, tune_or(T.copy_wgs, 16));
     const int blocks = (int)std::min<size_t>((size_t)cap, (total / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
 }
@@ -600,15 +592,11 @@ k_pull_images(BatchSrc src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int
 }
 
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
-                    int w, int h, int nimg, int from_host) {
+                    int w, int h, int nimg, int from_host, const vslam_tuning& T) {
     /* from_host: the rows come over PCIe.  Host reads stay in the L2's miss queues for microseconds; more of them in
      * flight than the link needs (bandwidth x latency ~ 150 KB) only delays the HBM requests of the kernels that run
      * beside the pull.  From device memory (the SDMA staging buffer) the deep variant simply finishes sooner. */
-    static int depth_host = -1; /* VSLAM_PULL_DEPTH; default: shallow beside other work (batches), deep for one or two images */
-    if (depth_host < 0) {
-        const char* e = getenv("VSLAM_PULL_DEPTH");
-        depth_host = e ? atoi(e) : 0;
-    }
+    const int depth_host = tune_or(T.pull_depth, 0); /* default: shallow beside other work (batches), deep for one or two images */
     /* a batch: 2 workgroups per image; one or two images (a synchronous single-frame call): spread each over 32 */
     const dim3 grid(nimg <= 2 ? 32 : PULL_WG_PER_IMG, nimg);
     const int depth = !from_host ? 8 : depth_host ? depth_host : nimg <= 2 ? 8 : 1;

@@ -981,6 +981,7 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         /* F. loop control (fextractor.cpp:658-729) */
         const int size = s_size, nToExpand = s_nexp;
         __syncthreads();
+        STAMP3(); /* one stamp per split pass */
         if (size >= N || size == size0) break;
         if (phase == 1 && size + nToExpand * 3 > N) phase = 2;
     }
@@ -1082,10 +1083,13 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
     __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
     const int tid = threadIdx.x, slot = blockIdx.x;
     const int L = g.nlevels;
+    uint32_t redo_mask = 0; /* levels of this slot that k_octree_v3 handed over (slot_counts[slot][2]: vslam_fe_octree_stats) */
     if (walk) {
         __shared__ int s_walk_ctl[4];
         int mine = 0;
         if (tid < L) mine = redo_flags[slot * VSLAM_MAX_LEVELS + tid] != 0;
+        if (tid == 0)
+            for (int lv = 0; lv < L; lv++) redo_mask |= redo_flags[slot * VSLAM_MAX_LEVELS + lv] ? 1u << lv : 0u;
         if (__syncthreads_or(mine)) { /* rare */
             for (int lv = 0; lv < L; lv++) {
                 if (!redo_flags[slot * VSLAM_MAX_LEVELS + lv]) continue; /* block-uniform */
@@ -1110,6 +1114,7 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
             atomicOr(err_flag, 2);
             slot_counts[slot * 4] = 0;
             slot_counts[slot * 4 + 1] = 0;
+            slot_counts[slot * 4 + 2] = (int32_t)redo_mask;
         }
         return;
     }
@@ -1149,6 +1154,7 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
     if (tid == 0) {
         slot_counts[slot * 4] = nk;
         slot_counts[slot * 4 + 1] = nk - (int)laptot; /* monoIndex */
+        slot_counts[slot * 4 + 2] = (int32_t)redo_mask;
     }
 }
 
@@ -1157,7 +1163,7 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
-               int32_t* redo_flags) {
+               int32_t* redo_flags, int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */) {
     (void)pts_b;
     (void)nid_b;
     const dim3 grid(nslots, nlevels);
@@ -1167,12 +1173,7 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
          * 104 instead of 80 allocated, and a 1024-thread workgroup at 104 leaves room for ONE 64-register wave per SIMD
          * next to it, at 80 for three.  With several contexts in flight the neighbours matter more than the re-read
          * (VSLAM_OCT_REGKEYS=0|1 overrides; default: registers only for single images, where latency is what counts). */
-        static int regkeys = -1;
-        if (regkeys < 0) {
-            const char* e = getenv("VSLAM_OCT_REGKEYS");
-            regkeys = e ? (atoi(e) != 0 ? 1 : 0) : 2;
-        }
-        const bool rk = regkeys == 2 ? nslots <= 2 : regkeys == 1;
+        const bool rk = regkeys < 0 ? nslots <= 2 : regkeys == 1;
         const size_t lds = P.fineLdsOff ? (size_t)P.fineLdsOff + (size_t)P.fineLdsBytes : vk_octree_lds_bytes(P.maxNodes);
 #define OCT3_LAUNCH(RK_, FL_)                                                                                                   \
     hipLaunchKernelGGL((k_octree_v3<RK_, FL_>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, pts_a, nid_a, pts_stride, \

@@ -19,7 +19,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VSLAM_HD __host__ __device__ __forceinline__
 #else
 #define VSLAM_HD static inline
