@@ -283,7 +283,6 @@ class Pipeline:
         # single GPU: the last frame of a step, which the NEXT step's first matcher job reads, is copied into a carry
         # buffer of its own, so that a context may start its next extraction without waiting for that matcher
         self.carry = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(0 if self.multi else self.NCTX)]
-        self.staged = [False] * self.NCTX  # pinned inputs: the context's staging buffer already holds its next step's frames
         self.state = {"matches": 0}
         self.job_cache = {}
         self.track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
@@ -332,23 +331,14 @@ class Pipeline:
         nxt, prv = self.ctxs[(t + 1) % NCTX], self.ctxs[(t - 1) % NCTX]
         ptrs, pitch = self._imgs(k)
         where = self.where
-        stage_next = False
         if where == V.IMGS_PINNED:
-            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream.  (Experiment,
-            # VSLAM_STAGE_AHEAD=1: uploads on a shared copy stream, issued NCTX steps ahead right behind the previous pass
-            # on this context -- slower, see vslam_fe_stage_images_async.)
-            if not self.staged[k]:
-                c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)  # first step on this context
-            self.staged[k] = False
-            stage_next = os.environ.get("VSLAM_STAGE_AHEAD", "0") != "0"  # experiment (see vslam_fe_stage_images_async)
+            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream.
+            c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
             where = V.IMGS_STAGED
         if self.track:
             npairs = B // 2
             c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last frame: it must finish first
             c.frame_stereo_async(ptrs, pitch, BF, FX, where=where)
-            if stage_next:
-                c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
-                self.staged[k] = True
             c.stereo_points_async(self.track_Twc, self.track_cam)  # UnprojectStereo of every left keypoint
             c.event_record(0)
             ck = (k, t == 0)
@@ -375,18 +365,12 @@ class Pipeline:
             return
         if self.stereo:
             c.frame_stereo_async(ptrs, pitch, BF, FX, where=where)
-            if stage_next:
-                c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
-                self.staged[k] = True
             return
         # The extraction overwrites only this context's own result slots, which nobody else reads: what the matcher of
         # the NEXT step (context nxt, step t-NCTX+1) read from us is the carry / exchange buffer, so only the copy into
         # that buffer has to wait for it -- not the extraction.  (With the wait in front of the extraction a context sat
         # idle for a whole step between two of its passes: 353 us per 1140-us cycle in the kernel trace.)
         c.compute_batch_async(ptrs, pitch, self.lap, where=where, to_host=os.environ.get("BENCH_NO_D2H") is None)
-        if stage_next:
-            c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)  # the same frames come round again on this context
-            self.staged[k] = True
         c.event_wait(nxt, 1)
         if self.multi:  # the right neighbour needs this rank's last frame: pack it and shift it round the ring
             c.pack_slots(1, self.packed[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)

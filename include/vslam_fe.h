@@ -75,8 +75,6 @@ typedef struct vslam_tuning {
     int32_t oct_debug;            /* VSLAM_OCT_DBG: 1 = allocate the stamp buffer of diagnostic builds */
     int32_t graphs;               /* VSLAM_GRAPH: 0 = never capture / replay HIP graphs */
     int32_t h2d_route;            /* VSLAM_H2D=pull|sdma: 1 = kernel reads pinned memory, 2 = DMA engines (default by batch size) */
-    int32_t copy_streams;         /* VSLAM_COPY_STREAMS: upload streams per device for staged-ahead uploads (1..4, default 2) */
-    int32_t stage_ahead;          /* VSLAM_STAGE_AHEAD: 1 = vslam_fe_stage_images_async uploads on a copy stream */
     int32_t d2h_route;            /* VSLAM_D2H=kernel|sdma: 1 = copy kernel, 2 = hipMemcpyAsync for every result transfer */
     int32_t copy_wgs;             /* VSLAM_COPY_WGS: workgroup cap of the copy kernel (default 16) */
     int32_t pull_depth;           /* VSLAM_PULL_DEPTH: loads in flight per lane of the pull kernel */
@@ -89,7 +87,7 @@ typedef struct vslam_tuning {
     int32_t wait_spin;            /* VSLAM_WAIT=spin: 1 = host waits poll hipStreamQuery instead of blocking */
     int32_t numa;                 /* VSLAM_NUMA: 0 = do not allocate pinned memory from the CPUs next to the device */
     int32_t host_prof;            /* VSLAM_HOST_PROF: 1 = host-side wall time per API phase, printed at destroy */
-    int32_t reserved[6];
+    int32_t reserved[8];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 
@@ -116,7 +114,7 @@ typedef struct vslam_fe vslam_fe;
 int vslam_fe_create(const vslam_fe_params* params, vslam_fe** out);
 /* Change switches of an existing context between calls (fields >= 0 of *t overwrite the context's; like every other
  * call on a context this is not re-entrant).  Takes effect for what is consulted per call -- the transport routes
- * (h2d_route, d2h_route, stage_ahead, pull_depth, copy_wgs), the matcher switches (init_topm, init_match_host, sbp_topm,
+ * (h2d_route, d2h_route, pull_depth, copy_wgs), the matcher switches (init_topm, init_match_host, sbp_topm,
  * sbp_sequential, si_queries_per_block), oct_regkeys, the FAST / pyramid launch shapes, graphs = 0; switches that shaped
  * the context's buffers at creation (pyramid plan, blur rows, quadtree grid depth and LDS placement) stay as created. */
 int vslam_fe_set_tuning(vslam_fe* fe, const vslam_tuning* t);

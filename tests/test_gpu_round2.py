@@ -300,7 +300,7 @@ def test_switches_do_not_change_results():
     """Every A/B switch must deliver exactly what the default does -- extraction from device and from staged pinned
     images, and the device-resident init matcher.  Per-context switches go through vslam_fe_params.tuning in THIS process
     (several contexts with different settings side by side: nothing is cached process-wide any more); the environment
-    defaults and the process-wide switches (wait mode, NUMA placement, upload streams) get one child process each."""
+    defaults and the process-wide switches (wait mode, NUMA placement) get one child process each."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("env_variant_check", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
@@ -309,10 +309,9 @@ def test_switches_do_not_change_results():
     spec.loader.exec_module(mod)
     ref = mod.digest()
     for tuning in ({"oct_regkeys": 1}, {"oct_regkeys": 0}, {"si_queries_per_block": 8}, {"si_queries_per_block": 32},
-                   {"stage_ahead": 1}, {"fast_lds_pad": 4096}, {"h2d_route": 1}, {"h2d_route": 2}, {"oct_fine_lds": 0},
+                   {"fast_lds_pad": 4096}, {"h2d_route": 1}, {"h2d_route": 2}, {"oct_fine_lds": 0},
                    {"oct_fine_lds": 0, "oct_regkeys": 1}, {"d2h_route": 1}, {"d2h_route": 2}, {"graphs": 0},
                    {"pyramid_per_level": 1}, {"fast_threads": 256}, {"pyr_threads": 512}, {"blur_rows": 16}):
         assert mod.digest(tuning) == ref, tuning
-    for env in ({"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0"}, {"VSLAM_STAGE_AHEAD": "1", "VSLAM_COPY_STREAMS": "1"},
-                {"VSLAM_D2H": "kernel", "VSLAM_OCT_REGKEYS": "1", "VSLAM_PYRAMID": "levels"}):
+    for env in ({"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0"}, {"VSLAM_D2H": "kernel", "VSLAM_OCT_REGKEYS": "1", "VSLAM_PYRAMID": "levels"}):
         assert _digest(env).split()[-1] == ref, env

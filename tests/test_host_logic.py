@@ -97,6 +97,25 @@ def test_octree_equals_oracle_on_extractor_candidates(H):
             assert np.array_equal(O, r), (w, h, nf, l)
 
 
+@pytest.mark.parametrize("W,Hh", [(1209, 344), (1002, 281), (314, 73), (1888, 1048), (720, 448), (178, 102), (766, 766), (65, 40)])
+def test_quadtree_path_tables_equal_the_literal_halvings(H, W, Hh):
+    """k_octree_v4 finds a key's leaf of the implicit quadtree as xs[x] | ys[y] (vslam::build_oct_lut) instead of walking D
+    halvings per key: every (x, y) of the level, depths 1..7, against DivideNode's arithmetic spelled out (oct_key_path)"""
+    for D in range(1, 8):
+        assert H.vslamh_oct_lut_check(W, Hh, D) == 0, D
+    # the literal walk itself: two keys in the same leaf at depth d share every shallower leaf
+    rng = np.random.default_rng(4)
+    H.vslamh_oct_key_path.restype = C.c_uint
+    for _ in range(200):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, Hh))
+        prev = None
+        for d in range(0, 13):
+            pth = H.vslamh_oct_key_path(x, y, W, Hh, d)
+            if prev is not None:
+                assert pth >> 2 == prev
+            prev = pth
+
+
 def test_octree_random_and_edge_cases(H):
     rng = np.random.default_rng(9)
     assert len(host_octree(H, np.zeros((0, 3)), 1209, 344, 100)) == 0

@@ -45,14 +45,16 @@ def digest(tuning=None):
             h.update(k.tobytes()); h.update(d.tobytes())
         # matcher between consecutive slots, device-resident
         fe.compute_batch_async([dev[s].data_ptr() for s in range(B)], pitch, (0, 1000))
-        fe.wait()
+        counts = [len(k) for k, _, _ in fe.wait()]
         M = V.FMatcher(fe, 0.9, True)
         jobs = []
         for s in range(1, B):
             p, q = fe.slot_dev_ptrs(s - 1), fe.slot_dev_ptrs(s)
             jobs.append((p[0], p[1], p[2], q[0], q[1], q[2], 0))
         M.search_init_dev_async(V.FMatcher.make_init_jobs(jobs), 100, (W, H))
-        for n, m12, prev in M.search_init_dev_wait([fe.cap] * len(jobs)):
+        # vnMatches12 has one entry per keypoint of the FIRST frame of a pair: hash exactly those (entries beyond the count
+        # are whatever the context's buffer held before)
+        for n, m12, prev in M.search_init_dev_wait([counts[s - 1] for s in range(1, B)]):
             h.update(str(n).encode()); h.update(np.asarray(m12).tobytes())
     pin.close()
     fe.close()

@@ -13,6 +13,11 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
+__global__ void k_spin(uint32_t* p, int us) { /* keeps a stream busy for ~us microseconds (100 MHz clock) */
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(8);
+    if (us < 0) p[0] = 1;
+}
 __global__ void k_fill(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v + (uint32_t)i;
 }
@@ -33,7 +38,7 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     printf("with_h2d=%d\n", (int)with_h2d);
-    if (!(argc > 3 && !strcmp(argv[1], "pipeline")))
+    if (!(argc > 3 && (!strcmp(argv[1], "pipeline") || !strcmp(argv[1], "busy"))))
     for (size_t bytes : {(size_t)64 << 10, (size_t)256 << 10, (size_t)1 << 20, (size_t)2 << 20, (size_t)4 << 20}) {
         std::vector<float> t;
         for (int r = 0; r < 60; r++) {
@@ -85,6 +90,54 @@ int main(int argc, char** argv) {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("pipeline %d streams kind %s: %.1f us per (kernel + 3 copies) per stream-iteration, %.1f GB/s aggregate\n", ns, argv[3],
                ms * 1e3 / iters, (double)ns * iters * (528 + (900 << 10) + (1 << 20)) / (ms * 1e-3) / 1e9);
+    }
+    /* the pipeline's real condition: the copy is enqueued while a LONG kernel of the same stream is still running.
+     *   d2h_route_probe busy <streams> <same|xstream>   same: copy on the kernel's stream; xstream: on ONE shared copy
+     *   stream that waits for an event recorded behind the kernel */
+    if (argc > 3 && !strcmp(argv[1], "busy")) {
+        const int ns = atoi(argv[2]);
+        const bool xs = !strcmp(argv[3], "xstream");
+        std::vector<hipStream_t> ss(ns);
+        std::vector<uint32_t*> dd(ns);
+        std::vector<uint8_t*> hh(ns);
+        std::vector<hipEvent_t> ev(ns), evc(ns);
+        hipStream_t cs;
+        CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        for (int i = 0; i < ns; i++) {
+            CHECK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+            CHECK(hipMalloc(&dd[i], MAXB));
+            CHECK(hipHostMalloc(&hh[i], MAXB, hipHostMallocDefault));
+            CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            CHECK(hipEventCreateWithFlags(&evc[i], hipEventDisableTiming));
+        }
+        CHECK(hipEventRecord(e0, ss[0]));
+        const int iters = 100;
+        for (int r = 0; r < iters; r++) {
+            for (int i = 0; i < ns; i++) {
+                if (xs && r) CHECK(hipStreamWaitEvent(ss[i], evc[i], 0)); /* the next kernel overwrites what the copy reads */
+                hipLaunchKernelGGL(k_spin, dim3(64), dim3(64), 0, ss[i], dd[i], 150);
+                hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, ss[i], dd[i], (size_t)(512 << 10), (uint32_t)r);
+                if (xs) {
+                    CHECK(hipEventRecord(ev[i], ss[i]));
+                    CHECK(hipStreamWaitEvent(cs, ev[i], 0));
+                    CHECK(hipMemcpyAsync(hh[i], dd[i], 2 << 20, hipMemcpyDeviceToHost, cs));
+                    CHECK(hipEventRecord(evc[i], cs));
+                } else {
+                    CHECK(hipMemcpyAsync(hh[i], dd[i], 2 << 20, hipMemcpyDeviceToHost, ss[i]));
+                }
+            }
+            if ((r & 3) == 3) {
+                for (int i = 0; i < ns; i++) CHECK(hipStreamSynchronize(ss[i]));
+                CHECK(hipStreamSynchronize(cs));
+            }
+        }
+        for (int i = 0; i < ns; i++) CHECK(hipStreamSynchronize(ss[i]));
+        CHECK(hipStreamSynchronize(cs));
+        CHECK(hipEventRecord(e1, ss[0]));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("busy %d streams %s: %.1f us per iteration (150-us kernel + 2 MB copy per stream)\n", ns, argv[3], ms * 1e3 / iters);
     }
     return 0;
 }

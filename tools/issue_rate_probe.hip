@@ -20,7 +20,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-struct WaveRec { unsigned long long cyc, rt; unsigned hwid, pad; };
+struct WaveRec { unsigned long long cyc, rt, r0, r1; unsigned hwid, pad; };
 
 #define R4(x) x x x x
 /* 8 independent destinations %0..%7, one shared source %8 (and %9 where three inputs are needed) */
@@ -39,7 +39,7 @@ struct WaveRec { unsigned long long cyc, rt; unsigned hwid, pad; };
     if ((threadIdx.x & 63) == 0) {                                                                          \
         unsigned hw;                                                                                        \
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                    \
-        WaveRec w; w.cyc = t1 - t0; w.rt = r1 - r0; w.hwid = hw; w.pad = 0;                                 \
+        WaveRec w; w.cyc = t1 - t0; w.rt = r1 - r0; w.r0 = r0; w.r1 = r1; w.hwid = hw; w.pad = 0;                                 \
         rec[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;                                       \
     }                                                                                                       \
     if ((sink) == 0x12345u) out[0] = (sink)
@@ -81,6 +81,29 @@ VKERNEL(k_dot4_u8, BLK8_3("v_dot4_u32_u8", ""))
 VKERNEL(k_mul_lo, BLK8("v_mul_lo_u32", ""))
 VKERNEL(k_mul_u24, BLK8("v_mul_u32_u24", ""))
 VKERNEL(k_min_u16, BLK8("v_min_u16", ""))
+VKERNEL(k_max_u16, BLK8("v_max_u16", ""))
+VKERNEL(k_min_i16, BLK8("v_min_i16", ""))
+VKERNEL(k_sub_u16, BLK8("v_sub_u16", ""))
+VKERNEL(k_add_u16, BLK8("v_add_u16", ""))
+VKERNEL(k_or_b32, BLK8("v_or_b32", ""))
+VKERNEL(k_sub_u32, BLK8("v_sub_u32", ""))
+VKERNEL(k_max_u32, BLK8("v_max_u32", ""))
+VKERNEL(k_min_i32, BLK8("v_min_i32", ""))
+VKERNEL(k_lshlrev, BLK8("v_lshlrev_b32", ""))
+VKERNEL(k_lshrrev, BLK8("v_lshrrev_b32", ""))
+VKERNEL(k_ashrrev, BLK8("v_ashrrev_i32", ""))
+VKERNEL(k_min_f32, BLK8("v_min_f32", ""))
+VKERNEL(k_max_f32, BLK8("v_max_f32", ""))
+VKERNEL(k_mul_f32, BLK8("v_mul_f32", ""))
+VKERNEL(k_sub_f32, BLK8("v_sub_f32", ""))
+VKERNEL(k_cndmask, BLK8("v_cndmask_b32", ", vcc"))
+VKERNEL(k_lshl_add, BLK8_3("v_lshl_add_u32", ""))
+VKERNEL(k_xad, BLK8_3("v_xad_u32", ""))
+VKERNEL(k_med3_i32, BLK8_3("v_med3_i32", ""))
+VKERNEL(k_pk_lshlrev_b16, BLK8("v_pk_lshlrev_b16", ""))
+VKERNEL(k_mov_b32, "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %8\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %8\n\tv_mov_b32 %5, %8\n\tv_mov_b32 %6, %8\n\tv_mov_b32 %7, %8\n\t")
+VKERNEL(k_cmp_vcc, "v_cmp_lt_u32 vcc, %0, %8\n\tv_cmp_lt_u32 vcc, %1, %8\n\tv_cmp_lt_u32 vcc, %2, %8\n\tv_cmp_lt_u32 vcc, %3, %8\n\tv_cmp_lt_u32 vcc, %4, %8\n\tv_cmp_lt_u32 vcc, %5, %8\n\tv_cmp_lt_u32 vcc, %6, %8\n\tv_cmp_lt_u32 vcc, %7, %8\n\t")
+VKERNEL(k_cvt_ubyte, "v_cvt_f32_ubyte0 %0, %8\n\tv_cvt_f32_ubyte1 %1, %8\n\tv_cvt_f32_ubyte2 %2, %8\n\tv_cvt_f32_ubyte3 %3, %8\n\tv_cvt_f32_ubyte0 %4, %8\n\tv_cvt_f32_ubyte1 %5, %8\n\tv_cvt_f32_ubyte2 %6, %8\n\tv_cvt_f32_ubyte3 %7, %8\n\t")
 /* DPP / SDWA forms as the FAST kernel uses them */
 VKERNEL(k_add_dpp, BLK8("v_add_u32_dpp", " row_shr:1 row_mask:0xf bank_mask:0xf"))
 VKERNEL(k_min_sdwa, BLK8("v_min_u16_sdwa", " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"))
@@ -166,11 +189,18 @@ int main(int argc, char** argv) {
     std::vector<WaveRec> h(maxw);
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device %s, %d CUs, reported clock %d kHz; iters %d x 32 instructions per wave\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, iters);
-    printf("cyc/instr = median over waves of (wave's s_memtime cycles) / (instructions per wave x waves per SIMD); MHz from s_memrealtime (100 MHz)\n");
+    printf("cyc/instr chip-wide = (last wave end - first wave start, 100 MHz s_memrealtime) x shader MHz / 100 / (instructions per wave x waves per SIMD); median wave = the same from one wave's own s_memtime span\n");
     const Row rows[] = {
         {"v_add_u32", k_add_u32, 32}, {"v_and_b32", k_and_b32, 32}, {"v_xor_b32", k_xor_b32, 32}, {"v_min_u32", k_min_u32, 32},
         {"v_min3_i32", k_min3_i32, 32}, {"v_max3_u32", k_max3_u32, 32}, {"v_pk_min_u16", k_pk_min_u16, 32}, {"v_pk_max_u16", k_pk_max_u16, 32},
         {"v_pk_sub_u16 clamp", k_pk_sub_u16c, 32}, {"v_pk_add_u16", k_pk_add_u16, 32}, {"v_min_u16", k_min_u16, 32},
+        {"v_max_u16", k_max_u16, 32}, {"v_min_i16", k_min_i16, 32}, {"v_sub_u16", k_sub_u16, 32}, {"v_add_u16", k_add_u16, 32},
+        {"v_or_b32", k_or_b32, 32}, {"v_sub_u32", k_sub_u32, 32}, {"v_max_u32", k_max_u32, 32}, {"v_min_i32", k_min_i32, 32},
+        {"v_lshlrev_b32", k_lshlrev, 32}, {"v_lshrrev_b32", k_lshrrev, 32}, {"v_ashrrev_i32", k_ashrrev, 32},
+        {"v_min_f32", k_min_f32, 32}, {"v_max_f32", k_max_f32, 32}, {"v_mul_f32", k_mul_f32, 32}, {"v_sub_f32", k_sub_f32, 32},
+        {"v_cndmask_b32", k_cndmask, 32}, {"v_lshl_add_u32", k_lshl_add, 32}, {"v_xad_u32", k_xad, 32}, {"v_med3_i32", k_med3_i32, 32},
+        {"v_pk_lshlrev_b16", k_pk_lshlrev_b16, 32},
+        {"v_mov_b32", k_mov_b32, 32}, {"v_cmp -> vcc", k_cmp_vcc, 32}, {"v_cvt_f32_ubyteN", k_cvt_ubyte, 32},
         {"v_min_u16 sdwa", k_min_sdwa, 32}, {"v_add_u32 dpp row_shr", k_add_dpp, 32}, {"v_perm_b32", k_perm_b32, 32},
         {"v_alignbyte_b32", k_alignbyte, 32}, {"v_bfe_u32", k_bfe_u32, 32}, {"v_lshl_or_b32", k_lshl_or, 32}, {"v_and_or_b32", k_and_or, 32},
         {"v_add3_u32", k_add3, 32}, {"v_mad_u32_u24", k_mad_u32_u24, 32}, {"v_mul_u32_u24", k_mul_u24, 32}, {"v_mul_lo_u32", k_mul_lo, 32},
@@ -188,8 +218,10 @@ int main(int argc, char** argv) {
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         CHECK(hipMemcpy(h.data(), rec, sizeof(WaveRec) * nw, hipMemcpyDeviceToHost));
         std::vector<double> cyc, mhz; std::map<unsigned, int> per_simd;
+        unsigned long long rmin = ~0ull, rmax = 0;
         for (int i = 0; i < nw; i++) {
             if (!h[i].cyc) continue;
+            rmin = std::min(rmin, h[i].r0); rmax = std::max(rmax, h[i].r1);
             cyc.push_back((double)h[i].cyc);
             if (h[i].rt) mhz.push_back((double)h[i].cyc / (double)h[i].rt * 100.0);
             /* HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13] (+ xcc from the dispatch: unknown here, counted modulo) */
@@ -197,10 +229,13 @@ int main(int argc, char** argv) {
         }
         if (cyc.empty()) { printf("%-30s wps %d: NO WAVE RECORDS (kernel did not run)\n", name, wps); return; }
         std::sort(cyc.begin(), cyc.end()); std::sort(mhz.begin(), mhz.end());
-        const double per = cyc[cyc.size() / 2] / ((double)iters * 32 * wps);
-        printf("%-30s wps %d: %6.2f cyc/%s  (min %.2f max %.2f)  clock %4.0f MHz  event %.3f ms  waves %zu\n", name, wps, per,
-               per_block == 64 ? "pair " : "instr", cyc.front() / ((double)iters * 32 * wps), cyc.back() / ((double)iters * 32 * wps),
-               mhz.empty() ? 0.0 : mhz[mhz.size() / 2], ms, cyc.size());
+        /* chip-wide: first wave's start to last wave's end on the 100 MHz clock, converted with the measured shader clock;
+         * every SIMD issued iters * 32 * wps instructions (pairs) in that span */
+        const double clk = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+        const double span_cyc = (double)(rmax - rmin) * clk / 100.0;
+        const double per = span_cyc / ((double)iters * 32 * wps);
+        printf("%-30s wps %d: %6.2f cyc/%s chip-wide  (median wave %.2f)  clock %4.0f MHz  event %.3f ms  waves %zu\n", name, wps, per,
+               per_block == 64 ? "pair " : "instr", cyc[cyc.size() / 2] / ((double)iters * 32 * wps), clk, ms, cyc.size());
     };
     for (const Row& r : rows)
         for (int wps : {1, 2, 4, 8})

@@ -46,13 +46,6 @@ struct vslam_fe {
     hipStream_t stream = nullptr;
     hipEvent_t ev_cand = nullptr;
     hipEvent_t ev_x = nullptr; /* cross-context ordering (vslam_fe_wait_for) */
-    /* vslam_fe_stage_images_async: the DMA upload runs on a stream of its own, so that it can be issued passes ahead
-     * (it only needs the staging buffer, which the re-pitch kernel at the head of the previous pass has drained) */
-    hipStream_t copy_stream = nullptr;  /* shared by the device's contexts, never destroyed */
-    hipEvent_t ev_upload = nullptr;     /* recorded on copy_stream behind the upload */
-    hipEvent_t ev_stage_free = nullptr; /* recorded on stream behind the re-pitch that read d_stage */
-    bool stage_pending = false;         /* d_stage holds images the next IMGS_STAGED pass has to re-pitch */
-    BatchSrc stage_src;
     hipEvent_t ev_user[4] = {};  /* vslam_fe_event_record / _wait */
 
     uint8_t* d_pyr = nullptr;
@@ -161,12 +154,11 @@ struct vslam_fe {
     /* GPU quadtree distribution */
     bool dev_octree = false;
     OctParams oct;
-    uint32_t* d_pts[2] = {nullptr, nullptr};  /* key ping-pong arrays, B x cand_cap */
-    uint16_t* d_nid[2] = {nullptr, nullptr};  /* node (list index) of every key */
-    uint32_t* d_fine = nullptr;               /* k_octree_v3: fine-cell counts + prefix sums, B x oct.fineStride */
-    uint8_t* d_walk = nullptr;                /* B x walk_stride: node arrays of the hand-over path in k_assign_out */
-    size_t walk_stride = 0;
-    int32_t* d_oct_redo = nullptr;            /* k_octree_v3 -> k_assign_out hand-over flags, B x VSLAM_MAX_LEVELS */
+    uint32_t* d_pts[2] = {nullptr, nullptr};  /* B x cand_cap each: keys in key order | k_octree_v4: fine cell and rank of every key */
+    uint16_t* d_nid = nullptr;                /* k_octree_v2 only: node (list index) of every key */
+    uint8_t* d_oct_sorted = nullptr;          /* k_octree_v4: {key, position} sorted by fine cell, B x cand_cap x 8 bytes */
+    uint32_t* d_oct_lut = nullptr;            /* k_octree_v4: per level the x and y path tables (vslam::build_oct_lut) */
+    int32_t* d_oct_redo = nullptr;            /* k_octree_v4: (slot, level) split nodes finer than the grid, B x VSLAM_MAX_LEVELS */
     uint32_t* d_sel_xyr = nullptr;            /* per slot / level result lists */
     int32_t* d_sel_cnt = nullptr;
     int32_t* d_counts = nullptr;              /* [slot][4] = n, monoIndex, -, - ; then [B*4] = error flags */

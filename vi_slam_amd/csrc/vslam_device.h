@@ -68,15 +68,16 @@ struct OctParams {
     int32_t ptsCap;                   /* entries per slot in the key ping-pong arrays */
     int32_t maxIter;                  /* split passes allowed (64; lower only for timing experiments) */
     void* dbg;                        /* timing stamps (diagnostic builds only) */
-    /* k_octree_v3: keys are counted ONCE into the leaves of an implicit quadtree of depth fineD below the initial nodes
-     * (nIni << 2*fineD fine cells, <= 65536); a node of depth d is a run of 4^(fineD-d) fine cells, so the child
-     * counts of every split pass are differences of one prefix-sum array */
+    /* k_octree_v4: keys are counted ONCE into the leaves of an implicit quadtree of depth fineD below the initial nodes
+     * (nIni << 2*fineD fine cells, <= 16384, counters and prefix sums in LDS) and sorted by leaf; a node of depth
+     * d <= fineD is a run of 4^(fineD-d) fine cells, so the child counts of every split pass are differences of one
+     * prefix-sum array; a key's leaf is lut[lutOff + x] | lut[lutOff + lutW + y] (vslam::build_oct_lut) */
     int32_t fineD[VSLAM_MAX_LEVELS];
-    int32_t fineOff[VSLAM_MAX_LEVELS]; /* uint32 offset of the level's two arrays (cells+1 each) in a slot's scratch */
-    int32_t fineStride;                /* uint32 entries of fine scratch per slot */
-    int32_t fineLdsOff;                /* != 0: the fine arrays live in LDS at this byte offset of the dynamic allocation ... */
-    int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays / its 16-bit counters) */
-    int32_t fineLdsMode;               /* 1: both arrays in LDS; 2: only the counters, as packed 16-bit pairs */
+    int32_t lutOff[VSLAM_MAX_LEVELS];  /* uint32 offset of the level's x table in lut; the y table follows it */
+    int32_t lutW[VSLAM_MAX_LEVELS];    /* entries of the x table (maxBorderX - minBorderX + 1) */
+    int32_t fineLdsOff;                /* the fine arrays live in LDS at this byte offset of the dynamic allocation ... */
+    int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays) */
+    const uint32_t* lut;               /* device; nullptr: no fine grid (walk-per-pass kernel only) */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

@@ -23,7 +23,6 @@ extern "C" const char* vslam_last_error(void) { return vslam_err().c_str(); }
 
 static void free_ctx(vslam_fe* fe) {
     if (!fe) return;
-    if (fe->copy_stream) hipStreamSynchronize(fe->copy_stream);
     if (fe->stream) hipStreamSynchronize(fe->stream);
     delete fe->pool;
     hipFree(fe->d_pyr);
@@ -57,12 +56,11 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_stereo);
     hipFree(fe->d_pts[0]);
     hipFree(fe->d_pts[1]);
-    hipFree(fe->d_nid[0]);
-    hipFree(fe->d_nid[1]);
+    hipFree(fe->d_nid);
+    hipFree(fe->d_oct_sorted);
+    hipFree(fe->d_oct_lut);
     hipFree(fe->d_sel_xyr);
-    hipFree(fe->d_fine);
     hipFree(fe->d_oct_redo);
-    hipFree(fe->d_walk);
     hipFree(fe->d_sel_cnt);
     hipFree(fe->d_counts);
     if (fe->h_counts) hipHostFree(fe->h_counts);
@@ -88,8 +86,6 @@ static void free_ctx(vslam_fe* fe) {
         if (fe->ev_user[i]) hipEventDestroy(fe->ev_user[i]);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
-    if (fe->ev_upload) hipEventDestroy(fe->ev_upload);
-    if (fe->ev_stage_free) hipEventDestroy(fe->ev_stage_free);
     if (fe->stream) hipStreamDestroy(fe->stream);
     delete fe;
 }
@@ -332,51 +328,48 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             if (nIni > 64) ok = false;
         }
         O.cellFirst[p.nlevels] = fe->level_cell_first[p.nlevels];
-        {
-            /* k_octree_v3's fine grid: deep enough that the split passes (which stop at N nodes) normally never reach
-             * a single fine cell -- a full quadtree has nIni * 4^d nodes at depth d -- plus two levels of slack for
-             * clustered keys; at most 65536 cells per level.  VSLAM_OCT_FINE_D forces a depth (tests: hand-over). */
-            const int fd = fe->tune.oct_fine_depth; /* -1: by the level's quota */
-            int fineOff = 0;
-            for (int l = 0; l < p.nlevels; l++) {
-                int D = 2;
-                while ((O.nIni[l] << (2 * D)) < O.N[l]) D++;
-                D += 2;
-                if (fd >= 0) D = fd;
-                D = std::max(1, std::min(D, 11));
-                while (D > 1 && ((long long)O.nIni[l] << (2 * D)) > 65536) D--;
-                O.fineD[l] = D;
-                O.fineOff[l] = fineOff;
-                fineOff += 2 * ((O.nIni[l] << (2 * D)) + 1) + 2;
-            }
-            O.fineStride = (fineOff + 3) & ~3;
-
-        }
         O.selStride = selOff;
         O.maxNodes = (maxNodes + 15) & ~15;
-        {   /* fine arrays in LDS when the largest level's pair fits next to the node arrays (VSLAM_OCT_FINE_LDS=0: never) */
-            int maxcells = 0;
-            for (int l = 0; l < p.nlevels; l++) maxcells = std::max(maxcells, O.nIni[l] << (2 * O.fineD[l]));
-            const size_t fb = 2 * ((size_t)maxcells + 1) * 4 + 16, nb = (vk_octree_lds_bytes(O.maxNodes) + 15) & ~(size_t)15;
-            /* a fine cell holds at most as many keys as it has pixels: 16-bit counters are safe below 65536 pixels */
-            bool small_cells = true;
-            for (int l = 0; l < p.nlevels; l++) {
-                const long long px = (long long)(fe->geom.lv[l].w) * fe->geom.lv[l].h;
-                if (px / std::max(1, O.nIni[l] << (2 * O.fineD[l])) + 64 >= 65536) small_cells = false;
-            }
-            const size_t fb16 = ((size_t)maxcells / 2 + 1) * 4 + 16;
-            const int flv = fe->tune.oct_fine_lds; /* 0 never, 1 full arrays only, 2 counters only */
-            /* LDS a quadtree workgroup may take in all (default 128: at 1080p the 64 KB of counters next to 49 KB of nodes are worth +3.4 %) */
+        std::vector<uint32_t> lut;
+        {
+            /* k_octree_v4's fine grid: one level deeper than the depth at which a full quadtree has N nodes (nIni * 4^d
+             * at depth d), so that the split passes, which stop at N nodes, mostly stay above it; keys that cluster
+             * below it are handled exactly by the kernel's in-cell path, so the depth only decides speed.  Both arrays
+             * of the largest level must fit LDS next to the node arrays (budget below), at most 16384 cells (the cell
+             * index travels in 16 bits), and no cell may be able to hold 65536 keys (the rank does too).
+             * vslam_tuning.oct_fine_depth forces a depth where it is admissible (tests: deep splits everywhere). */
+            const int fd = fe->tune.oct_fine_depth; /* -1: by the level's quota */
+            const size_t nb = (vk_octree_lds_bytes(O.maxNodes) + 15) & ~(size_t)15;
+            /* LDS a quadtree workgroup may take in all (default 128 KB of the CU's 160) */
             const size_t budget = (size_t)std::min(150, std::max(16, tune_or(fe->tune.oct_lds_budget_kb, 128))) * 1024;
-            if (flv != 0 && flv != 2 && nb + fb <= budget) {
-                O.fineLdsOff = (int32_t)nb;
-                O.fineLdsBytes = (int32_t)fb;
-                O.fineLdsMode = 1;
-            } else if (flv != 0 && flv != 1 && small_cells && nb + fb16 <= budget) {
-                O.fineLdsOff = (int32_t)nb;
-                O.fineLdsBytes = (int32_t)fb16;
-                O.fineLdsMode = 2;
+            int maxcells = 0;
+            for (int l = 0; l < p.nlevels; l++) {
+                const int W = fe->geom.lv[l].w - 2 * VSLAM_FAST_BORDER, H = O.H[l];
+                int D = 1;
+                while ((O.nIni[l] << (2 * D)) < O.N[l]) D++;
+                D += 1;
+                if (fd >= 0) D = fd;
+                D = std::max(1, std::min(D, 11));
+                auto cell_keys = [&](int d) { /* strict 3x3 maxima a cell of depth d can hold: every other pixel of every other row */
+                    const long long cw = (W / O.nIni[l] >> d) + 2, ch = (H >> d) + 2;
+                    return ((cw + 1) / 2) * ((ch + 1) / 2);
+                };
+                while (D < 11 && cell_keys(D) >= 65535) D++;
+                while (D > 1 && (((long long)O.nIni[l] << (2 * D)) > 16384 ||
+                                 nb + 2 * (((size_t)O.nIni[l] << (2 * D)) + 1) * 4 + 16 > budget) && cell_keys(D - 1) < 65535)
+                    D--;
+                O.fineD[l] = D;
+                maxcells = std::max(maxcells, O.nIni[l] << (2 * D));
+                std::vector<uint32_t> xs, ys;
+                vslam::build_oct_lut(W, H, D, xs, ys);
+                O.lutOff[l] = (int32_t)lut.size();
+                O.lutW[l] = (int32_t)xs.size();
+                lut.insert(lut.end(), xs.begin(), xs.end());
+                lut.insert(lut.end(), ys.begin(), ys.end());
             }
+            O.fineLdsOff = (int32_t)nb;
+            O.fineLdsBytes = (int32_t)(2 * ((size_t)maxcells + 1) * 4 + 16);
+            if (nb + (size_t)O.fineLdsBytes > 160 * 1024) ok = false; /* cannot happen with the limits above */
         }
         O.ptsCap = fe->cand_cap;
         O.dbg = nullptr;
@@ -388,24 +381,24 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         if (vk_octree_lds_bytes(O.maxNodes) > 150 * 1024) ok = false; /* list does not fit LDS: host quadtree */
         fe->dev_octree = ok;
         if (ok) {
-            if (vk_octree_set_max_lds(vk_octree_lds_bytes(O.maxNodes) + (O.fineLdsOff ? (size_t)O.fineLdsBytes + 16 : 0)) != 0) {
+            if (vk_octree_set_max_lds((size_t)O.fineLdsOff + (size_t)O.fineLdsBytes + 16) != 0) {
                 g_err = "hipFuncSetAttribute(k_octree, max dynamic LDS) failed";
                 return VSLAM_ERR_HIP;
             }
             const size_t np = (size_t)fe->B * fe->cand_cap;
             HIPCHK(hipMalloc((void**)&fe->d_pts[0], np * 4));
             HIPCHK(hipMalloc((void**)&fe->d_pts[1], np * 4));
-            HIPCHK(hipMalloc((void**)&fe->d_nid[0], np * 2));
-            HIPCHK(hipMalloc((void**)&fe->d_nid[1], np * 2));
             HIPCHK(hipMalloc((void**)&fe->d_sel_xyr, (size_t)fe->B * O.selStride * 4));
             HIPCHK(hipMalloc((void**)&fe->d_sel_cnt, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
             if (fe->tune.octree_walk_kernel != 1) { /* 1: the walk-per-pass kernel only (A/B runs) */
-                HIPCHK(hipMalloc((void**)&fe->d_fine, (size_t)fe->B * O.fineStride * 4));
+                HIPCHK(hipMalloc((void**)&fe->d_oct_sorted, np * 8));
                 HIPCHK(hipMalloc((void**)&fe->d_oct_redo, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
                 HIPCHK(hipMemset(fe->d_oct_redo, 0, (size_t)fe->B * VSLAM_MAX_LEVELS * 4));
-                /* node arrays of the walk-per-pass distribution for the problems k_octree_v3 hands over (k_assign_out) */
-                fe->walk_stride = (vk_octree_lds_bytes(O.maxNodes) + 255) & ~(size_t)255;
-                HIPCHK(hipMalloc((void**)&fe->d_walk, (size_t)fe->B * fe->walk_stride));
+                int rc;
+                if ((rc = upload(&fe->d_oct_lut, lut.data(), lut.size() * 4))) return rc;
+                O.lut = fe->d_oct_lut;
+            } else {
+                HIPCHK(hipMalloc((void**)&fe->d_nid, np * 2));
             }
         }
         HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
@@ -415,8 +408,6 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
 
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&fe->ev_upload, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&fe->ev_stage_free, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     fe->use_graph = fe->tune.graphs != 0; /* 0: never replay captured graphs */
     fe->sel_level.resize((size_t)fe->B * p.nlevels);
@@ -672,7 +663,7 @@ static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
  *         Measured beside the other contexts' kernels: 102 k frames/s against 64-72 k with the pull kernel, whose host
  *         reads (2-3 us each) sit in the L2's queues in front of everybody's HBM requests (describe 122 -> 274 us).
  *   pull: one kernel reads the host rows over PCIe itself (55 GB/s alone on the GPU; kept for A/B runs). */
-static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where, bool ahead = false) {
+static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where) {
     const vslam_fe_params& p = fe->p;
     hipStream_t st = fe->stream;
     const size_t lp = fe->geom.lv[0].pitch, img_bytes = lp * (size_t)p.height;
@@ -695,26 +686,7 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
             g_err = "internal: device staging buffer not allocated";
             return VSLAM_ERR_HIP;
         }
-        /* ahead: the copy goes onto the context's copy stream behind the last re-pitch that read the staging buffer; the
-         * re-pitch into level 0 is left to the pass that uses the images (enqueue_front, IMGS_STAGED) */
-        if (ahead && !fe->copy_stream) { /* ONE upload stream per device, shared by its contexts and created on first use:
-                                           a stream per context doubles the HIP streams of a pipeline, and with eight
-                                           streams on the hardware queues the mono workload ran 87 k instead of 118 k
-                                           frames/s even when the extra streams were never used */
-            static std::mutex mu;
-            static hipStream_t shared[64][4] = {};
-            static int next[64] = {};
-            static int nshared = 0; /* guarded by mu */
-            std::lock_guard<std::mutex> lk(mu);
-            if (nshared == 0) /* copy_streams = 1..4 upload streams per device (contexts take them in turn); process-wide */
-                nshared = std::min(4, std::max(1, tune_or(vslam_process_tuning().copy_streams, 2)));
-            const int dv = fe->p.device & 63, k = next[dv]++ % nshared;
-            if (!shared[dv][k]) HIPCHK(hipStreamCreateWithFlags(&shared[dv][k], hipStreamNonBlocking));
-            fe->copy_stream = shared[dv][k];
-        }
-        hipStream_t cs = ahead ? fe->copy_stream : st;
-        if (ahead) HIPCHK(hipStreamWaitEvent(cs, fe->ev_stage_free, 0));
-        else if (fe->stage_pending) HIPCHK(hipStreamWaitEvent(cs, fe->ev_upload, 0)); /* do not overtake an upload issued ahead */
+        hipStream_t cs = st;
         bool even = nimg > 1; /* equally spaced sources: one copy */
         const ptrdiff_t d = nimg > 1 ? hs.l0[1] - hs.l0[0] : 0;
         for (int s = 2; s < nimg && even; s++) even = hs.l0[s] - hs.l0[s - 1] == d;
@@ -728,16 +700,8 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
             }
         }
         from_host = 0;
-        if (ahead) {
-            HIPCHK(hipEventRecord(fe->ev_upload, cs));
-            fe->stage_src = hs;
-            fe->stage_pending = true;
-            return VSLAM_OK;
-        }
-        fe->stage_pending = false;
     }
     vk_pull_images(st, hs, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)lp, p.width, p.height, nimg, from_host, fe->tune);
-    if (!from_host) HIPCHK(hipEventRecord(fe->ev_stage_free, st));
     return VSLAM_OK;
 }
 
@@ -755,13 +719,6 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
             fe->src.pitch0[s] = (uint32_t)pitch;
         }
     } else if (on_device == VSLAM_IMGS_STAGED) {
-        if (fe->stage_pending) { /* uploaded ahead into the staging buffer: re-pitch into level 0 now */
-            HIPCHK(hipStreamWaitEvent(st, fe->ev_upload, 0));
-            vk_pull_images(st, fe->stage_src, fe->d_pyr, fe->slot_stride, fe->geom.lv[0].off, (int)fe->geom.lv[0].pitch, p.width,
-                           p.height, nimg, 0, fe->tune);
-            HIPCHK(hipEventRecord(fe->ev_stage_free, st));
-            fe->stage_pending = false;
-        }
         for (int s = 0; s < nimg; s++) { /* vslam_fe_stage_images_async put them there */
             fe->src.l0[s] = fe->d_pyr + (size_t)s * fe->slot_stride + fe->geom.lv[0].off;
             fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
@@ -921,11 +878,10 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
-              fe->d_nid[0], fe->d_nid[1], (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
-              fe->d_fine, fe->d_oct_redo, fe->tune.oct_regkeys);
+              fe->d_nid, fe->d_oct_sorted, (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
+              fe->d_oct_redo, fe->tune.oct_regkeys);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
-                  d_err, nimg, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->d_pts[0], fe->d_nid[0],
-                  (size_t)fe->cand_cap, fe->d_fine ? fe->d_oct_redo : nullptr, fe->d_walk, fe->walk_stride);
+                  d_err, nimg, fe->d_oct_redo);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
@@ -969,11 +925,7 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     }
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
      * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
-    /* a STAGED pass whose upload was issued ahead on a copy stream (stage_pending) waits for that upload and re-pitches at
-     * its head: an event recorded outside a capture is no dependency of the captured graph, so such a pass is never
-     * captured or replayed */
-    const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling &&
-                           !(on_device == VSLAM_IMGS_STAGED && fe->stage_pending);
+    const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
                     (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^
@@ -1193,20 +1145,16 @@ extern "C" int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t
     }
     HIPCHK(hipSetDevice(fe->p.device));
     if (where == VSLAM_IMGS_HOST) {
-        HIPCHK(vslam_stream_wait(fe->stream)); /* the pinned staging may still be read by the previous pull ... */
-        HIPCHK(hipEventSynchronize(fe->ev_upload)); /* ... or by an upload issued ahead */
+        HIPCHK(vslam_stream_wait(fe->stream)); /* the pinned staging may still be read by the previous pull */
         int rc = stage_host_images(fe, nimg, imgs, pitch);
         if (rc) return rc;
     }
     int rc2 = ensure_stage(fe, where == VSLAM_IMGS_PINNED ? pitch : (size_t)fe->geom.lv[0].pitch, nimg);
     if (rc2) return rc2;
-    /* VSLAM_STAGE_AHEAD=1: the DMA copy goes onto an upload stream shared by the device's contexts and may be issued
-     * passes ahead of its use (it waits only for the staging buffer); the pass re-pitches at its head.  Measured on the
-     * mono workload it is SLOWER than copy + re-pitch on the context's own stream at the head of the step (77-86 k against
-     * 85-103 k frames/s; one upload stream serialises copies that otherwise overlap on several DMA engines, and the
-     * host-input rate is bound by the link either way), so it is off by default. */
-    const bool stage_ahead = fe->tune.stage_ahead == 1;
-    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where, /*ahead=*/stage_ahead && h2d_uses_sdma(fe, nimg));
+    /* (Tried in round 2 and removed: the DMA copy on an upload stream of its own, issued passes ahead of its use.  One
+     * upload stream serialises copies that otherwise overlap on several DMA engines -- 77-86 k against 85-103 k mono
+     * frames/s -- and the host-input rate is bound by the link either way.) */
+    rc2 = upload_host_rows(fe, nimg, imgs, pitch, where);
     if (rc2) return rc2;
     HIPCHK(hipGetLastError());
     return VSLAM_OK;

@@ -498,6 +498,54 @@ bool distribute_octree(const Cand* cands, int n, int W, int H, int N, std::vecto
 }
 
 /* ------------------------------------------------------------------ matcher host logic */
+uint32_t oct_key_path(int x, int y, int W, int H, int depth) {
+    const int nIni = (int)std::round((float)W / (float)H);
+    const float hX = (float)W / (float)nIni;
+    int b = (int)((float)x / hX); /* fextractor.cpp:557-561 */
+    b = std::min(b, nIni - 1);
+    int x0 = (int)(hX * (float)b), x1 = (int)(hX * (float)(b + 1)), y0 = 0, y1 = H;
+    uint32_t code = 0;
+    for (int d = 0; d < depth; d++) { /* DivideNode: halfX = ceil((UR.x - UL.x) / 2); kp.x < n1.UR.x, kp.y < n1.BR.y */
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const int qx = x < mx ? 0 : 1, qy = y < my ? 0 : 1;
+        code = (code << 2) | (uint32_t)qx | ((uint32_t)qy << 1);
+        if (qx) x0 = mx; else x1 = mx;
+        if (qy) y0 = my; else y1 = my;
+    }
+    return ((uint32_t)b << (2 * depth)) | code;
+}
+
+void build_oct_lut(int W, int H, int D, std::vector<uint32_t>& xs, std::vector<uint32_t>& ys) {
+    const int nIni = (int)std::round((float)W / (float)H);
+    const float hX = (float)W / (float)nIni;
+    xs.assign((size_t)W + 1, 0u);
+    ys.assign((size_t)H + 1, 0u);
+    for (int x = 0; x <= W; x++) {
+        int b = (int)((float)x / hX);
+        b = std::min(b, nIni - 1);
+        int x0 = (int)(hX * (float)b), x1 = (int)(hX * (float)(b + 1));
+        uint32_t code = 0;
+        for (int d = 0; d < D; d++) {
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            const int q = x < mx ? 0 : 1;
+            code = (code << 2) | (uint32_t)q;
+            if (q) x0 = mx; else x1 = mx;
+        }
+        xs[x] = ((uint32_t)b << (2 * D)) | code;
+    }
+    for (int y = 0; y <= H; y++) {
+        int y0 = 0, y1 = H;
+        uint32_t code = 0;
+        for (int d = 0; d < D; d++) {
+            const int my = y0 + ((y1 - y0 + 1) >> 1);
+            const int q = y < my ? 0 : 1;
+            code = (code << 2) | ((uint32_t)q << 1);
+            if (q) y0 = my; else y1 = my;
+        }
+        ys[y] = code;
+    }
+}
+
 void compute_three_maxima(const int* hs, int L, int& ind1, int& ind2, int& ind3) {
     int max1 = 0, max2 = 0, max3 = 0; /* fmatcher.cpp:2813-2854 */
     for (int i = 0; i < L; i++) {
@@ -780,6 +828,17 @@ int vslamh_search_init(const vslam_kp* kps1, int n1, const vslam_kp* kps2, int n
     return vslam::search_for_initialization_replay(kps1, n1, kps2, n2, dmat_full, rows.data(), cols.data(), n2,
                                                    W, H, prevMatched, matches12, window, nnratio, checkOri != 0);
 }
+
+/* quadtree path tables of k_octree_v4 against the literal halvings: returns the number of (x, y) whose table path differs */
+int vslamh_oct_lut_check(int W, int H, int D) {
+    std::vector<uint32_t> xs, ys;
+    vslam::build_oct_lut(W, H, D, xs, ys);
+    int bad = 0;
+    for (int y = 0; y <= H; y++)
+        for (int x = 0; x <= W; x++) bad += (xs[x] | ys[y]) != vslam::oct_key_path(x, y, W, H, D);
+    return bad;
+}
+unsigned vslamh_oct_key_path(int x, int y, int W, int H, int depth) { return vslam::oct_key_path(x, y, W, H, depth); }
 
 } /* extern "C" */
 

@@ -102,6 +102,16 @@ struct Cand {
  * which is not reproducible).  Returns false when nIni < 1 (reference UB). */
 bool distribute_octree(const Cand* cands, int n, int W, int H, int N, std::vector<Cand>& out);
 
+/* The implicit quadtree under DistributeOctTree's initial nodes (fextractor.cpp:534-561 for the roots, DivideNode
+ * :472-517 for the halving): a key's root b = min((int)(x / hX), nIni - 1) and its quadrant at every depth depend on x and y
+ * SEPARATELY (midpoints mx = x0 + ceil((x1 - x0) / 2), kp.x < mx; the same in y), so the path to depth D is
+ *     path = xs[x] | ys[y],   xs[x] = b << 2D | (x's D decisions on the even bits), ys[y] = (y's on the odd bits),
+ * most significant decision first -- two table look-ups instead of D dependent halvings per key (k_octree_v4).
+ * W = maxBorderX - minBorderX, H = maxBorderY - minBorderY; xs gets W + 1 entries, ys H + 1.
+ * oct_key_path: the same path by walking the halvings, any depth (the kernel uses it below the tables' depth). */
+void build_oct_lut(int W, int H, int D, std::vector<uint32_t>& xs, std::vector<uint32_t>& ys);
+uint32_t oct_key_path(int x, int y, int W, int H, int depth);
+
 /* FMatcher::ComputeThreeMaxima (fmatcher.cpp:2813-2854) on bin sizes. */
 void compute_three_maxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3);
 

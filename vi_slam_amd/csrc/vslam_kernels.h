@@ -37,13 +37,12 @@ void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const 
 size_t vk_octree_lds_bytes(int maxNodes);
 int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
-               uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
-               int32_t* redo_flags, int regkeys);
+               uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
+               int regkeys);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
-                   const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a, size_t pts_stride,
-                   const int32_t* redo_flags, uint8_t* walk, size_t walk_stride);
+                   const int32_t* deep_flags);
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,

@@ -21,6 +21,8 @@
  */
 #include "vslam_kernels.h"
 
+#include <mutex>
+
 #define OT 1024
 #define OKPT 16  /* k_octree_v2: keys per thread kept in registers (problems up to 16384 keys) */
 #define OBATCH 8 /* k_octree_v2: keys per thread and batch when streaming a larger problem */
@@ -86,7 +88,7 @@ __device__ __forceinline__ int quadrant(uint32_t pt, const ONode& nd) {
  * launch at 1080p / 100 k candidates; it is in the git history).
  * ---------------------------------------------------------------------------------------------- */
 /* what one (slot, level) problem of the walk-per-pass distribution needs from OctParams: plain values, so that the body
- * can be shared by k_octree_v2 and the hand-over path of k_octree_v3 */
+ * is independent of the parameter block's layout */
 struct OctWalkLevel {
     int32_t N, H, nIni, c0, c1, selOff, selStride, maxNodes, ptsCap, maxIter;
     float hX;
@@ -496,44 +498,50 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 }
 
 /* ------------------------------------------------------------------------------------------------
- * k_octree_v3: the same distribution without a key walk per pass.
+ * k_octree_v4: the distribution with TWO key walks in all, no walk per pass, and no limit on how finely keys cluster.
  *
  * DivideNode's boundaries depend on the node alone (midpoints, fextractor.cpp:474-475), never on the keys, so the
- * quadtree below an initial node is a fixed implicit tree and a key's root-to-leaf path (one 2-bit quadrant per
- * depth) can be computed once.  Keys are counted into the 4^D leaves ("fine cells", D = fineD[level]) of every
- * initial node with ONE pass of atomics spread over thousands of addresses (k_octree_v2's per-pass histogram put
- * every key of a pass on a handful of LDS counters: ~2 cycles per key, serialised), the counts are prefix-summed
- * once, and from then on a node of depth d IS the run of 4^(D-d) fine cells under its path: the child counts a split
- * pass needs are four differences of the prefix array, per NODE, not per key.  The node-level logic (list order,
- * "largest first until N", creation ranks) is k_octree_v2's, unchanged.  The final "best response, first key wins"
- * needs each key's final node: final nodes mark their first fine cell, a forward fill gives every fine cell its
- * node, and one walk does the arg-max as before.  Key walks left: count, select (v2: two per pass + two).
- * One workgroup per (slot, level) as before -- the quadtree stays a narrow kernel that hides behind the grid-filling
- * ones.  A five-launch form with the two key walks as grid-wide kernels (wave-aggregated L2 atomics) was built and
- * measured: 134 us per 32 KITTI frames against 82 here and 100 for v2 (454 / 448 / 650 at 1080p), the same batch-1
- * latency, and its key kernels are wide -- they would compete with FAST and the blur for the CUs; dropped.
- * If a pass would have to split a node that is already a single fine cell (keys clustered more densely than the
- * fine grid resolves) the workgroup flags the problem and k_assign_out, the next kernel of the pass, redoes exactly that
- * (slot, level) with the walk-per-pass body (oct_walk_body) before it reads the level's result; VSLAM_OCT_FINE_D=<n> forces
- * a shallow grid so that tests exercise the hand-over.  (Normally every level of every image is resolved here.)
+ * quadtree below an initial node is a fixed implicit tree; and because x and y are halved separately, a key's path to
+ * depth D (one 2-bit quadrant per depth) is two table look-ups, path = xs[x] | ys[y] (vslam::build_oct_lut).
+ *   walk 1  every key is read ONCE from the FAST cells' segments (position in cell order = the reference's key order),
+ *           its leaf of depth D ("fine cell", nIni * 4^D of them, counters in LDS) is counted with a returning LDS
+ *           atomic: the old count is the key's rank inside its fine cell;
+ *           -> one prefix sum over the fine cells;
+ *   walk 2  every key is stored at sorted[PS[cell] + rank]: the keys are now sorted by fine cell, so a node of depth
+ *           d <= D IS the contiguous run of the 4^(D-d) fine cells under its path, in the prefix array and in the keys.
+ *   passes  k_octree_v2's node logic (list order, "largest first until N", creation ranks); the child counts a pass
+ *           needs are four differences of the prefix array, per NODE, not per key.  A node DEEPER than the grid (keys
+ *           closer together than a fine cell: real images do that on the sparse top levels, where every node is split
+ *           down to single keys) lies inside one fine cell: its few keys are enumerated from the sorted array and
+ *           tested against the node's path by walking the halvings -- exact at any depth, no fallback kernel.
+ *   select  "best response, first key wins" (fextractor.cpp:732-751): four lanes per final node reduce its run of
+ *           the sorted array (response, then original position); no atomics, no owner table.
+ * One workgroup per (slot, level): the quadtree stays a narrow kernel that hides behind the grid-filling ones.
+ * History (git): v3 kept an owner table instead of sorted keys (gather + count + owner fill + select walks, fine cell by D
+ * dependent halvings per key: 52 / 89 / 251 us for the level-0 problem at KITTI N=1000 / 2000 / 1080p N=4000) and
+ * handed problems whose keys cluster below the grid to the walk-per-pass code in k_assign_out -- which the reference's
+ * own test images (hut_stereo 752x480) triggered on 5-30 % of their (slot, level) problems.
  * ---------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ int oct_fine_cell(uint32_t key, float hX, int nIni, int Hh, int D) {
+#define ND4_DEPTH(nd) ((int)((nd).cf >> 28))
+#define ND4_COUNT(nd) (((nd).cf & 0x0FFFFFFFu) >> 1)
+
+__device__ __forceinline__ uint32_t oct_key_path(uint32_t key, float hX, int nIni, int Hh, int depth) {
     const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
     int b = (int)__fdiv_rn((float)x, hX); /* initial node, fextractor.cpp:557-561 */
     b = min(b, nIni - 1);
     int x0 = (int)__fmul_rn(hX, (float)b), x1 = (int)__fmul_rn(hX, (float)(b + 1)), y0 = 0, y1 = Hh;
-    int code = 0;
-    for (int d = 0; d < D; d++) { /* DivideNode: halfX = ceil((UR.x - UL.x) / 2); kp.x < n1.UR.x, kp.y < n1.BR.y */
+    uint32_t code = 0;
+    for (int d = 0; d < depth; d++) { /* DivideNode: halfX = ceil((UR.x - UL.x) / 2); kp.x < n1.UR.x, kp.y < n1.BR.y */
         const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
         const int qx = x < mx ? 0 : 1, qy = y < my ? 0 : 1;
-        code = (code << 2) | qx | (qy << 1);
+        code = (code << 2) | (uint32_t)qx | ((uint32_t)qy << 1);
         if (qx) x0 = mx; else x1 = mx;
         if (qy) y0 = my; else y1 = my;
     }
-    return (b << (2 * D)) | code;
+    return ((uint32_t)b << (2 * depth)) | code;
 }
 
-/* inclusive scans over 64-cell tiles, lane = cell: a wave owns a contiguous run of tiles, loads are coalesced */
+/* inclusive scan over a 64-cell tile, lane = cell */
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -542,54 +550,42 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
     }
     return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if ((int)(threadIdx.x & 63) >= o) v = max(v, t);
-    }
-    return v;
-}
 
-/* REGKEYS: keys (and their fine cells) of problems up to OKPT * 1024 keys stay in registers between the two key walks.
- * FINE = 1: the two fine-cell arrays (counts -> prefix sums, later owner markers -> owners) live in LDS behind the node
- * arrays instead of in a slot's global scratch: LDS atomics instead of 11.5 k L2 atomics from one CU, and every later
- * look-up a ds_read (vk_octree chooses it when the largest level's arrays fit: KITTI at 1000 features, 33 KB).
- * FINE = 2: the arrays do not fit, but the COUNTERS do as packed 16-bit pairs (a fine cell cannot hold more keys than it
- * has pixels; the host checks that this is < 65536): the count walk's atomics go to LDS, the prefix sums read them there
- * and write the (global) prefix array; everything after that is plain loads and stores as with FINE = 0. */
-template <bool REGKEYS, int FINE> /* FINE: 0 global arrays, 1 both arrays in LDS, 2 only 16-bit COUNTERS in LDS (see above) */
+/* REGKEYS: keys (and their cell | rank words) of problems up to OKPT * 1024 keys stay in registers between the two walks
+ * (1-2 images: latency); otherwise both are written to the slot's scratch by walk 1 and re-read, coalesced, by walk 2
+ * (batches: fewer VGPRs, so that foreign waves fit next to a 1024-thread workgroup). */
+template <bool REGKEYS>
 __global__ void __launch_bounds__(OT)
-k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* pts_a,
-            uint16_t* fc_a, size_t pts_stride, uint32_t* fine, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
-            int32_t* redo_flags) {
+k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* keys_a,
+            uint32_t* aux_a, uint2* sorted_a, size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
+            int32_t* deep_flags) {
     extern __shared__ __align__(16) uint8_t osm[];
     const int MAXN = P.maxNodes;
     ONode* cur = (ONode*)osm;
     ONode* nxt = cur + MAXN;
-    u64* Sbeg = (u64*)(nxt + MAXN);       /* arg-max array of the final selection */
-    u64* Cnt = Sbeg + MAXN;               /* packed per-quadrant key counts of a node */
+    uint32_t* Kq = (uint32_t*)(nxt + MAXN);   /* phase 2: sort key of every node (8 bytes per node reserved, 4 used) */
+    u64* Cnt = (u64*)(nxt + MAXN) + MAXN;     /* packed per-quadrant key counts of a node */
     uint16_t* cb = (uint16_t*)(Cnt + MAXN);   /* list index of a processed node's FIRST created child */
-    uint16_t* newIdx = cb + MAXN;
+    uint16_t* newIdx = cb + MAXN;             /* (k_octree_v2 only) */
     uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
-    uint16_t* ordv = prank + MAXN;            /* node at processing rank r (phase 2) */
+    uint16_t* ordv = prank + MAXN;            /* node at processing rank r */
     __shared__ uint32_t s_w32[OT / 64];
-    __shared__ int s_size, s_M, s_nexp, s_cut, s_redo;
+    __shared__ int s_size, s_M, s_nexp, s_cut, s_deep;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int level = blockIdx.y, slot = blockIdx.x;
-    int32_t* redo = redo_flags + slot * VSLAM_MAX_LEVELS + level;
     const int N = P.N[level];
     const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
     const CellOut* cout = (const CellOut*)(hdr + 2);
     const uint32_t* cand = (const uint32_t*)(cout + ncells);
-    uint32_t* pa = pts_a + (size_t)slot * pts_stride;
-    uint16_t* fca = fc_a + (size_t)slot * pts_stride; /* fine cell of every key (problems too large for registers) */
+    uint32_t* pa = keys_a + (size_t)slot * pts_stride;
+    uint32_t* aux = aux_a + (size_t)slot * pts_stride;   /* fine cell | rank in the cell << 16 of every key */
+    uint2* sorted = sorted_a + (size_t)slot * pts_stride; /* {key, position in key order}, sorted by fine cell */
     uint32_t* out = sel_xyr + (size_t)slot * P.selStride + P.selOff[level];
     int32_t* ocnt = sel_cnt + slot * VSLAM_MAX_LEVELS + level;
     if (tid == 0) {
-        *redo = 0;
-        s_redo = 0;
+        deep_flags[slot * VSLAM_MAX_LEVELS + level] = 0;
+        s_deep = 0;
     }
 #ifdef VSLAM_OCT_STAMPS
     int dbgn3 = 0;
@@ -601,8 +597,8 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     STAMP3();
 
     /* ---- 0. this level's candidates in cell order (vToDistributeKeys, fextractor.cpp:809-817): a key's position in
-     * the gathered array IS its rank in the reference's key order.  One binary search in the cells' offsets (LDS) for a
-     * lane's first position, then it walks on cell by cell. */
+     * that order is its rank in the reference's key order.  One binary search in the cells' offsets (LDS) for a lane's
+     * first position, then it walks on cell by cell. */
     const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
     uint32_t before = 0;
     for (int c = tid; c < c0; c += OT) before += cout[c].count;
@@ -621,7 +617,7 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint32_t ntot;
     uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
     const int n = (int)ntot;
-    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << FB) || hdr[1] != 0) {
+    if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << 20) || hdr[1] != 0) {
         if (tid == 0) {
             atomicOr(err_flag, 1);
             *ocnt = 0;
@@ -629,9 +625,10 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         return;
     }
     pa += off0;
-    fca += off0;
-    /* cell offsets (+ sentinel) and the cells' segment bases, borrowed from the node arrays and Sbeg (2 * ncl + 1 words
-     * <= 4 * MAXN + 2 * MAXN): the gather below then needs ONE global round trip (the keys), not three */
+    aux += off0;
+    sorted += off0;
+    /* cell offsets (+ sentinel) and the cells' segment bases, borrowed from the node arrays (2 * ncl + 1 words; the host
+     * sizes MAXN >= ncl / 4, i.e. 14 * MAXN words of node arrays): the walk needs ONE global round trip (the keys) */
     uint32_t* coff = (uint32_t*)nxt;
     uint32_t* cbas = coff + ncl + 1;
     for (int k = 0; k < K; k++) {
@@ -644,7 +641,6 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         }
     }
     if (tid == 0) coff[ncl] = ntot;
-    __syncthreads();
     if (n == 0) {
         if (tid == 0) *ocnt = 0;
         return;
@@ -654,30 +650,25 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     const int Hh = P.H[level];
     const int D = P.fineD[level];
     const int cells = nIni << (2 * D);
-    uint32_t* Hc = FINE == 1 ? (uint32_t*)(osm + P.fineLdsOff)
-                             : fine + (size_t)slot * P.fineStride + P.fineOff[level]; /* counts, later the owner markers */
-    uint32_t* Hc16 = (uint32_t*)(osm + P.fineLdsOff); /* FINE == 2: packed 16-bit counters, cell c in half c & 1 of word c >> 1 */
-    uint32_t* PS = Hc + cells + 1;                                          /* exclusive prefix sums, later the owners */
-    if (FINE == 2) {
-        for (int i = tid; i <= cells >> 1; i += OT) Hc16[i] = 0u;
-    } else {
-        for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
-    }
+    uint32_t* Hc = (uint32_t*)(osm + P.fineLdsOff); /* key counts of the fine cells */
+    uint32_t* PS = Hc + cells + 1;                  /* their exclusive prefix sums */
+    const uint32_t* __restrict__ xs = P.lut + P.lutOff[level];
+    const uint32_t* __restrict__ ys = xs + P.lutW[level];
+    for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+    __syncthreads();
 
-    /* keys of a problem of up to OKPT * 1024 keys (every KITTI-size level) and their fine cells stay in REGISTERS */
-    const bool inReg = REGKEYS && n <= OKPT * OT;
     /* positions are dealt to WAVES in contiguous chunks of EW (a multiple of 64) and to the lanes of a wave interleaved:
      * lane l holds positions wbeg + 64 k + l, so that a wave's loads (mostly one FAST cell segment after the other) and
-     * its stores into the gathered array are coalesced.  (Contiguous positions per THREAD made every store instruction
-     * touch 64 cache lines: 108 us of a 1080p level's 322.) */
+     * its stores are coalesced */
+    const bool inReg = REGKEYS && n <= OKPT * OT;
     const int KW = (n + OT - 1) / OT, EW = KW * 64; /* keys per lane, positions per wave */
     const int wbeg = wv * EW;
     uint32_t keyR[OKPT];
-    uint32_t cellR[OKPT / 2]; /* two 16-bit fine cells per register */
+    uint32_t auxR[OKPT];
 #pragma unroll
-    for (int k = 0; k < OKPT; k++) keyR[k] = 0u;
-#pragma unroll
-    for (int k = 0; k < OKPT / 2; k++) cellR[k] = 0u;
+    for (int k = 0; k < OKPT; k++) keyR[k] = auxR[k] = 0u;
+
+    /* ---- 1. walk 1: read every key, count it into its fine cell; the counter's old value is its rank in the cell */
     {
         const int p0 = wbeg + lane;
         int c = 0;
@@ -707,10 +698,13 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
 #pragma unroll
             for (int k = 0; k < OKPT; k++)
-                if (k < KW && p0 + 64 * k < n) pa[p0 + 64 * k] = keyR[k];
+                if (k < KW && p0 + 64 * k < n) auxR[k] = xs[keyR[k] & 0xFFF] | ys[(keyR[k] >> 12) & 0xFFF];
+#pragma unroll
+            for (int k = 0; k < OKPT; k++)
+                if (k < KW && p0 + 64 * k < n) auxR[k] |= atomicAdd(&Hc[auxR[k]], 1u) << 16;
         } else {
-            for (int kb = 0; kb < KW; kb += OBATCH) { /* OBATCH loads in flight, then the stores */
-                uint32_t kk[OBATCH];
+            for (int kb = 0; kb < KW; kb += OBATCH) { /* OBATCH loads in flight, then the table look-ups, then the atomics */
+                uint32_t kk[OBATCH], ff[OBATCH];
 #pragma unroll
                 for (int j = 0; j < OBATCH; j++) {
                     const int i = p0 + 64 * (kb + j);
@@ -727,76 +721,38 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                 }
 #pragma unroll
                 for (int j = 0; j < OBATCH; j++)
-                    if (kb + j < KW && p0 + 64 * (kb + j) < n) pa[p0 + 64 * (kb + j)] = kk[j];
+                    ff[j] = (kb + j < KW && p0 + 64 * (kb + j) < n) ? xs[kk[j] & 0xFFF] | ys[(kk[j] >> 12) & 0xFFF] : 0u;
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++)
+                    if (kb + j < KW && p0 + 64 * (kb + j) < n) ff[j] |= atomicAdd(&Hc[ff[j]], 1u) << 16;
+#pragma unroll
+                for (int j = 0; j < OBATCH; j++)
+                    if (kb + j < KW && p0 + 64 * (kb + j) < n) {
+                        pa[p0 + 64 * (kb + j)] = kk[j];
+                        aux[p0 + 64 * (kb + j)] = ff[j];
+                    }
             }
         }
     }
-    __syncthreads(); /* coff (in nxt) is free again; pa and the zeroed counters are complete */
+    __syncthreads(); /* coff (in the node arrays) is free again; the counters are complete */
     STAMP3();
-
-    /* ---- 1. count the keys per fine cell */
-    if (inReg) {
-#pragma unroll
-        for (int k = 0; k < OKPT; k++) {
-            const int i = wbeg + lane + 64 * k;
-            if (k < KW && i < n) {
-                const int f = oct_fine_cell(keyR[k], hX, nIni, Hh, D);
-                cellR[k >> 1] |= (uint32_t)f << (16 * (k & 1));
-                if (FINE == 2) atomicAdd(&Hc16[f >> 1], 1u << (16 * (f & 1)));
-                else atomicAdd(&Hc[f], 1u);
-            }
-        }
-    } else {
-        for (int base = tid; base < n; base += OBATCH * OT) {
-            uint32_t kk[OBATCH];
-#pragma unroll
-            for (int j = 0; j < OBATCH; j++) {
-                const int i = base + j * OT;
-                kk[j] = i < n ? pa[i] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < OBATCH; j++)
-                if (base + j * OT < n) {
-                    const int f = oct_fine_cell(kk[j], hX, nIni, Hh, D);
-                    fca[base + j * OT] = (uint16_t)f; /* the selection below reads it instead of walking the path again */
-                    if (FINE == 2) atomicAdd(&Hc16[f >> 1], 1u << (16 * (f & 1)));
-                    else atomicAdd(&Hc[f], 1u);
-                }
-        }
-    }
-    __syncthreads();
-    /* the counters were updated by atomics that execute in L2: drop whatever this CU's L1 holds of them (the zeroing
-     * stores may have allocated lines) before reading them with plain, coalesced loads */
-    if (FINE == 0) {
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-    }
-    STAMP3();
-    const int ntile = (cells + 63) >> 6, tpw = (ntile + OT / 64 - 1) / (OT / 64); /* tiles per wave */
-    {   /* exclusive prefix sums of the fine counts */
+    {   /* exclusive prefix sums of the fine counts, LDS to LDS */
+        const int ntile = (cells + 63) >> 6, tpw = (ntile + OT / 64 - 1) / (OT / 64); /* tiles per wave */
+        const int t1 = min((wv + 1) * tpw, ntile);
         uint32_t carry = 0;
-        for (int t0 = wv * tpw; t0 < min((wv + 1) * tpw, ntile); t0 += 8) { /* 8 tiles in flight */
-            uint32_t h8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int c = (t0 + u) * 64 + lane;
-                h8[u] = (t0 + u < min((wv + 1) * tpw, ntile) && c < cells)
-                            ? (FINE == 2 ? (Hc16[c >> 1] >> (16 * (c & 1))) & 0xFFFFu : Hc[c]) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int c = (t0 + u) * 64 + lane;
-                const uint32_t inc = wave_incl_add(h8[u]);
-                if (t0 + u < min((wv + 1) * tpw, ntile) && c < cells) PS[c] = carry + inc - h8[u];
-                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            }
+        for (int t = wv * tpw; t < t1; t++) {
+            const int c = t * 64 + lane;
+            const uint32_t h = c < cells ? Hc[c] : 0u;
+            const uint32_t inc = wave_incl_add(h);
+            if (c < cells) PS[c] = carry + inc - h;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) s_w32[wv] = carry;
         __syncthreads();
         uint32_t wo = 0;
         for (int k = 0; k < wv; k++) wo += s_w32[k];
         if (wo)
-            for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) {
+            for (int t = wv * tpw; t < t1; t++) {
                 const int c = t * 64 + lane;
                 if (c < cells) PS[c] += wo;
             }
@@ -804,7 +760,32 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     }
     __syncthreads();
     STAMP3();
-    /* initial nodes; ONode.begin = first fine cell | depth << 24 */
+
+    /* ---- 2. walk 2: the keys sorted by fine cell (order inside a cell: whatever the atomics gave; the selection below
+     * decides by original position, which travels with the key) */
+    if (inReg) {
+#pragma unroll
+        for (int k = 0; k < OKPT; k++) {
+            const int i = wbeg + lane + 64 * k;
+            if (k < KW && i < n) sorted[PS[auxR[k] & 0xFFFFu] + (auxR[k] >> 16)] = make_uint2(keyR[k], (uint32_t)i);
+        }
+    } else {
+        for (int base = tid; base < n; base += OBATCH * OT) {
+            uint32_t kk[OBATCH], ff[OBATCH];
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) {
+                const int i = base + j * OT;
+                kk[j] = i < n ? pa[i] : 0u;
+                ff[j] = i < n ? aux[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < OBATCH; j++) {
+                const int i = base + j * OT;
+                if (i < n) sorted[PS[ff[j] & 0xFFFFu] + (ff[j] >> 16)] = make_uint2(kk[j], (uint32_t)i);
+            }
+        }
+    }
+    /* initial nodes; ONode.begin = path code of the node (root << 2 depth | quadrants), depth in cf[31:28] */
     if (tid == 0) {
         int li = 0;
         for (int b = 0; b < nIni; b++) {
@@ -815,46 +796,53 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                 nd.x1 = (int16_t)(int)__fmul_rn(hX, (float)(b + 1));
                 nd.y0 = 0;
                 nd.y1 = (int16_t)Hh;
-                nd.begin = (uint32_t)(b << (2 * D));
+                nd.begin = (uint32_t)b;
                 nd.cf = (cb0 << 1) | (cb0 == 1 ? 1u : 0u);
                 cur[li++] = nd;
             }
         }
         s_size = li;
     }
-    __syncthreads();
+    __syncthreads(); /* also: the sorted keys (global memory, this CU's stores) are complete for the whole workgroup */
+    STAMP3();
 
-    /* ---- 2. split passes: k_octree_v2's node logic; the children's key counts come from the prefix sums */
+    /* ---- 3. split passes: k_octree_v2's node logic; the children's key counts come from the prefix sums */
     int phase = 1;
     const int KN = (MAXN + OT - 1) / OT;
     for (int iter = 0; iter < P.maxIter; iter++) {
         const int size0 = s_size;
-        /* A. children's key counts of every expandable node */
+        /* A. children's key counts of every expandable node; phase 2 also needs every node's sort key */
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
             if (v < size0) {
                 const ONode nd = cur[v];
                 u64 c = 0ull;
+                uint32_t kq = 0u;
                 if (!ND_NOMORE(nd)) {
-                    const int depth = (int)(nd.begin >> 24);
-                    if (depth >= D) s_redo = 1; /* finer than the grid resolves (benign race: all writers store 1) */
-                    else {
-                        const uint32_t cb0 = nd.begin & 0xFFFFFFu, q4 = 1u << (2 * (D - depth - 1));
-                        const uint32_t p0 = PS[cb0], p1 = PS[cb0 + q4], p2 = PS[cb0 + 2 * q4],
-                                       p3 = PS[cb0 + 3 * q4];
+                    const int depth = ND4_DEPTH(nd);
+                    const uint32_t path = nd.begin;
+                    if (depth < D) {
+                        const uint32_t cb0 = path << (2 * (D - depth)), q4 = 1u << (2 * (D - depth - 1));
+                        const uint32_t p0 = PS[cb0], p1 = PS[cb0 + q4], p2 = PS[cb0 + 2 * q4], p3 = PS[cb0 + 3 * q4];
                         c = (u64)(p1 - p0) | ((u64)(p2 - p1) << FB) | ((u64)(p3 - p2) << (2 * FB));
+                    } else { /* finer than the grid: the node's keys are among the few of ONE fine cell */
+                        s_deep = 1; /* statistics only (benign race: all writers store 1) */
+                        const uint32_t f = path >> (2 * (depth - D));
+                        for (uint32_t j = PS[f]; j < PS[f + 1]; j++) {
+                            const uint32_t kp = oct_key_path(sorted[j].x, hX, nIni, Hh, depth + 1);
+                            if ((kp >> 2) == path) c += onehot((int)(kp & 3u));
+                        }
                     }
+                    /* descending (count, "created later" == smaller list index): one unsigned compare */
+                    kq = (ND4_COUNT(nd) << 12) | (uint32_t)(4095 - v);
                 }
                 Cnt[v] = c;
+                Kq[v] = kq;
             }
         }
+        /* pad the sort keys to a multiple of four (the rank loop reads them four at a time) */
+        if (tid < 4 && size0 + tid < ((size0 + 3) & ~3)) Kq[size0 + tid] = 0u;
         __syncthreads();
-        if (s_redo) { /* block-uniform: a node that is a single fine cell would have to be split.  k_assign_out, the next
-                         kernel of the pass, redoes this (slot, level) with the walk-per-pass distribution before it reads
-                         the level's result (see there for why not here and not in a launch of its own) */
-            if (tid == 0) *redo = 1;
-            return;
-        }
         /* D1. processing rank of every expandable node */
         uint32_t nexp_mine = 0;
         for (int k = 0; k < KN; k++) {
@@ -874,16 +862,18 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                 }
             }
         } else {
-            /* descending (count, "created later" == smaller list index) */
+            /* rank = number of nodes with a larger sort key (nodes that cannot be split have key 0) */
+            const uint4* K4 = (const uint4*)Kq;
+            const int n4 = (size0 + 3) >> 2;
             for (int k = 0; k < KN; k++) {
                 const int v = tid * KN + k;
                 if (v < size0 && !ND_NOMORE(cur[v])) {
-                    const uint32_t cv = ND_COUNT(cur[v]);
+                    const uint32_t kv = Kq[v];
                     uint32_t r = 0;
-#pragma unroll 8
-                    for (int u = 0; u < size0; u++) {
-                        const uint32_t cfu = cur[u].cf; /* count << 1 | noMore */
-                        r += (!(cfu & 1u) && ((cfu >> 1) > cv || ((cfu >> 1) == cv && u < v))) ? 1u : 0u;
+#pragma unroll 4
+                    for (int u = 0; u < n4; u++) {
+                        const uint4 q = K4[u];
+                        r += (q.x > kv) + (q.y > kv) + (q.z > kv) + (q.w > kv);
                     }
                     prank[v] = (uint16_t)r;
                     ordv[r] = (uint16_t)v;
@@ -898,7 +888,7 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             const int r = tid * KE + k;
             if (r < (int)nexp) {
                 const int v = ordv[r];
-                chl += nchildren(Cnt[v], ND_COUNT(cur[v]));
+                chl += nchildren(Cnt[v], ND4_COUNT(cur[v]));
             }
         }
         uint32_t chtot;
@@ -912,7 +902,7 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                 const int r = tid * KE + k;
                 if (r < (int)nexp) {
                     const int v = ordv[r];
-                    const uint32_t nch = nchildren(Cnt[v], ND_COUNT(cur[v]));
+                    const uint32_t nch = nchildren(Cnt[v], ND4_COUNT(cur[v]));
                     if (phase == 2 && size0 + (int)cb_run - r >= N) atomicMin(&s_cut, r);
                     cb[v] = (uint16_t)cb_run; /* children created before this parent (creation rank base) */
                     cb_run += nch;
@@ -954,11 +944,10 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             } else {
                 const u64 c = Cnt[v];
                 const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                const int depth = (int)(nd.begin >> 24);
-                const uint32_t cb0 = nd.begin & 0xFFFFFFu, q4 = 1u << (2 * (D - depth - 1));
+                const uint32_t depth1 = (uint32_t)ND4_DEPTH(nd) + 1u;
                 int kq = 0;
                 const int first = M - 1 - (int)cb[v]; /* list index of the first created child */
-                const uint32_t c3 = ND_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
+                const uint32_t c3 = ND4_COUNT(nd) - fld(c, 0) - fld(c, 1) - fld(c, 2);
                 for (int q = 0; q < 4; q++) {
                     const uint32_t cq = q < 3 ? fld(c, q) : c3;
                     if (!cq) continue;
@@ -967,8 +956,8 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                     ch.x1 = (q & 1) ? nd.x1 : (int16_t)mx;
                     ch.y0 = (q & 2) ? (int16_t)my : nd.y0;
                     ch.y1 = (q & 2) ? nd.y1 : (int16_t)my;
-                    ch.begin = (cb0 + (uint32_t)q * q4) | ((uint32_t)(depth + 1) << 24);
-                    ch.cf = (cq << 1) | (cq == 1 ? 1u : 0u);
+                    ch.begin = (nd.begin << 2) | (uint32_t)q;
+                    ch.cf = (depth1 << 28) | (cq << 1) | (cq == 1 ? 1u : 0u);
                     nxt[first - kq] = ch;
                     if (cq > 1) nexp_children++;
                     kq++;
@@ -987,75 +976,66 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     }
 
     STAMP3();
-    /* ---- 3. best response per node, first in key order wins (fextractor.cpp:732-751).  Every final node marks its
-     * first fine cell with (cell << 16 | list index + 1); a forward max-fill gives every cell the node it lies in. */
+    /* ---- 4. best response per node, first in key order wins (fextractor.cpp:732-751): four lanes per node reduce its
+     * run of the sorted keys on (response, ~position) */
     const int size = s_size;
-    u64* best = Sbeg;
-    for (int v = tid; v < size; v += OT) best[v] = 0ull;
-    for (int i = tid; i < cells; i += OT) Hc[i] = 0u;
-    __syncthreads();
-    for (int v = tid; v < size; v += OT) {
-        const uint32_t cb0 = cur[v].begin & 0xFFFFFFu;
-        Hc[cb0] = (cb0 << 16) | (uint32_t)(v + 1);
-    }
-    __syncthreads();
-    {
-        uint32_t carry = 0;
-        for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) { /* the wave's last marker, for the waves behind */
-            const int c = t * 64 + lane;
-            const uint32_t h = c < cells ? Hc[c] : 0u;
-            carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(h), 63));
-        }
-        if (lane == 0) s_w32[wv] = carry;
-        __syncthreads();
-        uint32_t run = 0;
-        for (int k = 0; k < wv; k++) run = max(run, s_w32[k]);
-        for (int t = wv * tpw; t < min((wv + 1) * tpw, ntile); t++) {
-            const int c = t * 64 + lane;
-            const uint32_t h = c < cells ? Hc[c] : 0u;
-            const uint32_t inc = max(run, wave_incl_max(h));
-            if (c < cells) PS[c] = inc & 0xFFFFu; /* list index + 1 of the node this fine cell lies in */
-            run = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-    }
-    __syncthreads();
-    STAMP3();
-    if (inReg) {
+    for (int v0 = 0; v0 < size; v0 += OT / 4) {
+        const int v = v0 + (tid >> 2), sub = tid & 3;
+        u64 best = 0ull;
+        uint32_t bkey = 0u;
+        if (v < size) {
+            const ONode nd = cur[v];
+            const int depth = ND4_DEPTH(nd);
+            const uint32_t path = nd.begin;
+            if (depth <= D) {
+                const uint32_t lo = PS[path << (2 * (D - depth))], hi = PS[(path + 1u) << (2 * (D - depth))];
+                for (uint32_t j0 = lo + (uint32_t)sub; j0 < hi; j0 += 16) { /* four loads in flight per lane */
+                    uint2 r[4];
 #pragma unroll
-        for (int k = 0; k < OKPT; k++) {
-            const int i = wbeg + lane + 64 * k;
-            if (k < KW && i < n) {
-                const uint32_t nid = PS[(cellR[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] - 1u;
-                atomicMax(&best[nid], ((u64)(keyR[k] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+                    for (int u = 0; u < 4; u++) r[u] = j0 + 4 * u < hi ? sorted[j0 + 4 * u] : make_uint2(0u, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const u64 a = ((u64)(r[u].x >> 24) << 32) | (u64)(0xFFFFFFFFu - r[u].y);
+                        if (j0 + 4 * u < hi && a >= best) { /* >=: a key of response 0 at position 0xFFFFFFFF cannot exist, so 'best == 0' means none yet */
+                            best = a;
+                            bkey = r[u].x;
+                        }
+                    }
+                }
+            } else { /* a node inside one fine cell: test the cell's keys against the node's path */
+                const uint32_t f = path >> (2 * (depth - D));
+                for (uint32_t j = PS[f] + (uint32_t)sub; j < PS[f + 1]; j += 4) {
+                    const uint2 r = sorted[j];
+                    if (oct_key_path(r.x, hX, nIni, Hh, depth) == path) {
+                        const u64 a = ((u64)(r.x >> 24) << 32) | (u64)(0xFFFFFFFFu - r.y);
+                        if (a >= best) {
+                            best = a;
+                            bkey = r.x;
+                        }
+                    }
+                }
             }
         }
-    } else {
-        for (int base = tid; base < n; base += OBATCH * OT) {
-            uint32_t kk[OBATCH], ff[OBATCH];
 #pragma unroll
-            for (int j = 0; j < OBATCH; j++) {
-                const int i = base + j * OT;
-                kk[j] = i < n ? pa[i] : 0u;
-                ff[j] = i < n ? (uint32_t)fca[i] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < OBATCH; j++) ff[j] = base + j * OT < n ? PS[ff[j]] : 1u;
-#pragma unroll
-            for (int j = 0; j < OBATCH; j++) {
-                const int i = base + j * OT;
-                if (i < n) atomicMax(&best[ff[j] - 1u], ((u64)(kk[j] >> 24) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)i));
+        for (int o = 1; o < 4; o <<= 1) { /* the node's four lanes are neighbours in the wave */
+            const u64 ob = __shfl_xor(best, o, 64);
+            const uint32_t ok = __shfl_xor(bkey, o, 64);
+            if (ob > best) {
+                best = ob;
+                bkey = ok;
             }
         }
+        if (v < size && sub == 0) out[v] = bkey; /* every listed node holds at least one key */
     }
-    __syncthreads();
-    for (int v = tid; v < size; v += OT) /* every listed node holds at least one key */
-        out[v] = best[v] ? pa[0xFFFFFFFFu - (uint32_t)(best[v] & 0xFFFFFFFFull)] : 0u;
 #ifdef VSLAM_OCT_STAMPS
     __syncthreads();
     STAMP3();
     if (DBG3 && tid == 0 && level == 0 && slot == 0) DBG3[63] = dbgn3;
 #endif
-    if (tid == 0) *ocnt = size;
+    if (tid == 0) {
+        *ocnt = size;
+        if (s_deep) deep_flags[slot * VSLAM_MAX_LEVELS + level] = 1;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1064,41 +1044,17 @@ k_octree_v3(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
  * slot; writes the SelKp list the orientation/descriptor kernel consumes and the slot's counts.
  * ---------------------------------------------------------------------------------------------- */
 #define AO_T 256 /* a small workgroup finds a free CU slot quickly next to the other streams' kernels */
-/* Hand-over from k_octree_v3 (walk != null): before anything else the slot's workgroup redoes the levels k_octree_v3
- * flagged -- normally none -- with the walk-per-pass distribution in its streaming form, node arrays in GLOBAL scratch
- * (walk) instead of LDS.  Why here: what the hand-over costs in the pipeline is the common case, in which nothing is
- * handed over.  A launch of its own behind k_octree_v3 sits in the context's chain of kernels, and as a 1024-thread
- * workgroup that needs every register of a CU it waits for a CU to drain of the other contexts' waves (53 us under
- * load as a full grid of early-exit workgroups, 6 % of the mono rate; 3.5 % even as eight 256-thread workgroups, which
- * still ask for 60 KB of LDS each).  Inlined into k_octree_v3 it takes that kernel from 104 to 128 allocated VGPRs, i.e.
- * the last free registers of its CUs (5 %); called from it, it brings a stack, and a kernel with scratch memory ran
- * 134 instead of 78 us.  This kernel is launched anyway, its 256-thread workgroups fit next to anything, and the
- * registers the rare path adds cost one wave slot per SIMD. */
 __global__ void __launch_bounds__(AO_T)
 k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
-             int lap0, int lap1, SelKp* sel, int32_t* slot_counts /* [slot][4]: n, mono, 0, 0 */, int cap,
-             int32_t* err_flag, const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a,
-             size_t pts_stride, const int32_t* redo_flags, uint8_t* walk, size_t walk_stride) {
+             int lap0, int lap1, SelKp* sel, int32_t* slot_counts /* [slot][4]: n, mono, deep-level mask, 0 */, int cap,
+             int32_t* err_flag, const int32_t* deep_flags) {
     __shared__ uint32_t s_w32[AO_T / 64];
     __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
     const int tid = threadIdx.x, slot = blockIdx.x;
     const int L = g.nlevels;
-    uint32_t redo_mask = 0; /* levels of this slot that k_octree_v3 handed over (slot_counts[slot][2]: vslam_fe_octree_stats) */
-    if (walk) {
-        __shared__ int s_walk_ctl[4];
-        int mine = 0;
-        if (tid < L) mine = redo_flags[slot * VSLAM_MAX_LEVELS + tid] != 0;
-        if (tid == 0)
-            for (int lv = 0; lv < L; lv++) redo_mask |= redo_flags[slot * VSLAM_MAX_LEVELS + lv] ? 1u << lv : 0u;
-        if (__syncthreads_or(mine)) { /* rare */
-            for (int lv = 0; lv < L; lv++) {
-                if (!redo_flags[slot * VSLAM_MAX_LEVELS + lv]) continue; /* block-uniform */
-                oct_walk_body<AO_T, false>(cand_region, cand_stride, ncells, oct_walk_level(P, lv), lv, slot, pts_a, nid_a, pts_stride,
-                                           sel_xyr, sel_cnt, err_flag, walk + (size_t)slot * walk_stride, s_w32, s_walk_ctl);
-                __syncthreads(); /* results (global memory) visible to the whole workgroup; scratch reused by the next level */
-            }
-        }
-    }
+    uint32_t redo_mask = 0; /* levels of this slot on which k_octree_v4 split nodes finer than its grid (vslam_fe_octree_stats) */
+    if (deep_flags && tid == 0)
+        for (int lv = 0; lv < L; lv++) redo_mask |= deep_flags[slot * VSLAM_MAX_LEVELS + lv] ? 1u << lv : 0u;
     if (tid == 0) {
         int acc = 0;
         for (int l = 0; l < L; l++) {
@@ -1161,57 +1117,48 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
 size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 8 + 8 + 2 + 2 + 2 + 2) + 64; }
 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
-               uint32_t* pts_a, uint32_t* pts_b, uint16_t* nid_a, uint16_t* nid_b, size_t pts_stride,
-               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, uint32_t* fine,
-               int32_t* redo_flags, int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */) {
-    (void)pts_b;
-    (void)nid_b;
+               uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
+               uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
+               int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */) {
     const dim3 grid(nslots, nlevels);
-    if (fine && redo_flags) /* k_octree_v3; problems its fine grid cannot resolve are flagged and redone by k_assign_out */
+    if (P.lut && deep_flags) /* k_octree_v4 */
     {
-        /* Keys in registers save the second key walk its re-read (46 KB per KITTI level, L2 hits), at 24 VGPRs per thread:
-         * 104 instead of 80 allocated, and a 1024-thread workgroup at 104 leaves room for ONE 64-register wave per SIMD
-         * next to it, at 80 for three.  With several contexts in flight the neighbours matter more than the re-read
-         * (VSLAM_OCT_REGKEYS=0|1 overrides; default: registers only for single images, where latency is what counts). */
+        /* Keys in registers save walk 2 its re-read, at 32 VGPRs per thread; a 1024-thread workgroup then leaves less room
+         * for foreign waves on its CU.  With several contexts in flight the neighbours matter more than the re-read
+         * (default: registers only for one or two images, where latency is what counts). */
         const bool rk = regkeys < 0 ? nslots <= 2 : regkeys == 1;
-        const size_t lds = P.fineLdsOff ? (size_t)P.fineLdsOff + (size_t)P.fineLdsBytes : vk_octree_lds_bytes(P.maxNodes);
-#define OCT3_LAUNCH(RK_, FL_)                                                                                                   \
-    hipLaunchKernelGGL((k_octree_v3<RK_, FL_>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, pts_a, nid_a, pts_stride, \
-                       fine, sel_xyr, sel_cnt, err_flag, redo_flags)
-        if (P.fineLdsOff && P.fineLdsMode == 1) {
-            if (rk) OCT3_LAUNCH(true, 1);
-            else OCT3_LAUNCH(false, 1);
-        } else if (P.fineLdsOff && P.fineLdsMode == 2) {
-            if (rk) OCT3_LAUNCH(true, 2);
-            else OCT3_LAUNCH(false, 2);
-        } else {
-            if (rk) OCT3_LAUNCH(true, 0);
-            else OCT3_LAUNCH(false, 0);
-        }
-#undef OCT3_LAUNCH
+        const size_t lds = (size_t)P.fineLdsOff + (size_t)P.fineLdsBytes;
+        if (rk)
+            hipLaunchKernelGGL((k_octree_v4<true>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a,
+                               (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags);
+        else
+            hipLaunchKernelGGL((k_octree_v4<false>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a,
+                               (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags);
     }
     else
         hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
-                           pts_a, nid_a, pts_stride, sel_xyr, sel_cnt, err_flag);
+                           keys_a, nid_a, pts_stride, sel_xyr, sel_cnt, err_flag);
 }
 
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
-                   const uint8_t* cand_region, size_t cand_stride, int ncells, uint32_t* pts_a, uint16_t* nid_a, size_t pts_stride,
-                   const int32_t* redo_flags, uint8_t* walk, size_t walk_stride) {
+                   const int32_t* deep_flags) {
     hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(AO_T), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
-                       slot_counts, cap, err_flag, cand_region, cand_stride, ncells, pts_a, nid_a, pts_stride, redo_flags,
-                       redo_flags ? walk : (uint8_t*)nullptr, walk_stride);
+                       slot_counts, cap, err_flag, deep_flags);
 }
 
+/* hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION, shared by every context of the process: only
+ * ever raise it (a small context created after a large one must not lower the limit the large one launches with) */
 int vk_octree_set_max_lds(size_t bytes) {
-    int rc = (int)hipFuncSetAttribute((const void*)k_octree_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc) return rc;
-    const void* fns[6] = {(const void*)k_octree_v3<true, 0>, (const void*)k_octree_v3<false, 0>, (const void*)k_octree_v3<true, 1>,
-                          (const void*)k_octree_v3<false, 1>, (const void*)k_octree_v3<true, 2>, (const void*)k_octree_v3<false, 2>};
-    for (int i = 0; i < 6; i++) {
-        rc = (int)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static std::mutex mu;
+    static size_t have = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes <= have) return 0;
+    const void* fns[3] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true>, (const void*)k_octree_v4<false>};
+    for (int i = 0; i < 3; i++) {
+        const int rc = (int)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (rc) return rc;
     }
+    have = bytes;
     return 0;
 }

@@ -31,8 +31,6 @@ const EnvField kEnv[] = {
     TF("VSLAM_OCT_DBG", oct_debug, nullptr, nullptr),
     TF("VSLAM_GRAPH", graphs, nullptr, nullptr),
     TF("VSLAM_H2D", h2d_route, "pull", "sdma"),
-    TF("VSLAM_COPY_STREAMS", copy_streams, nullptr, nullptr),
-    TF("VSLAM_STAGE_AHEAD", stage_ahead, nullptr, nullptr),
     TF("VSLAM_D2H", d2h_route, "kernel", "sdma"),
     TF("VSLAM_COPY_WGS", copy_wgs, nullptr, nullptr),
     TF("VSLAM_PULL_DEPTH", pull_depth, nullptr, nullptr),
