@@ -37,8 +37,13 @@ sys.path.insert(0, ROOT)
 # Several extractor contexts (HIP streams) are kept in flight; with the runtime's default of 4 hardware
 # queues two of them end up behind each other on one queue (measured: 29k -> 38k frames/s with 8).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL / cross-process device memory need dmabuf IPC on this stack; must be in the environment of EVERY rank process before
+# the HIP runtime loads (torch import), whoever launched it (the driver's torch.distributed.run or self_launch below)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-VALU_NS_PER_WAVE_INST, NUM_SIMDS = 1.77, 1024  # measured issue time of a wave64 VALU instruction; 256 CUs x 4 SIMDs
+# issue time of a wave64 VALU instruction of the classes the FAST kernel is made of (packed 16-bit, v_perm, v_alignbyte, v_cmp,
+# v_mbcnt, DPP/SDWA forms: 4 cycles per SIMD at ~2.26 GHz; profiles/r03_issue_rate_probe.txt); 256 CUs x 4 SIMDs
+VALU_NS_PER_WAVE_INST, NUM_SIMDS = 1.77, 1024
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
@@ -50,12 +55,15 @@ WORKLOADS = {
     "kitti00_stereo_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True),
     # configs[4]: synthetic 1920x1080 stream, 4000 features/frame
     "synthetic_stereo_1920x1080_n4000": dict(w=1920, h=1080, nf=4000, stereo=True),
+    # SURVEY.md 8(d) "real-image sanity point": the reference's own hut_stereo PNGs (752x480; tests/golden/real_images.npz),
+    # pairs (01,02) (03,04) (04,05) cycled; fx from hut_stereo.json, the baseline is a bench parameter
+    "hut_stereo_752x480_n1200_real": dict(w=752, h=480, nf=1200, stereo=True, real="hut", bf=822.5 * 0.4, fx=822.5),
     # SURVEY.md 8(f) rank 1, the per-frame tracking front-end of TrackWithMotionModel: stereo frame construction +
     # UnprojectStereo + SearchByProjection(frame, previous frame); every rank follows its own sequence
     "kitti00_stereo_track_1241x376_n2000": dict(w=1241, h=376, nf=2000, stereo=True, track=True),
 }
 HEADLINE = "kitti00_mono_1241x376_n1000"
-EXTRAS = ["kitti00_stereo_1241x376_n2000", "synthetic_stereo_1920x1080_n4000"]
+EXTRAS = ["kitti00_stereo_1241x376_n2000", "synthetic_stereo_1920x1080_n4000", "hut_stereo_752x480_n1200_real"]
 BF, FX = 386.1448, 718.856  # config/KITTI00-Stereo.yaml Camera.bf, Camera.fx
 FY, CX, CY = 718.856, 607.1928, 185.2157
 TRACK_Z = 12.0  # the synthetic scene moves (+3,+1) px per frame; as a camera translation at this depth
@@ -93,6 +101,16 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def real_frames(cfg):
+    """the hut_stereo frames as L,R,L,R,... (three pairs; the generator of the fixture is tests/golden/make_golden.py)"""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "real_images.npz"))
+    out = []
+    for a, b in (("hut1", "hut2"), ("hut3", "hut4"), ("hut4", "hut5")):
+        out += [np.ascontiguousarray(z[a]), np.ascontiguousarray(z[b])]
+    return out
+
+
 def level_pixels(fe):
     return [fe.level_size(l)[0] * fe.level_size(l)[1] for l in range(fe.nlevels)]
 
@@ -109,9 +127,12 @@ def pmc_traffic(kernel, cfg, batch):
     FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of a coalesced
     stream (MI355X_MICROARCH.md 'HBM'); the factor 2 is applied here.  Only valid for the geometry / batch /
     feature count the profile was taken with; otherwise None."""
-    name = "r02_pmc_traffic_%dx%d_n%d_b%d.json" % (cfg["w"], cfg["h"], cfg["nf"], batch)
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
+    for rnd in ("r03", "r02"):  # the newest committed summary for this geometry
+        name = "%s_pmc_traffic_%dx%d_n%d_b%d.json" % (rnd, cfg["w"], cfg["h"], cfg["nf"], batch)
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return None
     k = json.load(open(path))["kernels"].get(kernel.split("(")[0])
     if not k or "fetch_bytes_raw" not in k or "write_bytes" not in k:
@@ -131,10 +152,16 @@ def cpu_baseline(cfg, seconds=12.0, all_seconds=8.0):
     from oracle import orbo
     from vi_slam_amd import synth
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    bf, fx = cfg.get("bf", BF), cfg.get("fx", FX)
     nsample = 6 if w * h < 1000000 else 3
     frames = 0
     if stereo:
-        pairs = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
+        if cfg.get("real"):
+            rf = real_frames(cfg)
+            pairs = [(rf[2 * j], rf[2 * j + 1]) for j in range(len(rf) // 2)]
+            nsample = len(pairs)
+        else:
+            pairs = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
         eL, eR = orbo.Extractor(nf), orbo.Extractor(nf)
         pool = ThreadPoolExecutor(2)
         prev_track = None
@@ -145,7 +172,7 @@ def cpu_baseline(cfg, seconds=12.0, all_seconds=8.0):
             fl = pool.submit(eL.compute, L)
             fr = pool.submit(eR.compute, R)
             (kL, dL, _), (kR, dR, _) = fl.result(), fr.result()
-            uR, depth = orbo.stereo(eL, eR, kL, dL, kR, dR, BF, FX)[:2]
+            uR, depth = orbo.stereo(eL, eR, kL, dL, kR, dR, bf, fx)[:2]
             if cfg.get("track"):
                 T0 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
                 x3, has = orbo.unproject_stereo(kL, depth, T0, CX, CY, 1.0 / FX, 1.0 / FY)
@@ -157,8 +184,8 @@ def cpu_baseline(cfg, seconds=12.0, all_seconds=8.0):
                 prev_track = (kL.copy(), dL.copy(), x3, has)
             frames += 1
         cores = 2
-        sample = "%d synthetic stereo frames %dx%d, %d features: 2 threads extract L/R + ComputeStereoMatches%s" % (
-            frames, w, h, nf, " + UnprojectStereo + SearchByProjection(prev frame)" if cfg.get("track") else "")
+        sample = "%d %s stereo frames %dx%d, %d features: 2 threads extract L/R + ComputeStereoMatches%s" % (
+            frames, "real (hut_stereo)" if cfg.get("real") else "synthetic", w, h, nf, " + UnprojectStereo + SearchByProjection(prev frame)" if cfg.get("track") else "")
     else:
         imgs = [synth.make_frame(w, h, step=s) for s in range(nsample)]
         e = orbo.Extractor(nf)
@@ -189,9 +216,14 @@ def cpu_baseline_all_cores(cfg, seconds=8.0):
     from oracle import orbo
     from vi_slam_amd import synth
     w, h, nf, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    bf, fx = cfg.get("bf", BF), cfg.get("fx", FX)
     ncores = max(1, min(os.cpu_count() or 1, 64))
     nsample = 3
-    if stereo:
+    if stereo and cfg.get("real"):
+        rf = real_frames(cfg)
+        data = [(rf[2 * j], rf[2 * j + 1]) for j in range(len(rf) // 2)]
+        nsample = len(data)
+    elif stereo:
         data = [synth.make_stereo_pair(w, h, step=s) for s in range(nsample)]
     else:
         data = [synth.make_frame(w, h, step=s) for s in range(nsample)]
@@ -205,7 +237,7 @@ def cpu_baseline_all_cores(cfg, seconds=8.0):
                 L, R = data[n % nsample]
                 kL, dL, _ = e.compute(L)
                 kR, dR, _ = e2.compute(R)
-                orbo.stereo(e, e2, kL, dL, kR, dR, BF, FX)
+                orbo.stereo(e, e2, kL, dL, kR, dR, bf, fx)
             else:
                 k, d, _ = e.compute(data[n % nsample], lap=(0, 1000))
                 if prev is not None:
@@ -257,7 +289,11 @@ class Pipeline:
         ndistinct = B if w * h < 1000000 else min(B, 16)  # 1080p frames are slow to synthesise; cycled
         self.ndistinct = ndistinct
         frames = []
-        for s in range(ndistinct):
+        self.bf, self.fx = cfg.get("bf", BF), cfg.get("fx", FX)
+        if cfg.get("real"):
+            frames = real_frames(cfg)
+            ndistinct = self.ndistinct = len(frames)
+        for s in range(0 if cfg.get("real") else ndistinct):
             if self.track:  # one contiguous sequence per rank
                 fr = synth.make_frame(w, h, seed=20250215 + rank, step=s // 2, right=bool(s & 1))
             elif self.stereo:
@@ -284,6 +320,7 @@ class Pipeline:
         # buffer of its own, so that a context may start its next extraction without waiting for that matcher
         self.carry = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(0 if self.multi else self.NCTX)]
         self.state = {"matches": 0}
+        self.stamps = None  # timed(): host time at which every step's results were delivered
         self.job_cache = {}
         self.track_Twc = [np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)] * (B // 2)
         self.track_cam = (CX, CY, float(np.float32(1.0) / np.float32(FX)), float(np.float32(1.0) / np.float32(FY)))
@@ -332,13 +369,21 @@ class Pipeline:
         ptrs, pitch = self._imgs(k)
         where = self.where
         if where == V.IMGS_PINNED:
-            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream.
+            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream, and the uploads of
+            # consecutive steps form ONE event chain: upload t+1 starts when upload t has landed.  Without the chain two
+            # contexts that happen to upload at the same time share the link, finish together, compute together and come
+            # back to the link together -- a phase the pipeline stayed locked in for whole runs (79 k vs 106 k mono
+            # frames/s between runs in round 2); chained, the contexts stagger by one upload time and the link never idles
+            # while the GPU still has work.
+            if t > 0 and self.args.upload_chain:
+                c.event_wait(prv, 2)
             c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
+            c.event_record(2)
             where = V.IMGS_STAGED
         if self.track:
             npairs = B // 2
             c.event_wait(nxt, 1)  # nxt's matcher (step t-NCTX+1) read our last frame: it must finish first
-            c.frame_stereo_async(ptrs, pitch, BF, FX, where=where)
+            c.frame_stereo_async(ptrs, pitch, self.bf, self.fx, where=where)
             c.stereo_points_async(self.track_Twc, self.track_cam)  # UnprojectStereo of every left keypoint
             c.event_record(0)
             ck = (k, t == 0)
@@ -364,7 +409,7 @@ class Pipeline:
             st.setdefault("njobs", {})[t] = njobs
             return
         if self.stereo:
-            c.frame_stereo_async(ptrs, pitch, BF, FX, where=where)
+            c.frame_stereo_async(ptrs, pitch, self.bf, self.fx, where=where)
             return
         # The extraction overwrites only this context's own result slots, which nobody else reads: what the matcher of
         # the NEXT step (context nxt, step t-NCTX+1) read from us is the carry / exchange buffer, so only the copy into
@@ -374,7 +419,15 @@ class Pipeline:
         c.event_wait(nxt, 1)
         if self.multi:  # the right neighbour needs this rank's last frame: pack it and shift it round the ring
             c.pack_slots(1, self.packed[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
+            # One exchange at a time per rank, in step order on every rank: step t's shift starts when step t-1's has
+            # finished (a GPU-side event between the two contexts' streams).  Each lane has its own communicator so that
+            # RCCL does not serialise whole streams, but operations of SEVERAL communicators in flight at once are only
+            # safe if every rank can run them all concurrently; the chain removes the question (the matcher of step t
+            # waits for step t-1's results anyway).
+            if t > 0 and self.args.exchange_chain:
+                c.event_wait(prv, 3)
             self.xchg.exchange(c, self.packed[k], self.recv[k], lane=k)  # RCCL: enqueued on c's own stream (no host sync)
+            c.event_record(3)
         else:
             c.pack_slots(1, self.carry[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
         c.event_record(0)  # step t's results (own, and the left neighbour's / the carried last frame) are complete
@@ -441,6 +494,8 @@ class Pipeline:
                 self.state["enq_s"] = self.state.get("enq_s", 0.0) + time.perf_counter() - t_e
             if 0 <= t - (NCTX - 1) < nsteps:
                 self.collect(t - (NCTX - 1))
+                if self.stamps is not None:
+                    self.stamps.append(time.perf_counter())  # step t - (NCTX - 1) delivered
 
     # -------------------------------------------------------------------------------------------- timing
     def timed(self, steps, warmup, min_seconds):
@@ -461,10 +516,12 @@ class Pipeline:
         for c in self.ctxs:
             c.set_profiling(True)
         env["barrier"]()
+        self.stamps = []
         t0 = time.perf_counter()
         self.run(steps * reps)
         env["barrier"]()
         dt = env["max_over_ranks"](time.perf_counter() - t0)
+        stamps, self.stamps = self.stamps, None
         prof = {}
         for c in self.ctxs:
             for k, v in c.get_profile().items():
@@ -472,7 +529,15 @@ class Pipeline:
             c.set_profiling(False)
         frames_per_step = (self.B // 2 if self.stereo else self.B) * env["world"]
         n = steps * reps
+        # spread over the repeats: the rate of every block of `steps` consecutive steps (delivery time stamps of this rank;
+        # the first block also carries the pipeline's fill)
+        blocks = [frames_per_step * steps / (stamps[(r + 1) * steps - 1] - stamps[r * steps - 1]) for r in range(1, reps)
+                  if stamps[(r + 1) * steps - 1] > stamps[r * steps - 1]]
+        blocks.sort()
+        spread = ({"min": blocks[0], "median": blocks[len(blocks) // 2], "max": blocks[-1], "blocks": len(blocks)}
+                  if blocks else None)
         return {"value": frames_per_step * n / dt, "ms_per_step": dt / n * 1e3, "reps": reps, "seconds": dt, "prof": prof,
+                "spread": spread,
                 "host_ms_per_step": {k: v / n * 1e3 for k, v in zip(("enqueue", "wait_step", "fetch_matches"),
                                                                    [self.state.get("enq_s", 0.0)] + self.state.get("host_s", [0, 0]))}}
 
@@ -486,7 +551,7 @@ class Pipeline:
             if i == passes:
                 c0.set_profiling(True)
             if self.stereo:
-                c0.frame_stereo_async(self.dev_ptrs, self.pitch, BF, FX)
+                c0.frame_stereo_async(self.dev_ptrs, self.pitch, self.bf, self.fx)
                 c0.frame_stereo_wait()
             else:
                 c0.compute_batch_async(self.dev_ptrs, self.pitch, self.lap)
@@ -538,6 +603,25 @@ def roofline_of(pl, stage_alone, stage_pipe, res_dev):
     return rl, detail
 
 
+def link_probe(nbytes):
+    """Host-to-device rate of the link as this process sees it: hipMemcpyAsync of one pinned block of a step's size on an
+    otherwise idle GPU (the DMA engines; median of 9).  The denominator of roofline_pcie."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for i in range(12):
+        e0.record()
+        b.copy_(a, non_blocking=True)
+        e1.record()
+        e1.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return nbytes / (ts[len(ts) // 2] * 1e-3) / 1e9
+
+
 def run_workload(name, args, env, want_cpu, cpu_seconds):
     pl = Pipeline(name, args, env)
     try:
@@ -553,7 +637,33 @@ def run_workload(name, args, env, want_cpu, cpu_seconds):
         main = res.get("device") or res["pinned"]
         out = {"workload": name, "value": main["value"] if "device" in res else None,
                "value_host_inputs": res["pinned"]["value"] if "pinned" in res else None,
-               "ms_per_step": main["ms_per_step"], "timed_repeats": main["reps"], "timed_seconds": main["seconds"]}
+               "ms_per_step": main["ms_per_step"], "timed_repeats": main["reps"], "timed_seconds": main["seconds"],
+               "spread": main.get("spread"), "spread_host_inputs": res["pinned"].get("spread") if "pinned" in res else None}
+        if "pinned" in res and env["rank"] == 0:
+            # the PCIe roofline of the host-input figure: image bytes that cross the link per second against what one
+            # hipMemcpyAsync of a step's images achieves alone on this box, measured here
+            img_bytes = pl.cfg["w"] * pl.cfg["h"] * (2 if pl.stereo else 1)
+            step_bytes = pl.cfg["w"] * pl.cfg["h"] * pl.B
+            peak = link_probe(step_bytes)
+            ach = res["pinned"]["value"] / env["world"] * img_bytes / 1e9
+            out["roofline_pcie"] = {"bound": "pcie_h2d", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                                    "bytes_per_frame": img_bytes, "peak_source": "hipMemcpyAsync of one step's images, idle GPU, this run"}
+        if pl.multi:  # the exchange step alone: every rank enqueues the same 50 shifts of its last packed slot and waits once
+            pl.torch.cuda.synchronize()
+            env["barrier"]()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                pl.xchg.exchange(pl.ctxs[0], pl.packed[0], pl.recv[0], lane=0)
+            pl.torch.cuda.synchronize()
+            out["exchange"] = {"us_per_exchange_alone": env["max_over_ranks"]((time.perf_counter() - t0) / 50 * 1e6),
+                               "bytes": pl.slot_bytes, "mode": pl.xchg.mode, "transport": pl.xchg.transport,
+                               "lanes": len(pl.xchg.comms) if pl.xchg.comms else 0}
+        if pl.cfg.get("real"):
+            prob, deep = 0, 0
+            for c in pl.ctxs:
+                a, b, _ = c.octree_stats()
+                prob, deep = prob + a, deep + b
+            out["quadtree"] = {"problems": prob, "split_below_grid": deep, "share": deep / max(prob, 1)}
         detail = {"workload": name, "matches_last_step_rank0": pl.state["matches"],
                   "track_matches_last_step_rank0": pl.state.get("track_matches"),
                   "host_ms_per_step": main["host_ms_per_step"],
@@ -595,6 +705,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=4, help="extractor contexts (HIP streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only")
+    ap.add_argument("--no-exchange-chain", dest="exchange_chain", action="store_false",
+                    help="N>1: let the lanes' exchanges overlap instead of ordering them by events (A/B)")
+    ap.add_argument("--no-upload-chain", dest="upload_chain", action="store_false",
+                    help="host inputs: do not chain the steps' uploads by events (A/B: the phase-locking of round 2)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -694,14 +808,23 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "inputs": "value: frames in HBM; value_host_inputs: frames in pinned host memory, H2D inside the step; results D2H in both",
+            "inputs": ("value: frames resident in HBM when the timed region starts (the bench contract's definition); value_host_inputs: "
+                       "the SURVEY 8(d) span -- frames in pinned host memory, H2D over PCIe inside the step (roofline_pcie); results D2H in both"),
             "value_device_inputs": sig(head["value"], 6),
             "value_host_inputs": sig(head["value_host_inputs"], 6),
+            "spread": {k: sig(v) for k, v in (head.get("spread") or {}).items()},
+            "spread_host_inputs": {k: sig(v) for k, v in (head.get("spread_host_inputs") or {}).items()},
             "timed_repeats": head["timed_repeats"],
             "timed_seconds": sig(head["timed_seconds"], 4),
             "config": head["config"],
             "roofline": rl,
         }
+        if "exchange" in head:
+            line["exchange"] = {k: sig(v) for k, v in head["exchange"].items()}
+        if "roofline" in head:
+            line["hbm_gbps_per_rank"] = sig(head["roofline"].get("pipeline_gbps_per_rank"))
+        if "roofline_pcie" in head:
+            line["roofline_pcie"] = {k: sig(v) for k, v in head["roofline_pcie"].items()}
         if "cpu_baseline" in head:
             cb = head["cpu_baseline"]
             line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -716,6 +839,13 @@ def main():
             if "roofline" in r:
                 e["roofline"] = {k: sig(r["roofline"][k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                                    "avg_launch_ms", "pipeline_gbps_per_rank")}
+            if "roofline_pcie" in r:
+                e["roofline_pcie"] = {k: sig(r["roofline_pcie"][k]) for k in ("achieved", "peak", "unit", "frac")}
+            for k in ("spread", "spread_host_inputs"):
+                if r.get(k):
+                    e[k] = {a: sig(b, 4) for a, b in r[k].items() if a != "blocks"}
+            if "quadtree" in r:
+                e["quadtree"] = {k: sig(v, 3) for k, v in r["quadtree"].items()}
             if "cpu_baseline" in r:
                 cb = r["cpu_baseline"]
                 e["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],

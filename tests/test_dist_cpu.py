@@ -161,3 +161,58 @@ def test_bench_self_launch_propagates_failure():
                         "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+_DEAD_PEER_RANK = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[4])
+import torch.distributed as dist
+from vi_slam_amd import dist as vd
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+dist.init_process_group("gloo", rank=rank, world_size=world)
+if rank == world - 1:
+    os._exit(0)            # this rank dies before the set-up vote
+time.sleep(1.0)
+vd.SlotExchange.create(rank, world, 0, mode="ring", transport="gloo", setup_timeout=10.0)
+print("rank %d: create returned" % rank)
+'''
+
+
+def test_a_rank_that_dies_before_the_vote_makes_the_others_exit_nonzero(tmp_path):
+    """VERDICT r2 item 7(d): nothing may wait for ever in SlotExchange.create.  Three gloo ranks; the last one exits right
+    after the rendezvous; the other two must leave with a non-zero code well inside the timeout (either gloo reports the
+    lost peer in the vote's all-reduce, or the set-up deadline fires: vi_slam_amd.dist.EXIT_SETUP_TIMEOUT)."""
+    import time
+    script = tmp_path / "dead_peer_rank.py"
+    script.write_text(_DEAD_PEER_RANK)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 3
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), ROOT], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    codes, outs = [], []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+            o += "\n<<killed by the test after 90 s>>"
+        codes.append(p.returncode)
+        outs.append((o + e)[-500:])
+    assert codes[world - 1] == 0
+    for r in range(world - 1):
+        assert codes[r] not in (0, None) and codes[r] > 0, (r, codes, outs[r])
+        assert "create returned" not in outs[r]
+    assert time.time() - t0 < 80, codes
+
+
+def test_deadline_is_disarmed_when_the_setup_finishes():
+    with vd._Deadline(0.3, "a block that finishes in time", 0):
+        pass
+    import time
+    time.sleep(0.6)  # the watcher must not fire afterwards

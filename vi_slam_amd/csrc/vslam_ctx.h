@@ -81,9 +81,12 @@ struct vslam_fe {
     /* selection + outputs */
     SelKp* d_sel = nullptr;
     SelKp* h_sel = nullptr; /* pinned, B*cap */
-    vslam_kp* d_kps = nullptr;
+    uint8_t* d_res = nullptr;  /* the context's result block: counts (res_counts_bytes) | kps B*cap | desc B*cap*32 */
+    uint8_t* h_res = nullptr;  /* pinned mirror, same layout */
+    size_t res_bytes = 0, res_counts_bytes = 0;
+    vslam_kp* d_kps = nullptr; /* views into d_res / h_res */
     uint8_t* d_desc = nullptr;
-    vslam_kp* h_kps = nullptr; /* pinned staging, B*cap */
+    vslam_kp* h_kps = nullptr;
     uint8_t* h_desc = nullptr;
     int8_t* d_pattern = nullptr;
     BatchSrc src;

@@ -42,10 +42,8 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_blur_tasks);
     hipFree(fe->d_sel);
     if (fe->h_sel) hipHostFree(fe->h_sel);
-    hipFree(fe->d_kps);
-    hipFree(fe->d_desc);
-    if (fe->h_kps) hipHostFree(fe->h_kps);
-    if (fe->h_desc) hipHostFree(fe->h_desc);
+    hipFree(fe->d_res); /* d_counts, d_kps and d_desc are views into it; h_res likewise */
+    if (fe->h_res) hipHostFree(fe->h_res);
     hipFree(fe->d_pattern);
     hipFree(fe->d_part);
     hipFree(fe->d_idx2);
@@ -62,8 +60,6 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_sel_xyr);
     hipFree(fe->d_oct_redo);
     hipFree(fe->d_sel_cnt);
-    hipFree(fe->d_counts);
-    if (fe->h_counts) hipHostFree(fe->h_counts);
     if (fe->h_stereo) hipHostFree(fe->h_stereo);
     hipFree(fe->d_init);
     hipFree(fe->d_init_scratch);
@@ -298,12 +294,20 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     const size_t nk = (size_t)fe->B * fe->cap;
     HIPCHK(hipMalloc((void**)&fe->d_sel, nk * sizeof(SelKp)));
     HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_sel, nk * sizeof(SelKp)));
-    HIPCHK(hipMalloc((void**)&fe->d_kps, nk * sizeof(vslam_kp)));
-    HIPCHK(hipMalloc((void**)&fe->d_desc, nk * 32));
-    HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_kps, nk * sizeof(vslam_kp)));
-    HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_desc, nk * 32));
-    HIPCHK(hipMemset(fe->d_kps, 0, nk * sizeof(vslam_kp)));
-    HIPCHK(hipMemset(fe->d_desc, 0, nk * 32));
+    /* ONE result block per context -- counts | keypoints | descriptors, back to back -- and one pinned mirror of it: a
+     * full batch leaves the device in a single transfer (vslam_fe.hip: enqueue_extract_plain) */
+    fe->res_counts_bytes = (((size_t)(fe->B * 4 + 4) * 4) + 255) & ~(size_t)255;
+    fe->res_bytes = fe->res_counts_bytes + nk * sizeof(vslam_kp) + nk * 32;
+    HIPCHK(hipMalloc((void**)&fe->d_res, fe->res_bytes));
+    HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_res, fe->res_bytes));
+    HIPCHK(hipMemset(fe->d_res, 0, fe->res_bytes));
+    memset(fe->h_res, 0, fe->res_bytes);
+    fe->d_counts = (int32_t*)fe->d_res;
+    fe->h_counts = (int32_t*)fe->h_res;
+    fe->d_kps = (vslam_kp*)(fe->d_res + fe->res_counts_bytes);
+    fe->h_kps = (vslam_kp*)(fe->h_res + fe->res_counts_bytes);
+    fe->d_desc = fe->d_res + fe->res_counts_bytes + nk * sizeof(vslam_kp);
+    fe->h_desc = fe->h_res + fe->res_counts_bytes + nk * sizeof(vslam_kp);
 
     /* GPU quadtree distribution (k_octree): per-level parameters, key ping-pong arrays, result lists */
     {
@@ -401,10 +405,6 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 HIPCHK(hipMalloc((void**)&fe->d_nid, np * 2));
             }
         }
-        HIPCHK(hipMalloc((void**)&fe->d_counts, (size_t)(fe->B * 4 + 4) * 4));
-        HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_counts, (size_t)(fe->B * 4 + 4) * 4));
-        HIPCHK(hipMemset(fe->d_counts, 0, (size_t)(fe->B * 4 + 4) * 4));
-        memset(fe->h_counts, 0, (size_t)(fe->B * 4 + 4) * 4);
     }
 
     HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
@@ -1003,6 +1003,16 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
     /* results go to pinned host memory by a kernel (whole blocks: the host does not know the counts yet) */
     CopyRanges R;
     memset(&R, 0, sizeof(R));
+    if (want_host && fe->dev_octree && nimg == fe->B) {
+        /* a full batch: counts, keypoints and descriptors are one contiguous block -> ONE transfer */
+        R.dst[0] = fe->h_res;
+        R.src[0] = fe->d_res;
+        R.bytes[0] = fe->res_bytes;
+        R.n = 1;
+        vk_copy_ranges(st, R, fe->tune);
+        HIPCHK(hipGetLastError());
+        return VSLAM_OK;
+    }
     if (fe->dev_octree) {
         R.dst[R.n] = fe->h_counts;
         R.src[R.n] = fe->d_counts;

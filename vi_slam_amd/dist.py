@@ -18,9 +18,44 @@ kept as `mode="allgather"`.)  No other collective exists on this path.
 Which slot of which buffer holds a frame's predecessor (`predecessor`, `left_block`, `slot_view`) is the same
 code for both transports.
 """
+import os
+import sys
+import threading
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+#: exit code of a rank that gave up waiting for its peers while the exchange was being set up (see `_Deadline`)
+EXIT_SETUP_TIMEOUT = 70
+
+
+class _Deadline:
+    """Bounded wait for the collective set-up.  ncclCommInitRank, the probe's synchronize and the vote's all-reduce all
+    block for ever if a peer died before it got there, and none of them can be cancelled from Python; what can be bounded
+    is the PROCESS: if the guarded block has not finished after `seconds`, the rank says why and exits with
+    EXIT_SETUP_TIMEOUT (os._exit: no re-exec, no second attempt -- the launcher sees a non-zero rank and tears the job
+    down).  Disarmed on normal exit of the block."""
+
+    def __init__(self, seconds, what, rank):
+        self.seconds, self.what, self.rank = float(seconds), what, rank
+        self._done = threading.Event()
+
+    def __enter__(self):
+        def watch():
+            if not self._done.wait(self.seconds):
+                sys.stderr.write("vi_slam_amd.dist: rank %d gave up after %.0f s in %s -- a peer did not arrive; exiting %d\n"
+                                 % (self.rank, self.seconds, self.what, EXIT_SETUP_TIMEOUT))
+                sys.stderr.flush()
+                os._exit(EXIT_SETUP_TIMEOUT)
+        if self.seconds > 0:
+            threading.Thread(target=watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
 
 
 def global_frame(rank, slot, world, batch):
@@ -84,67 +119,81 @@ class SlotExchange:
         self.comms = list(comms or [])  # rccl: one communicator per lane (extractor context in flight)
 
     @classmethod
-    def create(cls, rank, world, device, mode="ring", transport="rccl", lanes=1):
+    def create(cls, rank, world, device, mode="ring", transport="rccl", lanes=1, setup_timeout=180.0, probe_limit=30.0):
         """Collective constructor (every rank calls it).  transport "rccl": rank 0 makes the ncclUniqueIds, they travel
         through torch.distributed's broadcast, every rank builds the library's communicators, and ONE probe exchange
         per communicator decides -- by an all-reduce every rank takes part in -- whether the transport works; a failed
-        probe is fatal (no collective is ever switched mid-run).
+        probe of the FIRST communicator is fatal (no collective is ever switched mid-run); a later lane that fails or
+        whose probe takes longer than `probe_limit` seconds on any rank ends the lane set-up and the exchange runs on the
+        lanes that passed (down to one).  The whole set-up is guarded by `setup_timeout` seconds (`_Deadline`): a rank
+        whose peers never arrive exits with EXIT_SETUP_TIMEOUT instead of sitting in ncclCommInitRank for ever.
         lanes: communicators to build.  RCCL orders the operations of ONE communicator across streams (each launch
         waits for the communicator's previous one), which couples extractor contexts that are otherwise independent:
         with one communicator for four contexts in flight the mono workload lost a quarter of its rate at world size 1.
-        exchange(..., lane=k) uses communicator k % lanes; every rank must use the same lane for the same step."""
-        if transport != "rccl":
-            return cls(rank, world, mode, "gloo" if dist.is_initialized() else "local")
-        import vi_slam_amd as V
-        ctl = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        lanes = max(1, int(lanes))
-        idt = torch.zeros(lanes * V.COMM_ID_BYTES, dtype=torch.uint8, device=ctl)
-        if rank == 0:
-            ids = b"".join(bytes(V.Comm.unique_id()) for _ in range(lanes))
-            idt.copy_(torch.frombuffer(bytearray(ids), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(idt, 0)
-        raw = bytes(idt.cpu().numpy().tobytes())
-        x = cls(rank, world, mode, "rccl", [])
-        for k in range(lanes):  # one communicator at a time, each followed by a vote: all ranks end up with the same number
-            ok, err, comm = 1.0, "", None
-            try:
-                comm = V.Comm(device, rank, world, raw[k * V.COMM_ID_BYTES:(k + 1) * V.COMM_ID_BYTES])
-                x.comms.append(comm)
-                ok = 1.0 if x._probe(device, k) else 0.0
-            except Exception as e:  # noqa: BLE001 - reported below, after every rank has voted
-                ok, err = 0.0, str(e)
+        exchange(..., lane=k) uses communicator k % lanes; every rank must use the same lane for the same step.
+        Several communicators with operations in flight on different streams need all those kernels to be able to
+        co-reside on the GPU (RCCL's documented condition): the exchanges here are ONE send/recv pair of <= 125 KB per
+        lane, one workgroup each, next to kernels that never fill more than their own wave slots."""
+        with _Deadline(setup_timeout, "SlotExchange.create (%s, world %d)" % (transport, world), rank):
+            if transport != "rccl":
+                x = cls(rank, world, mode, "gloo" if dist.is_initialized() else "local")
+                if world > 1 and dist.is_initialized():  # every rank is here and its group works: one vote, as for rccl
+                    t = torch.tensor([1.0], dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return x
+            import vi_slam_amd as V
+            ctl = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            lanes = max(1, int(lanes))
+            idt = torch.zeros(lanes * V.COMM_ID_BYTES, dtype=torch.uint8, device=ctl)
+            if rank == 0:
+                ids = b"".join(bytes(V.Comm.unique_id()) for _ in range(lanes))
+                idt.copy_(torch.frombuffer(bytearray(ids), dtype=torch.uint8))
             if world > 1:
-                t = torch.tensor([ok], dtype=torch.float64, device=ctl)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                ok = float(t.item())
-            if not ok:
-                if comm is not None:
-                    x.comms.pop()
-                    comm.close()
-                if k == 0:
-                    raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
-                if rank == 0:
-                    print("SlotExchange: communicator %d of %d could not be set up on every rank (%s); continuing with %d"
-                          % (k + 1, lanes, err or "another rank", k), flush=True)
-                break
-        return x
+                dist.broadcast(idt, 0)
+            raw = bytes(idt.cpu().numpy().tobytes())
+            x = cls(rank, world, mode, "rccl", [])
+            fe = V.FExtractor(100, 1.2, 2, 20, 7, 128, 128, device=device, max_batch=1)  # ONE scratch stream context for all probes
+            try:
+                for k in range(lanes):  # one communicator at a time, each followed by a vote: all ranks end up with the same number
+                    ok, err, comm = 1.0, "", None
+                    t0 = time.perf_counter()
+                    try:
+                        comm = V.Comm(device, rank, world, raw[k * V.COMM_ID_BYTES:(k + 1) * V.COMM_ID_BYTES])
+                        x.comms.append(comm)
+                        ok = 1.0 if x._probe(fe, k) else 0.0
+                    except Exception as e:  # noqa: BLE001 - reported below, after every rank has voted
+                        ok, err = 0.0, str(e)
+                    took = time.perf_counter() - t0
+                    if ok and k > 0 and took > probe_limit:
+                        ok, err = 0.0, "lane %d took %.1f s to set up (limit %.0f s)" % (k, took, probe_limit)
+                    if world > 1:
+                        t = torch.tensor([ok], dtype=torch.float64, device=ctl)
+                        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                        ok = float(t.item())
+                    if not ok:
+                        if comm is not None:
+                            x.comms.pop()
+                            comm.close()
+                        if k == 0:
+                            raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
+                        if rank == 0:
+                            print("SlotExchange: communicator %d of %d could not be set up on every rank (%s); continuing with %d"
+                                  % (k + 1, lanes, err or "another rank", k), flush=True)
+                        break
+            finally:
+                fe.close()
+            return x
 
-    def _probe(self, device, lane=0):
+    def _probe(self, fe, lane=0):
         """One exchange of a stamped buffer on a scratch stream context: the left neighbour's stamp must arrive."""
-        import vi_slam_amd as V
-        fe = V.FExtractor(100, 1.2, 2, 20, 7, 128, 128, device=device, max_batch=1)
-        try:
-            n = 4096
-            send = torch.full((n,), self.rank + 1, dtype=torch.uint8, device="cuda")
-            recv = torch.zeros(n * (self.world if self.mode == "allgather" else 1), dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            self.exchange(fe, send, recv, lane)
-            torch.cuda.synchronize()  # the probe is the only place that waits for an exchange on the host
-            want = (self.rank - 1) % self.world + 1
-            return bool((self.left_block(recv) == want).all().item())
-        finally:
-            fe.close()
+        n = 4096
+        send = torch.full((n,), self.rank + 1, dtype=torch.uint8, device="cuda")
+        recv = torch.zeros(n * (self.world if self.mode == "allgather" else 1), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        self.exchange(fe, send, recv, lane)
+        torch.cuda.synchronize()  # the probe is the only place that waits for an exchange on the host
+        want = (self.rank - 1) % self.world + 1
+        return bool((self.left_block(recv) == want).all().item())
 
     # ------------------------------------------------------------------------------------------ the exchange
     def exchange(self, fe, send, recv, lane=0):
