@@ -369,14 +369,16 @@ class Pipeline:
         ptrs, pitch = self._imgs(k)
         where = self.where
         if where == V.IMGS_PINNED:
-            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream, and the uploads of
-            # consecutive steps form ONE event chain: upload t+1 starts when upload t has landed.  Without the chain two
-            # contexts that happen to upload at the same time share the link, finish together, compute together and come
-            # back to the link together -- a phase the pipeline stayed locked in for whole runs (79 k vs 106 k mono
-            # frames/s between runs in round 2); chained, the contexts stagger by one upload time and the link never idles
-            # while the GPU still has work.
-            if t > 0 and self.args.upload_chain:
-                c.event_wait(prv, 2)
+            # The PCIe upload of step t is enqueued at the head of the step, on the context's own stream, and the uploads are
+            # paced by an event chain of lag L (--upload-chain L): upload t starts when upload t-L has landed, so at most L
+            # are in flight.  Without any chain several contexts that happen to upload at the same time share the link,
+            # finish together, compute together and come back to the link together -- a phase the pipeline stayed locked
+            # in for whole runs in round 2 (79 k vs 106 k mono frames/s between runs); a strict chain (L = 1) is stable but
+            # leaves the link idle for the hand-over between two transfers (94.7 k, every run); L = 2 keeps a second
+            # transfer queued behind the running one.
+            lag = self.args.upload_chain
+            if lag > 0 and t >= lag:
+                c.event_wait(self.ctxs[(t - lag) % NCTX], 2)
             c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
             c.event_record(2)
             where = V.IMGS_STAGED
@@ -707,8 +709,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline workload only")
     ap.add_argument("--no-exchange-chain", dest="exchange_chain", action="store_false",
                     help="N>1: let the lanes' exchanges overlap instead of ordering them by events (A/B)")
-    ap.add_argument("--no-upload-chain", dest="upload_chain", action="store_false",
-                    help="host inputs: do not chain the steps' uploads by events (A/B: the phase-locking of round 2)")
+    ap.add_argument("--upload-chain", type=int, default=1,
+                    help="host inputs: upload of step t waits (GPU-side event) for the upload of step t-L; 0 = no pacing")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")

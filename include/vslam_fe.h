@@ -87,7 +87,10 @@ typedef struct vslam_tuning {
     int32_t wait_spin;            /* VSLAM_WAIT=spin: 1 = host waits poll hipStreamQuery instead of blocking */
     int32_t numa;                 /* VSLAM_NUMA: 0 = do not allocate pinned memory from the CPUs next to the device */
     int32_t host_prof;            /* VSLAM_HOST_PROF: 1 = host-side wall time per API phase, printed at destroy */
-    int32_t reserved[8];
+    int32_t stream_priority;      /* VSLAM_STREAM_PRIORITY: 0 normal, 1 low, 2 high (default) priority of the context's HIP stream: a
+                                     priority of its own gives the context hardware queues it does not share with the host
+                                     application's other streams */
+    int32_t reserved[7];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

@@ -407,7 +407,21 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         }
     }
 
-    HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+    {
+        /* The runtime multiplexes HIP streams onto a fixed number of hardware queues (GPU_MAX_HW_QUEUES), one pool per
+         * stream priority, least-used queue first.  In a process that already holds dozens of streams (torch, four RCCL
+         * communicators) two contexts ended up on ONE hardware queue and their passes ran one behind the other (mono
+         * 157 k -> 97 k frames/s, the kernel trace shows the shared queue id).  Streams of a priority of their own draw
+         * from a pool nobody else uses: the context's stream is created with high priority (stream_priority 2, the default;
+         * 1 = low, 0 = the default pool).  Measured: collective path at world size 1 97 k -> 143 k (high) / 141 k (low),
+         * the plain path unchanged at 157 k. */
+        const int pr = tune_or(fe->tune.stream_priority, 2);
+        int lo = 0, hi = 0;
+        if (pr != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HIPCHK(hipStreamCreateWithPriority(&fe->stream, hipStreamNonBlocking, pr == 1 ? lo : hi));
+        else
+            HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
+    }
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     fe->use_graph = fe->tune.graphs != 0; /* 0: never replay captured graphs */
     fe->sel_level.resize((size_t)fe->B * p.nlevels);

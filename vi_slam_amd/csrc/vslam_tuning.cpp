@@ -43,6 +43,7 @@ const EnvField kEnv[] = {
     TF("VSLAM_WAIT", wait_spin, "spin", nullptr),
     TF("VSLAM_NUMA", numa, nullptr, nullptr),
     TF("VSLAM_HOST_PROF", host_prof, nullptr, nullptr),
+    TF("VSLAM_STREAM_PRIORITY", stream_priority, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;

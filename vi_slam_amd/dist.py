@@ -178,7 +178,7 @@ class SlotExchange:
                             raise RuntimeError("rank %d: the RCCL exchange probe failed on at least one rank (%s)" % (rank, err or "another rank"))
                         if rank == 0:
                             print("SlotExchange: communicator %d of %d could not be set up on every rank (%s); continuing with %d"
-                                  % (k + 1, lanes, err or "another rank", k), flush=True)
+                                  % (k + 1, lanes, err or "another rank", k), file=sys.stderr, flush=True)
                         break
             finally:
                 fe.close()
