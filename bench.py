@@ -732,6 +732,12 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
 
+    # stdout carries ONE line, the result: whatever libraries print to file descriptor 1 from here on (RCCL's version banner
+    # under NCCL_DEBUG=VERSION, for one) goes to stderr; the JSON line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -741,7 +747,7 @@ def main():
         dist.all_reduce(t)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"launch_check": "ok", "world": world, "sum_of_ranks_plus_1": float(t.item())}))
+            os.write(result_fd, (json.dumps({"launch_check": "ok", "world": world, "sum_of_ranks_plus_1": float(t.item())}) + "\n").encode())
         dist.destroy_process_group()
         return
 
@@ -858,8 +864,8 @@ def main():
             extras.append(e)
         if extras:
             line["extra_workloads"] = extras
-        print(json.dumps(line))
         sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
         print(json.dumps({"bench_detail": details}), file=sys.stderr)
     if env.get("xchg"):
         env["xchg"].close()

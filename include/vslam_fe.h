@@ -263,6 +263,17 @@ int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batches, long* 
 int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
                        int32_t* idx2, int32_t* dist2);
 
+/* Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174), descriptor half: cv::BFMatcher(NORM_HAMMING).knnMatch of the
+ * lapping-area descriptors -- left rows [mono_left, n_left) against right rows [mono_right, n_right), k = 2 -- and the
+ * ratio test `m[0].distance < m[1].distance * 0.7` (a float times a double literal: compared in double).
+ * left_to_right[i] (n_left entries, host): index of the right keypoint (in the FULL right list, i.e. + mono_right) for every
+ * left keypoint that passes, else -1; best_dist / second_dist (nullable): the two Hamming distances; *n_candidates = the
+ * reference's descMatches.  The triangulation that decides mvLeftToRightMatch / mvDepth from these pairs
+ * (KannalaBrandt8::TriangulateMatches, :1176-1188) belongs to the camera model and stays with the caller. */
+int vslam_stereo_fisheye_candidates(vslam_fe* fe, const uint8_t* dev_desc_left, int n_left, int mono_left,
+                                    const uint8_t* dev_desc_right, int n_right, int mono_right, int32_t* left_to_right,
+                                    int32_t* best_dist, int32_t* second_dist, int* n_candidates);
+
 /* Dense distance matrix (nq x nt, uint8, 255 = distance >= 255) on the device -> host; used by the
  * order-dependent matchers whose sequential part is replayed on the host. */
 int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,

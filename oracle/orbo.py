@@ -246,6 +246,32 @@ def hamming_matrix(a, b):
     return out
 
 
+def stereo_fisheye_candidates(desc_left, mono_left, desc_right, mono_right):
+    """Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174) up to the ratio test, restated: cv::BFMatcher(NORM_HAMMING)
+    .knnMatch(left[mono_left:], right[mono_right:], k=2) -- the two smallest distances per query, equal distances in train
+    order (OpenCV's batchDistance keeps the first) -- then `m[0].distance < m[1].distance * 0.7` (float x double literal,
+    compared in double).  -> (left_to_right[n_left] with indices into the FULL right list or -1, best, second, descMatches).
+    The triangulation that follows (:1176-1188) is the camera model's (out of scope)."""
+    nl = len(desc_left)
+    l2r = np.full(nl, -1, np.int32)
+    d0 = np.full(nl, -1, np.int32)
+    d1 = np.full(nl, -1, np.int32)
+    q, t = desc_left[mono_left:], desc_right[mono_right:]
+    if len(q) == 0 or len(t) < 2:
+        return l2r, d0, d1, 0
+    dm = hamming_matrix(q, t).astype(np.int64)
+    order = np.argsort(dm, axis=1, kind="stable")[:, :2]
+    nc = 0
+    for i in range(len(q)):
+        a, b = int(order[i, 0]), int(order[i, 1])
+        fa, fb = np.float32(dm[i, a]), np.float32(dm[i, b])
+        if float(fa) < float(fb) * 0.7:
+            l2r[i + mono_left] = a + mono_right
+            d0[i + mono_left], d1[i + mono_left] = dm[i, a], dm[i, b]
+            nc += 1
+    return l2r, d0, d1, nc
+
+
 def distribute_octree(keys, minX, maxX, minY, maxY, N):
     keys = np.ascontiguousarray(keys, KP_DTYPE)
     out = np.zeros(len(keys) + 8, KP_DTYPE)

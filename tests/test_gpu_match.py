@@ -532,3 +532,42 @@ def test_matchers_on_tie_heavy_patterns(pattern, disp):
         assert nm == wn and np.array_equal(m12, wm) and np.array_equal(pm, wp)
     finally:
         fe.close()
+
+
+@pytest.mark.parametrize("lap", [(0, 0), (300, 900)])
+def test_stereo_fisheye_candidates_equal_knn_plus_ratio_test(fe, lap):
+    """Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174) up to the ratio test: knnMatch(k=2) of the lapping-area
+    descriptors (rows from monoIndex on: FExtractor::compute stores the lapping-area keypoints at the tail, :1118-1127) +
+    Lowe 0.7.  Synthetic pair and the reference's hut_stereo frames 01 / 02 (real pixels)."""
+    L, R = synth.make_stereo_pair(1241, 376, seed=5)
+    (kL, dL, mL), (kR, dR, mR) = fe.compute_batch([L, R], lap)
+    if lap == (0, 0):
+        assert mL == len(kL)  # nothing in the lapping area: every keypoint is "mono" -> match everything instead
+        mL = mR = 0
+    _, pd0, n0 = fe.slot_buffers(0)
+    _, pd1, n1 = fe.slot_buffers(1)
+    m = V.FMatcher(fe)
+    l2r, d0, d1, nc = m.ComputeStereoFishEyeCandidates(pd0, n0, mL, pd1, n1, mR)
+    wl, w0, w1, wn = orbo.stereo_fisheye_candidates(dL, mL, dR, mR)
+    assert nc == wn and nc > 50
+    assert np.array_equal(l2r, wl) and np.array_equal(d0, w0) and np.array_equal(d1, w1)
+    assert np.all(l2r[:mL] == -1) and np.all((l2r == -1) | (l2r >= mR))
+    # degenerate shapes: empty lapping area, a single right descriptor (knnMatch returns < 2 matches -> no candidate)
+    l2r, _, _, nc = m.ComputeStereoFishEyeCandidates(pd0, n0, n0, pd1, n1, mR)
+    assert nc == 0 and np.all(l2r == -1)
+    l2r, _, _, nc = m.ComputeStereoFishEyeCandidates(pd0, n0, mL, pd1, n1, n1 - 1)
+    assert nc == 0 and np.all(l2r == -1)
+
+
+def test_stereo_fisheye_candidates_on_the_reference_hut_frames():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_images.npz"))
+    f = V.FExtractor(1200, 1.2, 8, 20, 7, 752, 480, max_batch=2)
+    try:
+        (kL, dL, mL), (kR, dR, mR) = f.compute_batch([z["hut1"], z["hut2"]], (100, 650))
+        _, pd0, n0 = f.slot_buffers(0)
+        _, pd1, n1 = f.slot_buffers(1)
+        l2r, d0, d1, nc = V.FMatcher(f).ComputeStereoFishEyeCandidates(pd0, n0, mL, pd1, n1, mR)
+        wl, w0, w1, wn = orbo.stereo_fisheye_candidates(dL, mL, dR, mR)
+        assert nc == wn and nc > 20 and np.array_equal(l2r, wl) and np.array_equal(d0, w0) and np.array_equal(d1, w1)
+    finally:
+        f.close()

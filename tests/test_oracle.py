@@ -416,3 +416,33 @@ def test_fuse_search_hand_case():
     # the Sim3 overload has no chi2 gate
     bi4, _ = orbo.fuse_search(pts, md, kf, kd, ur_bad, sf, isig2, I3, z3, z3, (fx, fx, cx, cy, bf), 3.0, lsf, W, H, sim3=True)
     assert bi4[0] == 0
+
+
+def test_stereo_fisheye_candidates_hand_made_cases():
+    """frame.cpp:1149-1174 up to the ratio test: k = 2 nearest in train order on ties, `d0 < d1 * 0.7` in double,
+    indices offset by monoLeft / monoRight, fewer than two train rows -> no candidate."""
+    z = np.zeros((1, 32), np.uint8)
+
+    def with_bits(n):
+        d = np.zeros(32, np.uint8)
+        for b in range(n):
+            d[b // 8] |= 1 << (b % 8)
+        return d
+
+    right = np.stack([with_bits(10), with_bits(7), with_bits(7), with_bits(20)])
+    left = np.stack([with_bits(255), z[0], with_bits(7)])
+    # monoLeft = 1: query rows 1, 2.  row 1 (all zero): distances 10, 7, 7, 20 -> best 7 @1, second 7 @2: 7 < 4.9 false
+    # row 2 (7 bits): distances 3, 0, 0, 13 -> best 0 @1, second 0 @2: 0 < 0 false
+    l2r, d0, d1, nc = orbo.stereo_fisheye_candidates(left, 1, right, 0)
+    assert nc == 0 and list(l2r) == [-1, -1, -1]
+    # monoRight = 2: train rows 2, 3 -> row 1: 7, 20 -> 7 < 14 ok -> right index 2; row 2: 0, 13 -> ok -> 2
+    l2r, d0, d1, nc = orbo.stereo_fisheye_candidates(left, 1, right, 2)
+    assert nc == 2 and list(l2r) == [-1, 2, 2] and list(d0) == [-1, 7, 0] and list(d1) == [-1, 20, 13]
+    # the boundary of the ratio test: 10 * 0.7 rounds to exactly 7.0 in double -> 7 < 7.0 is false; 6 passes
+    r2 = np.stack([with_bits(7), with_bits(10)])
+    assert orbo.stereo_fisheye_candidates(z, 0, r2, 0)[3] == 0
+    r3 = np.stack([with_bits(10), with_bits(6)])
+    l2r, _, _, nc = orbo.stereo_fisheye_candidates(z, 0, r3, 0)
+    assert nc == 1 and list(l2r) == [1]
+    # a single train row: knnMatch returns one match per query -> `(*it).size() >= 2` fails
+    assert orbo.stereo_fisheye_candidates(left, 0, right, 3)[3] == 0

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_tuning_init", "vslam_fe_set_tuning",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
 ]
 
 
@@ -602,6 +602,20 @@ class FMatcher:
         dist = np.zeros((max(nq, 1), 2), np.int32)
         _check(lib().vslam_hamming_top2(self.fe._h, dev_q, nq, dev_t, nt, _p(idx), _p(dist)))
         return idx[:nq], dist[:nq]
+
+    def ComputeStereoFishEyeCandidates(self, dev_desc_left, n_left, mono_left, dev_desc_right, n_right, mono_right):
+        """Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174) up to the ratio test: -> (left_to_right[n_left],
+        best_dist, second_dist, descMatches)"""
+        l2r = np.zeros(max(n_left, 1), np.int32)
+        d0 = np.zeros(max(n_left, 1), np.int32)
+        d1 = np.zeros(max(n_left, 1), np.int32)
+        nc = C.c_int()
+        L = lib()
+        L.vslam_stereo_fisheye_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.vslam_stereo_fisheye_candidates(self.fe._h, dev_desc_left, n_left, mono_left, dev_desc_right, n_right,
+                                                 mono_right, _p(l2r), _p(d0), _p(d1), C.byref(nc)))
+        return l2r[:n_left], d0[:n_left], d1[:n_left], nc.value
 
     def hamming_matrix(self, dev_q, nq, dev_t, nt):
         out = np.zeros((max(nq, 1), max(nt, 1)), np.uint8)

@@ -1360,6 +1360,45 @@ extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, co
     return VSLAM_OK;
 }
 
+/* Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174), the descriptor half: BFmatcher.knnMatch(left rows
+ * [mono_left, n_left), right rows [mono_right, n_right), k = 2) + Lowe's ratio test.  What follows in the reference --
+ * KannalaBrandt8::TriangulateMatches per surviving pair (:1176-1188) -- is the camera model's and stays with the caller. */
+extern "C" int vslam_stereo_fisheye_candidates(vslam_fe* fe, const uint8_t* dev_desc_left, int n_left, int mono_left,
+                                               const uint8_t* dev_desc_right, int n_right, int mono_right,
+                                               int32_t* left_to_right, int32_t* best_dist, int32_t* second_dist,
+                                               int* n_candidates) {
+    if (!fe || !left_to_right || n_left < 0 || n_right < 0 || mono_left < 0 || mono_right < 0 || mono_left > n_left ||
+        mono_right > n_right || (n_left && !dev_desc_left) || (n_right && !dev_desc_right)) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    for (int i = 0; i < n_left; i++) {
+        left_to_right[i] = -1;
+        if (best_dist) best_dist[i] = -1;
+        if (second_dist) second_dist[i] = -1;
+    }
+    if (n_candidates) *n_candidates = 0;
+    const int nq = n_left - mono_left, nt = n_right - mono_right;
+    if (nq == 0) return VSLAM_OK;
+    std::vector<int32_t> idx2((size_t)nq * 2), dist2((size_t)nq * 2);
+    int rc = vslam_hamming_top2(fe, dev_desc_left + (size_t)mono_left * 32, nq, dev_desc_right + (size_t)mono_right * 32, nt,
+                                idx2.data(), dist2.data());
+    if (rc != VSLAM_OK) return rc;
+    int nc = 0;
+    for (int q = 0; q < nq; q++) {
+        if (idx2[2 * q] < 0 || idx2[2 * q + 1] < 0) continue; /* (*it).size() >= 2 */
+        /* DMatch::distance is a float; `distance * 0.7` is float x double: the comparison happens in double */
+        const float d0 = (float)dist2[2 * q], d1 = (float)dist2[2 * q + 1];
+        if (!((double)d0 < (double)d1 * 0.7)) continue;
+        left_to_right[q + mono_left] = idx2[2 * q] + mono_right;
+        if (best_dist) best_dist[q + mono_left] = dist2[2 * q];
+        if (second_dist) second_dist[q + mono_left] = dist2[2 * q + 1];
+        nc++;
+    }
+    if (n_candidates) *n_candidates = nc; /* the reference's descMatches */
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_hamming_matrix(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
                                     uint8_t* out) {
     if (!fe || nq < 0 || nt < 0 || (nq && nt && (!dev_q || !dev_t || !out))) {

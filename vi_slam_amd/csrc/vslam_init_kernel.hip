@@ -298,6 +298,7 @@ __device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const i
 /* ------------------------------------------------------------------------------------------------
  * phase B: one wave per pair, queries in index order.
  * ---------------------------------------------------------------------------------------------- */
+template <int MAXM> /* unrolled length of a query's sorted prefix: 8 (the default M) or SI_MAX_M */
 __global__ void __launch_bounds__(64)
 k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
             int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
@@ -312,13 +313,13 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     const SiQuery* gqry = (const SiQuery*)(gcand + max_c2);
     const uint32_t* topm = (const uint32_t*)(gqry + max_c2);
     const int c1 = hdr[0], c2 = hdr[1];
-    /* LDS: ownerDist | ownerEntry | log | m12 | kbuf | rotBin */
+    /* LDS: ownerDist | ownerEntry | log | m12 | markDp | rotBin */
     int32_t* ownerDist = (int32_t*)sism;            /* vMatchedDistance, max_c2 */
     int32_t* ownerEntry = ownerDist + max_c2;       /* log entry of the last query that took the slot */
     uint32_t* alog = (uint32_t*)(ownerEntry + max_c2); /* accepted (query position << 12 | slot), in order */
     int32_t* m12 = (int32_t*)(alog + max_c2);       /* vnMatches12, cap */
-    uint32_t* kbuf = (uint32_t*)(m12 + cap);        /* 64 queries x M keys */
-    uint8_t* rotBin = (uint8_t*)(kbuf + 64 * SI_MAX_M); /* bin of an accepted query, 255 = none */
+    int32_t* markDp = m12 + cap;                    /* rounds: smallest distance any lane of the round accepts the slot with */
+    uint8_t* rotBin = (uint8_t*)(markDp + max_c2);  /* bin of an accepted query, 255 = none */
     __shared__ int s_hist[SI_HISTO];
 
     int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
@@ -338,70 +339,135 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     __syncthreads();
 
     /* The sequential part carries ONE piece of state, vMatchedDistance (ownerDist): a query's decision needs
-     * nothing else.  Accepted (query, slot) pairs are appended to a log; ownership ("last acceptor wins", which
-     * is what the reference's steal/undo amounts to), vnMatches12 and the rotation histogram are rebuilt from
-     * the log in parallel afterwards.  The next query's keys and owner distances are fetched one iteration
-     * ahead (patched in registers when the current query takes one of those slots), so the loop never waits
-     * for LDS. */
+     * nothing else, and it reads that state only at the slots of its own M listed candidates.  So the queries are
+     * decided 64 at a time, lane = query, every lane against the state at the start of the round.  What can change a
+     * lane's decision is narrow: the decision is a function of its FIRST TWO non-skipped candidates (best and second
+     * best; skipped ones can never come back, vMatchedDistance only decreases), so it stands unless an EARLIER lane of
+     * the round accepts one of those two slots with a distance that makes it skipped for this lane (d_earlier <= d_mine).
+     * Accepting lanes publish (atomicMin) their lane number and their distance at their slot; a lane whose best or
+     * second-best slot shows a smaller lane number and a distance <= its own must wait (the two minima may come from
+     * different lanes: the test errs on the waiting side only).  The round commits the lanes in front of the first waiting
+     * lane -- in query order, which is lane order; two lanes taking the same slot in one round is fine, the later one's
+     * distance is the smaller one -- and starts again from it (it is then the first lane and cannot be overtaken, so every
+     * round commits at least one query).  A
+     * query whose sorted prefix ran out (rare: the re-scan of its whole window is a wave-cooperative loop) also ends a
+     * round and is then handled alone, as before.  Round 2 walked the queries one by one: ~0.4 us each for a single
+     * wave with nothing to hide its latencies behind, 90 us per pair of 220 queries; a round here costs about two of
+     * those steps and commits ten queries on average.
+     * Accepted (query, slot) pairs are appended to a log; ownership ("last acceptor wins", which is what the reference's
+     * steal/undo amounts to), vnMatches12 and the rotation histogram are rebuilt from the log in parallel afterwards. */
     const float r = (float)window;
     int nlog = 0, nfb = 0;
+    int32_t* mark = ownerEntry; /* during the rounds: smallest accepting lane per slot (INT_MAX: none); reset to -1 below */
+    for (int c = lane; c < c2; c += 64) {
+        mark[c] = 0x7FFFFFFF;
+        markDp[c] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    const unsigned long long lanes_before = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int qb = 0; qb < c1; qb += 64) {
         const int nq = min(64, c1 - qb);
-        __syncthreads();
-        for (int i = lane; i < nq * M; i += 64) kbuf[i] = topm[(size_t)qb * M + i];
-        __syncthreads();
-        uint32_t keyN = lane < M ? kbuf[lane] : 0xFFFFFFFFu;
-        uint32_t odN = keyN != 0xFFFFFFFFu ? (uint32_t)ownerDist[keyN & 0xFFF] : 0u;
-        for (int tq = 0; tq < nq; tq++) {
-            const uint32_t key = keyN, od = odN;
-            if (tq + 1 < nq) {
-                keyN = lane < M ? kbuf[(tq + 1) * M + lane] : 0xFFFFFFFFu;
-                odN = keyN != 0xFFFFFFFFu ? (uint32_t)ownerDist[keyN & 0xFFF] : 0u;
+        uint32_t key[MAXM];
+#pragma unroll
+        for (int j = 0; j < MAXM; j++) key[j] = (j < M && lane < nq) ? topm[(size_t)(qb + lane) * M + j] : 0xFFFFFFFFu;
+        unsigned long long done = nq < 64 ? ~0ull << nq : 0ull; /* wave-uniform */
+        while (done != ~0ull) {
+            const bool active = !((done >> lane) & 1ull);
+            /* ---- the reference's loop body (fmatcher.cpp:1003-1039) for this lane's query against the current state */
+            int nvalid = 0, first = -1, second = -1;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < MAXM; j++) {
+                    if (j < M && key[j] != 0xFFFFFFFFu) {
+                        nvalid++;
+                        const uint32_t od = (uint32_t)ownerDist[key[j] & 0xFFF];
+                        if (!(od <= (key[j] >> 24))) { /* not skipped: vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
+                            if (first < 0) first = j;
+                            else if (second < 0) second = j;
+                        }
+                    }
+                }
             }
-            const bool valid = key != 0xFFFFFFFFu;
-            const bool ok = valid && !(od <= (key >> 24)); /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
-            const unsigned long long mv = __ballot(valid), mk = __ballot(ok);
-            const bool full = __popcll(mv) == M;
+            const bool full = nvalid == M;
+            bool accept = false, scan = false;
             uint32_t gBest = 0xFFFFFFFFu, bestDist2 = 0x7FFFFFFFu;
-            bool need_scan = false;
-            if (mk == 0) {
-                if (!full) continue; /* vIndices2 empty or everything skipped: bestDist stays INT_MAX */
-                need_scan = true;
-            } else {
-                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-                gBest = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
-                if ((gBest >> 24) > SI_TH_LOW) continue; /* bestDist > TH_LOW */
-                const unsigned long long rest = mk & (mk - 1ull);
-                if (rest) {
-                    const int sec = __builtin_amdgcn_readfirstlane(__ffsll((long long)rest) - 1);
-                    bestDist2 = (uint32_t)__builtin_amdgcn_readlane((int)key, sec) >> 24;
-                } else if (full) {
-                    /* the second survivor lies beyond the list: it is at least as far as the last entry */
-                    const uint32_t dlast = (uint32_t)__builtin_amdgcn_readlane((int)key, M - 1) >> 24;
-                    if ((float)(int)(gBest >> 24) < __fmul_rn((float)(int)dlast, nnratio))
-                        bestDist2 = dlast; /* accepted whatever the true second is */
-                    else
-                        need_scan = true;
+            if (active) {
+                if (first < 0) {
+                    scan = full; /* !full: vIndices2 empty or everything skipped, bestDist stays INT_MAX */
+                } else {
+#pragma unroll
+                    for (int j = 0; j < MAXM; j++) { /* register arrays: no dynamic indexing */
+                        if (j == first) gBest = key[j];
+                        if (j == second) bestDist2 = key[j] >> 24;
+                    }
+                    if ((gBest >> 24) <= SI_TH_LOW) {
+                        if (second < 0 && full) {
+                            /* the second survivor lies beyond the list: it is at least as far as the last entry */
+                            uint32_t klast = 0u;
+#pragma unroll
+                            for (int j = 0; j < MAXM; j++)
+                                if (j == M - 1) klast = key[j];
+                            const uint32_t dlast = klast >> 24;
+                            if ((float)(int)(gBest >> 24) < __fmul_rn((float)(int)dlast, nnratio)) bestDist2 = dlast; /* accepted whatever the true second is */
+                            else scan = true;
+                        }
+                        if (!scan) accept = (float)(int)(gBest >> 24) < __fmul_rn((float)(int)bestDist2, nnratio);
+                    }
                 }
             }
-            if (need_scan) {
-                nfb++;
-                gBest = si_full_scan(jb, gcand, ownerDist, c2, lane, gqry[qb + tq], r, invW, invH, &bestDist2);
-                if (gBest == 0xFFFFFFFFu) continue;
-                if ((gBest >> 24) > SI_TH_LOW) continue;
-            }
-            const int bestDist = (int)(gBest >> 24);
             const uint32_t slot2 = gBest & 0xFFF;
-            if (bestDist <= SI_TH_LOW && (float)bestDist < __fmul_rn((float)(int)bestDist2, nnratio)) {
-                if (lane == 0) {
-                    ownerDist[slot2] = bestDist;
-                    alog[nlog] = ((uint32_t)(qb + tq) << 12) | slot2;
+            if (accept) {
+                atomicMin(&mark[slot2], lane);
+                atomicMin(&markDp[slot2], (int)(gBest >> 24));
+            }
+            __syncthreads();
+            bool stop = scan;
+            if (active && first >= 0) {
+                /* an earlier lane takes my best or second-best candidate with a distance that makes it skipped for me */
+                uint32_t k2 = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < MAXM; j++)
+                    if (j == second) k2 = key[j];
+                if (mark[slot2] < lane && markDp[slot2] <= (int)(gBest >> 24)) stop = true;
+                if (k2 != 0xFFFFFFFFu && mark[k2 & 0xFFF] < lane && markDp[k2 & 0xFFF] <= (int)(k2 >> 24)) stop = true;
+            }
+            const unsigned long long mstop = __ballot(stop && active);
+            const int f = mstop ? __ffsll((long long)mstop) - 1 : 64; /* wave-uniform: first lane that must wait */
+            const unsigned long long upto = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
+            const bool commit = accept && lane < f;
+            const unsigned long long mcommit = __ballot(commit);
+            __syncthreads(); /* every lane has read the marks */
+            if (accept) {
+                mark[slot2] = 0x7FFFFFFF;
+                markDp[slot2] = 0x7FFFFFFF;
+            }
+            if (commit) {
+                atomicMin(&ownerDist[slot2], (int)(gBest >> 24)); /* several lanes of a round may take one slot: the last one's distance is the smallest */
+                alog[nlog + __popcll(mcommit & lanes_before)] = ((uint32_t)(qb + lane) << 12) | slot2;
+            }
+            nlog += __popcll(mcommit);
+            done |= upto;
+            __syncthreads();
+            if (f < 64 && __builtin_amdgcn_readlane((int)(scan ? 1 : 0), f)) {
+                /* lane f's sorted prefix ran out.  vMatchedDistance only ever decreases, so a query that needed the re-scan
+                 * against the older state needs it against the current one too: everything in front of it is committed --
+                 * re-scan its whole window now, all lanes cooperating (fmatcher.cpp:1003-1035 literally) */
+                nfb++;
+                uint32_t d2;
+                const uint32_t gb = si_full_scan(jb, gcand, ownerDist, c2, lane, gqry[qb + f], r, invW, invH, &d2);
+                if (gb != 0xFFFFFFFFu && (gb >> 24) <= SI_TH_LOW && (float)(int)(gb >> 24) < __fmul_rn((float)(int)d2, nnratio)) {
+                    if (lane == 0) {
+                        ownerDist[gb & 0xFFF] = (int)(gb >> 24);
+                        alog[nlog] = ((uint32_t)(qb + f) << 12) | (gb & 0xFFF);
+                    }
+                    nlog++;
                 }
-                nlog++;
-                if (keyN != 0xFFFFFFFFu && (keyN & 0xFFF) == slot2) odN = (uint32_t)bestDist;
+                done |= 1ull << f;
+                __syncthreads();
             }
         }
     }
+    for (int c = lane; c < c2; c += 64) ownerEntry[c] = -1;
     __syncthreads();
     if (fallbacks && lane == 0 && nfb) atomicAdd(fallbacks, nfb);
     /* ownership: the last acceptor of a slot keeps it (fmatcher.cpp:1041-1049 undoes the previous owner) */
@@ -470,16 +536,16 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
 size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M) { return (size_t)npairs * si_pair_bytes(max_c2, M); }
 
 static size_t si_topm_lds(int max_c2) { return (size_t)max_c2 * (sizeof(SiCand) + 4 * 4); }
-static size_t si_replay_lds(int cap, int max_c2) {
-    return (size_t)max_c2 * 12 + (size_t)cap * 5 + 64 * SI_MAX_M * 4 + 64;
-}
+static size_t si_replay_lds(int cap, int max_c2) { return (size_t)max_c2 * 16 + (size_t)cap * 5 + 64; }
 
 size_t vk_search_init_lds(int cap, int max_c2) { return std::max(si_topm_lds(max_c2), si_replay_lds(cap, max_c2)); }
 
 int vk_search_init_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_si_topm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (rc) return rc;
-    return (int)hipFuncSetAttribute((const void*)k_si_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    rc = (int)hipFuncSetAttribute((const void*)k_si_replay<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute((const void*)k_si_replay<SI_MAX_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, int imgW, int imgH, int window,
@@ -493,8 +559,12 @@ void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, i
     const int chunks = (max_c2 + qpb - 1) / qpb;
     hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
                        window, max_c2, M, scratch, qpb);
-    hipLaunchKernelGGL(k_si_replay, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
-                       window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
+    if (M <= 8)
+        hipLaunchKernelGGL(k_si_replay<8>, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
+    else
+        hipLaunchKernelGGL(k_si_replay<SI_MAX_M>, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
 }
 
 /* ==================================================================================================

@@ -291,59 +291,70 @@ k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t stri
  *     list) by a two-level byte histogram, then reject every match with SAD >= 1.5*1.4*median.
  *     One workgroup per stereo pair.
  * ---------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t* sad, int cap) {
+    /* frame.cpp:983-996: median of the accepted SADs (element size/2 of the sorted list), drop SAD >= 1.5 * 1.4 * median.
+     * SADs are < 65536 (frame.cpp:919-949: 120 pixels x 255 + bias), so the median is found by two 256-bin histograms --
+     * high byte, then the low byte inside the selected bin -- and the bin holding rank k is found by a PREFIX SUM over
+     * the bins (thread = bin), not by one thread walking them (round 2: 2 x 256 dependent LDS reads by thread 0, most of
+     * the kernel's 16 us; and a 1024-thread workgroup that waited for a whole CU under load: 43 us). */
     __shared__ int s_hist[256];
+    __shared__ int s_wsum[4];
     __shared__ int s_sel, s_rank, s_total;
     const StereoJob jb = jobs.job[blockIdx.x];
     const size_t base = (size_t)blockIdx.x * cap;
-    const int tid = threadIdx.x;
-    if (tid < 256) s_hist[tid] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nl = JNL(jb);
+    /* bin b holds rank k  <=>  prefix(b) <= k < prefix(b) + hist[b]: exactly one thread finds it */
+    auto select = [&](int k) {
+        const int h = s_hist[tid];
+        int inc = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        int pre = inc - h;
+        for (int w = 0; w < wv; w++) pre += s_wsum[w];
+        if (h > 0 && pre <= k && k < pre + h) {
+            s_sel = tid;
+            s_rank = k - pre;
+        }
+        __syncthreads();
+    };
+    s_hist[tid] = 0;
     if (tid == 0) s_total = 0;
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < JNL(jb); i += 1024) {
+    for (int i = tid; i < nl; i += 256) {
         const int s = sad[base + i];
         if (s >= 0) {
             atomicAdd(&s_hist[(s >> 8) & 255], 1);
             mine++;
         }
     }
-    if (mine) atomicAdd(&s_total, mine);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0 && mine) atomicAdd(&s_total, mine);
     __syncthreads();
     const int total = s_total;
     if (total == 0) return; /* the reference indexes an empty vector here (UB); nothing to cut */
-    if (tid == 0) {
-        int k = total / 2, acc = 0, b = 0;
-        for (; b < 256; b++) {
-            if (acc + s_hist[b] > k) break;
-            acc += s_hist[b];
-        }
-        s_sel = b;
-        s_rank = k - acc;
-    }
-    __syncthreads();
+    select(total / 2);
     const int hi = s_sel, rank = s_rank;
     __syncthreads();
-    if (tid < 256) s_hist[tid] = 0;
+    s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < JNL(jb); i += 1024) {
+    for (int i = tid; i < nl; i += 256) {
         const int s = sad[base + i];
         if (s >= 0 && ((s >> 8) & 255) == hi) atomicAdd(&s_hist[s & 255], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0, b = 0;
-        for (; b < 256; b++) {
-            if (acc + s_hist[b] > rank) break;
-            acc += s_hist[b];
-        }
-        s_sel = (hi << 8) | b;
-    }
-    __syncthreads();
-    const float median = (float)s_sel;
+    select(rank);
+    const float median = (float)((hi << 8) | s_sel);
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
-    for (int i = tid; i < JNL(jb); i += 1024) {
+    for (int i = tid; i < nl; i += 256) {
         const int s = sad[base + i];
         if (s >= 0 && !((float)s < thDist)) {
             uRight[base + i] = -1.f;
@@ -385,7 +396,7 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
                        items, rattr, best, cap, capR);
     hipLaunchKernelGGL(k_stereo_refine, dim3((maxNL + 15) / 16, njobs), dim3(256), 0, st, jobs, g, pyrL, strideL,
                        srcL, pyrR, strideR, srcR, mbf, maxD, best, uRight, depth, sad, cap);
-    hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(1024), 0, st, jobs, uRight, depth, sad, cap);
+    hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(256), 0, st, jobs, uRight, depth, sad, cap);
 }
 
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst) {
