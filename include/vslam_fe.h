@@ -574,10 +574,11 @@ int vslam_dbg_fast_atan2(vslam_fe* fe, const float* y, const float* x, int n, in
 /* glibc logf as MapPoint::PredictScale uses it (mappoint.cpp:514); normal positive inputs, NaN otherwise */
 int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y);
 /* Quadtree statistics of a context: how many (slot, level) DistributeOctTree problems (fextractor.cpp:530-754) ran on the
- * device so far, how many of them the one-walk kernel could not finish on its own (keys clustered more finely than its
- * grid resolves: handed over to the walk-per-pass code, same result), and -- last_level_masks, max_batch words or NULL --
- * bit l of word s set if level l of slot s was handed over in the last pass.  Updated when a pass's results are collected. */
-int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* handed_over,
+ * device so far, on how many of them nodes had to be split BELOW the kernel's fine grid (keys closer together than a fine
+ * cell -- real images do that on sparse levels; resolved inside the kernel, same result, a little slower), and --
+ * last_level_masks, max_batch words or NULL -- bit l of word s set if that happened on level l of slot s in the last pass.
+ * Updated when a pass's results are collected. */
+int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* split_below_grid,
                           uint32_t* last_level_masks);
 /* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
  * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */

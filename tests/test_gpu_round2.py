@@ -248,10 +248,11 @@ def test_staged_upload_then_extract_equals_pinned_path():
 
 @pytest.mark.parametrize("env", [{}, {"oct_fine_depth": 1}, {"oct_fine_depth": 3}, {"octree_walk_kernel": 1}])
 @pytest.mark.parametrize("cfg", [(1241, 376, 1000), (640, 480, 3000), (1920, 1080, 4000)])
-def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(env, cfg):
-    """k_octree_v3 counts keys once into a fine grid and never walks them per pass; when a split would need a finer
-    grid than it has (forced here with a depth of 1 or 3) it hands the (slot, level) problem to k_octree_v2.  Every
-    variant must give the oracle's keypoints."""
+def test_quadtree_fine_grid_depths_and_the_walk_kernel(env, cfg):
+    """k_octree_v4 counts keys once into a fine grid, sorts them by fine cell and never walks them per pass; nodes finer
+    than the grid (forced here with a depth of 1 or 3: almost every node) are resolved inside the kernel from the sorted
+    keys of their cell.  The walk-per-pass kernel (k_octree_v2) stays selectable.  Every variant must give the oracle's
+    keypoints."""
     w, h, nf = cfg
     imgs = [synth.make_frame(w, h, seed=50 + nf, step=s) for s in range(2)]
     fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=2, tuning=env)
@@ -266,9 +267,9 @@ def test_quadtree_fine_grid_and_handover_to_the_walk_kernel(env, cfg):
 
 
 @pytest.mark.parametrize("env", [{"oct_fine_depth": 1}, {"oct_fine_depth": 3}])
-def test_quadtree_handover_with_keys_in_global_memory(env):
-    """batches of more than two images use the k_octree_v3 instantiation that re-reads its keys (80 VGPRs); the levels it
-    hands over are redone by k_assign_out with node arrays in global scratch"""
+def test_quadtree_shallow_grid_with_keys_in_global_memory(env):
+    """batches of more than two images use the k_octree_v4 instantiation that re-reads its keys between the two walks
+    (fewer VGPRs); with a shallow grid most nodes are split below it"""
     imgs = [synth.make_frame(1241, 376, seed=61, step=s) for s in range(4)]
     fe = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=4, tuning=env)
     try:
@@ -277,6 +278,10 @@ def test_quadtree_handover_with_keys_in_global_memory(env):
         for s in range(4):
             ko, do, _ = e.compute(imgs[s])
             _same_feats(res[s], (ko, do), "%s slot %d" % (env, s))
+        prob, deep, masks = fe.octree_stats()
+        assert prob == 4 * 8
+        if env["oct_fine_depth"] == 1:  # 4 roots x 4 leaves against 217 wanted nodes: level 0 of every slot splits below the grid
+            assert deep >= 4 and all(m & 1 for m in masks[:4])
     finally:
         fe.close()
 

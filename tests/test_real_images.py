@@ -5,7 +5,8 @@ SearchForInitialization.  tests/golden/real_images.npz holds the gray images, re
 
 CPU (-m "not gpu"): the oracle reproduces the committed outputs.
 GPU (-m gpu): the HIP path equals the oracle AND the committed outputs bit for bit, in batches, with the quadtree statistics
-(vslam_fe_octree_stats: how many (slot, level) problems the one-walk kernel handed over) reported per case."""
+(vslam_fe_octree_stats: on how many (slot, level) problems nodes had to be split below the kernel's fine grid) reported
+per case."""
 import hashlib
 import os
 
@@ -103,7 +104,7 @@ def test_gpu_hut_batch_equals_oracle_and_golden(real, nf, lap):
     try:
         res = fe.compute_batch([ims[n] for n in names], lap)
         prob, handed, masks = fe.octree_stats()
-        print("\nquadtree hut x5 N=%d: %d problems, %d handed over, level masks %s" % (nf, prob, handed, [hex(m) for m in masks[:5]]))
+        print("\nquadtree hut x5 N=%d: %d problems, %d split below the grid, level masks %s" % (nf, prob, handed, [hex(m) for m in masks[:5]]))
         assert prob == 5 * 8
         for s, n in enumerate(names):
             e = orbo.Extractor(nf)
@@ -129,7 +130,7 @@ def test_gpu_lenna_and_chessboard_equal_oracle_and_golden(real, name, nf, lap):
         for batch in (1, 2):
             res = fe.compute_batch([im] * batch, lap)
             prob, handed, masks = fe.octree_stats()
-            print("\nquadtree %s N=%d batch %d: %d problems, %d handed over so far, masks %s" % (name, nf, batch, prob, handed, [hex(m) for m in masks[:batch]]))
+            print("\nquadtree %s N=%d batch %d: %d problems, %d split below the grid so far, masks %s" % (name, nf, batch, prob, handed, [hex(m) for m in masks[:batch]]))
             for s in range(batch):
                 _check_against_golden(exp, _key(name, nf, lap), res[s][0], res[s][1], res[s][2])
         e = orbo.Extractor(nf)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 3: the measurements the documents quote (run through gpurun): tests, the default bench line, the same bench under
+# rocprofv3 (kernel + memory-copy trace), PMC passes (traffic, matcher counters), batch-1 latency, quadtree stamps
+set -o pipefail
+O=gpurun_out
+R=$PWD
+mkdir -p $O/final
+echo "== gpu tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/final/gpu_tests.log 2>&1; rc=$?; echo rc=$rc; tail -4 $O/final/gpu_tests.log
+if [ $rc -ne 0 ]; then exit 1; fi
+echo "== smoke"; timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -2
+echo "== bench default"; timeout -k 10 900 python bench.py > $O/final/default_bench.json 2> $O/final/default_bench.err; echo rc=$?; wc -c $O/final/default_bench.json
+echo "== latency"; timeout -k 10 300 python tools/latency_batch1.py 2>&1 | grep -v amdgpu > $O/final/latency_batch1.txt; cat $O/final/latency_batch1.txt
+cd /tmp && export TMPDIR=/tmp
+for wl in kitti00_mono_1241x376_n1000 kitti00_stereo_1241x376_n2000; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $R/$O/final/prof_$wl -o t -- python3 $R/bench.py --workload $wl --inputs device --no-cpu-baseline --steps 20 > $R/$O/final/prof_$wl.json 2> $R/$O/final/prof_$wl.err
+  echo "-- $wl rc=$?"
+  find $R/$O/final/prof_$wl -name "*_trace.csv" -delete
+done
+cd $R
+echo "== pmc traffic"; for cfg in "mono 32 1000 1241 376" "stereo 32 2000 1241 376" "stereo 32 4000 1920 1080"; do set -- $cfg; timeout -k 10 600 bash tools/collect_pmc.sh $R/$O/final/pmc_${4}x${5}_n${3} $1 $2 $3 $4 $5 > $O/final/pmc_${4}x${5}_n${3}.log 2>&1; echo "$cfg rc=$?"; done
+echo "== pmc matcher"; timeout -k 10 600 bash tools/collect_pmc_matcher.sh $R/$O/final/pmc_matcher > $O/final/pmc_matcher.log 2>&1; echo rc=$?
+find $O/final -name "*.csv" -size +2M -delete
+echo done

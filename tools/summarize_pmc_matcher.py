@@ -44,7 +44,12 @@ for k, d in out.items():
     if "TCC_HIT_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0.0), 1.0)
     if d.get("SQ_ACTIVE_INST_LDS"):
-        d["lds_bank_conflict_share_of_lds_active"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_ACTIVE_INST_LDS"]
+        # rocprof's own "LDSBankConflict" metric: conflict cycles over SQ_ACTIVE_INST_LDS -- which counts QUAD-cycles on this
+        # chip (MI355X_MICROARCH.md), so the ratio can exceed 1; kept for comparison with rounds 1-2
+        d["lds_bank_conflict_over_active_inst_lds"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_ACTIVE_INST_LDS"]
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        # both in LDS-array cycles: the share of the LDS pipe's busy cycles that were conflict replays
+        d["lds_bank_conflict_share_of_lds_cycles"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
 NQ = NT = 2000  # run_match_loop.py: one brute-force top-2 of a KITTI frame pair at 2000 features (actual counts ~1990)
 k = out.get("k_hamming_top2_partial")
 if k and k.get("avg_us"):

@@ -567,8 +567,8 @@ class FExtractor:
         _check(lib().vslam_fe_set_tuning(self._h, C.byref(t)))
 
     def octree_stats(self):
-        """(problems, handed_over, last_level_masks): (slot, level) quadtree problems distributed on the device so far, how
-        many of them k_octree_v3 handed over to the walk-per-pass code, and the level bit masks of the last pass's slots"""
+        """(problems, split_below_grid, last_level_masks): (slot, level) quadtree problems distributed on the device so far,
+        on how many of them nodes were split below the kernel's fine grid, and the level bit masks of the last pass's slots"""
         a, b = C.c_ulonglong(), C.c_ulonglong()
         m = (C.c_uint32 * MAX_BATCH)()
         lib().vslam_fe_octree_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

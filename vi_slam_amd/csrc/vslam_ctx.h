@@ -92,9 +92,9 @@ struct vslam_fe {
     BatchSrc src;
     int n_out[VSLAM_MAX_BATCH] = {};
     int mono_out[VSLAM_MAX_BATCH] = {};
-    /* quadtree statistics (vslam_fe_octree_stats): (slot, level) problems distributed on the device so far, how many of
-     * them k_octree_v3 could not finish on its own, and the per-slot level masks of the last pass */
-    unsigned long long oct_problems = 0, oct_handed_over = 0;
+    /* quadtree statistics (vslam_fe_octree_stats): (slot, level) problems distributed on the device so far, on how many
+     * of them k_octree_v4 split nodes below its fine grid, and the per-slot level masks of the last pass */
+    unsigned long long oct_problems = 0, oct_deep = 0;
     uint32_t oct_last_mask[VSLAM_MAX_BATCH] = {};
     int32_t pack_hdr[VSLAM_MAX_BATCH][4] = {}; /* headers of vslam_fe_pack_slots while the copy is in flight */
     std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */

@@ -479,11 +479,11 @@ extern "C" int vslam_fe_tables(const vslam_fe* fe, float* scale, float* inv_scal
     return fe->p.nlevels;
 }
 
-extern "C" int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* handed_over,
+extern "C" int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* split_below_grid,
                                      uint32_t* last_level_masks) {
     if (!fe) return VSLAM_ERR_INVALID;
     if (problems) *problems = fe->oct_problems;
-    if (handed_over) *handed_over = fe->oct_handed_over;
+    if (split_below_grid) *split_below_grid = fe->oct_deep;
     if (last_level_masks)
         for (int s = 0; s < fe->B; s++) last_level_masks[s] = s < fe->last_nimg ? fe->oct_last_mask[s] : 0u;
     return VSLAM_OK;
@@ -1064,7 +1064,7 @@ int vslam_finish_extract(vslam_fe* fe, int nimg) {
             fe->n_out[s] = fe->h_counts[s * 4];
             fe->mono_out[s] = fe->h_counts[s * 4 + 1];
             fe->oct_last_mask[s] = (uint32_t)fe->h_counts[s * 4 + 2];
-            fe->oct_handed_over += (unsigned)__builtin_popcount(fe->oct_last_mask[s]);
+            fe->oct_deep += (unsigned)__builtin_popcount(fe->oct_last_mask[s]);
         }
         fe->oct_problems += (unsigned long long)nimg * fe->p.nlevels;
     }

@@ -26,6 +26,9 @@
 #define OT 1024
 #define OKPT 16  /* k_octree_v2: keys per thread kept in registers (problems up to 16384 keys) */
 #define OBATCH 8 /* k_octree_v2: keys per thread and batch when streaming a larger problem */
+#ifndef O4BATCH
+#define O4BATCH 8 /* k_octree_v4: keys per thread and batch of the streaming walks (loads in flight per lane) */
+#endif
 typedef unsigned long long u64;
 
 struct ONode { /* 16 bytes, one entry of the list */
@@ -600,10 +603,10 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
      * that order is its rank in the reference's key order.  One binary search in the cells' offsets (LDS) for a lane's
      * first position, then it walks on cell by cell. */
     const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
-    uint32_t before = 0;
-    for (int c = tid; c < c0; c += OT) before += cout[c].count;
-    uint32_t off0;
-    {
+    uint32_t off0 = 0;
+    if (c0 > 0) { /* keys of the levels in front of this one (level 0: none, no scan) */
+        uint32_t before = 0;
+        for (int c = tid; c < c0; c += OT) before += cout[c].count;
         uint32_t tot;
         block_excl_scan<uint32_t>(before, s_w32, &tot);
         off0 = tot;
@@ -655,6 +658,10 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     const uint32_t* __restrict__ xs = P.lut + P.lutOff[level];
     const uint32_t* __restrict__ ys = xs + P.lutW[level];
     for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+    /* the path tables are cold (another XCD's L2 or HBM) the first time a workgroup touches them: start pulling their
+     * lines now, the key loads below hide the round trip */
+    uint32_t warm = 0u;
+    if (tid * 16 < P.lutW[level] + Hh + 1) warm = xs[tid * 16]; /* consumed (by nothing) behind walk 1 */
     __syncthreads();
 
     /* positions are dealt to WAVES in contiguous chunks of EW (a multiple of 64) and to the lanes of a wave interleaved:
@@ -703,10 +710,10 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             for (int k = 0; k < OKPT; k++)
                 if (k < KW && p0 + 64 * k < n) auxR[k] |= atomicAdd(&Hc[auxR[k]], 1u) << 16;
         } else {
-            for (int kb = 0; kb < KW; kb += OBATCH) { /* OBATCH loads in flight, then the table look-ups, then the atomics */
-                uint32_t kk[OBATCH], ff[OBATCH];
+            for (int kb = 0; kb < KW; kb += O4BATCH) { /* O4BATCH loads in flight, then the table look-ups, then the atomics */
+                uint32_t kk[O4BATCH], ff[O4BATCH];
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++) {
+                for (int j = 0; j < O4BATCH; j++) {
                     const int i = p0 + 64 * (kb + j);
                     kk[j] = 0u;
                     if (kb + j < KW && i < n) {
@@ -720,13 +727,13 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++)
+                for (int j = 0; j < O4BATCH; j++)
                     ff[j] = (kb + j < KW && p0 + 64 * (kb + j) < n) ? xs[kk[j] & 0xFFF] | ys[(kk[j] >> 12) & 0xFFF] : 0u;
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++)
+                for (int j = 0; j < O4BATCH; j++)
                     if (kb + j < KW && p0 + 64 * (kb + j) < n) ff[j] |= atomicAdd(&Hc[ff[j]], 1u) << 16;
 #pragma unroll
-                for (int j = 0; j < OBATCH; j++)
+                for (int j = 0; j < O4BATCH; j++)
                     if (kb + j < KW && p0 + 64 * (kb + j) < n) {
                         pa[p0 + 64 * (kb + j)] = kk[j];
                         aux[p0 + 64 * (kb + j)] = ff[j];
@@ -734,6 +741,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
     }
+    asm volatile("" ::"v"(warm));
     __syncthreads(); /* coff (in the node arrays) is free again; the counters are complete */
     STAMP3();
     {   /* exclusive prefix sums of the fine counts, LDS to LDS */
@@ -770,16 +778,16 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (k < KW && i < n) sorted[PS[auxR[k] & 0xFFFFu] + (auxR[k] >> 16)] = make_uint2(keyR[k], (uint32_t)i);
         }
     } else {
-        for (int base = tid; base < n; base += OBATCH * OT) {
-            uint32_t kk[OBATCH], ff[OBATCH];
+        for (int base = tid; base < n; base += O4BATCH * OT) {
+            uint32_t kk[O4BATCH], ff[O4BATCH];
 #pragma unroll
-            for (int j = 0; j < OBATCH; j++) {
+            for (int j = 0; j < O4BATCH; j++) {
                 const int i = base + j * OT;
                 kk[j] = i < n ? pa[i] : 0u;
                 ff[j] = i < n ? aux[i] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < OBATCH; j++) {
+            for (int j = 0; j < O4BATCH; j++) {
                 const int i = base + j * OT;
                 if (i < n) sorted[PS[ff[j] & 0xFFFFu] + (ff[j] >> 16)] = make_uint2(kk[j], (uint32_t)i);
             }
