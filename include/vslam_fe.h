@@ -68,7 +68,6 @@ typedef struct vslam_tuning {
     int32_t fast_lds_pad;         /* VSLAM_FAST_LDS_PAD: extra LDS bytes per FAST workgroup (occupancy experiments) */
     int32_t octree_walk_kernel;   /* VSLAM_OCTREE=v2: 1 = the walk-per-pass quadtree kernel only */
     int32_t oct_fine_depth;       /* VSLAM_OCT_FINE_D: depth of the one-walk kernel's fine grid (tests force 1 or 3) */
-    int32_t oct_fine_lds;         /* VSLAM_OCT_FINE_LDS: 0 never in LDS, 1 full arrays only, 2 counters only */
     int32_t oct_lds_budget_kb;    /* VSLAM_OCT_LDS_BUDGET_KB: LDS a quadtree workgroup may take (16..150, default 128) */
     int32_t oct_regkeys;          /* VSLAM_OCT_REGKEYS: 0 | 1 keys in registers between the key walks (default: batches <= 2) */
     int32_t oct_max_iter;         /* VSLAM_OCT_MAXITER: split-pass limit (default 64) */
@@ -90,7 +89,7 @@ typedef struct vslam_tuning {
     int32_t stream_priority;      /* VSLAM_STREAM_PRIORITY: 0 normal, 1 low, 2 high (default) priority of the context's HIP stream: a
                                      priority of its own gives the context hardware queues it does not share with the host
                                      application's other streams */
-    int32_t reserved[7];
+    int32_t reserved[8];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

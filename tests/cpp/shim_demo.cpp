@@ -7,6 +7,9 @@
  */
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
 #include <string>
 
 #include "vslam_shim.hpp"
@@ -110,7 +113,52 @@ int main(int argc, char** argv) {
                 flat.push_back((double)multi.getPoints()[i].level_);
             }
 
-        std::printf("{\"n1\": %zu, \"n2\": %zu, \"mono1\": %d, \"mono2\": %d, \"rc_empty\": %d, \"nmatches\": %d, "
+        /* ---- the C ABI directly: switches as per-context parameters, a staged upload consumed with imgs == NULL
+         * (twice, so that the second pass replays the captured graph), quadtree statistics, and the descriptor
+         * half of ComputeStereoFishEyeMatches on the stereo pair above */
+        vslam_tuning tn;
+        vslam_tuning_init(&tn);
+        tn.oct_fine_depth = 2; /* a shallow quadtree grid for THIS context only: same keypoints, more sub-grid splits */
+        tn.stream_priority = 1;
+        vslam_fe_params cp;
+        std::memset(&cp, 0, sizeof(cp));
+        cp.width = w; cp.height = h; cp.nfeatures = nf; cp.scale_factor = 1.2f; cp.nlevels = 8;
+        cp.ini_th_fast = 20; cp.min_th_fast = 7; cp.device = 0; cp.max_batch = 1; cp.tuning = &tn;
+        vslam_fe* cfe = nullptr;
+        if (vslam_fe_create(&cp, &cfe) != VSLAM_OK) throw std::runtime_error(vslam_last_error());
+        void* pin = nullptr;
+        if (vslam_host_alloc((size_t)w * h, &pin) != VSLAM_OK) throw std::runtime_error(vslam_last_error());
+        std::memcpy(pin, a.data, (size_t)w * h);
+        const uint8_t* pimgs[1] = {(const uint8_t*)pin};
+        const int ccap = vslam_fe_capacity(cfe);
+        std::vector<vslam_kp> ck((size_t)ccap);
+        std::vector<uint8_t> cd((size_t)ccap * 32);
+        vslam_kp* ckp[1] = {ck.data()};
+        uint8_t* cdp[1] = {cd.data()};
+        int staged_ok = 1, cn = 0, cmono = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            if (vslam_fe_stage_images_async(cfe, 1, pimgs, (size_t)w, VSLAM_IMGS_PINNED) != VSLAM_OK ||
+                vslam_fe_extract_batch(cfe, 1, nullptr, 0, VSLAM_IMGS_STAGED, 0, 1000, ckp, cdp, ccap, &cn, &cmono) != VSLAM_OK)
+                throw std::runtime_error(vslam_last_error());
+            staged_ok = staged_ok && cn == (int)k1.size() && cmono == mono1 &&
+                        !std::memcmp(ck.data(), k1.data(), (size_t)cn * sizeof(vslam_kp)) &&
+                        !std::memcmp(cd.data(), d1.data, (size_t)cn * 32);
+        }
+        unsigned long long oprob = 0, odeep = 0;
+        vslam_fe_octree_stats(cfe, &oprob, &odeep, nullptr);
+        vslam_host_free(pin);
+        vslam_fe_destroy(cfe);
+        const uint8_t *fdl = nullptr, *fdr = nullptr;
+        int fnl = 0, fnr = 0, fish_n = 0;
+        vslam_fe_slot_buffers(left.context(), 0, nullptr, &fdl, &fnl);
+        vslam_fe_slot_buffers(right.context(), 0, nullptr, &fdr, &fnr);
+        std::vector<int32_t> fish((size_t)(fnl > 0 ? fnl : 1));
+        if (vslam_stereo_fisheye_candidates(left.context(), fdl, fnl, 0, fdr, fnr, 0, fish.data(), nullptr, nullptr, &fish_n) != VSLAM_OK)
+            throw std::runtime_error(vslam_last_error());
+
+        std::printf("{\"staged_ok\": %d, \"oct_problems\": %llu, \"oct_deep\": %llu, \"fish_n\": %d, \"fish\": %llu, ", staged_ok, oprob,
+                    odeep, fish_n, fnv(fish.data(), (size_t)fnl * 4));
+        std::printf("\"n1\": %zu, \"n2\": %zu, \"mono1\": %d, \"mono2\": %d, \"rc_empty\": %d, \"nmatches\": %d, "
                     "\"dd01\": %d, \"kp1\": %llu, \"desc1\": %llu, \"kp2\": %llu, \"desc2\": %llu, \"m12\": %llu, "
                     "\"prev\": %llu, \"nL\": %zu, \"nR\": %zu, \"nstereo\": %d, \"uR\": %llu, \"depth\": %llu, "
                     "\"lvl3\": [%d, %d, %llu], \"levels\": %d, \"sf7\": %.9g, \"nsbp\": %d, \"sbp\": %llu, "

@@ -76,6 +76,8 @@ def test_shim_program_equals_ctypes_path(tmp_path):
         kL, dL, _ = f1.compute(L)
         kR, dR, _ = f2.compute(R)
         u, dep = V.ComputeStereoMatches(f1, 0, f2, 0, 386.1448, 718.856)
+        fish, _, _, fish_n = V.FMatcher(f1).ComputeStereoFishEyeCandidates(f1.slot_buffers(0)[1], len(kL), 0,
+                                                                             f2.slot_buffers(0)[1], len(kR), 0)
         lvl3 = f1.mvImagePyramid(3)
         from vi_slam_amd.fastgrid import FASTGPU
         aw = np.ascontiguousarray(a[:H & ~3, :W & ~3])
@@ -98,6 +100,10 @@ def test_shim_program_equals_ctypes_path(tmp_path):
     occ3 = np.nonzero(s3 > 0)[0]
     flat = np.stack([p3[occ3, 0], p3[occ3, 1], s3[occ3], l3[occ3]], 1).astype(np.float64)
     assert got["fast3_n"] == len(occ3) and got["fast3"] == _fnv(flat)
+    # the C ABI section: STAGED passes with imgs == NULL (capture, then graph replay) under a per-context tuning equal the
+    # plain pass; the shallow grid made the quadtree split below it; the fisheye candidates equal the ctypes path
+    assert got["staged_ok"] == 1 and got["oct_problems"] == 16 and got["oct_deep"] >= 2
+    assert got["fish_n"] == fish_n and fish_n > 50 and got["fish"] == _fnv(fish)
     assert got["n1"] == len(k1) and got["n2"] == len(k2) and got["mono1"] == mono1 and got["mono2"] == mono2
     assert got["rc_empty"] == -1
     assert got["kp1"] == _fnv(k1) and got["desc1"] == _fnv(d1) and got["kp2"] == _fnv(k2) and got["desc2"] == _fnv(d2)

@@ -24,7 +24,6 @@ const EnvField kEnv[] = {
     TF("VSLAM_FAST_LDS_PAD", fast_lds_pad, nullptr, nullptr),
     TF("VSLAM_OCTREE", octree_walk_kernel, "v2", nullptr),
     TF("VSLAM_OCT_FINE_D", oct_fine_depth, nullptr, nullptr),
-    TF("VSLAM_OCT_FINE_LDS", oct_fine_lds, nullptr, nullptr),
     TF("VSLAM_OCT_LDS_BUDGET_KB", oct_lds_budget_kb, nullptr, nullptr),
     TF("VSLAM_OCT_REGKEYS", oct_regkeys, nullptr, nullptr),
     TF("VSLAM_OCT_MAXITER", oct_max_iter, nullptr, nullptr),
