@@ -281,7 +281,9 @@ class Pipeline:
         self.B = B
         self.NCTX = max(3, args.inflight)
         self.multi = (world > 1 or args.force_collective) and not self.stereo
-        self.ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=env["local_rank"], max_batch=B) for _ in range(self.NCTX)]
+        tuning = dict(stage_split_event=2) if args.upload_split else None
+        self.ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=env["local_rank"], max_batch=B, tuning=tuning)
+                     for _ in range(self.NCTX)]
         self.fe = self.ctxs[0]
         self.matchers = [V.FMatcher(c, 0.9, True) for c in self.ctxs]
         self.lap = (0, 0) if self.stereo else (0, 1000)  # frame.cpp:107-108 vs :289
@@ -380,7 +382,8 @@ class Pipeline:
             if lag > 0 and t >= lag:
                 c.event_wait(self.ctxs[(t - lag) % NCTX], 2)
             c.stage_images_async(ptrs, pitch, V.IMGS_PINNED)
-            c.event_record(2)
+            if not self.args.upload_split:
+                c.event_record(2)  # (with --upload-split the library records event 2 between the two halves of the upload)
             where = V.IMGS_STAGED
         if self.track:
             npairs = B // 2
@@ -709,6 +712,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline workload only")
     ap.add_argument("--no-exchange-chain", dest="exchange_chain", action="store_false",
                     help="N>1: let the lanes' exchanges overlap instead of ordering them by events (A/B)")
+    ap.add_argument("--upload-split", type=int, default=0,
+                    help="host inputs: 1 = a step's upload goes as two transfers and the chain event sits between them")
     ap.add_argument("--upload-chain", type=int, default=1,
                     help="host inputs: upload of step t waits (GPU-side event) for the upload of step t-L; 0 = no pacing")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],

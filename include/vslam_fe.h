@@ -89,7 +89,9 @@ typedef struct vslam_tuning {
     int32_t stream_priority;      /* VSLAM_STREAM_PRIORITY: 0 normal, 1 low, 2 high (default) priority of the context's HIP stream: a
                                      priority of its own gives the context hardware queues it does not share with the host
                                      application's other streams */
-    int32_t reserved[8];
+    int32_t stage_split_event;    /* 0..3: uploads of more than one image go as two transfers with the context's user event of that
+                                     index (vslam_fe_event_wait) recorded between them; see vslam_fe_stage_images_async */
+    int32_t reserved[7];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

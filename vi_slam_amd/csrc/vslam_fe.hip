@@ -677,6 +677,11 @@ static int ensure_stage(vslam_fe* fe, size_t spitch, int nimg) {
  *         Measured beside the other contexts' kernels: 102 k frames/s against 64-72 k with the pull kernel, whose host
  *         reads (2-3 us each) sit in the L2's queues in front of everybody's HBM requests (describe 122 -> 274 us).
  *   pull: one kernel reads the host rows over PCIe itself (55 GB/s alone on the GPU; kept for A/B runs). */
+static bool hip_stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int where) {
     const vslam_fe_params& p = fe->p;
     hipStream_t st = fe->stream;
@@ -705,7 +710,20 @@ static int upload_host_rows(vslam_fe* fe, int nimg, const uint8_t* const* imgs, 
         const ptrdiff_t d = nimg > 1 ? hs.l0[1] - hs.l0[0] : 0;
         for (int s = 2; s < nimg && even; s++) even = hs.l0[s] - hs.l0[s - 1] == d;
         if (even && d > 0 && (size_t)d >= one && (size_t)d * (nimg - 1) + one <= fe->d_stage_bytes) {
-            HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * (nimg - 1) + one, hipMemcpyHostToDevice, cs));
+            /* vslam_tuning.stage_split_event = k (0..3): the upload goes as TWO transfers and the context's user event k
+             * (vslam_fe_event_wait) is recorded between them -- a pipelined caller that chains the uploads of its contexts
+             * on that event keeps a second transfer queued behind the running one, so the link does not idle for the
+             * hand-over between two chained uploads */
+            const int ek = fe->tune.stage_split_event;
+            const int h1 = nimg / 2;
+            if (ek >= 0 && ek < 4 && h1 >= 1 && !hip_stream_capturing(cs)) {
+                HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * h1, hipMemcpyHostToDevice, cs));
+                if (!fe->ev_user[ek]) HIPCHK(hipEventCreateWithFlags(&fe->ev_user[ek], hipEventDisableTiming));
+                HIPCHK(hipEventRecord(fe->ev_user[ek], cs));
+                HIPCHK(hipMemcpyAsync(fe->d_stage + (size_t)d * h1, hs.l0[0] + (size_t)d * h1, (size_t)d * (nimg - 1 - h1) + one,
+                                      hipMemcpyHostToDevice, cs));
+            } else
+                HIPCHK(hipMemcpyAsync(fe->d_stage, hs.l0[0], (size_t)d * (nimg - 1) + one, hipMemcpyHostToDevice, cs));
             for (int s = 0; s < nimg; s++) hs.l0[s] = fe->d_stage + (size_t)d * s;
         } else {
             for (int s = 0; s < nimg; s++) {
