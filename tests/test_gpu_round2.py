@@ -315,8 +315,26 @@ def test_switches_do_not_change_results():
     ref = mod.digest()
     for tuning in ({"oct_regkeys": 1}, {"oct_regkeys": 0}, {"si_queries_per_block": 8}, {"si_queries_per_block": 32},
                    {"fast_lds_pad": 4096}, {"h2d_route": 1}, {"h2d_route": 2}, {"oct_lds_budget_kb": 48},
-                   {"oct_fine_depth": 2, "oct_regkeys": 1}, {"d2h_route": 1}, {"d2h_route": 2}, {"graphs": 0},
+                   {"oct_fine_depth": 2, "oct_regkeys": 1}, {"oct_fine_depth": 1, "oct_regkeys": 0}, {"d2h_route": 1}, {"d2h_route": 2}, {"graphs": 0},
                    {"pyramid_per_level": 1}, {"fast_threads": 256}, {"pyr_threads": 512}, {"blur_rows": 16}):
         assert mod.digest(tuning) == ref, tuning
     for env in ({"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0"}, {"VSLAM_D2H": "kernel", "VSLAM_OCT_REGKEYS": "1", "VSLAM_PYRAMID": "levels"}):
         assert _digest(env).split()[-1] == ref, env
+
+
+def test_large_context_still_runs_after_a_small_one_was_created():
+    """the maximum dynamic LDS of the quadtree kernels is an attribute of the FUNCTION, shared by every context of
+    the process; creating a small context after a large one must not lower it (vk_octree_set_max_lds only ever raises)."""
+    big = V.FExtractor(4000, 1.2, 8, 20, 7, 1920, 1080, max_batch=1)
+    small = V.FExtractor(100, 1.2, 2, 20, 7, 128, 128, max_batch=1)
+    try:
+        im = synth.make_frame(1920, 1080, seed=71)
+        k, d, _ = big.compute(im)
+        ko, do, _ = orbo.Extractor(4000).compute(im)
+        _same_feats((k, d), (ko, do), "1080p context after a 128x128 one")
+        ks, ds, _ = small.compute(synth.make_frame(128, 128, seed=72))
+        kso, dso, _ = orbo.Extractor(100, nlevels=2).compute(synth.make_frame(128, 128, seed=72))
+        _same_feats((ks, ds), (kso, dso), "128x128 context")
+    finally:
+        small.close()
+        big.close()
