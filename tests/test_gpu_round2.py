@@ -338,3 +338,41 @@ def test_large_context_still_runs_after_a_small_one_was_created():
     finally:
         small.close()
         big.close()
+
+
+@pytest.mark.parametrize("seed,nf", [(1, 300), (2, 1500), (3, 6000)])
+def test_quadtree_on_clustered_dot_images(seed, nf):
+    """Adversarial candidate sets for the quadtree: isolated bright dots are FAST corners, so an image of dots IS a chosen
+    key set -- tight clusters (dots two and three pixels apart: nodes must be split to depth 8-9, far below the kernel's
+    fine grid), long runs on one row and one column, and a sparse background, with quotas below and above the number of
+    candidates.  Every level must equal the oracle; the statistics must report the sub-grid splits."""
+    rng = np.random.default_rng(seed)
+    w, h = 800, 600
+    img = np.full((h, w), 40, np.uint8)
+    for _ in range(60):  # clusters: 3x3 .. 6x6 dots with a pitch of 2 or 3 px
+        cx, cy = int(rng.integers(40, w - 60)), int(rng.integers(40, h - 60))
+        pitch, k = int(rng.integers(2, 4)), int(rng.integers(3, 7))
+        for a in range(k):
+            for b in range(k):
+                img[cy + pitch * a, cx + pitch * b] = int(rng.integers(200, 256))
+    for x in range(30, w - 30, 2):  # a row and a column of dots: all keys of a node share a coordinate
+        img[300, x] = 250
+    for y in range(30, h - 30, 3):
+        img[y, 401] = 251
+    ys, xs = rng.integers(30, h - 30, 400), rng.integers(30, w - 30, 400)
+    img[ys, xs] = rng.integers(180, 256, 400).astype(np.uint8)
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=3)
+    try:
+        res = fe.compute_batch([img, img[:, ::-1].copy(), img[::-1].copy()])
+        prob, deep, masks = fe.octree_stats()
+        e = orbo.Extractor(nf)
+        for s, im in enumerate((img, img[:, ::-1].copy(), img[::-1].copy())):
+            ko, do, _ = e.compute(im)
+            _same_feats(res[s], (ko, do), "dots seed %d N=%d slot %d" % (seed, nf, s))
+            if s == 0:
+                assert len(e.candidates(0)) > 1000
+        assert prob == 24
+        if nf == 6000:  # quotas above the candidate counts: every node is split down to single keys, clusters far below the grid
+            assert deep >= 3, (prob, deep, masks[:3])
+    finally:
+        fe.close()
