@@ -420,7 +420,10 @@ class Pipeline:
         # the NEXT step (context nxt, step t-NCTX+1) read from us is the carry / exchange buffer, so only the copy into
         # that buffer has to wait for it -- not the extraction.  (With the wait in front of the extraction a context sat
         # idle for a whole step between two of its passes: 353 us per 1140-us cycle in the kernel trace.)
-        c.compute_batch_async(ptrs, pitch, self.lap, where=where, to_host=os.environ.get("BENCH_NO_D2H") is None)
+        # ONE result transfer per step: the extraction's delivery is deferred to the matcher call below (want_host = 2) --
+        # counts, keypoints, descriptors and vnMatches12 of the step are one block (--delivery separate for A/B)
+        c.compute_batch_async(ptrs, pitch, self.lap, where=where,
+                              to_host="with_matcher" if self.args.delivery == "single" else True)
         c.event_wait(nxt, 1)
         if self.multi:  # the right neighbour needs this rank's last frame: pack it and shift it round the ring
             c.pack_slots(1, self.packed[k].data_ptr(), self.slot_bytes, first=B - 1, sync=False)
@@ -522,10 +525,12 @@ class Pipeline:
             c.set_profiling(True)
         env["barrier"]()
         self.stamps = []
+        sent0 = [c.delivery_stats() for c in self.ctxs]
         t0 = time.perf_counter()
         self.run(steps * reps)
         env["barrier"]()
         dt = env["max_over_ranks"](time.perf_counter() - t0)
+        sent = [tuple(b - a for a, b in zip(s0, c.delivery_stats())) for s0, c in zip(sent0, self.ctxs)]
         stamps, self.stamps = self.stamps, None
         prof = {}
         for c in self.ctxs:
@@ -543,6 +548,8 @@ class Pipeline:
                   if blocks else None)
         return {"value": frames_per_step * n / dt, "ms_per_step": dt / n * 1e3, "reps": reps, "seconds": dt, "prof": prof,
                 "spread": spread,
+                # result deliveries of this rank's contexts: copy operations towards the host per step, and their bytes
+                "result_transfers_per_step": sum(a for a, _ in sent) / n, "result_bytes_per_step": sum(b for _, b in sent) / n,
                 "host_ms_per_step": {k: v / n * 1e3 for k, v in zip(("enqueue", "wait_step", "fetch_matches"),
                                                                    [self.state.get("enq_s", 0.0)] + self.state.get("host_s", [0, 0]))}}
 
@@ -643,6 +650,7 @@ def run_workload(name, args, env, want_cpu, cpu_seconds):
         out = {"workload": name, "value": main["value"] if "device" in res else None,
                "value_host_inputs": res["pinned"]["value"] if "pinned" in res else None,
                "ms_per_step": main["ms_per_step"], "timed_repeats": main["reps"], "timed_seconds": main["seconds"],
+               "result_transfers_per_step": main["result_transfers_per_step"], "result_bytes_per_step": main["result_bytes_per_step"],
                "spread": main.get("spread"), "spread_host_inputs": res["pinned"].get("spread") if "pinned" in res else None}
         if "pinned" in res and env["rank"] == 0:
             # the PCIe roofline of the host-input figure: image bytes that cross the link per second against what one
@@ -712,6 +720,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline workload only")
     ap.add_argument("--no-exchange-chain", dest="exchange_chain", action="store_false",
                     help="N>1: let the lanes' exchanges overlap instead of ordering them by events (A/B)")
+    ap.add_argument("--delivery", default="single", choices=["single", "separate"],
+                    help="mono workload: extraction and matcher results in one device-to-host transfer per step, or one each")
     ap.add_argument("--upload-split", type=int, default=0,
                     help="host inputs: 1 = a step's upload goes as two transfers and the chain event sits between them")
     ap.add_argument("--upload-chain", type=int, default=1,
@@ -829,6 +839,8 @@ def main():
             "spread_host_inputs": {k: sig(v) for k, v in (head.get("spread_host_inputs") or {}).items()},
             "timed_repeats": head["timed_repeats"],
             "timed_seconds": sig(head["timed_seconds"], 4),
+            "result_delivery": {"transfers_per_step": sig(head["result_transfers_per_step"], 3),
+                                "bytes_per_step": sig(head["result_bytes_per_step"], 6), "mode": args.delivery},
             "config": head["config"],
             "roofline": rl,
         }
@@ -854,6 +866,8 @@ def main():
                                                                    "avg_launch_ms", "pipeline_gbps_per_rank")}
             if "roofline_pcie" in r:
                 e["roofline_pcie"] = {k: sig(r["roofline_pcie"][k]) for k in ("achieved", "peak", "unit", "frac")}
+            if r.get("result_transfers_per_step") is not None:
+                e["result_transfers_per_step"] = sig(r["result_transfers_per_step"], 3)
             for k in ("spread", "spread_host_inputs"):
                 if r.get(k):
                     e[k] = {a: sig(b, 4) for a, b in r[k].items() if a != "blocks"}

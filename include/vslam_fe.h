@@ -164,8 +164,11 @@ int vslam_fe_stage_images_async(vslam_fe* fe, int nimg, const uint8_t* const* im
 /* The same in two halves, so a caller can keep several contexts (streams) in flight: _async enqueues the
  * whole pass and returns without waiting for the GPU (with the device quadtree nothing in it touches the
  * host); _wait blocks until that pass is done and delivers the results like vslam_fe_extract_batch.
- * want_host != 0 also enqueues the D2H of keypoints and descriptors.  Device images: lifetime as above; pinned
- * host images must stay untouched until _wait returns. */
+ * want_host = 1 also enqueues the D2H of keypoints and descriptors (0: they stay in HBM, only the counts travel).
+ * want_host = 2 (full batches): the delivery is DEFERRED to the device SearchForInitialization that follows on this
+ * context (vslam_search_init_dev_async with at most max_batch pairs): counts, keypoints, descriptors and the matcher's
+ * outputs lie in one block and leave in ONE transfer behind the matcher; if no such call follows, _wait delivers.
+ * Device images: lifetime as above; pinned host images must stay untouched until _wait returns. */
 int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch,
                                  int imgs_on_device, int lap0, int lap1, int want_host);
 int vslam_fe_extract_wait(vslam_fe* fe, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
@@ -581,6 +584,10 @@ int vslam_dbg_logf(vslam_fe* fe, const float* x, int n, float* y);
  * Updated when a pass's results are collected. */
 int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* problems, unsigned long long* split_below_grid,
                           uint32_t* last_level_masks);
+/* Result deliveries of a context so far: how many copy operations (a runtime copy or one launch of the copy kernel) the
+ * extraction and SearchForInitialization paths put on the stream towards the host, and the bytes they carried.  A full
+ * batch with want_host = 1 is one operation, the matcher's outputs another; with want_host = 2 the step is ONE. */
+int vslam_fe_delivery_stats(const vslam_fe* fe, unsigned long long* transfers, unsigned long long* bytes);
 /* In-kernel time stamps of the quadtree kernel (100 MHz ticks; out64[63] = count).  Only a library built with
  * -DVSLAM_OCT_STAMPS and a context created under VSLAM_OCT_DBG=1 records them; otherwise VSLAM_ERR_INVALID. */
 int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);

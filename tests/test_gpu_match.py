@@ -571,3 +571,51 @@ def test_stereo_fisheye_candidates_on_the_reference_hut_frames():
         assert nc == wn and nc > 20 and np.array_equal(l2r, wl) and np.array_equal(d0, w0) and np.array_equal(d1, w1)
     finally:
         f.close()
+
+
+def test_deferred_delivery_rides_with_the_init_matcher(fe):
+    """want_host = 2 (to_host="with_matcher"): the extraction's keypoints / descriptors leave the device together with the
+    outputs of the SearchForInitialization that follows on the context -- one transfer per step; without a matcher call
+    the wait delivers.  A graph replay (pinned images, second pass) must defer too."""
+    B = fe.max_batch
+    frames = [synth.make_frame(1241, 376, seed=23, step=s) for s in range(B)]
+    e = orbo.Extractor(2000)
+    want = [e.compute(f, lap=(0, 1000)) for f in frames]
+    pin = V.PinnedImages(B, 376, 1241, 1241)
+    try:
+        for s in range(B):
+            pin.array[s][:] = frames[s]
+        m = V.FMatcher(fe, 0.9, True)
+        for rep in range(3):  # rep 0 captures the graph, rep 1 replays it, rep 2: no matcher call follows
+            sent0 = fe.delivery_stats()
+            fe.compute_batch_async(pin.ptrs, 1241, (0, 1000), to_host="with_matcher", where=V.IMGS_PINNED)
+            if rep < 2:
+                jobs = []
+                for s in range(1, B):
+                    p, c = fe.slot_dev_ptrs(s - 1), fe.slot_dev_ptrs(s)
+                    jobs.append((p[0], p[1], p[2], c[0], c[1], c[2], 0))
+                m.search_init_dev_async(jobs, 100)
+            res = fe.wait(copy=True)
+            sent = fe.delivery_stats()
+            assert sent[0] - sent0[0] == 1, (rep, sent0, sent)  # ONE transfer for the step, matcher outputs included
+            assert sent[1] - sent0[1] >= B * fe.cap * 60
+            for s in range(B):
+                assert len(res[s][0]) == len(want[s][0]), (rep, s)
+                assert all(np.array_equal(res[s][0][f], want[s][0][f]) for f in want[s][0].dtype.names), (rep, s)
+                assert np.array_equal(res[s][1], want[s][1]) and res[s][2] == want[s][2], (rep, s)
+            if rep < 2:
+                out = m.search_init_dev_wait([len(want[s - 1][0]) for s in range(1, B)])
+                for j, s in enumerate(range(1, B)):
+                    wn, wm, _ = orbo.search_for_initialization(want[s - 1][0], want[s - 1][1], want[s][0], want[s][1], 1241, 376,
+                                                               window=100, nnratio=0.9)
+                    assert out[j][0] == wn and np.array_equal(out[j][1], wm), (rep, j)
+    finally:
+        pin.close()
+    # the same step with separate deliveries: two transfers
+    sent0 = fe.delivery_stats()
+    dev = [_dev(f) for f in frames]
+    fe.compute_batch_async([t.data_ptr() for t in dev], 1241, (0, 1000), to_host=True)
+    m.search_init_dev_async(jobs, 100)
+    fe.wait()
+    m.search_init_dev_wait([len(want[s - 1][0]) for s in range(1, B)])
+    assert fe.delivery_stats()[0] - sent0[0] == 2

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
 ]
 
 
@@ -419,9 +419,10 @@ class FExtractor:
         (where=IMGS_PINNED, e.g. PinnedImages.ptrs: pulled over PCIe by the pass itself)."""
         nimg = len(device_ptrs)
         ptrs = device_ptrs if isinstance(device_ptrs, C.Array) else (C.c_void_p * nimg)(*device_ptrs)
-        self._pending = (nimg, to_host)
+        self._pending = (nimg, bool(to_host))
+        # to_host="with_matcher": want_host = 2, the delivery rides with the SearchForInitialization that follows
         _check(lib().vslam_fe_extract_batch_async(self._h, nimg, ptrs, pitch, where, vLappingArea[0], vLappingArea[1],
-                                                  int(to_host)))
+                                                  2 if to_host == "with_matcher" else int(bool(to_host))))
 
     def wait(self, copy=False):
         """Block until the enqueued pass is done.  Returns a list of (keypoints, descriptors, monoIndex);
@@ -574,6 +575,13 @@ class FExtractor:
         lib().vslam_fe_octree_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _check(lib().vslam_fe_octree_stats(self._h, C.byref(a), C.byref(b), m))
         return a.value, b.value, [int(v) for v in m]
+
+    def delivery_stats(self):
+        """(transfers, bytes): copy operations the extraction / SearchForInitialization paths sent to the host so far"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        lib().vslam_fe_delivery_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib().vslam_fe_delivery_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_profiling(self, on=True):
         _check(lib().vslam_fe_set_profiling(self._h, int(on)))

@@ -83,7 +83,11 @@ struct vslam_fe {
     SelKp* h_sel = nullptr; /* pinned, B*cap */
     uint8_t* d_res = nullptr;  /* the context's result block: counts (res_counts_bytes) | kps B*cap | desc B*cap*32 */
     uint8_t* h_res = nullptr;  /* pinned mirror, same layout */
-    size_t res_bytes = 0, res_counts_bytes = 0;
+    size_t res_bytes = 0, res_counts_bytes = 0, res_feat_bytes = 0, res_init_bytes = 0;
+    bool init_in_block = false;    /* d_init / h_init are the block's own matcher region (not allocations of their own) */
+    /* result deliveries of the extraction / SearchForInitialization paths so far (vslam_fe_delivery_stats) */
+    unsigned long long n_deliveries = 0, n_delivery_bytes = 0, graph_deliveries = 0, graph_delivery_bytes = 0;
+    bool deliver_deferred = false; /* an extraction with want_host = 2 is waiting for the matcher call that delivers both */
     vslam_kp* d_kps = nullptr; /* views into d_res / h_res */
     uint8_t* d_desc = nullptr;
     vslam_kp* h_kps = nullptr;
@@ -184,7 +188,7 @@ int vslam_ensure(void** p, size_t* have, size_t want);
 int vslam_ensure_pinned(uint8_t** p, size_t* have, size_t want); /* grow-only pinned host buffer */
 int vslam_pinned_alloc(void** p, size_t bytes);                  /* hipHostMalloc on the device's NUMA node; returns a hipError_t */
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                          int lap0, int lap1, bool want_host);
+                          int lap0, int lap1, int want_host);
 int vslam_finish_extract(vslam_fe* fe, int nimg);
 int vslam_deliver(vslam_fe* fe, int nimg, vslam_kp* const* kps, uint8_t* const* desc, int cap, int* n,
                   int* mono_index);
@@ -202,6 +206,12 @@ static inline hipError_t vslam_stream_wait(hipStream_t st) {
 #endif
     }
     return r;
+}
+
+/* bookkeeping of the result deliveries (vslam_fe_delivery_stats): `ops` copy operations carrying the ranges of R */
+static inline void vslam_count_delivery(vslam_fe* fe, int ops, const CopyRanges& R) {
+    fe->n_deliveries += (unsigned long long)ops;
+    for (int r = 0; r < R.n; r++) fe->n_delivery_bytes += R.bytes[r];
 }
 
 #endif

@@ -61,7 +61,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_oct_redo);
     hipFree(fe->d_sel_cnt);
     if (fe->h_stereo) hipHostFree(fe->h_stereo);
-    hipFree(fe->d_init);
+    if (!fe->init_in_block) hipFree(fe->d_init);
     hipFree(fe->d_init_scratch);
     hipFree(fe->d_proj);
     hipFree(fe->d_sbp);
@@ -75,7 +75,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_bow);
     if (fe->h_bow) hipHostFree(fe->h_bow);
     hipFree(fe->d_init_fb);
-    if (fe->h_init) hipHostFree(fe->h_init);
+    if (fe->h_init && !fe->init_in_block) hipHostFree(fe->h_init);
     if (fe->ev_cand) hipEventDestroy(fe->ev_cand);
     if (fe->ev_x) hipEventDestroy(fe->ev_x);
     for (int i = 0; i < 4; i++)
@@ -297,7 +297,11 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     /* ONE result block per context -- counts | keypoints | descriptors, back to back -- and one pinned mirror of it: a
      * full batch leaves the device in a single transfer (vslam_fe.hip: enqueue_extract_plain) */
     fe->res_counts_bytes = (((size_t)(fe->B * 4 + 4) * 4) + 255) & ~(size_t)255;
-    fe->res_bytes = fe->res_counts_bytes + nk * sizeof(vslam_kp) + nk * 32;
+    fe->res_feat_bytes = fe->res_counts_bytes + nk * sizeof(vslam_kp) + nk * 32; /* multiple of 16: cap % 4 == 0 */
+    /* ... followed by the outputs of the device SearchForInitialization for up to B pairs (vnMatches12 | vbPrevMatched |
+     * nmatches), so that extraction and matcher results of a step can leave in ONE transfer (want_host = 2) */
+    fe->res_init_bytes = (nk * 12 + (size_t)fe->B * 16 + 255) & ~(size_t)255; /* = init_scratch's need for B pairs */
+    fe->res_bytes = fe->res_feat_bytes + fe->res_init_bytes;
     HIPCHK(hipMalloc((void**)&fe->d_res, fe->res_bytes));
     HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_res, fe->res_bytes));
     HIPCHK(hipMemset(fe->d_res, 0, fe->res_bytes));
@@ -308,6 +312,10 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     fe->h_kps = (vslam_kp*)(fe->h_res + fe->res_counts_bytes);
     fe->d_desc = fe->d_res + fe->res_counts_bytes + nk * sizeof(vslam_kp);
     fe->h_desc = fe->h_res + fe->res_counts_bytes + nk * sizeof(vslam_kp);
+    fe->d_init = fe->d_res + fe->res_feat_bytes; /* grows into an allocation of its own for more than B pairs (vslam_match.hip) */
+    fe->h_init = fe->h_res + fe->res_feat_bytes;
+    fe->init_bytes = fe->h_init_bytes = fe->res_init_bytes;
+    fe->init_in_block = true;
 
     /* GPU quadtree distribution (k_octree): per-level parameters, key ping-pong arrays, result lists */
     {
@@ -486,6 +494,13 @@ extern "C" int vslam_fe_octree_stats(const vslam_fe* fe, unsigned long long* pro
     if (split_below_grid) *split_below_grid = fe->oct_deep;
     if (last_level_masks)
         for (int s = 0; s < fe->B; s++) last_level_masks[s] = s < fe->last_nimg ? fe->oct_last_mask[s] : 0u;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_fe_delivery_stats(const vslam_fe* fe, unsigned long long* transfers, unsigned long long* bytes) {
+    if (!fe) return VSLAM_ERR_INVALID;
+    if (transfers) *transfers = fe->n_deliveries;
+    if (bytes) *bytes = fe->n_delivery_bytes;
     return VSLAM_OK;
 }
 
@@ -942,10 +957,23 @@ void vslam_host_prof_report() {
 }
 
 static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                                 int lap0, int lap1, bool want_host);
+                                 int lap0, int lap1, int want_host);
+
+/* want_host: 0 results stay in HBM (counts still reach the host), 1 delivered by this pass, 2 delivery DEFERRED to the
+ * device SearchForInitialization that follows on this context (one transfer for both); if none follows, the wait delivers */
+static int enqueue_extract_impl(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device, int lap0,
+                                int lap1, int want_host);
 
 int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                          int lap0, int lap1, bool want_host) {
+                          int lap0, int lap1, int want_host) {
+    const int rc = enqueue_extract_impl(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
+    /* set on every path, a replayed graph included (the captured pass of want_host = 2 holds no copy) */
+    fe->deliver_deferred = rc == VSLAM_OK && want_host == 2 && fe->dev_octree && nimg == fe->B && fe->init_in_block;
+    return rc;
+}
+
+static int enqueue_extract_impl(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device, int lap0,
+                                int lap1, int want_host) {
     HIPCHK(hipSetDevice(fe->p.device));
     if (on_device == VSLAM_IMGS_HOST) {
         int rc = stage_host_images(fe, nimg, imgs, pitch);
@@ -960,7 +988,7 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
-                    (want_host ? 1 : 0) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^
+                    (long long)(want_host & 3) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^
                     ((long long)on_device << 56); /* host / pinned / staged passes capture different launches */
     if (on_device == VSLAM_IMGS_PINNED) {
         /* the caller's pointers are kernel arguments of the captured pull: a different set of images is a different
@@ -982,6 +1010,8 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
             fe->src.pitch0[s] = (uint32_t)fe->geom.lv[0].pitch;
         }
         HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
+        fe->n_deliveries += fe->graph_deliveries;
+        fe->n_delivery_bytes += fe->graph_delivery_bytes;
         return VSLAM_OK;
     }
     if (fe->graph_exec) {
@@ -993,8 +1023,13 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
         fe->use_graph = false; /* capture unavailable: plain launches from now on */
         return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     }
+    const unsigned long long del0 = fe->n_deliveries, delb0 = fe->n_delivery_bytes;
     int rc = enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     const hipError_t ce = hipStreamEndCapture(fe->stream, &graph);
+    fe->graph_deliveries = fe->n_deliveries - del0; /* what one replay of this graph sends to the host */
+    fe->graph_delivery_bytes = fe->n_delivery_bytes - delb0;
+    fe->n_deliveries = del0; /* the capture itself ran nothing */
+    fe->n_delivery_bytes = delb0;
     if (rc != VSLAM_OK || ce != hipSuccess || !graph ||
         hipGraphInstantiate(&fe->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
         if (graph) hipGraphDestroy(graph);
@@ -1012,11 +1047,13 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
     fe->graph_lap0 = lap0;
     fe->graph_lap1 = lap1;
     HIPCHK(hipGraphLaunch(fe->graph_exec, fe->stream));
+    fe->n_deliveries += fe->graph_deliveries;
+    fe->n_delivery_bytes += fe->graph_delivery_bytes;
     return VSLAM_OK;
 }
 
 static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* imgs, size_t pitch, int on_device,
-                                 int lap0, int lap1, bool want_host) {
+                                 int lap0, int lap1, int want_host) {
     const double t0 = hp_now();
     int rc = enqueue_front(fe, nimg, imgs, pitch, on_device);
     if (rc) return rc;
@@ -1035,13 +1072,15 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
     /* results go to pinned host memory by a kernel (whole blocks: the host does not know the counts yet) */
     CopyRanges R;
     memset(&R, 0, sizeof(R));
+    if (want_host == 2 && fe->dev_octree && nimg == fe->B && fe->init_in_block)
+        return VSLAM_OK; /* deferred: vslam_search_init_dev_async (or the wait) sends the block; vslam_enqueue_extract sets the flag */
     if (want_host && fe->dev_octree && nimg == fe->B) {
         /* a full batch: counts, keypoints and descriptors are one contiguous block -> ONE transfer */
         R.dst[0] = fe->h_res;
         R.src[0] = fe->d_res;
-        R.bytes[0] = fe->res_bytes;
+        R.bytes[0] = fe->res_feat_bytes;
         R.n = 1;
-        vk_copy_ranges(st, R, fe->tune);
+        vslam_count_delivery(fe, vk_copy_ranges(st, R, fe->tune), R);
         HIPCHK(hipGetLastError());
         return VSLAM_OK;
     }
@@ -1058,13 +1097,24 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
         R.src[R.n] = fe->d_desc;
         R.bytes[R.n++] = (size_t)nimg * fe->cap * 32;
     }
-    vk_copy_ranges(st, R, fe->tune);
+    vslam_count_delivery(fe, vk_copy_ranges(st, R, fe->tune), R);
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
 }
 
 int vslam_finish_extract(vslam_fe* fe, int nimg) {
     hipStream_t st = fe->stream;
+    if (fe->deliver_deferred) { /* a deferred delivery that no matcher call picked up */
+        fe->deliver_deferred = false;
+        CopyRanges R;
+        memset(&R, 0, sizeof(R));
+        R.dst[0] = fe->h_res;
+        R.src[0] = fe->d_res;
+        R.bytes[0] = fe->res_feat_bytes;
+        R.n = 1;
+        vslam_count_delivery(fe, vk_copy_ranges(st, R, fe->tune), R);
+        HIPCHK(hipGetLastError());
+    }
     const double t_sync = hp_now();
     HIPCHK(vslam_stream_wait(st));
     g_hp[3] += hp_now() - t_sync;
@@ -1149,7 +1199,7 @@ extern "C" int vslam_fe_extract_batch_async(vslam_fe* fe, int nimg, const uint8_
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
-    int rc = vslam_enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, want_host != 0);
+    int rc = vslam_enqueue_extract(fe, nimg, imgs, pitch, imgs_on_device, lap0, lap1, want_host < 0 ? 0 : want_host > 2 ? 1 : want_host);
     if (rc != VSLAM_OK) hipStreamSynchronize(fe->stream);
     return rc;
 }

@@ -82,7 +82,8 @@ void vk_unproject_stereo(hipStream_t st, const UnprojJobs& U, int njobs);
 void vk_fuse_search(hipStream_t st, const FuseArgsDev& A);
 void vk_reset_headers(hipStream_t st, uint8_t* d_cand, size_t cand_stride_bytes, int nimg, int32_t* d_err);
 /* device -> pinned host (or device) range copies / zero fills in one launch; see k_copy_ranges */
-void vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T = vslam_process_tuning());
+/* returns the number of copy operations put on the stream (runtime copies or one kernel launch) */
+int vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T = vslam_process_tuning());
 /* host (pinned) images -> level 0 of the slots, one launch; src.l0 / src.pitch0 describe the host rows */
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
                     int w, int h, int nimg, int from_host, const vslam_tuning& T);

@@ -80,7 +80,7 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
     R.src[0] = sc.uRight; /* uRight | depth */
     R.bytes[0] = n * 8;
     R.n = 1;
-    vk_copy_ranges(st, R);
+    vslam_count_delivery(feL, vk_copy_ranges(st, R, feL->tune), R);
     HIPCHK(hipGetLastError());
     feL->stereo_pairs = npairs;
     for (int j = 0; j < npairs; j++) feL->stereo_slotL[j] = slotsL[j];
@@ -159,6 +159,13 @@ extern "C" int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8
 /* ------------------------------------------------------------------ SearchForInitialization on the device */
 static int init_scratch(vslam_fe* fe, int npairs) {
     const size_t per = (size_t)fe->cap * 4 + (size_t)fe->cap * 8 + 16;
+    if (per * npairs <= fe->init_bytes) return VSLAM_OK; /* the result block's own region: up to max_batch pairs */
+    if (fe->init_in_block) { /* more pairs than image slots: buffers of their own from now on */
+        fe->init_in_block = false;
+        fe->d_init = nullptr;
+        fe->h_init = nullptr;
+        fe->init_bytes = fe->h_init_bytes = 0;
+    }
     int rc = vslam_ensure((void**)&fe->d_init, &fe->init_bytes, per * npairs);
     if (rc) return rc;
     if (fe->h_init_bytes < per * npairs) {
@@ -237,11 +244,20 @@ extern "C" int vslam_search_init_dev_async(vslam_fe* fe, int npairs, const vslam
     HIPCHK(hipGetLastError());
     CopyRanges R;
     memset(&R, 0, sizeof(R));
-    R.dst[0] = fe->h_init;
-    R.src[0] = fe->d_init;
-    R.bytes[0] = nm * 12 + (size_t)npairs * 4;
+    if (fe->deliver_deferred && fe->init_in_block) {
+        /* the extraction of this step asked for its delivery to be deferred (want_host = 2): counts, keypoints, descriptors
+         * and the matcher's outputs are contiguous in the result block -> ONE transfer for the whole step */
+        fe->deliver_deferred = false;
+        R.dst[0] = fe->h_res;
+        R.src[0] = fe->d_res;
+        R.bytes[0] = fe->res_feat_bytes + ((nm * 12 + (size_t)npairs * 4 + 15) & ~(size_t)15);
+    } else {
+        R.dst[0] = fe->h_init;
+        R.src[0] = fe->d_init;
+        R.bytes[0] = nm * 12 + (size_t)npairs * 4;
+    }
     R.n = 1;
-    vk_copy_ranges(fe->stream, R); /* device -> pinned host by a kernel (cheaper to enqueue than hipMemcpyAsync) */
+    vslam_count_delivery(fe, vk_copy_ranges(fe->stream, R, fe->tune), R);
     HIPCHK(hipGetLastError());
     fe->init_pairs = npairs;
     return VSLAM_OK;

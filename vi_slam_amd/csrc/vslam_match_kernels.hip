@@ -531,10 +531,10 @@ __global__ void __launch_bounds__(256) k_copy_ranges(CopyRanges R) {
     }
 }
 
-void vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T) {
+int vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T) {
     size_t total = 0;
     for (int r = 0; r < R.n; r++) total += R.bytes[r];
-    if (!total) return;
+    if (!total) return 0;
     /* Large transfers between HBM and pinned host memory are handed to the runtime (one hipMemcpyAsync per range on the
      * same stream; in a kernel trace they appear as __amd_rocclr_copyBuffer, ~27 us per megabyte-sized copy).  With the
      * keypoints and descriptors of a 32-frame step (2 MB) copied by the kernel below, the mono workload ran 117-124 k
@@ -543,15 +543,17 @@ void vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T) 
      * one ~5-us kernel, cheaper to enqueue.  VSLAM_D2H=kernel|sdma forces one route. */
     const int mode = T.d2h_route == 1 ? 1 : T.d2h_route == 2 ? 2 : 0; /* 1 copy kernel, 2 runtime copy, 0 by size */
     if (mode == 2 || (mode == 0 && total >= (256u << 10))) {
+        int ops = 0;
         for (int r = 0; r < R.n; r++)
-            if (R.bytes[r]) (void)hipMemcpyAsync(R.dst[r], R.src[r], R.bytes[r], hipMemcpyDefault, st);
-        return;
+            if (R.bytes[r]) (void)hipMemcpyAsync(R.dst[r], R.src[r], R.bytes[r], hipMemcpyDefault, st), ops++;
+        return ops;
     }
     /* a transfer to or from host memory is bound by the link, not by the GPU: a few workgroups with several loads in
      * flight per lane keep it busy without parking waves on every CU (VSLAM_COPY_WGS overrides the cap of 16) */
     const int cap = std::max(1, tune_or(T.copy_wgs, 16));
     const int blocks = (int)std::min<size_t>((size_t)cap, (total / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_copy_ranges, dim3(blocks), dim3(256), 0, st, R);
+    return 1;
 }
 
 /* Host images -> level 0 of the slots' pyramids, ONE launch per batch, sized for PCIe and not for the GPU: a handful of
