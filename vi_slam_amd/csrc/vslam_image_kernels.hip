@@ -607,6 +607,26 @@ extern "C" int vslam_dbg_fast_stamps(unsigned long long* out16, int reset) {
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
+#ifdef VSLAM_FAST_WGREC
+#define FAST_WGREC_END()                                                                                              \
+    do {                                                                                                              \
+        if (tid == 0) {                                                                                               \
+            const unsigned rec = blockIdx.y * gridDim.x + blockIdx.x;                                                 \
+            if (rec < FAST_WG_RECORDS) {                                                                              \
+                unsigned hw, xcc;                                                                                     \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                      \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                    \
+                g_fast_wg[rec * 4 + 0] = fst_entry_;                                                                  \
+                g_fast_wg[rec * 4 + 1] = __builtin_amdgcn_s_memtime();                                                \
+                g_fast_wg[rec * 4 + 2] = fst_real_;                                                                   \
+                const unsigned long long dreal = __builtin_amdgcn_s_memrealtime() - fst_real_;                        \
+                g_fast_wg[rec * 4 + 3] = (unsigned long long)(hw & 0xFFFFu) | ((unsigned long long)(xcc & 0xFu) << 16) | (dreal << 32); \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#else
+#define FAST_WGREC_END() do { } while (0)
+#endif
 #define FAST_XCD_CHUNK 16
 template <int NT, int P> /* P: LDS pitch, 48 for windows up to 42 px, else 72 */
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
@@ -672,7 +692,9 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
      * (global_load_lds_dwordx4 into a second tile, 7 waves per SIMD) -- and both were SLOWER (117-160 us against 111):
      * what this kernel is short of is issue slots per instruction, not latency cover. */
     constexpr int LPR = P / 8, RPS = NT / LPR;        /* 8-byte lanes per row, rows per sweep */
-    constexpr int NSW = (134 + RPS - 1) / RPS > 4 ? 4 : (134 + RPS - 1) / RPS; /* sweeps kept in registers at once */
+    /* sweeps kept in registers at once: two cover the 42 rows of the narrow-pitch geometries (KITTI, 1080p: windows of
+     * 36-38 rows); taller windows take the row loop below */
+    constexpr int NSW = P == 48 ? (42 + RPS - 1) / RPS : ((134 + RPS - 1) / RPS > 4 ? 4 : (134 + RPS - 1) / RPS);
     const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
     const bool stager = tid < RPS * LPR && scol < ww + 1;
     const uint8_t* gsrc = img + (size_t)cd.y0 * pitch + cd.x0 - 1;
@@ -710,9 +732,16 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
     const uint32_t* W32 = (const uint32_t*)win;
     int T = iniTh;
     for (int stage = 0; stage < 2; stage++) {
-        const uint32_t TT = (uint32_t)T | ((uint32_t)T << 16);
+        /* pixels outside the interior (the last quad's tail, rows past ih in the last sweep) are tested against a
+         * threshold nothing passes (v - 0x7FFF saturates to 0, v + 0x7FFF is above every pixel): no validity masks,
+         * no compares for them inside the sweep.  Halves of TTv[par]: pixels par and par + 2 of the quad */
+        uint32_t TTv[2];
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+            TTv[par] = (par < rem ? (uint32_t)T : 0x7FFFu) | ((par + 2 < rem ? (uint32_t)T : 0x7FFFu) << 16);
         for (int ly0 = 0; ly0 < ih; ly0 += (NT >> qsh)) { /* block-uniform trip count */
             const int ly = ly0 + qly;
+            const bool rowok = ly < ih;
             /* every lane computes (rows past the interior and quads past QW read other parts of the LDS allocation;
              * their results are dropped by rowok / rem below): no branch inside the sweep */
             const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
@@ -726,6 +755,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
 #pragma unroll
             for (int par = 0; par < 2; par++) {
                 const uint32_t v = par ? ODD(C) : EVN(C);
+                const uint32_t TT = rowok ? TTv[par] : 0x7FFF7FFFu;
                 const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
                 const uint32_t u = par ? ODD(U) : EVN(U), d = par ? ODD(Dn) : EVN(Dn);
                 const uint32_t l = par ? ODD(Lf) : EVN(Lf), r = par ? ODD(Rt) : EVN(Rt);
@@ -742,16 +772,12 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
              * scalar side, ONE LDS atomic per wave and sweep for the list space, stores under the lane mask.  (A
              * per-stage compaction pass over a byte-per-quad mask array -- wave scan, per-lane bit loops -- was ~150
              * instructions per wave on top of the bit extraction here; this is ~45 per sweep, and a barrier less.) */
-            const uint64_t rowm = __builtin_amdgcn_ballot_w64(ly < ih);
             uint64_t mD[4], mB[4], mX[4];
             uint32_t totD = 0, totB = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                /* lanes whose pixel j lies inside the interior: one compare here is cheaper than four lane masks kept in
-                 * SGPRs across the kernel (they spill: the kernel is capped at 80 SGPRs for 8 waves per SIMD) */
-                const uint64_t ok = rowm & __builtin_amdgcn_ballot_w64(j < rem);
-                const uint64_t dk = ((j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1])) & ok;
-                const uint64_t br = ((j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1])) & ok;
+                const uint64_t dk = (j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1]);
+                const uint64_t br = (j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1]);
                 mD[j] = dk;       /* dark, or both polarities possible: the latter are listed once, here, flagged */
                 mX[j] = dk & br;
                 mB[j] = br & ~dk;
@@ -854,6 +880,36 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
 
     /* ordered compaction: thread t owns the keep words [t*WPT, (t+1)*WPT) -- word w = (row w>>1, columns (w&1)*32 ..) --
      * so raster order is kept across threads */
+    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    CellOut* cout = (CellOut*)(hdr + 2);
+    uint32_t* cand = (uint32_t*)(cout + ncells);
+    if (nwords <= 64) {
+        /* the usual cell (interiors of up to 32 rows): wave 0 owns every keep word, one per lane -- the other waves are
+         * done, no barrier, no cross-wave offsets */
+        if (wv != 0) return;
+        uint32_t bits = lane < nwords ? keep[lane] : 0u;
+        const uint32_t c1 = (uint32_t)__popc(bits);
+        const uint32_t in1 = wave_incl_scan(c1);
+        const uint32_t total1 = (uint32_t)__builtin_amdgcn_readlane((int)in1, 63);
+        if (lane == 0) {
+            cout[cell].base = cd.base;
+            cout[cell].count = total1;
+        }
+        if (bits) {
+            uint32_t o = cd.base + in1 - c1;
+            const int kly = lane >> 1, kxb = (lane & 1) * 32;
+            const int ox = cd.x0 + 3 - VSLAM_BORDER + kxb, oy = cd.y0 + 3 - VSLAM_BORDER + kly;
+            const uint8_t* srow_ = sc + (kly + 1) * P + kxb + 1;
+            while (bits) {
+                const int k = __ffs(bits) - 1;
+                bits &= bits - 1;
+                cand[o++] = ((uint32_t)srow_[k] << 24) | ((uint32_t)oy << 12) | (uint32_t)(ox + k);
+            }
+        }
+        FSTAMP(12);
+        FAST_WGREC_END();
+        return;
+    }
     const int WPT = (nwords + NT - 1) / NT; /* 1 for NT = 256 */
     uint32_t cnt = 0;
     for (int j = 0; j < WPT; j++) {
@@ -871,9 +927,6 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         if (k < wv) wave_off += s_wave_tot[k];
         total += s_wave_tot[k];
     }
-    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
-    CellOut* cout = (CellOut*)(hdr + 2);
-    uint32_t* cand = (uint32_t*)(cout + ncells);
     if (tid == 0) {
         cout[cell].base = cd.base;
         cout[cell].count = total;
@@ -895,21 +948,7 @@ k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc sr
         }
     }
     FSTAMP(12);
-#ifdef VSLAM_FAST_WGREC
-    if (tid == 0) {
-        const unsigned rec = blockIdx.y * gridDim.x + blockIdx.x;
-        if (rec < FAST_WG_RECORDS) {
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            g_fast_wg[rec * 4 + 0] = fst_entry_;
-            g_fast_wg[rec * 4 + 1] = __builtin_amdgcn_s_memtime();
-            g_fast_wg[rec * 4 + 2] = fst_real_;
-            const unsigned long long dreal = __builtin_amdgcn_s_memrealtime() - fst_real_;
-            g_fast_wg[rec * 4 + 3] = (unsigned long long)(hw & 0xFFFFu) | ((unsigned long long)(xcc & 0xFu) << 16) | (dreal << 32);
-        }
-    }
-#endif
+    FAST_WGREC_END();
 }
 
 /* threads per cell: a cell is 900 pixels, and ~150 of the ~420 instructions a thread executes do not depend on how many
