@@ -594,6 +594,9 @@ int vslam_dbg_octree_stamps(vslam_fe* fe, unsigned long long* out64);
 /* Number of queries for which the device SearchForInitialization had to re-scan the whole window because the
  * sorted candidate prefix (length VSLAM_INIT_TOPM, default 8) was exhausted; read-and-reset, synchronises. */
 int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count);
+/* Rounds of the replay wave, queries and pairs it decided since the last call (read-and-reset, synchronises): the
+ * sequential half of SearchForInitialization commits `queries / rounds` queries per round on average. */
+int vslam_dbg_search_init_replay_stats(vslam_fe* fe, int* rounds, int* queries, int* pairs);
 
 #ifdef __cplusplus
 }

@@ -619,3 +619,63 @@ def test_deferred_delivery_rides_with_the_init_matcher(fe):
     fe.wait()
     m.search_init_dev_wait([len(want[s - 1][0]) for s in range(1, B)])
     assert fe.delivery_stats()[0] - sent0[0] == 2
+
+
+def _handmade_frames(rng, n1, n2, nproto, q_flips, s_flips, area=60, chain=False):
+    """keypoints crowded into one window, descriptors = a few prototypes with bit flips: most queries see several slots
+    within TH_LOW and steal from each other; chain=True: every query is a little closer to slot 0 than the one before"""
+    def kps(n):
+        k = np.zeros(n, V.KP_DTYPE)
+        k["x"] = 300 + rng.integers(0, area, n)
+        k["y"] = 150 + rng.integers(0, area, n)
+        k["angle"] = rng.integers(0, 360, n).astype(np.float32)
+        k["size"] = 31.0
+        k["octave"] = np.where(rng.random(n) < 0.1, 1, 0)
+        return k
+
+    def flip(d, nb):
+        d = d.copy()
+        bits = rng.choice(256, nb, replace=False)
+        for b in bits:
+            d[b >> 3] ^= 1 << (b & 7)
+        return d
+
+    proto = rng.integers(0, 256, (nproto, 32), dtype=np.uint8)
+    k1, k2 = kps(n1), kps(n2)
+    if chain:
+        k1["octave"] = 0
+        k2["octave"] = 0
+        d2 = np.stack([proto[0]] + [np.bitwise_not(proto[0])] * (n2 - 1))
+        d1 = np.stack([flip(proto[0], max(45 - i, 1)) for i in range(n1)])
+    else:
+        d2 = np.stack([flip(proto[rng.integers(nproto)], int(rng.integers(0, s_flips + 1))) for _ in range(n2)])
+        d1 = np.stack([flip(proto[rng.integers(nproto)], int(rng.integers(0, q_flips + 1))) for _ in range(n1)])
+    return k1, np.ascontiguousarray(d1), k2, np.ascontiguousarray(d2)
+
+
+@pytest.mark.parametrize("topm", [0, 2, 16])
+def test_search_init_replay_under_heavy_contention(topm):
+    """The replay decides all undecided queries per round and commits out of query order: hand-made frames where nearly
+    every query has several candidates within TH_LOW, long steal chains on one slot (more acceptances than a slot's entry
+    list holds) and lists that run out -- vnMatches12 / vbPrevMatched / nmatches equal the sequential oracle."""
+    rng = np.random.default_rng(77 + topm)
+    f = V.FExtractor(2000, 1.2, 8, 20, 7, 1241, 376, max_batch=1, tuning=dict(init_topm=topm) if topm else None)
+    try:
+        cases = [_handmade_frames(rng, 200, 30, 6, 45, 10), _handmade_frames(rng, 400, 120, 3, 40, 25),
+                 _handmade_frames(rng, 150, 150, 40, 30, 5, area=200), _handmade_frames(rng, 60, 4, 1, 0, 0, chain=True),
+                 _handmade_frames(rng, 300, 8, 2, 48, 2, area=20), _handmade_frames(rng, 1, 1, 1, 3, 0), _handmade_frames(rng, 250, 60, 2, 50, 50)]
+        for ratio, ori in ((0.9, True), (0.6, False), (1.0, True)):
+            m = V.FMatcher(f, ratio, ori)
+            dev = [(_dev(c[1]), _dev(c[3])) for c in cases]
+            pairs = [(c[0], dv[0].data_ptr(), c[2], dv[1].data_ptr(), np.stack([c[0]["x"], c[0]["y"]], 1)) for c, dv in zip(cases, dev)]
+            out = m.SearchForInitializationBatch(pairs, 100)
+            nacc = 0
+            for j, c in enumerate(cases):
+                wn, wm, wp = orbo.search_for_initialization(c[0], c[1], c[2], c[3], 1241, 376, window=100, nnratio=ratio, check_ori=ori)
+                assert out[j][0] == wn and np.array_equal(out[j][1], wm) and np.array_equal(out[j][2], wp), (topm, ratio, ori, j)
+                nacc += wn
+            assert nacc > 20
+            rounds, queries, npairs = m.search_init_replay_stats()
+            assert npairs == len(cases) and queries > 900 and rounds >= npairs
+    finally:
+        f.close()

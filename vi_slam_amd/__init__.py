@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
 ]
 
 
@@ -948,6 +948,12 @@ class FMatcher:
         c = C.c_int()
         _check(lib().vslam_dbg_search_init_fallbacks(self.fe._h, C.byref(c)))
         return c.value
+
+    def search_init_replay_stats(self):
+        """Diagnostics: (rounds, queries, pairs) of the replay wave since the last call (read-and-reset)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().vslam_dbg_search_init_replay_stats(self.fe._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def SearchForInitializationBatch(self, pairs, windowSize=10, img_size=None):
         """Several independent SearchForInitialization problems in one pass of the kernels.

@@ -262,10 +262,22 @@ k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, in
     }
 }
 
-/* Full re-scan of one query's window (the reference loop body, fmatcher.cpp:1003-1035): used by the replay wave
- * when its sorted prefix ran out.  Returns the best key; *second_out = bestDist2 (0x7FFFFFFF if none). */
-__device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const int32_t* ownerDist, int c2, int lane,
-                                 const SiQuery& qq, float r, float invW, float invH, uint32_t* second_out) {
+/* vMatchedDistance as the replay keeps it: per frame-2 slot up to four (writer + 1) << 8 | distance entries (0xFFFFFFFF =
+ * empty; writer field 0 = merged entries of queries that everybody still pending comes after).  A query sees the
+ * acceptances of EARLIER queries only -- later queries may have committed before it (see k_si_replay). */
+__device__ __forceinline__ uint32_t sir_od_eff(const uint4 L, uint32_t q) {
+    uint32_t od = 0x7FFFFFFFu;
+    if ((L.x >> 8) <= q) od = min(od, L.x & 0xFFu);
+    if ((L.y >> 8) <= q) od = min(od, L.y & 0xFFu);
+    if ((L.z >> 8) <= q) od = min(od, L.z & 0xFFu);
+    if ((L.w >> 8) <= q) od = min(od, L.w & 0xFFu);
+    return od;
+}
+
+/* Full re-scan of one query's window (the reference loop body, fmatcher.cpp:1003-1035) by ONE wave: used when the query's
+ * sorted prefix ran out.  Returns the best key; *second_out = bestDist2 (0x7FFFFFFF if none). */
+__device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const uint4* slotlog, int c2, int lane,
+                                 const SiQuery& qq, uint32_t qpos, float r, float invW, float invH, uint32_t* second_out) {
     const SiWindow win = si_window(qq.px, qq.py, r, invW, invH);
     uint32_t bestKey = 0xFFFFFFFFu, second = 0x7FFFFFFFu; /* per lane: best key, smallest other distance */
     if (!win.empty) {
@@ -277,7 +289,7 @@ __device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const i
             const uint4 ta = ((const uint4*)jb.d2)[(size_t)cd.idx * 2];
             const uint4 tb = ((const uint4*)jb.d2)[(size_t)cd.idx * 2 + 1];
             const uint32_t dist = min(si_hamming(da, db, ta, tb), 255u);
-            if ((uint32_t)ownerDist[c] <= dist) continue; /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
+            if (sir_od_eff(slotlog[c], qpos) <= dist) continue; /* vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
             const uint32_t key = (dist << 24) | ((uint32_t)cd.cell << 12) | (uint32_t)c;
             if (key < bestKey) {
                 if (bestKey != 0xFFFFFFFFu) second = min(second, bestKey >> 24);
@@ -295,17 +307,59 @@ __device__ uint32_t si_full_scan(const InitJob& jb, const SiCand* gcand, const i
     return gBest;
 }
 
+/* append (writer q, distance d) to a slot's entries; `merge`: the writer is the smallest pending query, so every entry
+ * present comes from an earlier query and is visible to everybody still pending -- they collapse into one.  Returns
+ * false if the slot is full and merging is not allowed. */
+__device__ __forceinline__ bool sir_slot_append(uint4* slotlog, uint32_t slot, uint32_t q, uint32_t d, bool merge) {
+    uint4 L = slotlog[slot];
+    const uint32_t e = ((q + 1u) << 8) | d;
+    if (L.x == 0xFFFFFFFFu) L.x = e;
+    else if (L.y == 0xFFFFFFFFu) L.y = e;
+    else if (L.z == 0xFFFFFFFFu) L.z = e;
+    else if (L.w == 0xFFFFFFFFu) L.w = e;
+    else if (merge) {
+        const uint32_t dm = min(min(L.x & 0xFFu, L.y & 0xFFu), min(L.z & 0xFFu, L.w & 0xFFu));
+        L = make_uint4(dm, e, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    } else {
+        return false;
+    }
+    slotlog[slot] = L;
+    return true;
+}
+
 /* ------------------------------------------------------------------------------------------------
- * phase B: one wave per pair, queries in index order.
+ * phase B: one workgroup per pair; the sequential loop of fmatcher.cpp:1003-1049 decided in a few rounds.
+ *
+ * The loop carries ONE piece of state, vMatchedDistance, and a query's decision is a function of its FIRST TWO
+ * candidates (in key order) that are not skipped (vMatchedDistance[i2] <= dist, :1022); skipped ones never come back,
+ * the array only decreases.  So a query's decision is final as soon as no EARLIER undecided query can still accept one
+ * of those two slots -- and an undecided query can only ever accept a slot that is in its sorted prefix, not skipped,
+ * with a distance <= TH_LOW (:1037).  Every round, all undecided queries at once:
+ *   1. each evaluates the loop body against the acceptances of the queries BEFORE it (the per-slot entries carry their
+ *      writer, so an acceptance committed early by a later query is invisible to it) and publishes its index at every
+ *      slot it might still accept (atomicMin);
+ *   2. a query whose best and second-best slots show no smaller index commits: appends its acceptance to the slot's
+ *      entries and to the log.  The smallest undecided query always commits, so the rounds end; on consecutive KITTI-like
+ *      frames 217 (436) queries take 4-6 rounds (tests/tools/replay_sim.py), where committing only the prefix in front of
+ *      the first dependent query of a 64-query window (round 3's first version) took 30 (48) and one query per step 217.
+ * Two rare cases wait until they are the smallest undecided query: a query whose sorted prefix ran out and that needs the
+ * re-scan of its whole window (its second-best lies beyond the list) -- and while an undecided query could accept a slot
+ * BEYOND its list (full list, last listed distance <= TH_LOW), nothing behind it commits.
+ * Ownership ("last acceptor wins", which is what the reference's steal/undo amounts to), vnMatches12 and the rotation
+ * histogram are rebuilt from the log in parallel afterwards.
  * ---------------------------------------------------------------------------------------------- */
+#define SIR_NT 256
+#define SIR_PEND 1u
+#define SIR_ACC 2u
+#define SIR_SCAN 4u
 template <int MAXM> /* unrolled length of a query's sorted prefix: 8 (the default M) or SI_MAX_M */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(SIR_NT)
 k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
             int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
-            int32_t* nmatch_out /* [pair] */, int max_c2, int M, const uint8_t* scratch, int* fallbacks) {
+            int32_t* nmatch_out /* [pair] */, int max_c2, int M, const uint8_t* scratch, int* fallbacks, int keys_lds_bytes) {
     extern __shared__ __align__(16) uint8_t sism[];
     const InitJob jb = jobs.job[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n1 = min(*jb.cnt1, cap);
     const uint8_t* sp = scratch + (size_t)blockIdx.x * si_pair_bytes(max_c2, M);
     const int32_t* hdr = (const int32_t*)sp;
@@ -313,172 +367,168 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     const SiQuery* gqry = (const SiQuery*)(gcand + max_c2);
     const uint32_t* topm = (const uint32_t*)(gqry + max_c2);
     const int c1 = hdr[0], c2 = hdr[1];
-    /* LDS: ownerDist | ownerEntry | log | m12 | markDp | rotBin */
-    int32_t* ownerDist = (int32_t*)sism;            /* vMatchedDistance, max_c2 */
-    int32_t* ownerEntry = ownerDist + max_c2;       /* log entry of the last query that took the slot */
-    uint32_t* alog = (uint32_t*)(ownerEntry + max_c2); /* accepted (query position << 12 | slot), in order */
-    int32_t* m12 = (int32_t*)(alog + max_c2);       /* vnMatches12, cap */
-    int32_t* markDp = m12 + cap;                    /* rounds: smallest distance any lane of the round accepts the slot with */
-    uint8_t* rotBin = (uint8_t*)(markDp + max_c2);  /* bin of an accepted query, 255 = none */
+    /* LDS: slotlog | lister[2] | kfirst | ksecond | alog | m12 | qstate | rotBin */
+    uint4* slotlog = (uint4*)sism;                                /* vMatchedDistance with writers, max_c2 */
+    int32_t* lister0 = (int32_t*)(slotlog + max_c2);              /* smallest undecided query that may still accept the slot */
+    int32_t* lister1 = lister0 + max_c2;                          /* (two buffers: one is reset while the other is in use) */
+    uint32_t* kfirst = (uint32_t*)(lister1 + max_c2);             /* this round's best / second-best key of a query */
+    uint32_t* ksecond = kfirst + max_c2;
+    uint32_t* alog = ksecond + max_c2;                            /* accepted (query position << 12 | slot), any order */
+    int32_t* m12 = (int32_t*)(alog + max_c2);                     /* vnMatches12, cap */
+    uint8_t* qstate = (uint8_t*)(m12 + cap);                      /* SIR_* flags per query, max_c2 */
+    uint8_t* rotBin = qstate + max_c2;                            /* bin of an accepted query, 255 = none; cap */
+    /* the queries' sorted prefixes are read once per round: kept in LDS when they fit what the host set aside */
+    uint32_t* keys_lds = (uint32_t*)(sism + (((size_t)max_c2 * 37 + (size_t)cap * 5 + 15) & ~(size_t)15));
+    const bool keys_in_lds = (size_t)c1 * M * 4 <= (size_t)keys_lds_bytes;
+    const uint32_t* keysrc = keys_in_lds ? keys_lds : topm;
+    if (keys_in_lds)
+        for (int i = tid; i < c1 * M; i += SIR_NT) keys_lds[i] = topm[i];
     __shared__ int s_hist[SI_HISTO];
+    __shared__ int s_minpend[2], s_minwild[2], s_scanq, s_nlog, s_cnt;
 
     int32_t* mo = matches_out + (size_t)blockIdx.x * cap;
     float* po = prev_out + (size_t)blockIdx.x * cap * 2;
     const float invW = __fdiv_rn((float)SI_GRID_COLS, (float)imgW);
     const float invH = __fdiv_rn((float)SI_GRID_ROWS, (float)imgH);
+    const float r = (float)window;
 
-    for (int c = lane; c < c2; c += 64) {
-        ownerDist[c] = 0x7FFFFFFF;
-        ownerEntry[c] = -1;
+    for (int c = tid; c < c2; c += SIR_NT) {
+        slotlog[c] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        lister0[c] = 0x7FFFFFFF;
+        lister1[c] = 0x7FFFFFFF;
     }
-    for (int i = lane; i < n1; i += 64) {
+    for (int q = tid; q < c1; q += SIR_NT) qstate[q] = (uint8_t)SIR_PEND;
+    for (int i = tid; i < n1; i += SIR_NT) {
         m12[i] = -1;
         rotBin[i] = 255;
     }
-    if (lane < SI_HISTO) s_hist[lane] = 0;
-    __syncthreads();
-
-    /* The sequential part carries ONE piece of state, vMatchedDistance (ownerDist): a query's decision needs
-     * nothing else, and it reads that state only at the slots of its own M listed candidates.  So the queries are
-     * decided 64 at a time, lane = query, every lane against the state at the start of the round.  What can change a
-     * lane's decision is narrow: the decision is a function of its FIRST TWO non-skipped candidates (best and second
-     * best; skipped ones can never come back, vMatchedDistance only decreases), so it stands unless an EARLIER lane of
-     * the round accepts one of those two slots with a distance that makes it skipped for this lane (d_earlier <= d_mine).
-     * Accepting lanes publish (atomicMin) their lane number and their distance at their slot; a lane whose best or
-     * second-best slot shows a smaller lane number and a distance <= its own must wait (the two minima may come from
-     * different lanes: the test errs on the waiting side only).  The round commits the lanes in front of the first waiting
-     * lane -- in query order, which is lane order; two lanes taking the same slot in one round is fine, the later one's
-     * distance is the smaller one -- and starts again from it (it is then the first lane and cannot be overtaken, so every
-     * round commits at least one query).  A
-     * query whose sorted prefix ran out (rare: the re-scan of its whole window is a wave-cooperative loop) also ends a
-     * round and is then handled alone, as before.  Round 2 walked the queries one by one: ~0.4 us each for a single
-     * wave with nothing to hide its latencies behind, 90 us per pair of 220 queries; a round here costs about two of
-     * those steps and commits ten queries on average.
-     * Accepted (query, slot) pairs are appended to a log; ownership ("last acceptor wins", which is what the reference's
-     * steal/undo amounts to), vnMatches12 and the rotation histogram are rebuilt from the log in parallel afterwards. */
-    const float r = (float)window;
-    int nlog = 0, nfb = 0;
-    int32_t* mark = ownerEntry; /* during the rounds: smallest accepting lane per slot (INT_MAX: none); reset to -1 below */
-    for (int c = lane; c < c2; c += 64) {
-        mark[c] = 0x7FFFFFFF;
-        markDp[c] = 0x7FFFFFFF;
+    if (tid < SI_HISTO) s_hist[tid] = 0;
+    if (tid == 0) {
+        s_minpend[0] = s_minpend[1] = 0x7FFFFFFF;
+        s_minwild[0] = s_minwild[1] = 0x7FFFFFFF;
+        s_scanq = -1;
+        s_nlog = 0;
+        s_cnt = 0;
     }
     __syncthreads();
-    const unsigned long long lanes_before = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (int qb = 0; qb < c1; qb += 64) {
-        const int nq = min(64, c1 - qb);
-        uint32_t key[MAXM];
+
+    int nfb = 0, nrounds = 0;
+    for (int par = 0;; par ^= 1) {
+        int32_t* lister = par ? lister1 : lister0;
+        /* ---- 1: the reference's loop body (fmatcher.cpp:1003-1039) for every undecided query, as the queries before it left the state */
+        for (int q = tid; q < c1; q += SIR_NT) {
+            if (!(qstate[q] & SIR_PEND)) continue;
+            uint32_t key[MAXM];
 #pragma unroll
-        for (int j = 0; j < MAXM; j++) key[j] = (j < M && lane < nq) ? topm[(size_t)(qb + lane) * M + j] : 0xFFFFFFFFu;
-        unsigned long long done = nq < 64 ? ~0ull << nq : 0ull; /* wave-uniform */
-        while (done != ~0ull) {
-            const bool active = !((done >> lane) & 1ull);
-            /* ---- the reference's loop body (fmatcher.cpp:1003-1039) for this lane's query against the current state */
-            int nvalid = 0, first = -1, second = -1;
-            if (active) {
+            for (int j = 0; j < MAXM; j++) key[j] = j < M ? keysrc[(size_t)q * M + j] : 0xFFFFFFFFu;
+            int nvalid = 0;
+            uint32_t gBest = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, klast = 0u;
 #pragma unroll
-                for (int j = 0; j < MAXM; j++) {
-                    if (j < M && key[j] != 0xFFFFFFFFu) {
-                        nvalid++;
-                        const uint32_t od = (uint32_t)ownerDist[key[j] & 0xFFF];
-                        if (!(od <= (key[j] >> 24))) { /* not skipped: vMatchedDistance[i2] <= dist, fmatcher.cpp:1022 */
-                            if (first < 0) first = j;
-                            else if (second < 0) second = j;
-                        }
+            for (int j = 0; j < MAXM; j++) {
+                if (j < M && key[j] != 0xFFFFFFFFu) {
+                    nvalid++;
+                    klast = key[j];
+                    const uint32_t slot = key[j] & 0xFFFu, d = key[j] >> 24;
+                    if (!(sir_od_eff(slotlog[slot], (uint32_t)q) <= d)) { /* not skipped */
+                        if (d <= SI_TH_LOW) atomicMin(&lister[slot], q); /* may still accept this slot */
+                        if (gBest == 0xFFFFFFFFu) gBest = key[j];
+                        else if (k2 == 0xFFFFFFFFu) k2 = key[j];
                     }
                 }
             }
             const bool full = nvalid == M;
+            const uint32_t dlast = klast >> 24;
+            const bool wild = full && dlast <= SI_TH_LOW; /* could accept a slot beyond its list once the list is used up */
             bool accept = false, scan = false;
-            uint32_t gBest = 0xFFFFFFFFu, bestDist2 = 0x7FFFFFFFu;
-            if (active) {
-                if (first < 0) {
-                    scan = full; /* !full: vIndices2 empty or everything skipped, bestDist stays INT_MAX */
-                } else {
-#pragma unroll
-                    for (int j = 0; j < MAXM; j++) { /* register arrays: no dynamic indexing */
-                        if (j == first) gBest = key[j];
-                        if (j == second) bestDist2 = key[j] >> 24;
-                    }
-                    if ((gBest >> 24) <= SI_TH_LOW) {
-                        if (second < 0 && full) {
-                            /* the second survivor lies beyond the list: it is at least as far as the last entry */
-                            uint32_t klast = 0u;
-#pragma unroll
-                            for (int j = 0; j < MAXM; j++)
-                                if (j == M - 1) klast = key[j];
-                            const uint32_t dlast = klast >> 24;
-                            if ((float)(int)(gBest >> 24) < __fmul_rn((float)(int)dlast, nnratio)) bestDist2 = dlast; /* accepted whatever the true second is */
-                            else scan = true;
-                        }
-                        if (!scan) accept = (float)(int)(gBest >> 24) < __fmul_rn((float)(int)bestDist2, nnratio);
-                    }
+            if (gBest == 0xFFFFFFFFu) {
+                scan = wild; /* else: vIndices2 empty, everything skipped, or nothing within TH_LOW beyond the list */
+            } else if ((gBest >> 24) <= SI_TH_LOW) {
+                uint32_t bestDist2 = k2 == 0xFFFFFFFFu ? 0x7FFFFFFFu : (k2 >> 24);
+                if (k2 == 0xFFFFFFFFu && full) {
+                    /* the second survivor lies beyond the list: it is at least as far as the last entry */
+                    if ((float)(int)(gBest >> 24) < __fmul_rn((float)(int)dlast, nnratio)) bestDist2 = dlast; /* accepted whatever the true second is */
+                    else scan = true;
                 }
+                if (!scan) accept = (float)(int)(gBest >> 24) < __fmul_rn((float)(int)bestDist2, nnratio);
             }
-            const uint32_t slot2 = gBest & 0xFFF;
-            if (accept) {
-                atomicMin(&mark[slot2], lane);
-                atomicMin(&markDp[slot2], (int)(gBest >> 24));
-            }
-            __syncthreads();
-            bool stop = scan;
-            if (active && first >= 0) {
-                /* an earlier lane takes my best or second-best candidate with a distance that makes it skipped for me */
-                uint32_t k2 = 0xFFFFFFFFu;
-#pragma unroll
-                for (int j = 0; j < MAXM; j++)
-                    if (j == second) k2 = key[j];
-                if (mark[slot2] < lane && markDp[slot2] <= (int)(gBest >> 24)) stop = true;
-                if (k2 != 0xFFFFFFFFu && mark[k2 & 0xFFF] < lane && markDp[k2 & 0xFFF] <= (int)(k2 >> 24)) stop = true;
-            }
-            const unsigned long long mstop = __ballot(stop && active);
-            const int f = mstop ? __ffsll((long long)mstop) - 1 : 64; /* wave-uniform: first lane that must wait */
-            const unsigned long long upto = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
-            const bool commit = accept && lane < f;
-            const unsigned long long mcommit = __ballot(commit);
-            __syncthreads(); /* every lane has read the marks */
-            if (accept) {
-                mark[slot2] = 0x7FFFFFFF;
-                markDp[slot2] = 0x7FFFFFFF;
-            }
-            if (commit) {
-                atomicMin(&ownerDist[slot2], (int)(gBest >> 24)); /* several lanes of a round may take one slot: the last one's distance is the smallest */
-                alog[nlog + __popcll(mcommit & lanes_before)] = ((uint32_t)(qb + lane) << 12) | slot2;
-            }
-            nlog += __popcll(mcommit);
-            done |= upto;
-            __syncthreads();
-            if (f < 64 && __builtin_amdgcn_readlane((int)(scan ? 1 : 0), f)) {
-                /* lane f's sorted prefix ran out.  vMatchedDistance only ever decreases, so a query that needed the re-scan
-                 * against the older state needs it against the current one too: everything in front of it is committed --
-                 * re-scan its whole window now, all lanes cooperating (fmatcher.cpp:1003-1035 literally) */
-                nfb++;
-                uint32_t d2;
-                const uint32_t gb = si_full_scan(jb, gcand, ownerDist, c2, lane, gqry[qb + f], r, invW, invH, &d2);
-                if (gb != 0xFFFFFFFFu && (gb >> 24) <= SI_TH_LOW && (float)(int)(gb >> 24) < __fmul_rn((float)(int)d2, nnratio)) {
-                    if (lane == 0) {
-                        ownerDist[gb & 0xFFF] = (int)(gb >> 24);
-                        alog[nlog] = ((uint32_t)(qb + f) << 12) | (gb & 0xFFF);
-                    }
-                    nlog++;
-                }
-                done |= 1ull << f;
-                __syncthreads();
+            kfirst[q] = gBest;
+            ksecond[q] = k2;
+            qstate[q] = (uint8_t)(SIR_PEND | (accept ? SIR_ACC : 0u) | (scan ? SIR_SCAN : 0u));
+            atomicMin(&s_minpend[par], q);
+            if (wild) atomicMin(&s_minwild[par], q);
+        }
+        __syncthreads();
+        const int minp = s_minpend[par], minw = s_minwild[par];
+        if (minp == 0x7FFFFFFF) break; /* nothing undecided (block-uniform) */
+        nrounds++;
+        /* ---- 2: commit what no earlier undecided query can change; reset the other round's buffers */
+        {
+            int32_t* other = par ? lister0 : lister1;
+            for (int c = tid; c < c2; c += SIR_NT) other[c] = 0x7FFFFFFF;
+            if (tid == 0) {
+                s_minpend[par ^ 1] = 0x7FFFFFFF;
+                s_minwild[par ^ 1] = 0x7FFFFFFF;
             }
         }
+        for (int q = tid; q < c1; q += SIR_NT) {
+            const uint32_t fl = qstate[q];
+            if (!(fl & SIR_PEND)) continue;
+            if (fl & SIR_SCAN) {
+                if (q == minp) s_scanq = q; /* everything in front of it is decided: re-scan below */
+                continue;
+            }
+            const uint32_t k1 = kfirst[q], k2 = ksecond[q];
+            bool blocked = q > minw;
+            if (k1 != 0xFFFFFFFFu && lister[k1 & 0xFFFu] < q) blocked = true;
+            if (k2 != 0xFFFFFFFFu && lister[k2 & 0xFFFu] < q) blocked = true;
+            if (blocked) continue;
+            if (fl & SIR_ACC) {
+                if (!sir_slot_append(slotlog, k1 & 0xFFFu, (uint32_t)q, k1 >> 24, q == minp)) continue; /* slot full: wait to be first */
+                alog[atomicAdd(&s_nlog, 1)] = ((uint32_t)q << 12) | (k1 & 0xFFFu);
+            }
+            qstate[q] = 0;
+        }
+        __syncthreads();
+        /* ---- 3 (rare): the smallest undecided query's sorted prefix ran out -- re-scan its whole window, one wave
+         * (fmatcher.cpp:1003-1035 literally); it sees the acceptances of the queries before it only */
+        const int sq = s_scanq;
+        if (sq >= 0) { /* block-uniform */
+            if (tid < 64) {
+                uint32_t d2;
+                const uint32_t gb = si_full_scan(jb, gcand, slotlog, c2, lane, gqry[sq], (uint32_t)sq, r, invW, invH, &d2);
+                if (tid == 0) {
+                    if (gb != 0xFFFFFFFFu && (gb >> 24) <= SI_TH_LOW && (float)(int)(gb >> 24) < __fmul_rn((float)(int)d2, nnratio)) {
+                        sir_slot_append(slotlog, gb & 0xFFFu, (uint32_t)sq, gb >> 24, true);
+                        alog[atomicAdd(&s_nlog, 1)] = ((uint32_t)sq << 12) | (gb & 0xFFFu);
+                    }
+                    qstate[sq] = 0;
+                    s_scanq = -1;
+                }
+            }
+            nfb++;
+            __syncthreads();
+        }
     }
-    for (int c = lane; c < c2; c += 64) ownerEntry[c] = -1;
     __syncthreads();
-    if (fallbacks && lane == 0 && nfb) atomicAdd(fallbacks, nfb);
-    /* ownership: the last acceptor of a slot keeps it (fmatcher.cpp:1041-1049 undoes the previous owner) */
-    for (int e = lane; e < nlog; e += 64) atomicMax(&ownerEntry[alog[e] & 0xFFF], e);
+    const int nlog = s_nlog;
+    if (fallbacks && tid == 0) { /* [0] re-scans (vslam_dbg_search_init_fallbacks), [1..3] rounds, queries, pairs */
+        if (nfb) atomicAdd(fallbacks, nfb);
+        atomicAdd(fallbacks + 1, nrounds);
+        atomicAdd(fallbacks + 2, c1);
+        atomicAdd(fallbacks + 3, 1);
+    }
+    /* ownership: the last acceptor of a slot (in query order) keeps it (fmatcher.cpp:1041-1049 undoes the previous owner) */
+    int32_t* ownerQ = lister0;
+    for (int c = tid; c < c2; c += SIR_NT) ownerQ[c] = -1;
+    __syncthreads();
+    for (int e = tid; e < nlog; e += SIR_NT) atomicMax(&ownerQ[alog[e] & 0xFFFu], (int)(alog[e] >> 12));
     __syncthreads();
     const float factor = 1.0f / SI_HISTO;
-    for (int e = lane; e < nlog; e += 64) {
+    for (int e = tid; e < nlog; e += SIR_NT) {
         const uint32_t le = alog[e];
         const SiQuery q = gqry[le >> 12];
-        const SiCand cd = gcand[le & 0xFFF];
-        if (ownerEntry[le & 0xFFF] == e) m12[q.idx] = cd.idx;
+        const SiCand cd = gcand[le & 0xFFFu];
+        if (ownerQ[le & 0xFFFu] == (int)(le >> 12)) m12[q.idx] = cd.idx;
         if (checkOri) {
             float rot = __fsub_rn(q.angle, cd.angle);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
@@ -508,37 +558,64 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
         }
         if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        for (int i = lane; i < n1; i += 64) {
+        for (int i = tid; i < n1; i += SIR_NT) {
             const int b = rotBin[i];
             if (b != 255 && b != ind1 && b != ind2 && b != ind3) m12[i] = -1;
         }
         __syncthreads();
     }
     int cnt = 0;
-    for (int i = lane; i < n1; i += 64) {
-        const int m = m12[i];
-        mo[i] = m;
-        /* vbPrevMatched update (fmatcher.cpp:1093-1095) */
-        float ox = jb.prev ? jb.prev[2 * i] : jb.k1[i].x, oy = jb.prev ? jb.prev[2 * i + 1] : jb.k1[i].y;
-        if (m >= 0) {
-            ox = jb.k2[m].x;
-            oy = jb.k2[m].y;
-            cnt++;
+    /* four keypoints per thread and pass: their (dependent) global loads are in flight together */
+    for (int i0 = tid; i0 < n1; i0 += 4 * SIR_NT) {
+        int m[4];
+        float2 o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * SIR_NT;
+            m[u] = i < n1 ? m12[i] : -1;
         }
-        po[2 * i] = ox;
-        po[2 * i + 1] = oy;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * SIR_NT;
+            o[u] = make_float2(0.0f, 0.0f);
+            if (i < n1) {
+                /* vbPrevMatched update (fmatcher.cpp:1093-1095) */
+                if (m[u] >= 0) o[u] = make_float2(jb.k2[m[u]].x, jb.k2[m[u]].y);
+                else if (jb.prev) o[u] = make_float2(jb.prev[2 * i], jb.prev[2 * i + 1]);
+                else o[u] = make_float2(jb.k1[i].x, jb.k1[i].y);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * SIR_NT;
+            if (i < n1) {
+                mo[i] = m[u];
+                po[2 * i] = o[u].x;
+                po[2 * i + 1] = o[u].y;
+                cnt += m[u] >= 0;
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) nmatch_out[blockIdx.x] = hdr[2] ? -1 : cnt; /* -1: capacity overflow (vslam_search_init_dev_wait) */
+    if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) nmatch_out[blockIdx.x] = hdr[2] ? -1 : s_cnt; /* -1: capacity overflow (vslam_search_init_dev_wait) */
 }
 
 size_t vk_search_init_scratch_bytes(int npairs, int max_c2, int M) { return (size_t)npairs * si_pair_bytes(max_c2, M); }
 
 static size_t si_topm_lds(int max_c2) { return (size_t)max_c2 * (sizeof(SiCand) + 4 * 4); }
-static size_t si_replay_lds(int cap, int max_c2) { return (size_t)max_c2 * 16 + (size_t)cap * 5 + 64; }
+/* state (37 bytes per octave-0 keypoint, 5 per keypoint) + the sorted prefixes of up to max_c2 queries if that stays within 64 KB */
+static size_t si_replay_keys_lds(int max_c2, int M) {
+    const size_t want = (size_t)max_c2 * M * 4;
+    return want <= (64u << 10) ? want : 0;
+}
+static size_t si_replay_lds(int cap, int max_c2, int M = 0) {
+    return (((size_t)max_c2 * 37 + (size_t)cap * 5 + 15) & ~(size_t)15) + si_replay_keys_lds(max_c2, M) + 16;
+}
 
-size_t vk_search_init_lds(int cap, int max_c2) { return std::max(si_topm_lds(max_c2), si_replay_lds(cap, max_c2)); }
+size_t vk_search_init_lds(int cap, int max_c2) { return std::max(si_topm_lds(max_c2), si_replay_lds(cap, max_c2)); } /* without the optional key cache */
 
 int vk_search_init_set_max_lds(size_t bytes) {
     int rc = (int)hipFuncSetAttribute((const void*)k_si_topm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -559,12 +636,16 @@ void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, i
     const int chunks = (max_c2 + qpb - 1) / qpb;
     hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
                        window, max_c2, M, scratch, qpb);
+    /* the key cache only if the whole allocation stays within what vk_search_init_set_max_lds allowed (150 KB) */
+    int keys_lds = (int)si_replay_keys_lds(max_c2, M);
+    if (si_replay_lds(cap, max_c2, M) > (150u << 10)) keys_lds = 0;
+    const size_t rlds = keys_lds ? si_replay_lds(cap, max_c2, M) : si_replay_lds(cap, max_c2);
     if (M <= 8)
-        hipLaunchKernelGGL(k_si_replay<8>, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
-                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
+        hipLaunchKernelGGL(k_si_replay<8>, dim3(npairs), dim3(SIR_NT), rlds, st, jobs, cap, imgW, imgH,
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds);
     else
-        hipLaunchKernelGGL(k_si_replay<SI_MAX_M>, dim3(npairs), dim3(64), si_replay_lds(cap, max_c2), st, jobs, cap, imgW, imgH,
-                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks);
+        hipLaunchKernelGGL(k_si_replay<SI_MAX_M>, dim3(npairs), dim3(SIR_NT), rlds, st, jobs, cap, imgW, imgH,
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds);
 }
 
 /* ==================================================================================================

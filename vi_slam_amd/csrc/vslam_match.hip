@@ -503,6 +503,22 @@ extern "C" int vslam_dbg_search_init_fallbacks(vslam_fe* fe, int* count) {
     return VSLAM_OK;
 }
 
+/* rounds / queries / pairs of the replay wave since the last call (k_si_replay's own counters; read-and-reset) */
+extern "C" int vslam_dbg_search_init_replay_stats(vslam_fe* fe, int* rounds, int* queries, int* pairs) {
+    if (!fe) return VSLAM_ERR_INVALID;
+    int v[4] = {0, 0, 0, 0};
+    if (fe->d_init_fb) {
+        HIPCHK(hipSetDevice(fe->p.device));
+        HIPCHK(vslam_stream_wait(fe->stream));
+        HIPCHK(hipMemcpy(v, fe->d_init_fb, 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(fe->d_init_fb + 1, 0, 12));
+    }
+    if (rounds) *rounds = v[1];
+    if (queries) *queries = v[2];
+    if (pairs) *pairs = v[3];
+    return VSLAM_OK;
+}
+
 /* ------------------------------------------------------------------ SearchByProjection(CurrentFrame, LastFrame) */
 extern "C" int vslam_projection_direction(const float* Tcw, const float* Tlw, float mb, int mono, int gemm_float,
                                           int* forward, int* backward) {
