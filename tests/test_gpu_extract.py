@@ -340,6 +340,37 @@ def test_host_image_with_row_padding_and_context_churn():
             fe.close()
 
 
+def test_dense_and_padded_host_images_alternate_on_one_context():
+    """Dense host images (pitch == width) are staged densely -- one copy per image, their own captured graph -- padded
+    ones row by row; alternating between the two on ONE context (single image and a batch, which takes the DMA route)
+    must replay the right graph each time.  Odd width: dense rows start at unaligned addresses."""
+    import ctypes as C
+    w, h = 501, 300
+    imgs = [synth.make_frame(w, h, seed=80 + i) for i in range(4)]
+    refs = [orbo.Extractor(400).compute(im) for im in imgs]
+    fe = V.FExtractor(400, 1.2, 8, 20, 7, w, h, max_batch=4)
+    try:
+        cap = fe.cap
+        for rep in range(3):
+            for pitch in (w, 640, w, 1024):
+                for nimg in (1, 4):
+                    buf = np.full((nimg, h, pitch), 255, np.uint8)
+                    for s in range(nimg):
+                        buf[s, :, :w] = imgs[s]
+                    ptrs = (C.c_void_p * nimg)(*[buf[s].ctypes.data for s in range(nimg)])
+                    kps = np.zeros((nimg, cap), V.KP_DTYPE)
+                    desc = np.zeros((nimg, cap, 32), np.uint8)
+                    n, mono = (C.c_int * nimg)(), (C.c_int * nimg)()
+                    kp = (C.c_void_p * nimg)(*[kps[s].ctypes.data for s in range(nimg)])
+                    dp = (C.c_void_p * nimg)(*[desc[s].ctypes.data for s in range(nimg)])
+                    rc = V.lib().vslam_fe_extract_batch(fe._h, nimg, ptrs, C.c_size_t(pitch), V.IMGS_HOST, 0, 0, kp, dp, cap, n, mono)
+                    assert rc == 0, V.lib().vslam_last_error()
+                    for s in range(nimg):
+                        _assert_same((kps[s, :n[s]], desc[s, :n[s]], mono[s]), refs[s], "pitch %d, %d images, image %d, rep %d" % (pitch, nimg, s, rep))
+    finally:
+        fe.close()
+
+
 def test_small_geometries_are_rejected_or_exact():
     """Tiny images / few levels: either vslam_fe_create refuses the geometry (no 30-px FAST cell fits anywhere -- the
     reference divides by that count) or the result equals the oracle; never a failed launch."""

@@ -140,6 +140,7 @@ struct vslam_fe {
     const uint8_t* graph_imgs[VSLAM_MAX_BATCH] = {};
     int graph_lap0 = 0, graph_lap1 = 0;
     uint8_t* h_img = nullptr;   /* pinned staging for host images: B x height x level-0 pitch */
+    size_t h_img_pitch = 0;     /* row pitch of the images staged last: the level-0 pitch, or the width for dense sources */
     uint8_t* d_stage = nullptr; /* device staging of pinned caller images copied by the DMA engines (VSLAM_H2D=sdma) */
     size_t d_stage_bytes = 0;
     uint8_t* d_sbp = nullptr;   /* batched device-resident SearchByProjection: scratch + results per job */
