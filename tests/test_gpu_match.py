@@ -679,3 +679,63 @@ def test_search_init_replay_under_heavy_contention(topm):
             assert npairs == len(cases) and queries > 900 and rounds >= npairs
     finally:
         f.close()
+
+
+def test_stereo_step_leaves_in_one_transfer_and_the_block_region_has_one_owner():
+    """A full stereo batch with host delivery: counts | keypoints | descriptors | mvuRight | mvDepth are one block and one
+    transfer (plain launches and the replayed graph of pinned images); a SearchForInitialization on the same context then
+    takes buffers of its own, and a context whose init matcher came first keeps the stereo outputs separate."""
+    import torch
+    W, H, bf, fx = 1241, 376, 386.1448, 718.856
+    frames = [synth.make_stereo_pair(W, H, step=s) for s in range(2)]
+    want = []
+    for L, R in frames:
+        eL, eR = orbo.Extractor(1500), orbo.Extractor(1500)
+        kL, dL, _ = eL.compute(L)
+        kR, dR, _ = eR.compute(R)
+        wu, wd, _, _ = orbo.stereo(eL, eR, kL, dL, kR, dR, bf, fx)
+        want.append((kL, dL, kR, dR, wu, wd))
+    dev = [torch.from_numpy(np.ascontiguousarray(im)).cuda() for pair in frames for im in pair]
+    torch.cuda.synchronize()
+    pin = V.PinnedImages(4, H, W, W)
+    for i, im in enumerate([im for pair in frames for im in pair]):
+        pin.array[i][:] = im
+
+    def check(fe, expect_transfers):
+        for rep, (ptrs, where) in enumerate([([t.data_ptr() for t in dev], V.IMGS_DEVICE), (pin.ptrs, V.IMGS_PINNED), (pin.ptrs, V.IMGS_PINNED)]):
+            s0 = fe.delivery_stats()
+            fe.frame_stereo_async(ptrs, W, bf, fx, where=where)
+            feats, st = fe.frame_stereo_wait()
+            assert fe.delivery_stats()[0] - s0[0] == expect_transfers, (rep, expect_transfers)
+            for s, (kL, dL, kR, dR, wu, wd) in enumerate(want):
+                assert all(np.array_equal(feats[2 * s][0][f], kL[f]) for f in kL.dtype.names), (rep, s)
+                assert np.array_equal(feats[2 * s][1], dL) and np.array_equal(feats[2 * s + 1][1], dR), (rep, s)
+                assert np.array_equal(st[s][0], wu) and np.array_equal(st[s][1], wd), (rep, s)
+
+    def init_pair(fe):
+        p, c = fe.slot_dev_ptrs(0), fe.slot_dev_ptrs(2)  # left image of frame 0 -> left image of frame 1
+        m = V.FMatcher(fe, 0.9, True)
+        m.search_init_dev_async([(p[0], p[1], p[2], c[0], c[1], c[2], 0)], 100)
+        out = m.search_init_dev_wait([len(want[0][0])])
+        wn, wm, _ = orbo.search_for_initialization(want[0][0], want[0][1], want[1][0], want[1][1], W, H, window=100, nnratio=0.9)
+        assert out[0][0] == wn and np.array_equal(out[0][1], wm)
+
+    try:
+        a = V.FExtractor(1500, 1.2, 8, 20, 7, W, H, max_batch=4)
+        try:
+            check(a, 1)
+            init_pair(a)   # the region belongs to the stereo outputs: the matcher allocates its own
+            check(a, 1)
+            init_pair(a)
+        finally:
+            a.close()
+        b = V.FExtractor(1500, 1.2, 8, 20, 7, W, H, max_batch=4)
+        try:
+            b.compute_batch([im for pair in frames for im in pair])
+            init_pair(b)   # init matcher first: it owns the region, stereo outputs travel on their own
+            check(b, 2)
+            init_pair(b)
+        finally:
+            b.close()
+    finally:
+        pin.close()

@@ -9,6 +9,7 @@ echo "== gpu tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/
 if [ $rc -ne 0 ]; then exit 1; fi
 echo "== smoke"; timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -2
 echo "== bench default"; timeout -k 10 900 python bench.py > $O/final/default_bench.json 2> $O/final/default_bench.err; echo rc=$?; wc -c $O/final/default_bench.json
+echo "== replay rounds"; timeout -k 10 300 python tools/replay_stats.py 2>&1 | grep -v amdgpu > $O/final/replay_stats.txt; cat $O/final/replay_stats.txt
 echo "== latency"; timeout -k 10 300 python tools/latency_batch1.py 2>&1 | grep -v amdgpu > $O/final/latency_batch1.txt; cat $O/final/latency_batch1.txt
 cd /tmp && export TMPDIR=/tmp
 for wl in kitti00_mono_1241x376_n1000 kitti00_stereo_1241x376_n2000; do

@@ -35,6 +35,7 @@ std::string& vslam_err();
     } while (0)
 
 /* ------------------------------------------------------------------ context */
+enum { VSLAM_REGION_NONE = 0, VSLAM_REGION_INIT = 1, VSLAM_REGION_STEREO = 2 };
 struct vslam_fe {
     vslam_fe_params p;
     vslam_tuning tune; /* the context's behaviour switches, resolved once by vslam_fe_create (vslam_tuning.h) */
@@ -154,6 +155,9 @@ struct vslam_fe {
     void* d_stereo = nullptr;
     size_t stereo_bytes = 0;
     float* h_stereo = nullptr; /* pinned: [uRight | depth] x pairs x cap */
+    float *d_stereo_u = nullptr, *d_stereo_depth = nullptr; /* mvuRight / mvDepth of the last stereo pass on the device */
+    float* h_stereo_cur = nullptr; /* where the last stereo pass delivered: h_stereo, or the result block's matcher region */
+    int block_region_owner = 0;    /* VSLAM_REGION_*: which matcher's outputs live in the result block's extra region */
     size_t h_stereo_bytes = 0;
     int stereo_pairs = 0;
     int stereo_capR = 0; /* slot capacity of the right context of the last stereo enqueue (scratch carving) */

@@ -996,7 +996,7 @@ int vslam_enqueue_extract(vslam_fe* fe, int nimg, const uint8_t* const* imgs, si
                           int lap0, int lap1, int want_host) {
     const int rc = enqueue_extract_impl(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     /* set on every path, a replayed graph included (the captured pass of want_host = 2 holds no copy) */
-    fe->deliver_deferred = rc == VSLAM_OK && want_host == 2 && fe->dev_octree && nimg == fe->B && fe->init_in_block;
+    fe->deliver_deferred = rc == VSLAM_OK && want_host == 2 && fe->dev_octree && nimg == fe->B && fe->res_init_bytes != 0;
     return rc;
 }
 
@@ -1101,7 +1101,7 @@ static int enqueue_extract_plain(vslam_fe* fe, int nimg, const uint8_t* const* i
     /* results go to pinned host memory by a kernel (whole blocks: the host does not know the counts yet) */
     CopyRanges R;
     memset(&R, 0, sizeof(R));
-    if (want_host == 2 && fe->dev_octree && nimg == fe->B && fe->init_in_block)
+    if (want_host == 2 && fe->dev_octree && nimg == fe->B && fe->res_init_bytes != 0)
         return VSLAM_OK; /* deferred: vslam_search_init_dev_async (or the wait) sends the block; vslam_enqueue_extract sets the flag */
     if (want_host && fe->dev_octree && nimg == fe->B) {
         /* a full batch: counts, keypoints and descriptors are one contiguous block -> ONE transfer */

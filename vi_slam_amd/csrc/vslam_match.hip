@@ -37,7 +37,7 @@ static int stereo_scratch(vslam_fe* fe, int njobs, int capR, StereoScratch* s) {
 /* enqueue the matcher kernels and the D2H of mvuRight/mvDepth (whole capacity: the keypoint counts may
  * not be known on the host yet); nothing waits */
 static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* slotsL, const int* slotsR,
-                          float bf, float fx) {
+                          float bf, float fx, bool in_block = false) {
     if (feL->p.device != feR->p.device || feL->p.width != feR->p.width || feL->p.height != feR->p.height ||
         feL->p.nlevels != feR->p.nlevels || feL->p.scale_factor != feR->p.scale_factor) {
         g_err = "left/right extractors must share device and geometry";
@@ -66,6 +66,12 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
     int rc = stereo_scratch(feL, npairs, feR->cap, &sc);
     feL->stereo_capR = feR->cap;
     if (rc) return rc;
+    if (in_block) { /* mvuRight | mvDepth behind the extraction's results in the context's result block: one delivery */
+        sc.uRight = (float*)(feL->d_res + feL->res_feat_bytes);
+        sc.depth = sc.uRight + (size_t)npairs * feL->cap;
+    }
+    feL->d_stereo_u = sc.uRight; /* device-side consumers (UnprojectStereo, vslam_stereo_points_buffers) read them here */
+    feL->d_stereo_depth = sc.depth;
     /* frame.cpp:853-855: mb = mbf/fx (frame.cpp:157), minZ = mb, maxD = mbf/minZ */
     const float mb = bf / fx;
     const float maxD = bf / mb;
@@ -76,9 +82,20 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
     const size_t n = (size_t)npairs * feL->cap;
     CopyRanges R;
     memset(&R, 0, sizeof(R));
-    R.dst[0] = feL->h_stereo;
-    R.src[0] = sc.uRight; /* uRight | depth */
-    R.bytes[0] = n * 8;
+    if (in_block && feL->deliver_deferred) {
+        /* the extraction of this call left its delivery to us (want_host = 2): counts | keypoints | descriptors | mvuRight |
+         * mvDepth are contiguous -> ONE transfer for the whole stereo step */
+        feL->deliver_deferred = false;
+        R.dst[0] = feL->h_res;
+        R.src[0] = feL->d_res;
+        R.bytes[0] = feL->res_feat_bytes + n * 8;
+        feL->h_stereo_cur = (float*)(feL->h_res + feL->res_feat_bytes);
+    } else {
+        R.dst[0] = in_block ? (void*)(feL->h_res + feL->res_feat_bytes) : (void*)feL->h_stereo;
+        R.src[0] = sc.uRight; /* uRight | depth */
+        R.bytes[0] = n * 8;
+        feL->h_stereo_cur = in_block ? (float*)(feL->h_res + feL->res_feat_bytes) : feL->h_stereo;
+    }
     R.n = 1;
     vslam_count_delivery(feL, vk_copy_ranges(st, R, feL->tune), R);
     HIPCHK(hipGetLastError());
@@ -92,8 +109,8 @@ static void deliver_stereo(vslam_fe* feL, float* const* u_right, float* const* d
     for (int j = 0; j < feL->stereo_pairs; j++) {
         const int nL = feL->n_out[feL->stereo_slotL[j]];
         if (!nL) continue;
-        if (u_right && u_right[j]) memcpy(u_right[j], feL->h_stereo + (size_t)j * feL->cap, (size_t)nL * 4);
-        if (depth && depth[j]) memcpy(depth[j], feL->h_stereo + n + (size_t)j * feL->cap, (size_t)nL * 4);
+        if (u_right && u_right[j]) memcpy(u_right[j], feL->h_stereo_cur + (size_t)j * feL->cap, (size_t)nL * 4);
+        if (depth && depth[j]) memcpy(depth[j], feL->h_stereo_cur + n + (size_t)j * feL->cap, (size_t)nL * 4);
     }
 }
 
@@ -129,14 +146,20 @@ extern "C" int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const ui
         g_err = "invalid arguments";
         return VSLAM_ERR_INVALID;
     }
-    int rc = vslam_enqueue_extract(fe, 2 * npairs, imgs, pitch, imgs_on_device, 0, 0, want_host != 0);
+    /* a full batch whose results go to the host: mvuRight / mvDepth live behind the extraction's results in the result
+     * block (the region SearchForInitialization's outputs use in a context that runs that matcher: whoever comes first
+     * in a context's life owns it) and the whole step leaves in one transfer */
+    const bool blk = want_host && fe->dev_octree && 2 * npairs == fe->B && fe->res_init_bytes >= (size_t)npairs * fe->cap * 8 &&
+                     fe->block_region_owner != VSLAM_REGION_INIT && fe->d_res;
+    if (blk) fe->block_region_owner = VSLAM_REGION_STEREO;
+    int rc = vslam_enqueue_extract(fe, 2 * npairs, imgs, pitch, imgs_on_device, 0, 0, blk ? 2 : (want_host != 0));
     if (rc == VSLAM_OK) {
         int sl[VSLAM_MAX_STEREO_JOBS], sr[VSLAM_MAX_STEREO_JOBS];
         for (int j = 0; j < npairs; j++) {
             sl[j] = 2 * j;
             sr[j] = 2 * j + 1;
         }
-        rc = enqueue_stereo(fe, fe, npairs, sl, sr, bf, fx);
+        rc = enqueue_stereo(fe, fe, npairs, sl, sr, bf, fx, blk);
     }
     if (rc != VSLAM_OK) hipStreamSynchronize(fe->stream);
     return rc;
@@ -159,8 +182,12 @@ extern "C" int vslam_frame_stereo_wait(vslam_fe* fe, vslam_kp* const* kps, uint8
 /* ------------------------------------------------------------------ SearchForInitialization on the device */
 static int init_scratch(vslam_fe* fe, int npairs) {
     const size_t per = (size_t)fe->cap * 4 + (size_t)fe->cap * 8 + 16;
-    if (per * npairs <= fe->init_bytes) return VSLAM_OK; /* the result block's own region: up to max_batch pairs */
-    if (fe->init_in_block) { /* more pairs than image slots: buffers of their own from now on */
+    const bool stereo_owns = fe->init_in_block && fe->block_region_owner == VSLAM_REGION_STEREO;
+    if (per * npairs <= fe->init_bytes && !stereo_owns) { /* the result block's own region: up to max_batch pairs */
+        if (fe->init_in_block) fe->block_region_owner = VSLAM_REGION_INIT;
+        return VSLAM_OK;
+    }
+    if (fe->init_in_block) { /* more pairs than image slots, or the stereo matcher's outputs live there: buffers of their own from now on */
         fe->init_in_block = false;
         fe->d_init = nullptr;
         fe->h_init = nullptr;
@@ -886,7 +913,7 @@ extern "C" int vslam_stereo_points_dev_async(vslam_fe* fe, int npairs, const flo
         const int sl = fe->stereo_slotL[j];
         J.kps = fe->d_kps + (size_t)sl * fe->cap;
         J.nPtr = fe->d_counts + sl * 4;
-        J.depth = sc.depth + (size_t)j * fe->cap;
+        J.depth = fe->d_stereo_depth + (size_t)j * fe->cap;
         J.x3Dw = fe->d_x3dw + (size_t)j * fe->cap * 3;
         J.flags = fe->d_mpflags + (size_t)j * fe->cap;
     }
@@ -913,8 +940,8 @@ extern "C" int vslam_stereo_points_buffers(vslam_fe* fe, int pair, const float**
         StereoScratch sc;
         int rc = stereo_scratch(fe, fe->stereo_pairs, fe->stereo_capR, &sc);
         if (rc) return rc;
-        if (dev_u_right) *dev_u_right = sc.uRight + (size_t)pair * fe->cap;
-        if (dev_depth) *dev_depth = sc.depth + (size_t)pair * fe->cap;
+        if (dev_u_right) *dev_u_right = fe->d_stereo_u + (size_t)pair * fe->cap;
+        if (dev_depth) *dev_depth = fe->d_stereo_depth + (size_t)pair * fe->cap;
     }
     return VSLAM_OK;
 }
