@@ -810,11 +810,16 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     fe->cand_on_host = false;
     /* per-slot candidate header (total, overflow) and the device-quadtree error word: one tiny kernel instead
      * of two runtime memsets */
-    vk_reset_headers(st, fe->d_cand, fe->cand_stride, nimg, fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr);
+    int32_t* d_errw = fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr;
+    if (fe->pyr_groups.empty()) vk_reset_headers(st, fe->d_cand, fe->cand_stride, nimg, d_errw); /* else: the first pyramid launch does it */
     const bool prof = fe->profiling;
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[0], st));
-    for (const auto& g : fe->pyr_groups)
-        vk_pyramid_group(st, fe->d_pyr, fe->slot_stride, fe->src, g.dev, g.lds_bytes, nimg, fe->tune);
+    bool first_group = true;
+    for (const auto& g : fe->pyr_groups) {
+        vk_pyramid_group(st, fe->d_pyr, fe->slot_stride, fe->src, g.dev, g.lds_bytes, nimg, fe->tune,
+                         first_group ? fe->d_cand : nullptr, fe->cand_stride, first_group ? d_errw : nullptr);
+        first_group = false;
+    }
     for (int l = 1; l < L && fe->pyr_groups.empty(); l++) {
         if (fe->d_quads[l])
             vk_resize_level_v2(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom.lv[l - 1], fe->geom.lv[l], l - 1,

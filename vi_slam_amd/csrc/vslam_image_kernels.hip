@@ -350,10 +350,17 @@ __device__ __forceinline__ uint4 pyr_load16_tail(const uint8_t* p, int nvalid) {
 
 template <int NT> /* threads per workgroup: NT / 64 waves share the rows of a tile */
 __global__ void __launch_bounds__(NT)
-k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, int nslots) {
+k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, int nslots, uint8_t* reset_cand,
+                size_t cand_stride, int32_t* reset_err) {
     extern __shared__ __align__(16) uint8_t psm[];
     constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    /* the pass's first launch also zeroes the (total, overflow) header of every slot's candidate buffer and the
+     * quadtree's error word (FAST and the quadtree come later on the stream): no launch of its own for 33 stores */
+    if (reset_cand && blockIdx.x == 0) {
+        if ((int)threadIdx.x < nslots) *(uint2*)(reset_cand + (size_t)threadIdx.x * cand_stride) = make_uint2(0u, 0u);
+        if (reset_err && threadIdx.x < 4) reset_err[threadIdx.x] = 0;
+    }
     /* XCD-aware order: the (slot, tile) list is cut into 8 contiguous parts, one per XCD (workgroups b, b+8 share an L2),
      * so the tiles of one image -- whose source halos overlap -- are fetched through one L2 */
     const int nwork = G.ntiles * nslots, per_xcd = (nwork + 7) >> 3;
@@ -485,13 +492,16 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
 }
 
 void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
-                      size_t lds_bytes, int nslots, const vslam_tuning& T) {
+                      size_t lds_bytes, int nslots, const vslam_tuning& T, uint8_t* reset_cand, size_t cand_stride,
+                      int32_t* reset_err) {
     const int nwork = G.ntiles * nslots;
     const int nt = T.pyr_threads == 512 ? 512 : 256; /* waves per tile (A/B runs) */
     if (nt == 512)
-        hipLaunchKernelGGL(k_pyramid_group<512>, dim3(((nwork + 7) / 8) * 8), dim3(512), lds_bytes, st, pyr, slot_stride, src, G, nslots);
+        hipLaunchKernelGGL(k_pyramid_group<512>, dim3(((nwork + 7) / 8) * 8), dim3(512), lds_bytes, st, pyr, slot_stride, src, G, nslots,
+                           reset_cand, cand_stride, reset_err);
     else
-        hipLaunchKernelGGL(k_pyramid_group<256>, dim3(((nwork + 7) / 8) * 8), dim3(256), lds_bytes, st, pyr, slot_stride, src, G, nslots);
+        hipLaunchKernelGGL(k_pyramid_group<256>, dim3(((nwork + 7) / 8) * 8), dim3(256), lds_bytes, st, pyr, slot_stride, src, G, nslots,
+                           reset_cand, cand_stride, reset_err);
 }
 
 /* ------------------------------------------------------------------------------------------------

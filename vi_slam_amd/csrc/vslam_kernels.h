@@ -26,7 +26,8 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
                  int nslots);
 /* T: the context's resolved switches (vslam_tuning.h); the launchers read their A/B knobs from it, never from the environment */
 void vk_pyramid_group(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyrGroupDev& G,
-                      size_t lds_bytes, int nslots, const vslam_tuning& T);
+                      size_t lds_bytes, int nslots, const vslam_tuning& T, uint8_t* reset_cand = nullptr, size_t cand_stride = 0,
+                      int32_t* reset_err = nullptr);
 void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src,
                       const PyramidGeom& g, const CellDesc* cells, int ncells, uint8_t* cand_region,
                       size_t cand_stride, int iniTh, int minTh, int tile_rows, int max_window_w, int max_px, int nslots,
