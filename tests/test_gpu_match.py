@@ -739,3 +739,31 @@ def test_stereo_step_leaves_in_one_transfer_and_the_block_region_has_one_owner()
             b.close()
     finally:
         pin.close()
+
+
+def test_search_init_replay_random_frames_many_seeds():
+    """48 random hand-made problems (sizes, prototype counts, flip ranges, crowding drawn per case), windows centred on
+    vbPrevMatched positions that differ from the keypoints' own: every output equals the sequential oracle."""
+    rng = np.random.default_rng(2025)
+    f = V.FExtractor(1000, 1.2, 8, 20, 7, 1241, 376, max_batch=1)
+    try:
+        m = V.FMatcher(f, 0.9, True)
+        total = 0
+        for batch in range(3):
+            cases, prevs = [], []
+            for _ in range(16):
+                n1, n2 = int(rng.integers(1, 210)), int(rng.integers(1, 210))
+                c = _handmade_frames(rng, n1, n2, int(rng.integers(1, 12)), int(rng.integers(0, 60)), int(rng.integers(0, 40)),
+                                     area=int(rng.integers(10, 250)))
+                cases.append(c)
+                prevs.append((np.stack([c[0]["x"], c[0]["y"]], 1) + rng.integers(-40, 41, (n1, 2))).astype(np.float32))
+            dev = [(_dev(c[1]), _dev(c[3])) for c in cases]
+            pairs = [(c[0], dv[0].data_ptr(), c[2], dv[1].data_ptr(), pv) for c, dv, pv in zip(cases, dev, prevs)]
+            out = m.SearchForInitializationBatch(pairs, 100)
+            for j, (c, pv) in enumerate(zip(cases, prevs)):
+                wn, wm, wp = orbo.search_for_initialization(c[0], c[1], c[2], c[3], 1241, 376, prev_matched=pv, window=100, nnratio=0.9)
+                assert out[j][0] == wn and np.array_equal(out[j][1], wm) and np.array_equal(out[j][2], wp), (batch, j)
+                total += wn
+        assert total > 100
+    finally:
+        f.close()

@@ -8,6 +8,7 @@ mkdir -p $O/final
 echo "== gpu tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/final/gpu_tests.log 2>&1; rc=$?; echo rc=$rc; tail -4 $O/final/gpu_tests.log
 if [ $rc -ne 0 ]; then exit 1; fi
 echo "== smoke"; timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -2
+echo "== multi-rank rehearsal"; bash tools/rehearse_multi.sh > $O/final/rehearse_multi.txt 2>&1; tail -6 $O/final/rehearse_multi.txt
 echo "== bench default"; timeout -k 10 900 python bench.py > $O/final/default_bench.json 2> $O/final/default_bench.err; echo rc=$?; wc -c $O/final/default_bench.json
 echo "== replay rounds"; timeout -k 10 300 python tools/replay_stats.py 2>&1 | grep -v amdgpu > $O/final/replay_stats.txt; cat $O/final/replay_stats.txt
 echo "== latency"; timeout -k 10 300 python tools/latency_batch1.py 2>&1 | grep -v amdgpu > $O/final/latency_batch1.txt; cat $O/final/latency_batch1.txt
