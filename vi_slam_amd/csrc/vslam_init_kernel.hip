@@ -415,6 +415,7 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
     int nfb = 0, nrounds = 0;
     for (int par = 0;; par ^= 1) {
         int32_t* lister = par ? lister1 : lister0;
+        if (tid == 0) s_scanq = -1; /* everybody has read last round's value (it is only set in part 2, behind a barrier) */
         /* ---- 1: the reference's loop body (fmatcher.cpp:1003-1039) for every undecided query, as the queries before it left the state */
         for (int q = tid; q < c1; q += SIR_NT) {
             if (!(qstate[q] & SIR_PEND)) continue;
@@ -502,7 +503,6 @@ k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnrati
                         alog[atomicAdd(&s_nlog, 1)] = ((uint32_t)sq << 12) | (gb & 0xFFFu);
                     }
                     qstate[sq] = 0;
-                    s_scanq = -1;
                 }
             }
             nfb++;
