@@ -56,6 +56,14 @@ def digest(tuning=None):
         # are whatever the context's buffer held before)
         for n, m12, prev in M.search_init_dev_wait([counts[s - 1] for s in range(1, B)]):
             h.update(str(n).encode()); h.update(np.asarray(m12).tobytes())
+        # the same step with ONE delivery: the extraction's results ride with the matcher's (want_host = 2), pinned images
+        # (second rep: the replayed graph)
+        fe.compute_batch_async(pin.ptrs, W, (0, 1000), to_host="with_matcher", where=V.IMGS_PINNED)
+        M.search_init_dev_async(V.FMatcher.make_init_jobs(jobs), 100, (W, H))
+        for k, d, m in fe.wait(copy=True):
+            h.update(k.tobytes()); h.update(d.tobytes()); h.update(str(m).encode())
+        for n, m12, prev in M.search_init_dev_wait([counts[s - 1] for s in range(1, B)]):
+            h.update(str(n).encode()); h.update(np.asarray(m12).tobytes())
     pin.close()
     fe.close()
     return h.hexdigest()
