@@ -624,22 +624,31 @@ def roofline_of(pl, stage_alone, stage_pipe, res_dev):
 
 
 def link_probe(nbytes):
-    """Host-to-device rate of the link as this process sees it: hipMemcpyAsync of one pinned block of a step's size on an
-    otherwise idle GPU (the DMA engines; median of 9).  The denominator of roofline_pcie."""
+    """Host-to-device rate of the link as this process sees it: one asynchronous copy of a pinned block of a step's size on
+    an otherwise idle GPU (the DMA engines), from memory allocated the way the pipeline's pinned images are
+    (vslam_host_alloc: on the CPUs next to the device).  A peak is the BEST of the 9 timed copies.  The denominator of
+    roofline_pcie."""
     import torch
-    a = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ts = []
-    for i in range(12):
-        e0.record()
-        b.copy_(a, non_blocking=True)
-        e1.record()
-        e1.synchronize()
-        if i >= 3:
-            ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return nbytes / (ts[len(ts) // 2] * 1e-3) / 1e9
+    import vi_slam_amd as V
+    pin = V.PinnedImages(1, 1, nbytes)
+    try:
+        a = torch.from_numpy(pin._flat)  # torch sees hipHostMalloc memory as pinned: copy_ is one hipMemcpyAsync
+        b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for i in range(12):
+            e0.record()
+            b.copy_(a, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1))
+        del a
+    finally:
+        torch.cuda.synchronize()
+        pin.close()
+    return nbytes / (min(ts) * 1e-3) / 1e9
 
 
 def run_workload(name, args, env, want_cpu, cpu_seconds):
@@ -668,7 +677,7 @@ def run_workload(name, args, env, want_cpu, cpu_seconds):
             peak = link_probe(step_bytes)
             ach = res["pinned"]["value"] / env["world"] * img_bytes / 1e9
             out["roofline_pcie"] = {"bound": "pcie_h2d", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
-                                    "bytes_per_frame": img_bytes, "peak_source": "hipMemcpyAsync of one step's images, idle GPU, this run"}
+                                    "bytes_per_frame": img_bytes, "peak_source": "best of 9 hipMemcpyAsync of one step's images from vslam_host_alloc memory, idle GPU, this run"}
         if pl.multi:  # the exchange step alone: every rank enqueues the same 50 shifts of its last packed slot and waits once
             pl.torch.cuda.synchronize()
             env["barrier"]()

@@ -18,6 +18,9 @@ for wl in kitti00_mono_1241x376_n1000 kitti00_stereo_1241x376_n2000; do
   echo "-- $wl rc=$?"
   find $R/$O/final/prof_$wl -name "*_trace.csv" -delete
 done
+echo "== single-context kernel stats (what roofline.avg_launch_ms is compared with)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/final/prof_single -o t -- python3 $R/tools/run_extract_loop.py mono 100 32 1000 1241 376 > $R/$O/final/prof_single.log 2>&1; echo "rc=$?"
+find $R/$O/final/prof_single -name "*_trace.csv" -delete
 cd $R
 echo "== pmc traffic"; for cfg in "mono 32 1000 1241 376" "stereo 32 2000 1241 376" "stereo 32 4000 1920 1080"; do set -- $cfg; timeout -k 10 600 bash tools/collect_pmc.sh $R/$O/final/pmc_${4}x${5}_n${3} $1 $2 $3 $4 $5 > $O/final/pmc_${4}x${5}_n${3}.log 2>&1; echo "$cfg rc=$?"; done
 echo "== pmc matcher"; timeout -k 10 600 bash tools/collect_pmc_matcher.sh $R/$O/final/pmc_matcher > $O/final/pmc_matcher.log 2>&1; echo rc=$?
