@@ -623,6 +623,20 @@ def roofline_of(pl, stage_alone, stage_pipe, res_dev):
     return rl, detail
 
 
+def host_cpu_description():
+    """'<model name>, <n> hardware threads' of the box the CPU baseline ran on"""
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return "%s, %d hardware threads" % (model, os.cpu_count() or 0)
+
+
 def link_probe(nbytes):
     """Host-to-device rate of the link as this process sees it: one asynchronous copy of a pinned block of a step's size on
     an otherwise idle GPU (the DMA engines), from memory allocated the way the pipeline's pinned images are
@@ -873,6 +887,7 @@ def main():
                                     "sample": cb["sample"]}
             if "all_cores" in cb:
                 line["cpu_baseline"]["all_cores"] = {"value": sig(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}
+            line["cpu_baseline"]["host"] = host_cpu_description()  # CPU model and thread count beside the number
         extras = []
         for r in results[1:]:
             e = {"workload": r["workload"], "value": sig(r["value"], 6), "value_host_inputs": sig(r["value_host_inputs"], 6),
