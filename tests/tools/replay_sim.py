@@ -138,6 +138,96 @@ def rounds_listers(L, M=8, nnratio=0.9, window=None, th_filter=True):
     return od, log, rounds
 
 
+def rounds_kernel_scheme(L, M=8, nnratio=0.9, slot_capacity=4):
+    """k_si_replay as built: every undecided query per round against the acceptances of EARLIER queries only (per-slot
+    (writer, distance) entries), sorted prefixes of length M, re-scan of the whole window when the prefix runs out (only as
+    the smallest undecided query), wildcard blocking, slot entries merged when full.  -> (od, log, rounds, rescans)"""
+    n = len(L)
+    slots = {}  # slot -> list of (writer or -1 for merged, d)
+    pend = list(range(n))
+    log, rounds, rescans = [], 0, 0
+
+    def view(q, s):
+        return min([d for w, d in slots.get(s, []) if w < q], default=INF)
+
+    while pend:
+        rounds += 1
+        minp = pend[0]
+        lister, wild_min, dec = {}, INF, {}
+        for q in pend:
+            top = L[q][:M]
+            full = len(top) == M
+            first = second = None
+            for d, s in top:
+                if view(q, s) <= d:
+                    continue
+                if d <= TH_LOW:
+                    lister[s] = min(lister.get(s, INF), q)
+                if first is None:
+                    first = (d, s)
+                elif second is None:
+                    second = (d, s)
+            dlast = top[-1][0] if top else 0
+            wild = full and dlast <= TH_LOW
+            if wild:
+                wild_min = min(wild_min, q)
+            accept = scan = False
+            if first is None:
+                scan = wild
+            elif first[0] <= TH_LOW:
+                d2 = second[0] if second else INF
+                if second is None and full:
+                    if float(np.float32(first[0])) < float(np.float32(dlast) * np.float32(nnratio)):
+                        d2 = dlast
+                    else:
+                        scan = True
+                if not scan:
+                    accept = float(np.float32(first[0])) < float(np.float32(d2) * np.float32(nnratio))
+            dec[q] = (accept, scan, first, second)
+        done = set()
+        scanq = None
+        for q in pend:
+            accept, scan, first, second = dec[q]
+            if scan:
+                if q == minp:
+                    scanq = q
+                continue
+            blocked = q > wild_min
+            if first is not None and lister.get(first[1], INF) < q:
+                blocked = True
+            if second is not None and lister.get(second[1], INF) < q:
+                blocked = True
+            if blocked:
+                continue
+            if accept:
+                ent = slots.setdefault(first[1], [])
+                if len(ent) >= slot_capacity:
+                    if q != minp:
+                        continue
+                    assert all(w < q for w, _ in ent)
+                    ent[:] = [(-1, min(d for _, d in ent))]
+                ent.append((q, first[0]))
+                log.append((q, first[1]))
+            done.add(q)
+        if scanq is not None:  # the reference's loop body over the WHOLE window, as the smallest undecided query
+            rescans += 1
+            q = scanq
+            od_q = {s: view(q, s) for _, s in L[q]}
+            acc, s1, d1, _, _ = decide(L[q], od_q, nnratio)
+            if acc:
+                ent = slots.setdefault(s1, [])
+                if len(ent) >= slot_capacity:
+                    assert all(w < q for w, _ in ent)
+                    ent[:] = [(-1, min(d for _, d in ent))]
+                ent.append((q, d1))
+                log.append((q, s1))
+            done.add(q)
+        assert minp in done  # the smallest undecided query always commits
+        pend = [q for q in pend if q not in done]
+    od = {s: min(d for _, d in e) for s, e in slots.items()}
+    return od, log, rounds, rescans
+
+
 def owners(log):
     o = {}
     for g, s in sorted(log):
@@ -158,6 +248,10 @@ if __name__ == "__main__":
             od1, log1, r1 = rounds_prefix64(L)
             assert owners(log0) == owners(log1) and od0 == od1
             out = ["N=%d pair %d: %d queries, avg list %.1f, accepted %d; prefix64 rounds %d" % (nf, s, len(L), np.mean([len(l) for l in L]), len(log0), r1)]
+            for M in (8, 2):
+                od3, log3, r3, rs3 = rounds_kernel_scheme(L, M=M)
+                ok = owners(log0) == owners(log3) and od0 == od3
+                out.append("kernel scheme M=%d: %d rounds, %d re-scans%s" % (M, r3, rs3, "" if ok else " MISMATCH"))
             for M in (8, 16):
                 for win in (None, 64):
                     od2, log2, r2 = rounds_listers(L, M=M, window=win)
