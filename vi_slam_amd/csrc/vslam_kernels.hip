@@ -123,7 +123,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
  *               accesses per keypoint against ~90 now.
  * Keypoints are >= 19 px from the level border (EDGE_THRESHOLD), so every patch byte is inside the level; the dword
  * rows may overrun the 37-px support by up to 3 bytes, still inside the row (or its padding). */
-#define DESC_KPW 4          /* keypoints per wave */
+#ifndef DESC_KPW
+#define DESC_KPW 4          /* keypoints per wave (2 and 8 measured: see DESIGN.md section 8) */
+#endif
 #define DESC_TP 40          /* LDS tile pitch: 10 dwords cover 18 + 18 + 1 columns from a dword-aligned start */
 #define DESC_TROWS 37
 #define DESC_TILE_BYTES (DESC_TP * DESC_TROWS + 8)
