@@ -214,10 +214,16 @@ bool build_pyramid_group(const std::vector<const PyrLevelTables*>& tabs, int l0,
     for (const PyrLevelTables* t : tabs)
         if (!t || t->qbase.empty()) return false; /* a level without the quad table: per-level launches */
     const int nq1 = (tabs[0]->dw + 3) / 4, h1 = tabs[0]->dh;
-    int rows = 28; /* output rows of the first computed level per tile (vslam_tuning.pyr_rows for A/B runs) */
+    /* output rows of the first computed level per tile (vslam_tuning.pyr_rows for A/B runs).  Taller tiles recompute less
+     * halo and amortise the per-tile prologue over more rows: 28 -> 48 rows is +3 % mono, +2 % stereo, +3 % at 1080p in the
+     * pipeline (36 / 40 / 48 / 56 / 64 measured; the LDS limit of the plan, 64 KB, is the brake at 64) */
+    int rows = 48;
     if (rows_override >= 0) rows = std::min(64, std::max(4, rows_override));
     const int nty = std::max(1, (h1 + rows - 1) / rows);
-    for (int ntx = std::max(1, (nq1 + 51) / 52); ntx <= std::max(1, nq1 / 8); ntx++)
+#ifndef VSLAM_PYR_TILE_QUADS
+#define VSLAM_PYR_TILE_QUADS 52 /* widest tile tried first: quads of the first computed level (a wave's lanes, halo included) */
+#endif
+    for (int ntx = std::max(1, (nq1 + VSLAM_PYR_TILE_QUADS - 1) / VSLAM_PYR_TILE_QUADS); ntx <= std::max(1, nq1 / 8); ntx++)
         if (plan_with(tabs, l0, ntx, nty, max_lds, plan)) return true;
     return false;
 }

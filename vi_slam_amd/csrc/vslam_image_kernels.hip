@@ -637,7 +637,9 @@ extern "C" int vslam_dbg_fast_stamps(unsigned long long* out16, int reset) {
 #else
 #define FAST_WGREC_END() do { } while (0)
 #endif
+#ifndef FAST_XCD_CHUNK
 #define FAST_XCD_CHUNK 16
+#endif
 template <int NT, int P> /* P: LDS pitch, 48 for windows up to 42 px, else 72 */
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 k_fast_cells_v3(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
