@@ -197,7 +197,12 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             std::vector<const vslam::PyrLevelTables*> gt;
             for (int j = 1; j <= nl; j++) gt.push_back(&pyr_tabs[l0 + j]);
             vslam::PyrGroupPlan plan;
-            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan, fe->tune.pyr_rows)) {
+            /* tile height: tall tiles (48 rows: less halo, fewer prologues) for batches, where the pyramid competes for
+             * issue slots; short ones (16) for contexts of one or two images, where a frame's latency counts and more
+             * workgroups per image finish sooner (batch-1 latency through the C ABI: 0.135 ms with 12-16 rows, 0.137 with
+             * 20-28, 0.142 with 36, 0.146 with 48) */
+            const int pyr_rows = fe->tune.pyr_rows >= 0 ? fe->tune.pyr_rows : (fe->B <= 2 ? 16 : 48);
+            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan, pyr_rows)) {
                 fused = false;
                 break;
             }
@@ -275,6 +280,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     {
         /* marching-rows blur: one wave task per (level, row chunk, 248-column strip) */
         if (fe->tune.blur_rows >= 0) fe->blur_rows = std::min(512, std::max(8, (int)fe->tune.blur_rows));
+        else if (fe->B <= 2) fe->blur_rows = 8; /* one or two images: more, shorter tasks finish sooner (batch-1 latency -5 us) */
         std::vector<uint32_t> tasks;
         for (int l = 0; l < p.nlevels; l++) {
             const int br = fe->blur_rows;

@@ -248,6 +248,7 @@ __device__ __forceinline__ void desc_lane_tables(const int8_t* __restrict__ patt
  *      issue time when they ran once per keypoint on 64 identical lanes -- run ONCE, lane k working on keypoint k;
  *   C  per keypoint: blurred support -> LDS tile, 512 rotated samples, 4 ballots; the support of keypoint k+1 is loaded
  *      while keypoint k is sampled. */
+template <int KPW>
 __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                              size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                                              const SelKp* __restrict__ sel, int k0, int kend,
@@ -255,26 +256,26 @@ __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, co
                                              int atan_fma, uint8_t* tile) {
     const int lane = threadIdx.x & 63;
     if (k0 >= kend) return; /* wave-uniform */
-    const int nk = kend - k0; /* 1 .. DESC_KPW, wave-uniform */
+    const int nk = kend - k0; /* 1 .. KPW, wave-uniform */
     uint32_t wu[4], wm[4];
     char4 pat[4];
     desc_lane_tables(pattern, lane, wu, wm, pat);
-    SelKp s[DESC_KPW];
-    DescAddr A[DESC_KPW];
-    uint32_t raw[DESC_KPW][4];
+    SelKp s[KPW];
+    DescAddr A[KPW];
+    uint32_t raw[KPW][4];
 #pragma unroll
-    for (int k = 0; k < DESC_KPW; k++) { /* slots past the wave's last keypoint repeat it (looked up, never loaded) */
+    for (int k = 0; k < KPW; k++) { /* slots past the wave's last keypoint repeat it (looked up, never loaded) */
         s[k] = sel[k0 + min(k, nk - 1)];
         A[k] = desc_addr(pyr, blur, slot_stride, src, g, s[k]);
     }
 #pragma unroll
-    for (int k = 0; k < DESC_KPW; k++)
+    for (int k = 0; k < KPW; k++)
         if (k < nk) desc_issue_raw(A[k], lane, raw[k]);
     uint32_t blr[6], blrn[6];
     desc_issue_blur(A[0], lane, blr);
     int my01 = 0, my10 = 0;
 #pragma unroll
-    for (int k = 0; k < DESC_KPW; k++)
+    for (int k = 0; k < KPW; k++)
         if (k < nk) {
             int m01, m10;
             desc_moments(raw[k], wu, wm, lane, &m01, &m10);
@@ -288,9 +289,9 @@ __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, co
     const float rad = __fmul_rn(angle, factorPI);
     const float ca = vslam_trig::glibc_cosf(rad), sb = vslam_trig::glibc_sinf(rad);
 #pragma unroll
-    for (int k = 0; k < DESC_KPW; k++)
+    for (int k = 0; k < KPW; k++)
         if (k < nk) {
-            if (k + 1 < nk) desc_issue_blur(A[min(k + 1, DESC_KPW - 1)], lane, blrn);
+            if (k + 1 < nk) desc_issue_blur(A[min(k + 1, KPW - 1)], lane, blrn);
             const float ang_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle), k));
             const float a_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), k));
             const float b_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), k));
@@ -310,11 +311,14 @@ k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ b
     __shared__ __align__(16) uint8_t s_tile[4][DESC_TILE_BYTES];
     const int wave = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wave) * DESC_KPW;
-    describe_run(pyr, blur, slot_stride, src, g, sel, k0, min(k0 + DESC_KPW, nsel), pattern, kps, desc, cap, atan_fma,
-                 s_tile[wave]);
+    describe_run<DESC_KPW>(pyr, blur, slot_stride, src, g, sel, k0, min(k0 + DESC_KPW, nsel), pattern, kps, desc, cap, atan_fma,
+                           s_tile[wave]);
 }
 
-/* device-selected keypoints (k_octree + k_assign_out): per-slot lists, counts read from HBM */
+/* device-selected keypoints (k_octree + k_assign_out): per-slot lists, counts read from HBM.  KPW keypoints per wave:
+ * DESC_KPW for batches (2 and 8 measured: -6 % / -10 % in the pipeline), ONE for one or two images, where the launch is a
+ * frame's latency and four times the waves finish sooner (batch-1 latency -4 us) */
+template <int KPW>
 __global__ void __launch_bounds__(256)
 k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
                       BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
@@ -329,10 +333,10 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
     if (w >= nwork) return;
     const int slot = w / bps;
     const int wave = threadIdx.x >> 6;
-    const int k0 = ((w - slot * bps) * 4 + wave) * DESC_KPW;
+    const int k0 = ((w - slot * bps) * 4 + wave) * KPW;
     const int n = slot_counts[slot * 4];
-    describe_run(pyr, blur, slot_stride, src, g, sel + (size_t)slot * cap, k0, min(k0 + DESC_KPW, n), pattern, kps, desc,
-                 cap, atan_fma, s_tile[wave]);
+    describe_run<KPW>(pyr, blur, slot_stride, src, g, sel + (size_t)slot * cap, k0, min(k0 + KPW, n), pattern, kps, desc,
+                      cap, atan_fma, s_tile[wave]);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -487,10 +491,15 @@ void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* b
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
                             int cap, int atan_fma, int nslots) {
-    const int per_wg = 4 * DESC_KPW;
+    const int kpw = nslots <= 2 ? 1 : DESC_KPW;
+    const int per_wg = 4 * kpw;
     const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
-    hipLaunchKernelGGL(k_orient_describe_dev, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
-                       src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
+    if (kpw == 1)
+        hipLaunchKernelGGL(k_orient_describe_dev<1>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
+                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
+    else
+        hipLaunchKernelGGL(k_orient_describe_dev<DESC_KPW>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
+                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
 }
 
 void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out) {
