@@ -91,7 +91,9 @@ typedef struct vslam_tuning {
                                      application's other streams */
     int32_t stage_split_event;    /* 0..3: uploads of more than one image go as two transfers with the context's user event of that
                                      index (vslam_fe_event_wait) recorded between them; see vslam_fe_stage_images_async */
-    int32_t reserved[7];
+    int32_t oct_threads;          /* VSLAM_OCT_THREADS: 256 | 512 | 1024 threads per quadtree problem (default: 1024 for contexts of
+                                     one or two images, 512 for frames above a megapixel, else 256) */
+    int32_t reserved[6];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

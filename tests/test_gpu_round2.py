@@ -317,7 +317,8 @@ def test_switches_do_not_change_results():
                    {"fast_lds_pad": 4096}, {"h2d_route": 1}, {"h2d_route": 2}, {"oct_lds_budget_kb": 48},
                    {"oct_fine_depth": 2, "oct_regkeys": 1}, {"oct_fine_depth": 1, "oct_regkeys": 0}, {"d2h_route": 1}, {"d2h_route": 2}, {"graphs": 0},
                    {"pyramid_per_level": 1}, {"fast_threads": 256}, {"pyr_threads": 512}, {"blur_rows": 16}, {"init_topm": 16}, {"init_topm": 3},
-                   {"d2h_route": 1, "copy_wgs": 4}, {"fast_threads": 64}):
+                   {"d2h_route": 1, "copy_wgs": 4}, {"fast_threads": 64}, {"oct_threads": 1024}, {"oct_threads": 512}, {"oct_threads": 256},
+                   {"oct_threads": 256, "oct_regkeys": 1}, {"oct_threads": 512, "oct_fine_depth": 1}):
         assert mod.digest(tuning) == ref, tuning
     for env in ({"VSLAM_WAIT": "spin", "VSLAM_NUMA": "0"}, {"VSLAM_D2H": "kernel", "VSLAM_OCT_REGKEYS": "1", "VSLAM_PYRAMID": "levels"}):
         assert _digest(env).split()[-1] == ref, env

@@ -98,11 +98,12 @@ TUNING_FIELDS = ["pyramid_per_level", "pyr_rows", "pyr_threads", "blur_rows", "f
                  "octree_walk_kernel", "oct_fine_depth", "oct_lds_budget_kb", "oct_regkeys", "oct_max_iter",
                  "oct_debug", "graphs", "h2d_route", "d2h_route", "copy_wgs", "pull_depth",
                  "init_topm", "init_match_host", "sbp_topm", "sbp_sequential", "si_queries_per_block", "fg_threads",
-                 "wait_spin", "numa", "host_prof", "stream_priority", "stage_split_event"]
+                 "wait_spin", "numa", "host_prof", "stream_priority", "stage_split_event",
+                 "oct_threads"]
 
 
 class _Tuning(C.Structure):  # vslam_tuning
-    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 7)]
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 6)]
 
 
 def make_tuning(**kw):

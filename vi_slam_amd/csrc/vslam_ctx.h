@@ -78,6 +78,7 @@ struct vslam_fe {
     int32_t taps[7];
     uint32_t* d_blur_tasks = nullptr;
     int n_blur_tasks = 0;
+    int oct_threads = 1024; /* threads per quadtree problem (k_octree_v4), chosen at creation */
     int blur_rows = 32; /* output rows per wave task of k_blur7_v2 (VSLAM_BLUR_ROWS) */
     /* selection + outputs */
     SelKp* d_sel = nullptr;

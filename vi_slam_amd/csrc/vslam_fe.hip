@@ -441,6 +441,10 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
     }
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     fe->use_graph = fe->tune.graphs != 0; /* 0: never replay captured graphs */
+    /* threads per quadtree problem (vk_octree): 1024 for one or two images, else 256, 512 for frames above a megapixel */
+    fe->oct_threads = fe->tune.oct_threads == 256 || fe->tune.oct_threads == 512 || fe->tune.oct_threads == 1024
+                          ? fe->tune.oct_threads
+                          : fe->B <= 2 ? 1024 : (size_t)p.width * p.height > 1000000 ? 512 : 256;
     fe->sel_level.resize((size_t)fe->B * p.nlevels);
     fe->cand_level.resize((size_t)fe->B * p.nlevels);
     unsigned hw = std::thread::hardware_concurrency();
@@ -965,7 +969,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
               fe->d_nid, fe->d_oct_sorted, (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
-              fe->d_oct_redo, fe->tune.oct_regkeys);
+              fe->d_oct_redo, fe->tune.oct_regkeys, fe->oct_threads);
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
                   d_err, nimg, fe->d_oct_redo);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));

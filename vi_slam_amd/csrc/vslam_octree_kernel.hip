@@ -23,7 +23,9 @@
 
 #include <mutex>
 
+#ifndef OT
 #define OT 1024
+#endif
 #define OKPT 16  /* k_octree_v2: keys per thread kept in registers (problems up to 16384 keys) */
 #define OBATCH 8 /* k_octree_v2: keys per thread and batch when streaming a larger problem */
 #ifndef O4BATCH
@@ -557,8 +559,8 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 /* REGKEYS: keys (and their cell | rank words) of problems up to OKPT * 1024 keys stay in registers between the two walks
  * (1-2 images: latency); otherwise both are written to the slot's scratch by walk 1 and re-read, coalesced, by walk 2
  * (batches: fewer VGPRs, so that foreign waves fit next to a 1024-thread workgroup). */
-template <bool REGKEYS>
-__global__ void __launch_bounds__(OT)
+template <bool REGKEYS, int OTV> /* OTV: threads of the workgroup (256 / 512 / 1024, vk_octree) */
+__global__ void __launch_bounds__(OTV)
 k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* keys_a,
             uint32_t* aux_a, uint2* sorted_a, size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
             int32_t* deep_flags) {
@@ -572,7 +574,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint16_t* newIdx = cb + MAXN;             /* (k_octree_v2 only) */
     uint16_t* prank = newIdx + MAXN;          /* processing rank of an expandable node */
     uint16_t* ordv = prank + MAXN;            /* node at processing rank r */
-    __shared__ uint32_t s_w32[OT / 64];
+    __shared__ uint32_t s_w32[OTV / 64];
     __shared__ int s_size, s_M, s_nexp, s_cut, s_deep;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -606,19 +608,19 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint32_t off0 = 0;
     if (c0 > 0) { /* keys of the levels in front of this one (level 0: none, no scan) */
         uint32_t before = 0;
-        for (int c = tid; c < c0; c += OT) before += cout[c].count;
+        for (int c = tid; c < c0; c += OTV) before += cout[c].count;
         uint32_t tot;
-        block_excl_scan<uint32_t>(before, s_w32, &tot);
+        block_excl_scan<uint32_t, OTV>(before, s_w32, &tot);
         off0 = tot;
     }
-    const int ncl = c1 - c0, K = (ncl + OT - 1) / OT;
+    const int ncl = c1 - c0, K = (ncl + OTV - 1) / OTV;
     uint32_t mine = 0;
     for (int k = 0; k < K; k++) {
         const int c = c0 + tid * K + k;
         if (c < c1) mine += cout[c].count;
     }
     uint32_t ntot;
-    uint32_t woff = block_excl_scan<uint32_t>(mine, s_w32, &ntot);
+    uint32_t woff = block_excl_scan<uint32_t, OTV>(mine, s_w32, &ntot);
     const int n = (int)ntot;
     if (off0 + ntot > (uint32_t)P.ptsCap || n >= (1 << 20) || hdr[1] != 0) {
         if (tid == 0) {
@@ -657,7 +659,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint32_t* PS = Hc + cells + 1;                  /* their exclusive prefix sums */
     const uint32_t* __restrict__ xs = P.lut + P.lutOff[level];
     const uint32_t* __restrict__ ys = xs + P.lutW[level];
-    for (int i = tid; i <= cells; i += OT) Hc[i] = 0u;
+    for (int i = tid; i <= cells; i += OTV) Hc[i] = 0u;
     /* the path tables are cold (another XCD's L2 or HBM) the first time a workgroup touches them: start pulling their
      * lines now, the key loads below hide the round trip */
     uint32_t warm = 0u;
@@ -667,8 +669,8 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     /* positions are dealt to WAVES in contiguous chunks of EW (a multiple of 64) and to the lanes of a wave interleaved:
      * lane l holds positions wbeg + 64 k + l, so that a wave's loads (mostly one FAST cell segment after the other) and
      * its stores are coalesced */
-    const bool inReg = REGKEYS && n <= OKPT * OT;
-    const int KW = (n + OT - 1) / OT, EW = KW * 64; /* keys per lane, positions per wave */
+    const bool inReg = REGKEYS && n <= OKPT * OTV;
+    const int KW = (n + OTV - 1) / OTV, EW = KW * 64; /* keys per lane, positions per wave */
     const int wbeg = wv * EW;
     uint32_t keyR[OKPT];
     uint32_t auxR[OKPT];
@@ -745,7 +747,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     __syncthreads(); /* coff (in the node arrays) is free again; the counters are complete */
     STAMP3();
     {   /* exclusive prefix sums of the fine counts, LDS to LDS */
-        const int ntile = (cells + 63) >> 6, tpw = (ntile + OT / 64 - 1) / (OT / 64); /* tiles per wave */
+        const int ntile = (cells + 63) >> 6, tpw = (ntile + OTV / 64 - 1) / (OTV / 64); /* tiles per wave */
         const int t1 = min((wv + 1) * tpw, ntile);
         uint32_t carry = 0;
         for (int t = wv * tpw; t < t1; t++) {
@@ -778,17 +780,17 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (k < KW && i < n) sorted[PS[auxR[k] & 0xFFFFu] + (auxR[k] >> 16)] = make_uint2(keyR[k], (uint32_t)i);
         }
     } else {
-        for (int base = tid; base < n; base += O4BATCH * OT) {
+        for (int base = tid; base < n; base += O4BATCH * OTV) {
             uint32_t kk[O4BATCH], ff[O4BATCH];
 #pragma unroll
             for (int j = 0; j < O4BATCH; j++) {
-                const int i = base + j * OT;
+                const int i = base + j * OTV;
                 kk[j] = i < n ? pa[i] : 0u;
                 ff[j] = i < n ? aux[i] : 0u;
             }
 #pragma unroll
             for (int j = 0; j < O4BATCH; j++) {
-                const int i = base + j * OT;
+                const int i = base + j * OTV;
                 if (i < n) sorted[PS[ff[j] & 0xFFFFu] + (ff[j] >> 16)] = make_uint2(kk[j], (uint32_t)i);
             }
         }
@@ -816,7 +818,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
 
     /* ---- 3. split passes: k_octree_v2's node logic; the children's key counts come from the prefix sums */
     int phase = 1;
-    const int KN = (MAXN + OT - 1) / OT;
+    const int KN = (MAXN + OTV - 1) / OTV;
     for (int iter = 0; iter < P.maxIter; iter++) {
         const int size0 = s_size;
         /* A. children's key counts of every expandable node; phase 2 also needs every node's sort key */
@@ -858,7 +860,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             if (v < size0 && !ND_NOMORE(cur[v])) nexp_mine++;
         }
         uint32_t nexp;
-        uint32_t rbase = block_excl_scan<uint32_t>(nexp_mine, s_w32, &nexp);
+        uint32_t rbase = block_excl_scan<uint32_t, OTV>(nexp_mine, s_w32, &nexp);
         if (nexp == 0) break; /* nothing expandable: lNodes.size() == prevSize -> finish */
         if (phase == 1) {
             for (int k = 0; k < KN; k++) {
@@ -890,7 +892,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         }
         __syncthreads();
         /* D2. in processing order: children created before me, running list size -> cut */
-        const int KE = ((int)nexp + OT - 1) / OT;
+        const int KE = ((int)nexp + OTV - 1) / OTV;
         uint32_t chl = 0;
         for (int k = 0; k < KE; k++) {
             const int r = tid * KE + k;
@@ -900,7 +902,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
         uint32_t chtot;
-        uint32_t chbase = block_excl_scan<uint32_t>(chl, s_w32, &chtot);
+        uint32_t chbase = block_excl_scan<uint32_t, OTV>(chl, s_w32, &chtot);
         if (tid == 0) s_cut = (int)nexp; /* number of processed parents */
         __syncthreads();
         {
@@ -939,7 +941,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             }
         }
         uint32_t svtot;
-        uint32_t svbase = block_excl_scan<uint32_t>(sv, s_w32, &svtot);
+        uint32_t svbase = block_excl_scan<uint32_t, OTV>(sv, s_w32, &svtot);
         int nexp_children = 0;
         for (int k = 0; k < KN; k++) {
             const int v = tid * KN + k;
@@ -987,7 +989,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     /* ---- 4. best response per node, first in key order wins (fextractor.cpp:732-751): four lanes per node reduce its
      * run of the sorted keys on (response, ~position) */
     const int size = s_size;
-    for (int v0 = 0; v0 < size; v0 += OT / 4) {
+    for (int v0 = 0; v0 < size; v0 += OTV / 4) {
         const int v = v0 + (tid >> 2), sub = tid & 3;
         u64 best = 0ull;
         uint32_t bkey = 0u;
@@ -1127,7 +1129,7 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
-               int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */) {
+               int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */, int threads /* 256 | 512 | 1024 */) {
     const dim3 grid(nslots, nlevels);
     if (P.lut && deep_flags) /* k_octree_v4 */
     {
@@ -1136,12 +1138,19 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
          * (default: registers only for one or two images, where latency is what counts). */
         const bool rk = regkeys < 0 ? nslots <= 2 : regkeys == 1;
         const size_t lds = (size_t)P.fineLdsOff + (size_t)P.fineLdsBytes;
-        if (rk)
-            hipLaunchKernelGGL((k_octree_v4<true>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a,
-                               (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags);
-        else
-            hipLaunchKernelGGL((k_octree_v4<false>), grid, dim3(OT), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a,
-                               (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags);
+        /* Threads per problem.  1024 finish a single frame's level-0 problem soonest (and hold its keys in registers); in a
+         * batch every (slot, level) problem has a workgroup of its own anyway, and a SMALL workgroup leaves the CU's wave
+         * slots and issue cycles to the other contexts' kernels: 256 instead of 1024 threads is +4 % mono, +7 % stereo,
+         * +13 % mono at 2000 features in the pipeline; 1080p, with 65 k keys on level 0, wants 512 (+2 %; 256: -2 %) */
+        const int th = rk ? 1024 : (threads == 256 || threads == 512) ? threads : 1024;
+#define OCT4_LAUNCH(RK, TH)                                                                                               \
+    hipLaunchKernelGGL((k_octree_v4<RK, TH>), grid, dim3(TH), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a, \
+                       (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags)
+        if (rk) OCT4_LAUNCH(true, 1024);
+        else if (th == 256) OCT4_LAUNCH(false, 256);
+        else if (th == 512) OCT4_LAUNCH(false, 512);
+        else OCT4_LAUNCH(false, 1024);
+#undef OCT4_LAUNCH
     }
     else
         hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
@@ -1162,8 +1171,9 @@ int vk_octree_set_max_lds(size_t bytes) {
     static size_t have = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (bytes <= have) return 0;
-    const void* fns[3] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true>, (const void*)k_octree_v4<false>};
-    for (int i = 0; i < 3; i++) {
+    const void* fns[5] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true, 1024>, (const void*)k_octree_v4<false, 1024>,
+                          (const void*)k_octree_v4<false, 512>, (const void*)k_octree_v4<false, 256>};
+    for (int i = 0; i < 5; i++) {
         const int rc = (int)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (rc) return rc;
     }

@@ -44,6 +44,7 @@ const EnvField kEnv[] = {
     TF("VSLAM_HOST_PROF", host_prof, nullptr, nullptr),
     TF("VSLAM_STREAM_PRIORITY", stream_priority, nullptr, nullptr),
     TF("VSLAM_STAGE_SPLIT_EVENT", stage_split_event, nullptr, nullptr),
+    TF("VSLAM_OCT_THREADS", oct_threads, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;
