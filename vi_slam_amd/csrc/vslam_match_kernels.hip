@@ -42,7 +42,9 @@ __device__ __forceinline__ int refl101(int p, int len) {
  *   k_stereo_best  one WAVE per left keypoint, lane = candidate of its row bucket: gates |octR - octL| <= 1 and
  *                  uL - maxD <= uR <= uL, 256-bit Hamming distance for the lanes that pass, wave minimum.
  * ---------------------------------------------------------------------------------------------- */
+#ifndef SROWS_T
 #define SROWS_T 1024
+#endif
 __global__ void __launch_bounds__(SROWS_T)
 k_stereo_rows(StereoJobs jobs, PyramidGeom g, int nrows, int max_band, uint32_t* row_start /* [job][nrows + 1] */,
               uint16_t* items /* [job][cap * max_band] */, float2* rattr /* [job][cap] */, int cap /* of the RIGHT context */) {
