@@ -318,13 +318,16 @@ k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ b
 /* device-selected keypoints (k_octree + k_assign_out): per-slot lists, counts read from HBM.  KPW keypoints per wave:
  * DESC_KPW for batches (2 and 8 measured: -6 % / -10 % in the pipeline), ONE for one or two images, where the launch is a
  * frame's latency and four times the waves finish sooner (batch-1 latency -4 us) */
+#ifndef DESC_WPB
+#define DESC_WPB 4 /* waves per workgroup of k_orient_describe_dev (independent of each other; 1 and 2 measured) */
+#endif
 template <int KPW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * DESC_WPB)
 k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
                       BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
                       const int32_t* __restrict__ slot_counts, const int8_t* __restrict__ pattern, vslam_kp* kps,
                       uint8_t* desc, int cap, int atan_fma, int bps, int nwork) {
-    __shared__ __align__(16) uint8_t s_tile[4][DESC_TILE_BYTES];
+    __shared__ __align__(16) uint8_t s_tile[DESC_WPB][DESC_TILE_BYTES];
     /* XCD-aware order: workgroups b and b+8 share an XCD/L2.  The (slot, keypoint-block) work list is
      * slot-major and level-major inside a slot, so handing XCD k the k-th contiguous eighth keeps one image
      * (or a few of its levels) per L2 instead of streaming every pyramid through all eight. */
@@ -333,7 +336,7 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
     if (w >= nwork) return;
     const int slot = w / bps;
     const int wave = threadIdx.x >> 6;
-    const int k0 = ((w - slot * bps) * 4 + wave) * KPW;
+    const int k0 = ((w - slot * bps) * DESC_WPB + wave) * KPW;
     const int n = slot_counts[slot * 4];
     describe_run<KPW>(pyr, blur, slot_stride, src, g, sel + (size_t)slot * cap, k0, min(k0 + KPW, n), pattern, kps, desc,
                       cap, atan_fma, s_tile[wave]);
@@ -492,13 +495,13 @@ void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* b
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
                             int cap, int atan_fma, int nslots) {
     const int kpw = nslots <= 2 ? 1 : DESC_KPW;
-    const int per_wg = 4 * kpw;
+    const int per_wg = DESC_WPB * kpw;
     const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
     if (kpw == 1)
-        hipLaunchKernelGGL(k_orient_describe_dev<1>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
+        hipLaunchKernelGGL(k_orient_describe_dev<1>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
                            src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
     else
-        hipLaunchKernelGGL(k_orient_describe_dev<DESC_KPW>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, blur, slot_stride,
+        hipLaunchKernelGGL(k_orient_describe_dev<DESC_KPW>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
                            src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
 }
 
