@@ -348,7 +348,9 @@ __device__ __forceinline__ bool sir_slot_append(uint4* slotlog, uint32_t slot, u
  * Ownership ("last acceptor wins", which is what the reference's steal/undo amounts to), vnMatches12 and the rotation
  * histogram are rebuilt from the log in parallel afterwards.
  * ---------------------------------------------------------------------------------------------- */
+#ifndef SIR_NT
 #define SIR_NT 256
+#endif
 #define SIR_PEND 1u
 #define SIR_ACC 2u
 #define SIR_SCAN 4u
