@@ -47,17 +47,20 @@ struct BlurTapsV2 {
     uint32_t k[7];
 };
 
+#ifndef BLUR_WPB
+#define BLUR_WPB 4 /* wave tasks per workgroup of k_blur7_v2 (independent of each other; 1 and 2 measured) */
+#endif
 template <bool SYM> /* SYM: k[j] == k[6-j] (every Gaussian): the column pass folds mirrored rows first */
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * BLUR_WPB)
 k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
            const uint32_t* __restrict__ tasks, int ntasks, int nslots, int rows_per_task, BlurTapsV2 T) {
     const int lane = threadIdx.x & 63;
     /* XCD-aware order (workgroups b, b+8 share an L2): the (slot, task) list is cut into 8 contiguous parts */
-    const int tpb = (ntasks + 3) >> 2, nwork = tpb * nslots, per_xcd = (nwork + 7) >> 3;
+    const int tpb = (ntasks + BLUR_WPB - 1) / BLUR_WPB, nwork = tpb * nslots, per_xcd = (nwork + 7) >> 3;
     const int wk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (wk >= nwork) return;
     const int slot = wk / tpb;
-    const int task = (wk - slot * tpb) * 4 + (threadIdx.x >> 6);
+    const int task = (wk - slot * tpb) * BLUR_WPB + (threadIdx.x >> 6);
     if (task >= ntasks) return; /* wave-uniform */
     /* level << 24 | rowchunk << 12 | strip; wave-uniform by construction -- say so, or every loop bound and
      * branch below is treated as divergent */
@@ -156,13 +159,13 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
     T.l2 = pk(0, 0, 0, k0);   T.c2 = pk(k1, k2, k3, k4); T.r2 = pk(k5, k6, 0, 0);
     T.c3 = pk(k0, k1, k2, k3); T.r3 = pk(k4, k5, k6, 0);
     for (int i = 0; i < 7; i++) T.k[i] = taps[i];
-    const int nwork = ((ntasks + 3) / 4) * nslots;
+    const int nwork = ((ntasks + BLUR_WPB - 1) / BLUR_WPB) * nslots;
     const bool sym = taps[0] == taps[6] && taps[1] == taps[5] && taps[2] == taps[4];
     if (sym)
-        hipLaunchKernelGGL(k_blur7_v2<true>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
+        hipLaunchKernelGGL(k_blur7_v2<true>, dim3(((nwork + 7) / 8) * 8), dim3(64 * BLUR_WPB), 0, st, pyr, slot_stride, src, g, blur, tasks,
                        ntasks, nslots, rows_per_task, T);
     else
-        hipLaunchKernelGGL(k_blur7_v2<false>, dim3(((nwork + 7) / 8) * 8), dim3(256), 0, st, pyr, slot_stride, src, g, blur, tasks,
+        hipLaunchKernelGGL(k_blur7_v2<false>, dim3(((nwork + 7) / 8) * 8), dim3(64 * BLUR_WPB), 0, st, pyr, slot_stride, src, g, blur, tasks,
                        ntasks, nslots, rows_per_task, T);
 }
 
