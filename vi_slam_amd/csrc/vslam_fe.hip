@@ -202,7 +202,10 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
              * workgroups per image finish sooner (batch-1 latency through the C ABI: 0.135 ms with 12-16 rows, 0.137 with
              * 20-28, 0.142 with 36, 0.146 with 48) */
             const int pyr_rows = fe->tune.pyr_rows >= 0 ? fe->tune.pyr_rows : (fe->B <= 2 ? 16 : 48);
-            if (!vslam::build_pyramid_group(gt, l0, 64 * 1024, plan, pyr_rows)) {
+#ifndef VSLAM_PYR_LDS_KB
+#define VSLAM_PYR_LDS_KB 64 /* LDS a pyramid tile's cascade may take (32 / 48 / 96 measured) */
+#endif
+            if (!vslam::build_pyramid_group(gt, l0, VSLAM_PYR_LDS_KB * 1024, plan, pyr_rows)) {
                 fused = false;
                 break;
             }
