@@ -1,6 +1,6 @@
 /* vslam_octree_kernel.hip -- FExtractor::DistributeOctTree (fextractor.cpp:530-754) on the GPU.
  *
- * One 1024-thread workgroup per (image slot, pyramid level).  The reference algorithm is a sequential
+ * One workgroup (256, 512 or 1024 threads: vk_octree) per (image slot, pyramid level).  The reference algorithm is a sequential
  * walk over a std::list, but every pass of it splits a whole generation of nodes, and the only
  * order-dependent facts are (a) the relative order of the keys inside a node (DivideNode keeps it),
  * (b) the order of the list and (c) the "largest node first, stop at N" rule.  All three are prefix sums:
