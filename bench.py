@@ -281,7 +281,15 @@ class Pipeline:
         self.B = B
         self.NCTX = max(3, args.inflight)
         self.multi = (world > 1 or args.force_collective) and not self.stereo
-        tuning = dict(stage_split_event=2) if args.upload_split else None
+        # a stream priority of its own keeps the four contexts off the hardware queues torch's and RCCL's streams use
+        # (DESIGN section 6); the library's default is the normal pool, a pipelined caller opts in
+        tuning = dict(stream_priority=args.stream_priority)
+        if args.upload_split:
+            tuning["stage_split_event"] = 2
+        if args.fast_kernel >= 0:
+            tuning["fast_kernel"] = args.fast_kernel
+        if args.wave_prio >= 0:
+            tuning["wave_prio"] = args.wave_prio
         self.ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=env["local_rank"], max_batch=B, tuning=tuning)
                      for _ in range(self.NCTX)]
         self.fe = self.ctxs[0]
@@ -757,6 +765,10 @@ def main():
                     help="host inputs: 1 = a step's upload goes as two transfers and the chain event sits between them")
     ap.add_argument("--upload-chain", type=int, default=1,
                     help="host inputs: upload of step t waits (GPU-side event) for the upload of step t-L; 0 = no pacing")
+    ap.add_argument("--stream-priority", type=int, default=2, choices=[0, 1, 2],
+                    help="vslam_tuning.stream_priority of the extractor contexts (0 normal, 1 low, 2 high)")
+    ap.add_argument("--fast-kernel", type=int, default=-1, help="vslam_tuning.fast_kernel (3 cells, 4 bands; -1 library default)")
+    ap.add_argument("--wave-prio", type=int, default=-1, help="vslam_tuning.wave_prio bit mask (-1 library default)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (slots staged through host memory) only exists to rehearse the N>1 path on one GPU")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")

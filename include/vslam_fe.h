@@ -86,14 +86,23 @@ typedef struct vslam_tuning {
     int32_t wait_spin;            /* VSLAM_WAIT=spin: 1 = host waits poll hipStreamQuery instead of blocking */
     int32_t numa;                 /* VSLAM_NUMA: 0 = do not allocate pinned memory from the CPUs next to the device */
     int32_t host_prof;            /* VSLAM_HOST_PROF: 1 = host-side wall time per API phase, printed at destroy */
-    int32_t stream_priority;      /* VSLAM_STREAM_PRIORITY: 0 normal, 1 low, 2 high (default) priority of the context's HIP stream: a
+    int32_t stream_priority;      /* VSLAM_STREAM_PRIORITY: 0 normal (default), 1 low, 2 high priority of the context's HIP stream: a
                                      priority of its own gives the context hardware queues it does not share with the host
-                                     application's other streams */
+                                     application's other streams -- and, being a priority, lets the context's kernels
+                                     pre-empt the application's default-priority work: opt in (bench.py does), see
+                                     INTEGRATION.md */
     int32_t stage_split_event;    /* 0..3: uploads of more than one image go as two transfers with the context's user event of that
                                      index (vslam_fe_event_wait) recorded between them; see vslam_fe_stage_images_async */
     int32_t oct_threads;          /* VSLAM_OCT_THREADS: 256 | 512 | 1024 threads per quadtree problem (default: 1024 for contexts of
                                      one or two images, 512 for frames above a megapixel, else 256) */
-    int32_t reserved[6];
+    int32_t fast_kernel;          /* VSLAM_FAST_KERNEL: 3 = one workgroup per FAST cell (k_fast_cells_v3), 4 = one workgroup per
+                                     band of cells of a cell row sharing one staged window (k_fast_bands, default) */
+    int32_t fast_band_cells;      /* VSLAM_FAST_BAND_CELLS: cells per band of k_fast_bands (1..4, default 4; fewer where 4 cell
+                                     interiors are wider than 128 px) */
+    int32_t wave_prio;            /* VSLAM_WAVE_PRIO: bit mask of kernel classes that raise their wave priority (s_setprio 3)
+                                     at entry: 1 = quadtree + output order, 2 = orientation/descriptors, 4 = matchers
+                                     (k_si_*, k_stereo_*), 8 = result packing; default 0 */
+    int32_t reserved[3];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

@@ -67,6 +67,7 @@ struct OctParams {
     int32_t maxNodes;                 /* list capacity (LDS) */
     int32_t ptsCap;                   /* entries per slot in the key ping-pong arrays */
     int32_t maxIter;                  /* split passes allowed (64; lower only for timing experiments) */
+    int32_t wavePrio;                 /* != 0: the quadtree / output-order waves raise their priority (vslam_tuning.wave_prio & 1) */
     void* dbg;                        /* timing stamps (diagnostic builds only) */
     /* k_octree_v4: keys are counted ONCE into the leaves of an implicit quadtree of depth fineD below the initial nodes
      * (nIni << 2*fineD fine cells, <= 16384, counters and prefix sums in LDS) and sorted by leaf; a node of depth

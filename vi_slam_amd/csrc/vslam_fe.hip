@@ -432,10 +432,11 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
          * stream priority, least-used queue first.  In a process that already holds dozens of streams (torch, four RCCL
          * communicators) two contexts ended up on ONE hardware queue and their passes ran one behind the other (mono
          * 157 k -> 97 k frames/s, the kernel trace shows the shared queue id).  Streams of a priority of their own draw
-         * from a pool nobody else uses: the context's stream is created with high priority (stream_priority 2, the default;
-         * 1 = low, 0 = the default pool).  Measured: collective path at world size 1 97 k -> 143 k (high) / 141 k (low),
+         * from a pool nobody else uses: with stream_priority 2 (1 = low) the context's stream is created with a priority of
+         * its own.  The library default is 0 -- the default pool -- because a high-priority stream also pre-empts the
+         * host application's own default-priority work; a pipelined caller opts in (bench.py does).  Measured: collective path at world size 1 97 k -> 143 k (high) / 141 k (low),
          * the plain path unchanged at 157 k. */
-        const int pr = tune_or(fe->tune.stream_priority, 2);
+        const int pr = tune_or(fe->tune.stream_priority, 0);
         int lo = 0, hi = 0;
         if (pr != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
             HIPCHK(hipStreamCreateWithPriority(&fe->stream, hipStreamNonBlocking, pr == 1 ? lo : hi));
@@ -487,6 +488,15 @@ extern "C" int vslam_fe_set_tuning(vslam_fe* fe, const vslam_tuning* t) {
     if (!fe || !t) return VSLAM_ERR_INVALID;
     vslam_apply_tuning(fe->tune, t);
     fe->use_graph = fe->use_graph && fe->tune.graphs != 0;
+    /* a captured graph froze the launch shapes and transport routes it was captured with, and its key does not cover the
+     * tuning fields: drop it, so that the next host-image pass captures again under the new switches (otherwise an A/B
+     * run through this call would compare a configuration with itself) */
+    if (fe->graph_exec) {
+        if (fe->stream) hipStreamSynchronize(fe->stream);
+        hipGraphExecDestroy(fe->graph_exec);
+        fe->graph_exec = nullptr;
+        fe->graph_key = 0;
+    }
     return VSLAM_OK;
 }
 
@@ -599,7 +609,7 @@ static int pack_range(vslam_fe* fe, int first, int nslots, void* dev_dst, size_t
     HIPCHK(hipSetDevice(fe->p.device));
     /* one kernel; the keypoint counts are read from HBM, so this may be enqueued before the host knows them */
     vk_pack_slots(fe->stream, fe->d_kps, fe->d_desc, fe->d_counts, fe->cap, first, nslots, (uint8_t*)dev_dst,
-                  slot_bytes);
+                  slot_bytes, wave_prio_on(fe->tune, 8));
     HIPCHK(hipGetLastError());
     if (sync) HIPCHK(vslam_stream_wait(fe->stream));
     return VSLAM_OK;
@@ -972,14 +982,14 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
               fe->d_nid, fe->d_oct_sorted, (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
-              fe->d_oct_redo, fe->tune.oct_regkeys, fe->oct_threads);
+              fe->d_oct_redo, fe->tune.oct_regkeys, fe->oct_threads, wave_prio_on(fe->tune, 1));
     vk_assign_out(st, fe->oct, fe->geom, fe->d_sel_xyr, fe->d_sel_cnt, lap0, lap1, fe->d_sel, fe->d_counts, fe->cap,
-                  d_err, nimg, fe->d_oct_redo);
+                  d_err, nimg, fe->d_oct_redo, wave_prio_on(fe->tune, 1));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
-                           nimg);
+                           nimg, wave_prio_on(fe->tune, 2));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
     HIPCHK(hipGetLastError());
     return VSLAM_OK; /* counts travel to the host with the results (vslam_enqueue_extract) */

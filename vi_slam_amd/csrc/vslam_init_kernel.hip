@@ -92,8 +92,9 @@ __device__ __forceinline__ uint32_t si_hamming(const uint4& da, const uint4& db,
  * candidates of its own queries.  Chunk 0 also publishes the compacted candidate list and the counts.
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
-k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, int M, uint8_t* scratch, int SI_QPB) {
+k_si_topm(InitJobs jobs, int cap, int imgW, int imgH, int window, int max_c2, int M, uint8_t* scratch, int SI_QPB, int prio) {
     extern __shared__ __align__(16) uint8_t sism[];
+    wave_prio_raise(prio);
     SiCandL* cand = (SiCandL*)sism;                  /* max_c2, sorted by grid column */
     uint32_t* wkeys = (uint32_t*)(cand + max_c2);    /* 4 waves x max_c2: window keys of the current query */
     SiCandL* tmpc = (SiCandL*)wkeys;                 /* ... and, before that, the list in keypoint order */
@@ -358,8 +359,10 @@ template <int MAXM> /* unrolled length of a query's sorted prefix: 8 (the defaul
 __global__ void __launch_bounds__(SIR_NT)
 k_si_replay(InitJobs jobs, int cap, int imgW, int imgH, int window, float nnratio, int checkOri,
             int32_t* matches_out /* [pair][cap] */, float* prev_out /* [pair][2*cap] */,
-            int32_t* nmatch_out /* [pair] */, int max_c2, int M, const uint8_t* scratch, int* fallbacks, int keys_lds_bytes) {
+            int32_t* nmatch_out /* [pair] */, int max_c2, int M, const uint8_t* scratch, int* fallbacks, int keys_lds_bytes,
+            int prio) {
     extern __shared__ __align__(16) uint8_t sism[];
+    wave_prio_raise(prio);
     const InitJob jb = jobs.job[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
     const int n1 = min(*jb.cnt1, cap);
@@ -636,18 +639,19 @@ void vk_search_init(hipStream_t st, const InitJobs& jobs, int npairs, int cap, i
     const int qv = T.si_queries_per_block;
     const int qpb = (qv == 8 || qv == 16 || qv == 32) ? qv : 16;
     const int chunks = (max_c2 + qpb - 1) / qpb;
+    const int prio = T.wave_prio > 0 && (T.wave_prio & 4) ? 1 : 0;
     hipLaunchKernelGGL(k_si_topm, dim3(chunks, npairs), dim3(256), si_topm_lds(max_c2), st, jobs, cap, imgW, imgH,
-                       window, max_c2, M, scratch, qpb);
+                       window, max_c2, M, scratch, qpb, prio);
     /* the key cache only if the whole allocation stays within what vk_search_init_set_max_lds allowed (150 KB) */
     int keys_lds = (int)si_replay_keys_lds(max_c2, M);
     if (si_replay_lds(cap, max_c2, M) > (150u << 10)) keys_lds = 0;
     const size_t rlds = keys_lds ? si_replay_lds(cap, max_c2, M) : si_replay_lds(cap, max_c2);
     if (M <= 8)
         hipLaunchKernelGGL(k_si_replay<8>, dim3(npairs), dim3(SIR_NT), rlds, st, jobs, cap, imgW, imgH,
-                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds);
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds, prio);
     else
         hipLaunchKernelGGL(k_si_replay<SI_MAX_M>, dim3(npairs), dim3(SIR_NT), rlds, st, jobs, cap, imgW, imgH,
-                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds);
+                           window, nnratio, checkOri, matches_out, prev_out, nmatch_out, max_c2, M, scratch, fallbacks, keys_lds, prio);
 }
 
 /* ==================================================================================================

@@ -40,14 +40,14 @@ int vk_octree_set_max_lds(size_t bytes);
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
-               int regkeys, int threads = 1024);
+               int regkeys, int threads = 1024, int prio = 0);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
-                   const int32_t* deep_flags);
+                   const int32_t* deep_flags, int prio = 0);
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
-                            int cap, int atan_fma, int nslots);
+                            int cap, int atan_fma, int nslots, int prio = 0);
 
 void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c);
 void vk_dbg_logf(hipStream_t st, const float* x, int n, float* y);
@@ -56,7 +56,7 @@ void vk_dbg_atan2(hipStream_t st, const float* y, const float* x, int n, int fma
 void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
                const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
                const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
-               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch);
+               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch, int prio = 0);
 /* bytes of rows_scratch: row table, bucket items and {uR, octave} records of njobs stereo pairs */
 size_t vk_stereo_rows_bytes(int njobs, int nrows, int max_band, int cap);
 void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int maxr, int maxc, const int32_t* idx,
@@ -89,7 +89,7 @@ int vk_copy_ranges(hipStream_t st, const CopyRanges& R, const vslam_tuning& T = 
 void vk_pull_images(hipStream_t st, const BatchSrc& src, uint8_t* pyr, size_t slot_stride, uint32_t off0, int dpitch,
                     int w, int h, int nimg, int from_host, const vslam_tuning& T);
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
-                   int nslots, uint8_t* dst, size_t slot_bytes);
+                   int nslots, uint8_t* dst, size_t slot_bytes, int prio = 0);
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst);
 
 #endif

@@ -5,6 +5,7 @@
  * wave = 64 everywhere.  Reference lines each kernel reproduces are cited at the kernel.
  */
 #include "vslam_kernels.h"
+#include "vslam_wave.h"
 
 #include "../../include/vslam_orb_pattern.h"
 #include "vslam_trig.h"
@@ -326,8 +327,9 @@ __global__ void __launch_bounds__(64 * DESC_WPB)
 k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride,
                       BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
                       const int32_t* __restrict__ slot_counts, const int8_t* __restrict__ pattern, vslam_kp* kps,
-                      uint8_t* desc, int cap, int atan_fma, int bps, int nwork) {
+                      uint8_t* desc, int cap, int atan_fma, int bps, int nwork, int prio) {
     __shared__ __align__(16) uint8_t s_tile[DESC_WPB][DESC_TILE_BYTES];
+    wave_prio_raise(prio);
     /* XCD-aware order: workgroups b and b+8 share an XCD/L2.  The (slot, keypoint-block) work list is
      * slot-major and level-major inside a slot, so handing XCD k the k-th contiguous eighth keeps one image
      * (or a few of its levels) per L2 instead of streaming every pyramid through all eight. */
@@ -493,16 +495,16 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
-                            int cap, int atan_fma, int nslots) {
+                            int cap, int atan_fma, int nslots, int prio) {
     const int kpw = nslots <= 2 ? 1 : DESC_KPW;
     const int per_wg = DESC_WPB * kpw;
     const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
     if (kpw == 1)
         hipLaunchKernelGGL(k_orient_describe_dev<1>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
-                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
+                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork, prio);
     else
         hipLaunchKernelGGL(k_orient_describe_dev<DESC_KPW>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
-                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork);
+                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork, prio);
 }
 
 void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out) {

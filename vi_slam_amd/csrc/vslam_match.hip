@@ -77,7 +77,8 @@ static int enqueue_stereo(vslam_fe* feL, vslam_fe* feR, int npairs, const int* s
     const float maxD = bf / mb;
     hipStream_t st = feL->stream;
     vk_stereo(st, jobs, npairs, feL->cap, feR->cap, feL->geom, feL->d_pyr, feL->slot_stride, feL->src, feR->d_pyr,
-              feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap, sc.max_band, sc.rows);
+              feR->slot_stride, feR->src, bf, maxD, sc.best, sc.uRight, sc.depth, sc.sad, feL->cap, sc.max_band, sc.rows,
+              wave_prio_on(feL->tune, 4));
     HIPCHK(hipGetLastError());
     const size_t n = (size_t)npairs * feL->cap;
     CopyRanges R;

@@ -3,6 +3,7 @@
  * depth) uses explicit round-to-nearest intrinsics, no fusion.
  */
 #include "vslam_kernels.h"
+#include "vslam_wave.h"
 #include <cstring>
 #include <cstdlib>
 
@@ -47,8 +48,10 @@ __device__ __forceinline__ int refl101(int p, int len) {
 #endif
 __global__ void __launch_bounds__(SROWS_T)
 k_stereo_rows(StereoJobs jobs, PyramidGeom g, int nrows, int max_band, uint32_t* row_start /* [job][nrows + 1] */,
-              uint16_t* items /* [job][cap * max_band] */, float2* rattr /* [job][cap] */, int cap /* of the RIGHT context */) {
+              uint16_t* items /* [job][cap * max_band] */, float2* rattr /* [job][cap] */, int cap /* of the RIGHT context */,
+              int prio) {
     extern __shared__ uint32_t s_cnt[]; /* nrows + 1 */
+    wave_prio_raise(prio);
     __shared__ uint32_t s_w32[SROWS_T / 64];
     const StereoJob jb = jobs.job[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -104,7 +107,8 @@ k_stereo_rows(StereoJobs jobs, PyramidGeom g, int nrows, int max_band, uint32_t*
 
 __global__ void __launch_bounds__(256)
 k_stereo_best(StereoJobs jobs, float maxD, int nrows, int max_band, const uint32_t* __restrict__ row_start,
-              const uint16_t* __restrict__ items, const float2* __restrict__ rattr, uint32_t* best, int cap, int capR) {
+              const uint16_t* __restrict__ items, const float2* __restrict__ rattr, uint32_t* best, int cap, int capR, int prio) {
+    wave_prio_raise(prio);
     const StereoJob jb = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -148,8 +152,9 @@ k_stereo_best(StereoJobs jobs, float maxD, int nrows, int max_band, const uint32
 __global__ void __launch_bounds__(256)
 k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t strideL, BatchSrc srcL,
                 const uint8_t* pyrR, size_t strideR, BatchSrc srcR, float mbf, float maxD,
-                const uint32_t* best, float* uRight, float* depth, int32_t* sad, int cap) {
+                const uint32_t* best, float* uRight, float* depth, int32_t* sad, int cap, int prio) {
     __shared__ float s_d[16][12];
+    wave_prio_raise(prio);
     const StereoJob jb = jobs.job[blockIdx.y];
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int iL = blockIdx.x * 16 + grp;
@@ -294,7 +299,8 @@ k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t stri
  *     One workgroup per stereo pair.
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
-k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t* sad, int cap) {
+k_stereo_median_cut(StereoJobs jobs, float* uRight, float* depth, const int32_t* sad, int cap, int prio) {
+    wave_prio_raise(prio);
     /* frame.cpp:983-996: median of the accepted SADs (element size/2 of the sorted list), drop SAD >= 1.5 * 1.4 * median.
      * SADs are < 65536 (frame.cpp:919-949: 120 pixels x 255 + bias), so the median is found by two 256-bin histograms --
      * high byte, then the low byte inside the selected bin -- and the bin holding rank k is found by a PREFIX SUM over
@@ -381,7 +387,7 @@ size_t vk_stereo_rows_bytes(int njobs, int nrows, int max_band, int cap) {
 void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int maxNR, const PyramidGeom& g,
                const uint8_t* pyrL, size_t strideL, const BatchSrc& srcL, const uint8_t* pyrR, size_t strideR,
                const BatchSrc& srcR, float mbf, float maxD, uint32_t* best, float* uRight, float* depth,
-               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch) {
+               int32_t* sad, int cap, int max_band, uint8_t* rows_scratch, int prio) {
     if (njobs <= 0 || maxNL <= 0) return;
     const int capR = maxNR; /* capacity of the right context's slots */
     const int nrows = g.lv[0].h;
@@ -393,12 +399,12 @@ void vk_stereo(hipStream_t st, const StereoJobs& jobs, int njobs, int maxNL, int
     off += (size_t)njobs * (((size_t)capR * max_band * 2 + 15) & ~(size_t)15);
     float2* rattr = (float2*)(rows_scratch + off);
     hipLaunchKernelGGL(k_stereo_rows, dim3(njobs), dim3(SROWS_T), ((size_t)nrows + 1) * 4, st, jobs, g, nrows, max_band,
-                       row_start, items, rattr, capR);
+                       row_start, items, rattr, capR, prio);
     hipLaunchKernelGGL(k_stereo_best, dim3((maxNL + 3) / 4, njobs), dim3(256), 0, st, jobs, maxD, nrows, max_band, row_start,
-                       items, rattr, best, cap, capR);
+                       items, rattr, best, cap, capR, prio);
     hipLaunchKernelGGL(k_stereo_refine, dim3((maxNL + 15) / 16, njobs), dim3(256), 0, st, jobs, g, pyrL, strideL,
-                       srcL, pyrR, strideR, srcR, mbf, maxD, best, uRight, depth, sad, cap);
-    hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(256), 0, st, jobs, uRight, depth, sad, cap);
+                       srcL, pyrR, strideR, srcR, mbf, maxD, best, uRight, depth, sad, cap, prio);
+    hipLaunchKernelGGL(k_stereo_median_cut, dim3(njobs), dim3(256), 0, st, jobs, uRight, depth, sad, cap, prio);
 }
 
 void vk_gather_rows32(hipStream_t st, const uint8_t* src, const int32_t* idx, int n, uint8_t* dst) {
@@ -470,7 +476,8 @@ void vk_hamming_matrix_batch(hipStream_t st, const MatJobs& jobs, int njobs, int
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
 k_pack_slots(const vslam_kp* __restrict__ kps, const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
-             int cap, int first, uint8_t* __restrict__ dst, size_t slot_bytes) {
+             int cap, int first, uint8_t* __restrict__ dst, size_t slot_bytes, int prio) {
+    wave_prio_raise(prio);
     const int slot = first + blockIdx.y;
     const int n = min(counts[slot * 4], cap);
     uint8_t* d = dst + (size_t)blockIdx.y * slot_bytes;
@@ -491,9 +498,9 @@ k_pack_slots(const vslam_kp* __restrict__ kps, const uint8_t* __restrict__ desc,
 }
 
 void vk_pack_slots(hipStream_t st, const vslam_kp* kps, const uint8_t* desc, const int32_t* counts, int cap, int first,
-                   int nslots, uint8_t* dst, size_t slot_bytes) {
+                   int nslots, uint8_t* dst, size_t slot_bytes, int prio) {
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(k_pack_slots, dim3(8, nslots), dim3(256), 0, st, kps, desc, counts, cap, first, dst, slot_bytes);
+    hipLaunchKernelGGL(k_pack_slots, dim3(8, nslots), dim3(256), 0, st, kps, desc, counts, cap, first, dst, slot_bytes, prio);
 }
 
 /* --------------------------------------------------------------------------------------------------

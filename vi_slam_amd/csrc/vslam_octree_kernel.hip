@@ -20,6 +20,7 @@
  * exactly as in the reference (fextractor.cpp:560).
  */
 #include "vslam_kernels.h"
+#include "vslam_wave.h"
 
 #include <mutex>
 
@@ -497,6 +498,7 @@ k_octree_v2(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     extern __shared__ __align__(16) uint8_t osm[];
     __shared__ uint32_t s_w32[OT / 64];
     __shared__ int s_ctl[4];
+    wave_prio_raise(P.wavePrio);
     const int level = blockIdx.y, slot = blockIdx.x;
     oct_walk_body<OT, true>(cand_region, cand_stride, ncells, oct_walk_level(P, level), level, slot, pts_a, nid_a, pts_stride, sel_xyr,
                       sel_cnt, err_flag, osm, s_w32, s_ctl);
@@ -565,6 +567,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
             uint32_t* aux_a, uint2* sorted_a, size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
             int32_t* deep_flags) {
     extern __shared__ __align__(16) uint8_t osm[];
+    wave_prio_raise(P.wavePrio);
     const int MAXN = P.maxNodes;
     ONode* cur = (ONode*)osm;
     ONode* nxt = cur + MAXN;
@@ -753,6 +756,10 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
         for (int t = wv * tpw; t < t1; t++) {
             const int c = t * 64 + lane;
             const uint32_t h = c < cells ? Hc[c] : 0u;
+            /* a key's rank inside its fine cell travels in 16 bits next to the cell index (walk 1); the host sizes the
+             * grid so that no cell can hold that many keys, this is the runtime guard behind that bound: the pass is
+             * reported (VSLAM_ERR_CAPACITY), never silently mis-sorted */
+            if (h >= 65536u) atomicOr(err_flag, 1);
             const uint32_t inc = wave_incl_add(h);
             if (c < cells) PS[c] = carry + inc - h;
             carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1060,6 +1067,7 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
              int32_t* err_flag, const int32_t* deep_flags) {
     __shared__ uint32_t s_w32[AO_T / 64];
     __shared__ int s_lvl_off[VSLAM_MAX_LEVELS + 1];
+    wave_prio_raise(P.wavePrio);
     const int tid = threadIdx.x, slot = blockIdx.x;
     const int L = g.nlevels;
     uint32_t redo_mask = 0; /* levels of this slot on which k_octree_v4 split nodes finer than its grid (vslam_fe_octree_stats) */
@@ -1129,8 +1137,11 @@ size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
-               int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */, int threads /* 256 | 512 | 1024 */) {
+               int regkeys /* vslam_tuning.oct_regkeys: -1 by batch size, 0 | 1 forced */, int threads /* 256 | 512 | 1024 */,
+               int prio /* vslam_tuning.wave_prio & 1 */) {
     const dim3 grid(nslots, nlevels);
+    OctParams Pq = P;
+    Pq.wavePrio = prio;
     if (P.lut && deep_flags) /* k_octree_v4 */
     {
         /* Keys in registers save walk 2 its re-read, at 32 VGPRs per thread; a 1024-thread workgroup then leaves less room
@@ -1144,7 +1155,7 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
          * +13 % mono at 2000 features in the pipeline; 1080p, with 65 k keys on level 0, wants 512 (+2 %; 256: -2 %) */
         const int th = rk ? 1024 : (threads == 256 || threads == 512) ? threads : 1024;
 #define OCT4_LAUNCH(RK, TH)                                                                                               \
-    hipLaunchKernelGGL((k_octree_v4<RK, TH>), grid, dim3(TH), lds, st, cand_region, cand_stride, ncells, P, keys_a, aux_a, \
+    hipLaunchKernelGGL((k_octree_v4<RK, TH>), grid, dim3(TH), lds, st, cand_region, cand_stride, ncells, Pq, keys_a, aux_a, \
                        (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags)
         if (rk) OCT4_LAUNCH(true, 1024);
         else if (th == 256) OCT4_LAUNCH(false, 256);
@@ -1153,23 +1164,30 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
 #undef OCT4_LAUNCH
     }
     else
-        hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, P,
+        hipLaunchKernelGGL(k_octree_v2, grid, dim3(OT), vk_octree_lds_bytes(P.maxNodes), st, cand_region, cand_stride, ncells, Pq,
                            keys_a, nid_a, pts_stride, sel_xyr, sel_cnt, err_flag);
 }
 
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
-                   const int32_t* deep_flags) {
-    hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(AO_T), 0, st, P, g, sel_xyr, sel_cnt, lap0, lap1, sel,
+                   const int32_t* deep_flags, int prio) {
+    OctParams Pq = P;
+    Pq.wavePrio = prio;
+    hipLaunchKernelGGL(k_assign_out, dim3(nslots), dim3(AO_T), 0, st, Pq, g, sel_xyr, sel_cnt, lap0, lap1, sel,
                        slot_counts, cap, err_flag, deep_flags);
 }
 
 /* hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION, shared by every context of the process: only
  * ever raise it (a small context created after a large one must not lower the limit the large one launches with) */
 int vk_octree_set_max_lds(size_t bytes) {
+    /* ... and of the DEVICE: hipFuncSetAttribute acts on the current device, so the raised limit is remembered per
+     * device (a context on device 1 created after one on device 0 must set it again) */
     static std::mutex mu;
-    static size_t have = 0;
+    static size_t have_dev[64] = {0};
     std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    size_t& have = have_dev[dev];
     if (bytes <= have) return 0;
     const void* fns[5] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true, 1024>, (const void*)k_octree_v4<false, 1024>,
                           (const void*)k_octree_v4<false, 512>, (const void*)k_octree_v4<false, 256>};

@@ -45,6 +45,9 @@ const EnvField kEnv[] = {
     TF("VSLAM_STREAM_PRIORITY", stream_priority, nullptr, nullptr),
     TF("VSLAM_STAGE_SPLIT_EVENT", stage_split_event, nullptr, nullptr),
     TF("VSLAM_OCT_THREADS", oct_threads, nullptr, nullptr),
+    TF("VSLAM_FAST_KERNEL", fast_kernel, nullptr, nullptr),
+    TF("VSLAM_FAST_BAND_CELLS", fast_band_cells, nullptr, nullptr),
+    TF("VSLAM_WAVE_PRIO", wave_prio, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;

@@ -11,4 +11,6 @@ vslam_tuning vslam_resolve_tuning(const vslam_tuning* user);
 void vslam_apply_tuning(vslam_tuning& t, const vslam_tuning* user); /* fields of *user that are >= 0 overwrite t */
 /* v if the caller or the environment set it (>= 0), else the built-in default */
 static inline int tune_or(int v, int dflt) { return v >= 0 ? v : dflt; }
+/* vslam_tuning.wave_prio is a bit mask of kernel classes (1 quadtree + output order, 2 descriptors, 4 matchers, 8 packing) */
+static inline int wave_prio_on(const vslam_tuning& t, int cls) { return t.wave_prio > 0 && (t.wave_prio & cls) ? 1 : 0; }
 #endif

@@ -21,4 +21,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+/* vslam_tuning.wave_prio: the narrow kernels on a step's dependency chain (quadtree, output order, descriptors,
+ * matchers) raise their wave priority at entry, so that next to the grid-filling FAST / blur / pyramid waves of the
+ * other contexts -- which can issue at any time -- the SIMD's arbiter (priority, then age) hands them the issue slots.
+ * `on` is a kernel argument: a scalar branch around one s_setprio. */
+__device__ __forceinline__ void wave_prio_raise(int on) {
+    if (on) __builtin_amdgcn_s_setprio(3);
+}
+
 #endif /* VSLAM_WAVE_H */

@@ -41,15 +41,32 @@ class _Deadline:
     def __init__(self, seconds, what, rank):
         self.seconds, self.what, self.rank = float(seconds), what, rank
         self._done = threading.Event()
+        self._lock = threading.Lock()
+        self._expires = time.monotonic() + self.seconds
+
+    def rearm(self, what=None):
+        """A step of the guarded block has finished (e.g. one lane's communicator is up and voted on): the next step
+        gets the full `seconds` again, so that a large world whose every lane is slow but healthy is not shot for the sum."""
+        with self._lock:
+            self._expires = time.monotonic() + self.seconds
+            if what:
+                self.what = what
 
     def __enter__(self):
         def watch():
-            if not self._done.wait(self.seconds):
-                sys.stderr.write("vi_slam_amd.dist: rank %d gave up after %.0f s in %s -- a peer did not arrive; exiting %d\n"
-                                 % (self.rank, self.seconds, self.what, EXIT_SETUP_TIMEOUT))
-                sys.stderr.flush()
-                os._exit(EXIT_SETUP_TIMEOUT)
+            while True:
+                with self._lock:
+                    left = self._expires - time.monotonic()
+                if left <= 0:
+                    break
+                if self._done.wait(min(left, 1.0)):
+                    return
+            sys.stderr.write("vi_slam_amd.dist: rank %d gave up after %.0f s in %s -- a peer did not arrive; exiting %d\n"
+                             % (self.rank, self.seconds, self.what, EXIT_SETUP_TIMEOUT))
+            sys.stderr.flush()
+            os._exit(EXIT_SETUP_TIMEOUT)
         if self.seconds > 0:
+            self.rearm()
             threading.Thread(target=watch, daemon=True).start()
         return self
 
@@ -134,11 +151,12 @@ class SlotExchange:
         Several communicators with operations in flight on different streams need all those kernels to be able to
         co-reside on the GPU (RCCL's documented condition): the exchanges here are ONE send/recv pair of <= 125 KB per
         lane, one workgroup each, next to kernels that never fill more than their own wave slots."""
-        with _Deadline(setup_timeout, "SlotExchange.create (%s, world %d)" % (transport, world), rank):
+        with _Deadline(setup_timeout, "SlotExchange.create (%s, world %d)" % (transport, world), rank) as deadline:
             if transport != "rccl":
                 x = cls(rank, world, mode, "gloo" if dist.is_initialized() else "local")
                 if world > 1 and dist.is_initialized():  # every rank is here and its group works: one vote, as for rccl
-                    t = torch.tensor([1.0], dtype=torch.float64)
+                    # the vote travels on the process group's own backend: an nccl group reduces device tensors only
+                    t = torch.tensor([1.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
                     dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return x
             import vi_slam_amd as V
@@ -155,6 +173,7 @@ class SlotExchange:
             fe = V.FExtractor(100, 1.2, 2, 20, 7, 128, 128, device=device, max_batch=1)  # ONE scratch stream context for all probes
             try:
                 for k in range(lanes):  # one communicator at a time, each followed by a vote: all ranks end up with the same number
+                    deadline.rearm("SlotExchange.create (rccl, world %d, lane %d of %d)" % (world, k + 1, lanes))  # `setup_timeout` per lane
                     ok, err, comm = 1.0, "", None
                     t0 = time.perf_counter()
                     try:
