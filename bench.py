@@ -515,6 +515,62 @@ class Pipeline:
                 if self.stamps is not None:
                     self.stamps.append(time.perf_counter())  # step t - (NCTX - 1) delivered
 
+    # -------------------------------------------------------------------------------------------- exchange proof
+    def verify_exchange(self, xchg):
+        """One UNTIMED step that proves the exchange on the GPU, without the oracle: this rank extracts its own batch,
+        packs its last frame and sends it round `xchg`; then it extracts the LEFT neighbour's last frame ITSELF (frames are
+        synthesised from their global index, so every rank can make any frame) and compares the packed slot that arrived
+        with the one it packed locally -- count, monoIndex, keypoints, descriptors, byte for byte -- and the matcher output
+        of its own slot 0 against the arrived predecessor with the one against the local copy.
+        -> dict(ok, n, reason, matcher_ok, matches, us)"""
+        import ctypes
+        torch, V, vd, np = self.torch, self.V, self.vd, self.np
+        from vi_slam_amd import synth
+        rank, world, B = self.env["rank"], self.env["world"], self.B
+        w, h = self.cfg["w"], self.cfg["h"]
+        c, c2 = self.ctxs[0], self.ctxs[1]
+        sb = self.slot_bytes
+        torch.cuda.synchronize()
+        self.env["barrier"]()
+        # 1. own step on context 0: extract, pack the last frame, exchange
+        c.compute_batch_async(self.dev_ptrs, self.pitch, self.lap, where=V.IMGS_DEVICE, to_host=False)
+        send = torch.zeros(sb, dtype=torch.uint8, device="cuda")
+        recv = torch.zeros(sb * (world if xchg.mode == "allgather" else 1), dtype=torch.uint8, device="cuda")
+        c.pack_slots(1, send.data_ptr(), sb, first=B - 1, sync=False)
+        t0 = time.perf_counter()
+        xchg.exchange(c, send, recv, lane=0)
+        c.wait()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) * 1e6
+        got = xchg.left_block(recv)[:sb]
+        # 2. the left neighbour's last frame, extracted HERE (every slot of context 1 gets the same image; slot B-1 is packed)
+        lr, ls, _ = vd.left_last_frame(rank, world, B)
+        fr = synth.make_frame(w, h, step=vd.global_frame(lr, ls % self.ndistinct, world, B))
+        dev = torch.zeros((h, self.pitch), dtype=torch.uint8, device="cuda")
+        dev[:, :w] = torch.from_numpy(fr).cuda()
+        ptrs2 = (ctypes.c_void_p * B)(*[dev.data_ptr()] * B)
+        c2.compute_batch_async(ptrs2, self.pitch, self.lap, where=V.IMGS_DEVICE, to_host=False)
+        local = torch.zeros(sb, dtype=torch.uint8, device="cuda")
+        c2.pack_slots(1, local.data_ptr(), sb, first=B - 1, sync=False)
+        c2.wait()
+        torch.cuda.synchronize()
+        res = vd.compare_packed_slots(got.cpu().numpy(), local.cpu().numpy())
+        # 3. the matcher on slot 0 with the arrived predecessor and with the local copy
+        q = c.slot_dev_ptrs(0)
+        m = []
+        for buf in (got, local):
+            p0 = self._slot_ptrs_in(buf, 0)
+            self.matchers[0].search_init_dev_async([(p0[0], p0[1], p0[2], q[0], q[1], q[2], 0)], 100, (w, h))
+            m.append(self.matchers[0].search_init_dev_wait([self.fe.cap])[0])
+        res["matcher_ok"] = bool(m[0][0] == m[1][0] and np.array_equal(m[0][1], m[1][1]))
+        res["matches"] = int(m[1][0])
+        res["us"] = us
+        res["ok"] = bool(res["ok"])
+        if not (res["ok"] and res["matcher_ok"]):
+            print("rank %d: exchange verification FAILED (%s): %s; matcher %s" % (rank, xchg.mode, res["reason"], res["matcher_ok"]),
+                  file=sys.stderr, flush=True)
+        return res
+
     # -------------------------------------------------------------------------------------------- timing
     def timed(self, steps, warmup, min_seconds):
         """W warmup steps, then R x K steps bracketed by barrier + synchronize; max over ranks.  R is agreed by all ranks
@@ -712,6 +768,26 @@ def run_workload(name, args, env, want_cpu, cpu_seconds):
             out["exchange"] = {"us_per_exchange_alone": env["max_over_ranks"]((time.perf_counter() - t0) / 50 * 1e6),
                                "bytes": pl.slot_bytes, "mode": pl.xchg.mode, "transport": pl.xchg.transport,
                                "lanes": len(pl.xchg.comms) if pl.xchg.comms else 0}
+            if args.verify_exchange:
+                # the GPU-side proof for the first N > 1 run (no oracle involved), for BOTH exchange forms: the mode of the
+                # timed region on its own SlotExchange, the other one on a one-lane SlotExchange built for this check
+                ver = {}
+                other = "allgather" if pl.xchg.mode == "ring" else "ring"
+                for mode in (pl.xchg.mode, other):
+                    x = pl.xchg if mode == pl.xchg.mode else pl.vd.SlotExchange.create(
+                        env["rank"], env["world"], env["local_rank"], mode=mode, transport=pl.xchg.transport, lanes=1)
+                    try:
+                        r = pl.verify_exchange(x)
+                    finally:
+                        if x is not pl.xchg:
+                            x.close()
+                    bad = env["max_over_ranks"](0.0 if (r["ok"] and r["matcher_ok"]) else 1.0)  # every rank must agree
+                    ver[mode] = {"verified": bad == 0.0, "keypoints_compared_rank0": r["n"], "matches_rank0": r["matches"],
+                                 "us_first_exchange": env["max_over_ranks"](r["us"])}
+                    if r["reason"]:
+                        ver[mode]["reason_rank0"] = r["reason"]
+                out["exchange"]["exchange_verified"] = all(v["verified"] for v in ver.values())
+                out["exchange"]["verify"] = ver
         if pl.cfg.get("real"):
             prob, deep = 0, 0
             for c in pl.ctxs:
@@ -776,6 +852,8 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--exchange", default="ring", choices=["ring", "allgather"],
                     help="N>1 exchange step: ring shift (ncclSend/ncclRecv pair) or the north_star-literal all-gather")
+    ap.add_argument("--no-verify-exchange", dest="verify_exchange", action="store_false",
+                    help="skip the untimed GPU-side proof of the exchange (on by default whenever the exchange runs)")
     ap.add_argument("--force-collective", action="store_true",
                     help="take the N>1 code path (pack + exchange on the extractor stream) at world size 1")
     ap.add_argument("--print-launch", action="store_true", help="with --gpus N and no launcher: print the launch command, do not run")
@@ -891,6 +969,8 @@ def main():
         }
         if "exchange" in head:
             line["exchange"] = {k: sig(v) for k, v in head["exchange"].items()}
+            if "exchange_verified" in head["exchange"]:
+                line["exchange_verified"] = head["exchange"]["exchange_verified"]
         if "roofline" in head:
             line["hbm_gbps_per_rank"] = sig(head["roofline"].get("pipeline_gbps_per_rank"))
         if "roofline_pcie" in head:

@@ -124,6 +124,56 @@ def test_exchange_delivers_predecessors_and_matches_equal_single_process(world, 
     assert sum(v[0] for v in want.values()) > 20 * len(want)
 
 
+def _verify_worker(rank, world, port, batch, mode, q):
+    """the proof bench.py --verify-exchange makes on the GPU, with the oracle as the extractor: what arrives through the
+    exchange equals the slot this rank produces ITSELF from the left neighbour's frame"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sb = vd.slot_bytes_for(CAP)
+        x = vd.SlotExchange.create(rank, world, 0, mode=mode, transport="gloo")
+        k, d, mono = _extract(vd.global_frame(rank, batch - 1, world, batch))
+        send = torch.from_numpy(vd.pack_slot_host(k, d, mono, CAP, sb))
+        recv = torch.zeros(sb * (world if mode == "allgather" else 1), dtype=torch.uint8)
+        x.exchange(None, send, recv)
+        lr, ls, lg = vd.left_last_frame(rank, world, batch)
+        assert (lr, ls) == ((rank - 1) % world, batch - 1)
+        lk, ld, lmono = _extract(lg)
+        want = vd.pack_slot_host(lk, ld, lmono, CAP, sb)
+        got = vd.slot_view(x.left_block(recv), 0, sb).numpy()
+        good = vd.compare_packed_slots(got, want)
+        bad = got.copy()
+        bad[16 + 28 * 3 + 5] ^= 1  # one bit of keypoint 3
+        bad2 = got.copy()
+        bad2[16 + CAP * 28 + 32 * (good["n"] - 1)] ^= 0x80  # one bit of the last descriptor
+        q.put((rank, good, vd.compare_packed_slots(bad, want), vd.compare_packed_slots(bad2, want),
+               vd.compare_packed_slots(want, vd.pack_slot_host(k, d, mono, CAP, sb))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "ring"), (2, "allgather")])
+def test_verify_exchange_compares_the_arrived_slot_with_a_local_extraction(world, mode):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_verify_worker, args=(r, world, port, 2, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, good, bad, bad2, other in res:
+        assert good["ok"] and good["n"] > 100, (rank, good)
+        assert not bad["ok"] and "keypoint 3" in bad["reason"]
+        assert not bad2["ok"] and "descriptor %d" % (good["n"] - 1) in bad2["reason"]
+        assert not other["ok"]  # the rank's own last frame is not the left neighbour's
+
+
 def test_world1_exchange_is_a_copy_without_process_group():
     x = vd.SlotExchange.create(0, 1, 0, mode="ring", transport="gloo")
     a = torch.arange(64, dtype=torch.uint8)

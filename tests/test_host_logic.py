@@ -82,6 +82,40 @@ def test_cell_grid_counts_kitti(H):
     assert counts == [429, 297, 189, 132, 72, 45, 36, 20] and sum(counts) == 1220
 
 
+@pytest.mark.parametrize("size", [(1241, 376), (1920, 1080), (752, 480), (640, 360), (512, 512), (179, 100), (143, 143), (95, 70)])
+@pytest.mark.parametrize("per", [1, 3, 4])
+def test_bands_cover_every_cell_once(H, size, per):
+    """k_fast_bands' work list (vslam::build_bands): consecutive cells of one cell row, constant pitch, interiors of a
+    band at most 128 px wide, every cell in exactly one band, band windows = the union of their cells' windows"""
+    w0, h0 = size
+    for l in range(8):
+        w, h = int(round(w0 / 1.2 ** l)), int(round(h0 / 1.2 ** l))
+        cells = np.zeros((8192, 5), np.uint16)
+        nc = H.vslamh_cells(l, w, h, _p(cells), 8192)
+        bands = np.zeros((8192, 8), np.uint32)
+        nb = H.vslamh_bands(l, w, h, per, 128, _p(bands), 8192)
+        if nc == 0:
+            assert nb == 0
+            continue
+        cells, bands = cells[:nc].astype(int), bands[:nb].astype(int)
+        seen = np.zeros(nc, int)
+        for cell0, lev, ncell, wcell, x0, y0, ww, wh in bands:
+            assert 1 <= ncell <= per and lev == l and ww - 6 <= 128
+            for k in range(ncell):
+                c = cells[cell0 + k]
+                seen[cell0 + k] += 1
+                assert c[2] == y0 and c[4] == y0 + wh            # one cell row
+                assert c[1] == x0 + k * wcell                    # constant pitch
+                # cell k's interior columns inside the band's interior: [k * wcell, min((k + 1) * wcell, iw))
+                assert c[3] - c[1] - 6 == min((k + 1) * wcell, ww - 6) - k * wcell > 0
+            assert cells[cell0 + ncell - 1][3] == x0 + ww
+            assert (wcell * ((65536 + wcell - 1) // wcell)) >> 16 >= 1  # the kernel's x / wcell by multiplication ...
+            rc = (65536 + wcell - 1) // wcell
+            assert all((x * rc) >> 16 == x // wcell for x in range(256))   # ... is exact on its domain
+        assert np.all(seen == 1)
+        assert np.all(np.diff(bands[:, 0]) > 0)
+
+
 def test_octree_equals_oracle_on_extractor_candidates(H):
     for (w, h, nf) in [(1241, 376, 2000), (1241, 376, 1000), (752, 480, 500), (640, 480, 10000)]:
         e = orbo.Extractor(nf)

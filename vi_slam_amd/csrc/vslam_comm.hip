@@ -1,11 +1,14 @@
 /* vslam_comm.hip -- the multi-GPU exchange step of the front-end, inside the library.
  *
- * Frames shard one per GPU; extraction and L<->R stereo matching need no collective.  Cross-frame matching
- * (SearchForInitialization, SearchByProjection(Current, Last)) needs the predecessor frame's packed result slot,
- * which lives on the LEFT neighbour rank (vi_slam_amd/dist.py: frame g -> rank g % world), so the exchange is a ring
- * shift: one ncclSend to rank+1 and one ncclRecv from rank-1 inside ncclGroupStart/End, enqueued on the extractor
- * context's own HIP stream right behind k_pack_slots -- the matcher that follows on the same stream needs no host
- * synchronisation.  vslam_exchange_allgather is the north_star-literal variant (world times the volume).
+ * Frames are dealt to the GPUs in BLOCKS: of a step's world x B consecutive frames rank r holds r*B .. (r+1)*B - 1
+ * (vi_slam_amd/dist.py: global_frame(rank, slot) = rank * B + slot); extraction and L<->R stereo matching need no
+ * collective.  Cross-frame matching (SearchForInitialization, SearchByProjection(Current, Last)) needs the predecessor
+ * frame's packed result slot, which is the rank's own previous slot for every frame but the first of its block; slot 0
+ * needs the LAST frame of the LEFT neighbour rank (for rank 0: rank world-1's last frame of the previous step).  So the
+ * exchange is a ring shift of ONE packed slot per rank and step: one ncclSend to rank+1 and one ncclRecv from rank-1
+ * inside ncclGroupStart/End, enqueued on the extractor context's own HIP stream right behind k_pack_slots -- the
+ * matcher that follows on the same stream needs no host synchronisation.  vslam_exchange_allgather is the
+ * north_star-literal variant (world times the volume).
  *
  * RCCL is resolved at run time (dlopen "librccl.so.1"): a single-GPU consumer of libvslam_fe.so needs only
  * libamdhip64, and inside a PyTorch process the already loaded RCCL is reused instead of a second copy.

@@ -70,6 +70,9 @@ struct vslam_fe {
     int level_cell_first[VSLAM_MAX_LEVELS + 1] = {};
     CellDesc* d_cells = nullptr;
     int tile_pitch = 0, tile_rows = 0, max_px = 0;
+    /* FAST bands (k_fast_bands): up to four cells of a cell row per workgroup; nbands == 0: not available for this geometry */
+    BandDesc* d_bands = nullptr;
+    int nbands = 0, band_max_wh = 0;
     /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
     uint8_t* d_cand = nullptr;
     uint8_t* h_cand = nullptr; /* pinned */

@@ -39,6 +39,15 @@ struct CellDesc {
                       most strict 3x3 local maxima an iw x ih interior can hold -> no allocation atomics */
 };
 
+/* One band of k_fast_bands (vslam::HostBand): consecutive cells of one cell row that share one staged window.  16 bytes,
+ * read as one scalar dwordx4. */
+struct BandDesc {
+    uint32_t cell0; /* first cell (index into the CellDesc table / the slot's CellOut table) */
+    uint32_t lnw;   /* level | ncell << 4 | wcell << 8 | ceil(65536 / wcell) << 16 */
+    uint32_t xy;    /* x0 | y0 << 16 */
+    uint32_t wh;    /* window width | height << 16 */
+};
+
 /* Per-slot candidate region, contiguous so one D2H moves header + cell table + candidates:
  *   uint32 unused; uint32 overflow; CellOut cells[ncells]; uint32 cand[cap]
  * cand = (score << 24) | ((y-16) << 12) | (x-16), level coordinates. */

@@ -268,6 +268,32 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         int rc;
         if ((rc = upload(&fe->d_cells, dc.data(), dc.size() * sizeof(CellDesc)))) return rc;
     }
+    {   /* bands of k_fast_bands: up to four cells of a cell row whose interiors are together at most 128 px wide */
+        std::vector<vslam::HostBand> hb;
+        const int per = std::min(4, std::max(1, tune_or(fe->tune.fast_band_cells, 4)));
+        vslam::build_bands(fe->cells, per, 128, hb);
+        int mwh = 0, miw = 0, mc = 0;
+        std::vector<BandDesc> db(hb.size());
+        for (size_t i = 0; i < hb.size(); i++) {
+            const vslam::HostBand& b = hb[i];
+            mwh = std::max(mwh, (int)b.wh);
+            miw = std::max(miw, (int)b.ww - 6);
+            mc = std::max(mc, (int)b.ncell);
+            const uint32_t rcpw = (65536u + b.wcell - 1u) / b.wcell;
+            db[i].cell0 = b.cell0;
+            db[i].lnw = (uint32_t)b.level | ((uint32_t)b.ncell << 4) | ((uint32_t)b.wcell << 8) | (rcpw << 16);
+            db[i].xy = (uint32_t)b.x0 | ((uint32_t)b.y0 << 16);
+            db[i].wh = (uint32_t)b.ww | ((uint32_t)b.wh << 16);
+        }
+        bool ok = !hb.empty() && vk_fast_bands_check(mwh, miw, mc) == 0 && p.nlevels <= 16;
+        for (const vslam::HostBand& b : hb) ok = ok && b.wcell < 256 && (65536u + b.wcell - 1u) / b.wcell < 65536u;
+        if (ok) {
+            int rc;
+            if ((rc = upload(&fe->d_bands, db.data(), db.size() * sizeof(BandDesc)))) return rc;
+            fe->nbands = (int)db.size();
+            fe->band_max_wh = mwh;
+        }
+    }
     const int ncells = (int)fe->cells.size();
     /* every cell owns a fixed segment sized by the exact upper bound of its NMS survivors */
     fe->cand_cap = (int)std::max<size_t>(cand_total, 16);
@@ -852,8 +878,14 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
-                     fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg, fe->tune);
+    /* vslam_tuning.fast_kernel: 4 (default) = one workgroup per band of cells, 3 = one per cell */
+    if (fe->nbands > 0 && tune_or(fe->tune.fast_kernel, 4) != 3)
+        vk_fast_bands(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_bands, fe->nbands, fe->d_cells,
+                      (int)fe->cells.size(), fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->band_max_wh, 0, nimg,
+                      fe->tune);
+    else
+        vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
+                         fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg, fe->tune);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     return VSLAM_OK;
 }

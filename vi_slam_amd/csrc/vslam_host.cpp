@@ -326,6 +326,36 @@ void build_cells(int level, int lw, int lh, std::vector<HostCell>& out) {
     }
 }
 
+void build_bands(const std::vector<HostCell>& cells, int max_cells, int max_width, std::vector<HostBand>& out) {
+    const size_t n = cells.size();
+    size_t i = 0;
+    while (i < n) {
+        /* the cells of one cell row: same level, same window rows */
+        size_t e = i + 1;
+        while (e < n && cells[e].level == cells[i].level && cells[e].y0 == cells[i].y0 && cells[e].y1 == cells[i].y1 &&
+               cells[e].x0 > cells[e - 1].x0)
+            e++;
+        const int nrow = (int)(e - i);
+        /* pitch of the cells in x; a row of one cell is its own pitch */
+        const int wcell = nrow > 1 ? cells[i + 1].x0 - cells[i].x0 : std::max(1, cells[i].x1 - cells[i].x0 - 6);
+        const int per = std::max(1, std::min(max_cells, max_width / std::max(wcell, 1)));
+        for (size_t b = i; b < e; b += (size_t)per) {
+            const size_t last = std::min(e, b + (size_t)per) - 1;
+            HostBand hb;
+            hb.cell0 = (uint32_t)b;
+            hb.level = cells[b].level;
+            hb.ncell = (uint16_t)(last - b + 1);
+            hb.wcell = (uint16_t)wcell;
+            hb.x0 = cells[b].x0;
+            hb.y0 = cells[b].y0;
+            hb.ww = (uint16_t)(cells[last].x1 - cells[b].x0);
+            hb.wh = (uint16_t)(cells[b].y1 - cells[b].y0);
+            out.push_back(hb);
+        }
+        i = e;
+    }
+}
+
 /* ------------------------------------------------------------------ quadtree distribution */
 namespace {
 struct QNode {
@@ -799,6 +829,20 @@ int vslamh_cells(int level, int lw, int lh, uint16_t* out5, int cap) {
         out5[5 * i + 3] = c[i].x1; out5[5 * i + 4] = c[i].y1;
     }
     return (int)c.size();
+}
+
+/* bands of all cells of one level: out8 rows = (cell0, level, ncell, wcell, x0, y0, ww, wh) */
+int vslamh_bands(int level, int lw, int lh, int max_cells, int max_width, uint32_t* out8, int cap) {
+    std::vector<vslam::HostCell> c;
+    vslam::build_cells(level, lw, lh, c);
+    std::vector<vslam::HostBand> b;
+    vslam::build_bands(c, max_cells, max_width, b);
+    for (int i = 0; i < (int)b.size() && i < cap; i++) {
+        uint32_t* o = out8 + 8 * i;
+        o[0] = b[i].cell0; o[1] = b[i].level; o[2] = b[i].ncell; o[3] = b[i].wcell;
+        o[4] = b[i].x0; o[5] = b[i].y0; o[6] = b[i].ww; o[7] = b[i].wh;
+    }
+    return (int)b.size();
 }
 
 /* keys: n x (x, y, response) int32 triples; returns count, writes triples */

@@ -89,6 +89,17 @@ struct HostCell {
 };
 void build_cells(int level, int lw, int lh, std::vector<HostCell>& out);
 
+/* Bands of k_fast_bands: up to max_cells CONSECUTIVE cells of one cell row (same level, same y0) whose interiors together
+ * are at most max_width px wide; the cells of a row are visited left to right with a constant pitch `wcell` (the last
+ * one may be clipped, fextractor.cpp:791-795), so cell k of a band has the interior columns [k * wcell, min((k + 1) * wcell,
+ * ww - 6)) of the band's interior.  Bands are listed in cell order (cell0 ascending) and cover every cell exactly once. */
+struct HostBand {
+    uint32_t cell0;                  /* index of the band's first cell in the cell list */
+    uint16_t level, ncell, wcell;
+    uint16_t x0, y0, ww, wh;         /* shared window: [x0, x0 + ww) x [y0, y0 + wh) in level coordinates */
+};
+void build_bands(const std::vector<HostCell>& cells, int max_cells, int max_width, std::vector<HostBand>& out);
+
 /* A FAST candidate / selected keypoint in level coordinates relative to the 16-px border. */
 struct Cand {
     int16_t x, y;

@@ -1007,3 +1007,372 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
     }
 #undef FAST3_LAUNCH
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * FAST bands (round 4): one workgroup per BAND -- up to four consecutive cells of one cell row -- instead of one per cell.
+ * Why: k_fast_cells_v3 spent ~45 % of its instructions on things that exist once per WORKGROUP (cell record, level
+ * geometry, staging addresses, zeroing, loop set-up, the output prologue: ~190 of ~1220 wave-instructions per cell in two
+ * waves) or once per WINDOW (the 6-px ring of every 30-px cell is staged 1.42 times).  A band stages ONE window of
+ * (ncell * wcell + 6) x (hcell + 6) px (1.05 x 1.19), decodes one record, and its four waves share every loop:
+ *   - pre-test: the same packed four-pixel compass test, lanes dealt to (row, quad) with 32 / 16 / 8 quads per row, so a
+ *     wave sweeps two, four or eight whole rows per iteration and skips iterations that lie below the band;
+ *   - ONE survivor list for the band (dark from the front, bright-only from the back of one array that can hold every
+ *     pixel of the rows swept at once -- taller bands than that are swept in row chunks that overlap by one row, so that
+ *     the list-driven NMS of a chunk never needs a score of the next one);
+ *   - one pass of the two-pixel score networks over the band's list: dark pairs from thread 0 up, bright pairs right
+ *     behind them, so all but one wave run a single polarity;
+ *   - cell-local NMS (fextractor.cpp:800: every cell is its own cv::FAST call) through a per-column flag table -- first /
+ *     last column of its cell -- that masks the neighbours across a cell border;
+ *   - "empty at iniThFAST => the whole cell at minThFAST" (fextractor.cpp:800-807) per cell: the second stage sweeps only
+ *     the quad columns of the band's empty cells;
+ *   - output: wave w writes cell w's candidates in raster order into the cell's fixed segment (same layout as v3).
+ * Scores do not depend on the cell a pixel belongs to, so the result is identical to one cv::FAST per cell.
+ * ---------------------------------------------------------------------------------------------- */
+#define FB_P 136      /* LDS pitch: 128 interior columns + the 6-px ring + the one-column shift, a multiple of 8 */
+#define FB_KW 4       /* keep words per interior row (128 columns) */
+#define FB_MAXC 4     /* cells per band */
+#ifndef FB_XCD_CHUNK
+#define FB_XCD_CHUNK 4
+#endif
+template <int NT>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
+k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
+             const BandDesc* __restrict__ bands, int nbands, const CellDesc* __restrict__ cells, uint8_t* cand_region,
+             size_t cand_stride, int ncells, int iniTh, int minTh, int nslots, int lds_total, int by_image) {
+    extern __shared__ __align__(16) uint8_t smemb[];
+    constexpr int P = FB_P;
+    constexpr int NW = NT / 64;
+    __shared__ uint32_t s_cnt[2]; /* nD (+ both) | nB << 16 of the chunk being swept; the other one is zeroed meanwhile */
+    __shared__ uint32_t s_any;    /* bit c: cell c of the band kept a corner */
+    __shared__ uint32_t s_nq;     /* stage 2: quad columns to sweep */
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    /* XCD-aware order (workgroups b and b + 8 share an XCD and its L2).  Full batches: XCD k takes the images k, k + 8, ...
+     * whole -- neighbouring bands share six window columns, the next cell row shares six window rows, and the eight XCDs
+     * get the same mix of levels -- so every image byte is fetched into one L2 once.  Fewer than eight images: chunks of
+     * FB_XCD_CHUNK bands dealt round-robin (rotated by the slot), as k_fast_cells_v3 does with cells. */
+    int slot, band;
+    {
+        const int xi = (int)(blockIdx.x >> 3), xk = (int)(blockIdx.x & 7);
+        if (by_image) {
+            const int sl = xi / nbands;
+            band = xi - sl * nbands;
+            slot = xk + 8 * sl;
+        } else {
+            slot = blockIdx.y;
+            band = ((xi / FB_XCD_CHUNK) * 8 + (int)((blockIdx.x + blockIdx.y) & 7)) * FB_XCD_CHUNK + xi % FB_XCD_CHUNK;
+        }
+        if (slot >= nslots || band >= nbands) return;
+    }
+    const uint4 bd = ((const uint4*)bands)[band]; /* scalar cache */
+    const int cell0 = (int)bd.x;
+    const int level = (int)(bd.y & 15u), ncell = (int)((bd.y >> 4) & 15u), wcell = (int)((bd.y >> 8) & 255u);
+    const uint32_t rcpw = bd.y >> 16;
+    const int bx0 = (int)(bd.z & 0xFFFFu), by0 = (int)(bd.z >> 16);
+    const int ww = (int)(bd.w & 0xFFFFu), wh = (int)(bd.w >> 16);
+    const int iw = ww - 6, ih = wh - 6;
+    const LevelGeom lg = g.lv[level];
+    int pitch;
+    const uint8_t* img = level_base_v2(pyr, slot_stride, src, lg, level, slot, &pitch);
+
+    /* LDS: window | score tile (ih + 2 rows, interior at row 1, column 1) | keep words | column tables | survivor list */
+    const int whe = (wh + 1) & ~1; /* 136 * even: the score tile stays 16-byte aligned */
+    uint8_t* win = smemb;          /* window column c at LDS column c + 1 */
+    uint8_t* sc = win + whe * P;
+    uint32_t* keep = (uint32_t*)(sc + (((ih + 2) * P + 15) & ~15));
+    uint8_t* cellbit = (uint8_t*)(keep + ih * FB_KW); /* 1 << (cell of interior column x), 0 outside the interior */
+    uint8_t* cellfl = cellbit + 136;                  /* bit 0: first column of its cell, bit 1: last column */
+    uint8_t* qtab = cellfl + 136;                     /* stage 2: the quad columns of the empty cells */
+    uint16_t* list = (uint16_t*)(qtab + 32);
+    const int lcap = ((lds_total - (int)((uint8_t*)list - smemb)) >> 1) & ~1; /* entries; even */
+
+    /* stage the window: columns bx0 - 1 .. of wh rows, 17 eight-byte lanes per row; every load is issued before the first
+     * LDS store, and the tiles are zeroed / the tables built while they are in flight */
+    constexpr int LPR = P / 8, RPS = NT / LPR;
+    constexpr int NSW = (52 + RPS - 1) / RPS > 4 ? 4 : (52 + RPS - 1) / RPS; /* sweeps kept in registers: windows of up to 52 rows */
+    const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
+    const bool stager = tid < RPS * LPR && scol < ww + 1;
+    const uint8_t* gsrc = img + (size_t)by0 * pitch + bx0 - 1;
+    uint2 wreg[NSW];
+#pragma unroll
+    for (int u = 0; u < NSW; u++) {
+        const int y = srow + u * RPS;
+        wreg[u] = make_uint2(0u, 0u);
+        if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (uint32_t)(__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)scol));
+    }
+    {
+        const int nz = (int)(((uint8_t*)(keep + ih * FB_KW) - sc) >> 4); /* score tile + keep words, 16-byte stores */
+        for (int i = tid; i < nz; i += NT) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 136) {
+            const int x = tid;
+            const int c = (int)(((uint32_t)x * rcpw) >> 16); /* x / wcell, exact for x < 256 (rcpw = ceil(65536 / wcell)) */
+            const bool inside = x < iw;
+            const int cend = min((c + 1) * wcell, iw) - 1;
+            cellbit[x] = inside ? (uint8_t)(1u << c) : (uint8_t)0;
+            cellfl[x] = inside ? (uint8_t)((x == c * wcell ? 1 : 0) | (x == cend ? 2 : 0)) : (uint8_t)0;
+        }
+        if (tid < 8) ((uint32_t*)qtab)[tid] = 0u;
+        if (tid == 0) {
+            s_cnt[0] = 0u;
+            s_cnt[1] = 0u;
+            s_any = 0u;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NSW; u++) {
+        const int y = srow + u * RPS;
+        if (stager && y < wh) *(uint2*)(win + y * P + scol) = wreg[u];
+    }
+    if (stager)
+        for (int y = srow + NSW * RPS; y < wh; y += RPS)
+            *(uint2*)(win + y * P + scol) = *(const uint2*)(gsrc + (uint32_t)(__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)scol));
+    __syncthreads();
+
+    const uint32_t* W32 = (const uint32_t*)win;
+    const int QW = (iw + 3) >> 2;            /* quad columns of the band */
+    const int CR = min(ih, lcap / (4 * QW)); /* rows swept at once: every pixel of them has a list entry (>= 2, host) */
+    const int sc_off = whe * P - 2 * P - 3;  /* score byte of a pixel relative to its window byte */
+    int T = iniTh;
+    uint32_t act = 0xFFu; /* cells swept in this stage */
+    int nq = QW;
+    int par = 0;          /* which s_cnt the current chunk counts in */
+    for (int stage = 0; stage < 2; stage++) {
+        /* lanes per row: 32, 16 or 8 quad slots; a wave sweeps 2, 4 or 8 whole rows per iteration */
+        const int sh = nq > 16 ? 5 : nq > 8 ? 4 : 3;
+        const int qs = tid & ((1 << sh) - 1), qly = tid >> sh;
+        const int qx = stage ? (int)qtab[qs] : qs; /* slots past nq read column 0 and pass nothing */
+        /* per-pixel thresholds: T inside the cells swept in this stage, else one nothing passes (v - 0x7FFF saturates to 0,
+         * v + 0x7FFF is above every pixel): no validity masks inside the sweep.  Halves of TTv[par]: pixels par, par + 2 */
+        uint32_t TTv[2];
+        {
+            const uint32_t cb = *(const uint32_t*)(cellbit + 4 * qx);
+            const bool lv = qs < nq;
+            uint32_t t4[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) t4[p] = (lv && (((cb >> (8 * p)) & act) != 0u)) ? (uint32_t)T : 0x7FFFu;
+            TTv[0] = t4[0] | (t4[2] << 16);
+            TTv[1] = t4[1] | (t4[3] << 16);
+        }
+        const int RPI = NT >> sh;             /* rows per iteration of the workgroup */
+        const int wrow = (wv * 64) >> sh;     /* first row of this wave inside an iteration */
+        for (int r0 = 0;;) {
+            const int r1 = min(r0 + CR, ih);
+            for (int ly0 = r0; ly0 + wrow < r1; ly0 += RPI) { /* wave-uniform: iterations below the chunk are skipped */
+                const int ly = ly0 + qly;
+                const bool rowok = ly < r1;
+                const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
+                const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
+                const uint32_t U = W32[ly * (P / 4) + qx + 1], Dn = W32[(ly + 6) * (P / 4) + qx + 1];
+                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, A0, 1); /* columns x-3 */
+                const uint32_t Rt = __builtin_amdgcn_alignbyte(E, C, 3);  /* columns x+3 */
+#define EVN(x) __builtin_amdgcn_perm(0u, (x), 0x0c020c00u) /* pixels 0,2 as u16 halves */
+#define ODD(x) __builtin_amdgcn_perm(0u, (x), 0x0c030c01u) /* pixels 1,3 */
+                uint32_t passD[2], passB[2];
+#pragma unroll
+                for (int pp = 0; pp < 2; pp++) {
+                    const uint32_t v = pp ? ODD(C) : EVN(C);
+                    const uint32_t TT = rowok ? TTv[pp] : 0x7FFF7FFFu;
+                    const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
+                    const uint32_t u = pp ? ODD(U) : EVN(U), d = pp ? ODD(Dn) : EVN(Dn);
+                    const uint32_t l = pp ? ODD(Lf) : EVN(Lf), r = pp ? ODD(Rt) : EVN(Rt);
+                    passD[pp] = pk_sub_sat(vm, pk_max(pk_min(d, u), pk_min(r, l)));
+                    passB[pp] = pk_sub_sat(pk_min(pk_max(d, u), pk_max(r, l)), vp);
+                }
+#undef EVN
+#undef ODD
+                uint64_t mD[4], mB[4], mX[4];
+                uint32_t totD = 0, totB = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t dk = (j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1]);
+                    const uint64_t br = (j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1]);
+                    mD[j] = dk;
+                    mX[j] = dk & br;
+                    mB[j] = br & ~dk;
+                    totD += (uint32_t)__popcll(mD[j]);
+                    totB += (uint32_t)__popcll(mB[j]);
+                }
+                if (totD | totB) { /* wave-uniform */
+                    uint32_t base = 0;
+                    if (lane == 0) base = lds_add_rtn(lds_addr(&s_cnt[par]), totD | (totB << 16));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    /* dark entries grow from the front of the list, bright-only ones from its back */
+                    const uint32_t aD = lds_addr(list) + 2u * (base & 0xFFFFu);
+                    const uint32_t aB = lds_addr(list) + 2u * (uint32_t)(lcap - 1) - 2u * (base >> 16);
+                    const uint32_t code0 = (uint32_t)((ly << 8) + 4 * qx);
+                    uint32_t pD = 0, pB = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t code = code0 + j;
+                        const uint32_t atD = aD + 2u * pD + 2u * lane_rank(mD[j]);
+                        const uint32_t atB = aB - 2u * pB - 2u * lane_rank(mB[j]);
+                        lds_store_b16_masked2(mD[j] | mB[j], mX[j], lane_select(mD[j], atD, atB), code, code | 0x8000u);
+                        pD += (uint32_t)__popcll(mD[j]);
+                        pB += (uint32_t)__popcll(mB[j]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the masked stores above are not tracked by the compiler */
+            __syncthreads();
+            int nD, nB;
+            {
+                const uint32_t tot = s_cnt[par];
+                nD = (int)(tot & 0xFFFFu);
+                nB = (int)(tot >> 16);
+            }
+            if (tid == 0) s_cnt[par ^ 1] = 0u; /* the next chunk's / stage's counter: its last readers passed a barrier ago */
+            /* networks: TWO list entries per thread in the halves of packed registers; dark pairs go to the threads 0 ..,
+             * bright pairs to the threads right behind them, so only the wave that holds the seam runs both polarities */
+            const int nDp = (nD + 1) >> 1, nBp = (nB + 1) >> 1;
+            for (int u = tid; u < nDp + nBp; u += NT) {
+                if (u < nDp) {
+                    const uint32_t e2 = *(const uint32_t*)(list + 2 * u);
+                    const uint32_t eA = e2 & 0xFFFFu, eB = 2 * u + 1 < nD ? e2 >> 16 : eA;
+                    const uint8_t* cA = win + (((eA >> 8) & 0x7Fu) + 3) * P + (eA & 255u) + 4;
+                    const uint8_t* cB = win + (((eB >> 8) & 0x7Fu) + 3) * P + (eB & 255u) + 4;
+                    uint32_t a = fast_pair_score<1, P>(cA, cB);
+                    if ((eA | eB) & 0x8000u) {
+                        const uint32_t b = fast_pair_score<-1, P>(cA, cB);
+                        const uint32_t m = ((eA & 0x8000u) ? 0xFFFFu : 0u) | ((eB & 0x8000u) ? 0xFFFF0000u : 0u);
+                        a = pk_max(a, b & m);
+                    }
+                    a = pk_sub_sat(a, 0x00010001u); /* OpenCV's score: max(dark, bright) - 1, not below 0 */
+                    ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                    ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
+                } else {
+                    const int j = u - nDp; /* bright entries 2j (high half) and 2j + 1 (low half), counted from the back */
+                    const uint32_t e2 = *(const uint32_t*)(list + lcap - 2 - 2 * j);
+                    const uint32_t eA = e2 >> 16, eB = 2 * j + 1 < nB ? e2 & 0xFFFFu : eA;
+                    const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
+                    const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
+                    const uint32_t a = pk_sub_sat(fast_pair_score<-1, P>(cA, cB), 0x00010001u);
+                    ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                    ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
+                }
+            }
+            __syncthreads();
+            /* NMS at T where a score exists (listed pixels below T cannot suppress anything), for the rows whose 3x3
+             * neighbourhood is complete: all of a chunk but its last row, which the next chunk lists again */
+            const bool last = r1 >= ih;
+            const int nhi = last ? ih - 1 : r1 - 2;
+            const int ntot = nD + nB;
+            for (int i = tid; i < ntot; i += NT) {
+                const int code = (i < nD ? list[i] : list[lcap - 1 - (i - nD)]) & 0x7FFF;
+                const int ly = code >> 8, x = code & 255;
+                const uint8_t* q = sc + (ly + 1) * P + x + 1;
+                const int s = q[0];
+                if (s >= T && ly <= nhi) {
+                    const int fl = cellfl[x];
+                    /* every cell is its own cv::FAST call: scores across a cell border count as 0 */
+                    int ml = max(max((int)q[-P - 1], (int)q[-1]), (int)q[P - 1]);
+                    int mr = max(max((int)q[-P + 1], (int)q[1]), (int)q[P + 1]);
+                    if (fl & 1) ml = 0;
+                    if (fl & 2) mr = 0;
+                    const int mx = max(max((int)q[-P], (int)q[P]), max(ml, mr));
+                    if (s > mx) {
+                        atomicOr(&keep[ly * FB_KW + (x >> 5)], 1u << (x & 31));
+                        atomicOr(&s_any, (uint32_t)cellbit[x]);
+                    }
+                }
+            }
+            par ^= 1;
+            if (last) break;
+            __syncthreads(); /* the next chunk's sweep overwrites the list */
+            r0 = r1 - 1;
+        }
+        __syncthreads();
+        /* cells empty at iniThFAST: again, whole, at minThFAST (fextractor.cpp:800-807).  Scores already in the tile
+         * belong to pixels that are listed again (the pre-test is monotone in T) and get rewritten. */
+        const uint32_t empty = ((1u << ncell) - 1u) & ~s_any;
+        if (stage == 1 || minTh == iniTh || empty == 0u) break; /* block-uniform */
+        T = minTh;
+        act = empty;
+        if (wv == 0) { /* the quad columns that touch an empty cell, in order */
+            const uint32_t cb = lane < QW ? *(const uint32_t*)(cellbit + 4 * lane) : 0u;
+            const bool on = (cb & (empty * 0x01010101u)) != 0u;
+            const uint64_t m = __ballot(on);
+            if (on) qtab[lane_rank(m)] = (uint8_t)lane;
+            if (lane == 0) s_nq = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        nq = (int)s_nq;
+    }
+
+    /* ordered output: wave w owns cell w; lane = (row, 32-column half) of a pass of 32 rows, so raster order is the
+     * lane order and one wave scan places every candidate */
+    uint32_t* hdr = (uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    CellOut* cout = (CellOut*)(hdr + 2);
+    uint32_t* cand = (uint32_t*)(cout + ncells);
+    for (int c = wv; c < ncell; c += NW) {
+        const int cx0 = c * wcell, cw = min(wcell, iw - cx0);
+        const uint32_t cbase = ((const uint4*)cells)[cell0 + c].w; /* CellDesc::base */
+        const int half = lane & 1;
+        const int b0 = cx0 + 32 * half, nb = cw - 32 * half; /* first column and columns of this lane's half */
+        const int ox = bx0 + 3 - VSLAM_BORDER + b0, oy = by0 + 3 - VSLAM_BORDER;
+        uint32_t running = 0;
+        for (int rb = 0; rb < ih; rb += 32) {
+            const int row = rb + (lane >> 1);
+            uint32_t bits = 0u;
+            if (row < ih && nb > 0) {
+                const uint32_t* kr = keep + row * FB_KW;
+                const int w = b0 >> 5;
+                const uint32_t lo = kr[w], hi = w + 1 < FB_KW ? kr[w + 1] : 0u;
+                bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b0 & 31));
+                if (nb < 32) bits &= (1u << nb) - 1u;
+            }
+            const uint32_t c1 = (uint32_t)__popc(bits);
+            const uint32_t in1 = wave_incl_scan(c1);
+            const uint32_t total1 = (uint32_t)__builtin_amdgcn_readlane((int)in1, 63);
+            if (bits) {
+                uint32_t o = cbase + running + in1 - c1;
+                const uint8_t* srow_ = sc + (row + 1) * P + b0 + 1;
+                while (bits) {
+                    const int k = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    cand[o++] = ((uint32_t)srow_[k] << 24) | ((uint32_t)(oy + row) << 12) | (uint32_t)(ox + k);
+                }
+            }
+            running += total1;
+        }
+        if (lane == 0) {
+            cout[cell0 + c].base = cbase;
+            cout[cell0 + c].count = running;
+        }
+    }
+}
+
+/* LDS a band of wh window rows needs before its survivor list (k_fast_bands' layout) */
+static size_t fast_band_fixed_lds(int wh) {
+    const int ih = wh - 6, whe = (wh + 1) & ~1;
+    return (size_t)whe * FB_P + (size_t)((((ih + 2) * FB_P) + 15) & ~15) + (size_t)ih * FB_KW * 4 + 136 + 136 + 32;
+}
+
+int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band) {
+    /* the kernel's limits: 128 interior columns, codes ly << 8 | x with ly < 128, FB_MAXC cells per band */
+    if (max_iw > 128 || max_wh > 6 + 127 || max_cells_per_band > FB_MAXC) return -1;
+    return 0;
+}
+
+void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
+                   const BandDesc* bands, int nbands, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                   size_t cand_stride, int iniTh, int minTh, int max_wh, int std_wh, int nslots, const vslam_tuning& T) {
+    constexpr int NT = 256;
+    /* LDS per workgroup: eight workgroups (32 waves) per CU fit when a band takes at most 20 KB.  The list gets what the
+     * window, the score tile and the tables leave: enough for every pixel of the usual band (cells of up to ~34 rows: one
+     * chunk); taller bands are swept in chunks (the kernel derives the chunk height from the space it finds).  Never
+     * less than the tallest band needs for chunks of 8 rows, nor than what a sweep's idle lanes may READ (rows up to an
+     * iteration's height below the window: results dropped, but the addresses stay inside the allocation). */
+    const size_t budget = 20480 - 64; /* 64: the kernel's static variables */
+    size_t lds = std::max(budget, fast_band_fixed_lds(max_wh) + 2 * (size_t)(8 * 128));
+    lds = std::max(lds, (size_t)(max_wh + NT / 8 + 1) * FB_P + 256);
+    lds = (lds + 15) & ~(size_t)15;
+    (void)std_wh;
+    const int lds_pad = std::max(0, tune_or(T.fast_lds_pad, 0)); /* extra LDS per workgroup (occupancy experiments) */
+    const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
+    const int by_image = nslots >= 8 ? 1 : 0;
+    dim3 grid;
+    if (by_image) grid = dim3((unsigned)(8 * nbands * ((nslots + 7) / 8)), 1);
+    else grid = dim3((unsigned)((nbands + 8 * FB_XCD_CHUNK - 1) / (8 * FB_XCD_CHUNK) * (8 * FB_XCD_CHUNK)), (unsigned)nslots);
+    hipLaunchKernelGGL((k_fast_bands<NT>), grid, dim3(NT), lds + lds_pad, st, pyr, slot_stride, src, g, bands, nbands, cells,
+                       cand_region, cand_stride, ncells, it, mt, nslots, (int)lds, by_image);
+}

@@ -125,6 +125,39 @@ def unpack_slot_host(buf):
     return kps, buf[off:off + n * 32].reshape(n, 32).copy(), mono
 
 
+def left_last_frame(rank, world, batch):
+    """(rank, slot, global frame index inside a step) of the frame whose packed slot arrives through the exchange: the
+    LAST frame of the left neighbour."""
+    lr = (rank - 1) % world
+    return lr, batch - 1, global_frame(lr, batch - 1, world, batch)
+
+
+def compare_packed_slots(got, want):
+    """Byte-for-byte comparison of two packed result slots (k_pack_slots layout): header (n, monoIndex, cap), the n
+    keypoints and the n descriptors -- what lies behind entry n is never written by the packer and not compared.
+    -> dict(ok, n, reason).  Used by bench.py --verify-exchange and its tests: `got` is what arrived through the exchange,
+    `want` what this rank produced ITSELF from the left neighbour's frame (frames are synthesised from their global index)."""
+    a = np.ascontiguousarray(got).reshape(-1).view(np.uint8)
+    b = np.ascontiguousarray(want).reshape(-1).view(np.uint8)
+    if a.size < 16 or b.size < 16:
+        return dict(ok=False, n=0, reason="slot shorter than its header")
+    ha, hb = a[:16].view(np.int32), b[:16].view(np.int32)
+    n, cap = int(hb[0]), int(hb[2])
+    if not np.array_equal(ha[:3], hb[:3]):
+        return dict(ok=False, n=n, reason="header differs: got n=%d mono=%d cap=%d, want n=%d mono=%d cap=%d"
+                    % (ha[0], ha[1], ha[2], hb[0], hb[1], hb[2]))
+    if n < 0 or n > cap or 16 + cap * 60 > min(a.size, b.size):
+        return dict(ok=False, n=n, reason="inconsistent header (n=%d cap=%d, %d bytes)" % (n, cap, min(a.size, b.size)))
+    if not np.array_equal(a[16:16 + n * 28], b[16:16 + n * 28]):
+        bad = int(np.flatnonzero(a[16:16 + n * 28] != b[16:16 + n * 28])[0]) // 28
+        return dict(ok=False, n=n, reason="keypoint %d of %d differs" % (bad, n))
+    off = 16 + cap * 28
+    if not np.array_equal(a[off:off + n * 32], b[off:off + n * 32]):
+        bad = int(np.flatnonzero(a[off:off + n * 32] != b[off:off + n * 32])[0]) // 32
+        return dict(ok=False, n=n, reason="descriptor %d of %d differs" % (bad, n))
+    return dict(ok=True, n=n, reason="")
+
+
 class SlotExchange:
     """The exchange step.  exchange(fe, send, recv): `send` = what this rank's right neighbour needs (its last packed
     slot); afterwards left_block(recv) holds what the left neighbour sent.  mode "ring": recv has send's size;
