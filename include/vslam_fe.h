@@ -278,6 +278,12 @@ int vslam_fe_get_profile(vslam_fe* fe, double stage_ms[5], long* batches, long* 
 int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
                        int32_t* idx2, int32_t* dist2);
 
+/* The same for nprob (<= 32) INDEPENDENT problems in one launch -- e.g. the brute-force matches of all stereo pairs of a
+ * step (frame.cpp:1167-1174 once per frame): problem p matches dev_q[p] (nq[p] x 32 bytes in HBM) against dev_t[p]
+ * (nt[p] <= 65535).  idx2[p] / dist2[p]: host arrays of nq[p] * 2 entries, semantics as above. */
+int vslam_hamming_top2_batch(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
+                             const uint8_t* const* dev_t, const int32_t* nt, int32_t* const* idx2, int32_t* const* dist2);
+
 /* Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174), descriptor half: cv::BFMatcher(NORM_HAMMING).knnMatch of the
  * lapping-area descriptors -- left rows [mono_left, n_left) against right rows [mono_right, n_right), k = 2 -- and the
  * ratio test `m[0].distance < m[1].distance * 0.7` (a float times a double literal: compared in double).

@@ -68,6 +68,76 @@ def test_hamming_extremes_and_empty(fe):
     assert idx.shape == (0, 2)
 
 
+def test_hamming_top2_batch_ragged_problems_in_one_launch(fe):
+    """vslam_hamming_top2_batch: independent problems of different sizes (incl. empty query / train sets, exact duplicates,
+    sizes that end inside a 256-descriptor tile or a 64-query tile) == the one-problem path == the oracle"""
+    rng = np.random.default_rng(20260101)
+    shapes = [(1, 1), (64, 256), (63, 257), (500, 300), (2011, 2013), (300, 5000), (0, 10), (7, 0), (129, 1025), (1, 2)]
+    host, dev, probs = [], [], []
+    for nq, nt in shapes:
+        q = rng.integers(0, 256, (max(nq, 1), 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (max(nt, 1), 32), dtype=np.uint8)
+        if nq and nt:
+            t[rng.integers(0, nt, max(nt // 10, 1))] = q[rng.integers(0, nq, max(nt // 10, 1))]  # ties
+        dq, dt = _dev(q), _dev(t)
+        host.append((q[:nq], t[:nt]))
+        dev.append((dq, dt))
+        probs.append((dq.data_ptr() if nq else 0, nq, dt.data_ptr() if nt else 0, nt))
+    m = V.FMatcher(fe)
+    out = m.hamming_top2_batch(probs)
+    for (q, t), (idx, dist), (nq, nt) in zip(host, out, shapes):
+        assert idx.shape == (nq, 2)
+        if nq == 0:
+            continue
+        if nt == 0:
+            assert np.all(idx == -1) and np.all(dist == 2**31 - 1)
+            continue
+        widx, wdist = _top2_ref(q, t)
+        if nt == 1:
+            assert np.array_equal(idx[:, 0], widx[:, 0]) and np.array_equal(dist[:, 0], wdist[:, 0])
+            assert np.all(idx[:, 1] == -1) and np.all(dist[:, 1] == 2**31 - 1)
+        else:
+            assert np.array_equal(idx, widx) and np.array_equal(dist, wdist), (nq, nt)
+    # the same problems one at a time
+    for pr, (idx, dist) in zip(probs, out):
+        if pr[1]:
+            i1, d1 = m.hamming_top2(*pr)
+            assert np.array_equal(i1, idx) and np.array_equal(d1, dist)
+    with pytest.raises(V.VslamError):
+        m.hamming_top2_batch([probs[1]] * 33)  # more than VSLAM_MAX_TOP2_JOBS
+
+
+def test_hamming_top2_batch_sixteen_stereo_pairs_full_size(fe):
+    """the brute-force matches of the 16 stereo pairs of a step (frame.cpp:1167-1174 per frame) in one launch, at
+    BASELINE size, against the oracle on two pairs and through size-independent properties on all"""
+    rng = np.random.default_rng(5)
+    N = 2000
+    base = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+    host, dev, probs = [], [], []
+    for p in range(16):
+        l = base.copy()
+        flip = rng.integers(0, 256, (N, 32), dtype=np.uint8) & rng.integers(0, 256, (N, 32), dtype=np.uint8) & rng.integers(0, 256, (N, 32), dtype=np.uint8)
+        perm = rng.permutation(N)
+        r = (l ^ flip)[perm]  # every left descriptor has a near twin somewhere on the right
+        dl, dr = _dev(l), _dev(r)
+        host.append((l, r, perm))
+        dev.append((dl, dr))
+        probs.append((dl.data_ptr(), N, dr.data_ptr(), N))
+    out = V.FMatcher(fe).hamming_top2_batch(probs)
+    for p in (0, 15):
+        widx, wdist = _top2_ref(host[p][0], host[p][1])
+        assert np.array_equal(out[p][0], widx) and np.array_equal(out[p][1], wdist)
+    for p in range(16):
+        l, r, perm = host[p]
+        idx, dist = out[p]
+        inv = np.empty(N, np.int64)
+        inv[perm] = np.arange(N)
+        assert np.mean(idx[:, 0] == inv) > 0.99            # the twin is the nearest
+        assert np.all(dist[:, 0] <= dist[:, 1])
+        d0 = np.unpackbits(l ^ r[idx[:, 0]], axis=1).sum(1)
+        assert np.array_equal(d0, dist[:, 0])                # the reported distance is the distance to the reported index
+
+
 def test_hamming_on_real_descriptors_full_size(fe):
     """BASELINE size (2000 x 2000): extractor output fed straight from HBM."""
     L, R = synth.make_stereo_pair(1241, 376)

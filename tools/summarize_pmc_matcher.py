@@ -11,7 +11,7 @@ import sys
 
 root = sys.argv[1]
 MATCHER = ("k_stereo_rows", "k_stereo_best", "k_stereo_refine", "k_stereo_median_cut", "k_si_topm", "k_si_replay",
-           "k_hamming_top2_partial", "k_hamming_top2_merge")
+           "k_hamming_top2_batch", "k_hamming_top2_merge_batch")
 
 
 def short(name):
@@ -51,7 +51,7 @@ for k, d in out.items():
         # both in LDS-array cycles: the share of the LDS pipe's busy cycles that were conflict replays
         d["lds_bank_conflict_share_of_lds_cycles"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
 NQ = NT = 2000  # run_match_loop.py: one brute-force top-2 of a KITTI frame pair at 2000 features (actual counts ~1990)
-k = out.get("k_hamming_top2_partial")
+k = out.get("k_hamming_top2_batch")
 if k and k.get("avg_us"):
     words = NQ * NT * 8.0
     k["xor_popcount_words_per_s"] = words / (k["avg_us"] * 1e-6)

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates", "vslam_hamming_top2_batch", "vslam_hamming_top2_batch_dev_async",
 ]
 
 
@@ -611,6 +611,29 @@ class FMatcher:
         dist = np.zeros((max(nq, 1), 2), np.int32)
         _check(lib().vslam_hamming_top2(self.fe._h, dev_q, nq, dev_t, nt, _p(idx), _p(dist)))
         return idx[:nq], dist[:nq]
+
+    def hamming_top2_batch(self, problems):
+        """problems: list of (dev_q, nq, dev_t, nt) -- independent brute-force matches in ONE launch (vslam_hamming_top2_batch)
+        -> list of (idx2[nq, 2], dist2[nq, 2])"""
+        n = len(problems)
+        idx = [np.zeros((max(p[1], 1), 2), np.int32) for p in problems]
+        dist = [np.zeros((max(p[1], 1), 2), np.int32) for p in problems]
+        vp, ip = C.c_void_p * n, C.c_int32 * n
+        L = lib()
+        L.vslam_hamming_top2_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.vslam_hamming_top2_batch(self.fe._h, n, vp(*[p[0] for p in problems]), ip(*[p[1] for p in problems]),
+                                          vp(*[p[2] for p in problems]), ip(*[p[3] for p in problems]),
+                                          vp(*[a.ctypes.data for a in idx]), vp(*[a.ctypes.data for a in dist])))
+        return [(idx[i][:problems[i][1]], dist[i][:problems[i][1]]) for i in range(n)]
+
+    def hamming_top2_batch_async(self, problems):
+        """enqueue the same launch again without waiting or copying (profilers; sizes as in a previous hamming_top2_batch)"""
+        n = len(problems)
+        vp, ip = C.c_void_p * n, C.c_int32 * n
+        L = lib()
+        L.vslam_hamming_top2_batch_dev_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.vslam_hamming_top2_batch_dev_async(self.fe._h, n, vp(*[p[0] for p in problems]), ip(*[p[1] for p in problems]),
+                                                    vp(*[p[2] for p in problems]), ip(*[p[3] for p in problems])))
 
     def ComputeStereoFishEyeCandidates(self, dev_desc_left, n_left, mono_left, dev_desc_right, n_right, mono_right):
         """Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174) up to the ratio test: -> (left_to_right[n_left],

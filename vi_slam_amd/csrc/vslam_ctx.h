@@ -72,6 +72,7 @@ struct vslam_fe {
     int tile_pitch = 0, tile_rows = 0, max_px = 0;
     /* FAST bands (k_fast_bands): up to four cells of a cell row per workgroup; nbands == 0: not available for this geometry */
     BandDesc* d_bands = nullptr;
+    uint8_t* d_band_classes = nullptr; /* 272-byte column tables, BandDesc::lnw >> 16 indexes them */
     int nbands = 0, band_max_wh = 0;
     /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
     uint8_t* d_cand = nullptr;
@@ -109,6 +110,8 @@ struct vslam_fe {
     std::vector<std::vector<vslam::Cand>> sel_level; /* [slot*nlevels + level] */
     std::vector<std::vector<vslam::Cand>> cand_level;
     /* matcher scratch (grown on demand) */
+    uint8_t* h_top2 = nullptr; /* pinned: idx2 | dist2 of the batched brute-force matcher */
+    size_t h_top2_bytes = 0;
     uint32_t* d_part = nullptr;
     size_t part_bytes = 0;
     int32_t* d_idx2 = nullptr;

@@ -43,7 +43,7 @@ struct CellDesc {
  * read as one scalar dwordx4. */
 struct BandDesc {
     uint32_t cell0; /* first cell (index into the CellDesc table / the slot's CellOut table) */
-    uint32_t lnw;   /* level | ncell << 4 | wcell << 8 | ceil(65536 / wcell) << 16 */
+    uint32_t lnw;   /* level | ncell << 4 | wcell << 8 | column-table class << 16 */
     uint32_t xy;    /* x0 | y0 << 16 */
     uint32_t wh;    /* window width | height << 16 */
 };
@@ -117,6 +117,19 @@ struct MatJob {
 #define VSLAM_MAX_MAT_JOBS 64
 struct MatJobs {
     MatJob job[VSLAM_MAX_MAT_JOBS];
+};
+
+/* One problem of the batched brute-force matcher (k_hamming_top2_batch): nq query against nt train descriptors. */
+struct Top2Job {
+    const uint32_t* q;
+    const uint32_t* t;
+    int32_t nq, nt;
+    uint32_t row0;   /* first row of this problem in the partial / result arrays (queries of all problems back to back) */
+    uint32_t pad;
+};
+#define VSLAM_MAX_TOP2_JOBS 32
+struct Top2Jobs {
+    Top2Job job[VSLAM_MAX_TOP2_JOBS];
 };
 
 /* k_resize_level_v2: four consecutive output pixels of a row.  base[] (separate u16 array) is the first source

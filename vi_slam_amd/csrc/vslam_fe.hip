@@ -40,6 +40,8 @@ static void free_ctx(vslam_fe* fe) {
     }
     for (auto& g : fe->pyr_groups) hipFree(g.d_tiles);
     hipFree(fe->d_cells);
+    hipFree(fe->d_bands);
+    hipFree(fe->d_band_classes);
     hipFree(fe->d_cand);
     if (fe->h_cand) hipHostFree(fe->h_cand);
     hipFree(fe->d_blur_tasks);
@@ -48,6 +50,7 @@ static void free_ctx(vslam_fe* fe) {
     hipFree(fe->d_res); /* d_counts, d_kps and d_desc are views into it; h_res likewise */
     if (fe->h_res) hipHostFree(fe->h_res);
     hipFree(fe->d_pattern);
+    if (fe->h_top2) hipHostFree(fe->h_top2);
     hipFree(fe->d_part);
     hipFree(fe->d_idx2);
     hipFree(fe->d_dist2);
@@ -274,21 +277,38 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         vslam::build_bands(fe->cells, per, 128, hb);
         int mwh = 0, miw = 0, mc = 0;
         std::vector<BandDesc> db(hb.size());
+        /* column tables, one 272-byte record per (cell pitch, interior width) class: cellbit[136] = 1 << (cell of interior
+         * column x), 0 past the interior; cellfl[136] = bit 0 first / bit 1 last column of its cell */
+        std::vector<std::pair<int, int>> cls;
+        std::vector<uint8_t> tab;
         for (size_t i = 0; i < hb.size(); i++) {
             const vslam::HostBand& b = hb[i];
             mwh = std::max(mwh, (int)b.wh);
             miw = std::max(miw, (int)b.ww - 6);
             mc = std::max(mc, (int)b.ncell);
-            const uint32_t rcpw = (65536u + b.wcell - 1u) / b.wcell;
+            const int iw = (int)b.ww - 6, wc = std::max(1, (int)b.wcell);
+            size_t ci = 0;
+            while (ci < cls.size() && cls[ci] != std::make_pair(wc, iw)) ci++;
+            if (ci == cls.size()) {
+                cls.push_back(std::make_pair(wc, iw));
+                tab.resize(tab.size() + 272, 0);
+                uint8_t* cb = tab.data() + ci * 272;
+                for (int x = 0; x < 136 && x < iw; x++) {
+                    const int c = x / wc, cend = std::min((c + 1) * wc, iw) - 1;
+                    cb[x] = (uint8_t)(1u << std::min(c, 7));
+                    cb[136 + x] = (uint8_t)((x == c * wc ? 1 : 0) | (x == cend ? 2 : 0));
+                }
+            }
             db[i].cell0 = b.cell0;
-            db[i].lnw = (uint32_t)b.level | ((uint32_t)b.ncell << 4) | ((uint32_t)b.wcell << 8) | (rcpw << 16);
+            db[i].lnw = (uint32_t)b.level | ((uint32_t)b.ncell << 4) | ((uint32_t)b.wcell << 8) | ((uint32_t)ci << 16);
             db[i].xy = (uint32_t)b.x0 | ((uint32_t)b.y0 << 16);
             db[i].wh = (uint32_t)b.ww | ((uint32_t)b.wh << 16);
         }
-        bool ok = !hb.empty() && vk_fast_bands_check(mwh, miw, mc) == 0 && p.nlevels <= 16;
-        for (const vslam::HostBand& b : hb) ok = ok && b.wcell < 256 && (65536u + b.wcell - 1u) / b.wcell < 65536u;
+        bool ok = !hb.empty() && vk_fast_bands_check(mwh, miw, mc) == 0 && p.nlevels <= 16 && cls.size() < 65536;
+        for (const vslam::HostBand& b : hb) ok = ok && b.wcell < 256;
         if (ok) {
             int rc;
+            if ((rc = upload(&fe->d_band_classes, tab.data(), tab.size()))) return rc;
             if ((rc = upload(&fe->d_bands, db.data(), db.size() * sizeof(BandDesc)))) return rc;
             fe->nbands = (int)db.size();
             fe->band_max_wh = mwh;
@@ -880,7 +900,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
     /* vslam_tuning.fast_kernel: 4 (default) = one workgroup per band of cells, 3 = one per cell */
     if (fe->nbands > 0 && tune_or(fe->tune.fast_kernel, 4) != 3)
-        vk_fast_bands(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_bands, fe->nbands, fe->d_cells,
+        vk_fast_bands(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_bands, fe->nbands, fe->d_band_classes, fe->d_cells,
                       (int)fe->cells.size(), fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->band_max_wh, 0, nimg,
                       fe->tune);
     else
@@ -1488,6 +1508,10 @@ int vslam_ensure_pinned(uint8_t** p, size_t* have, size_t want) {
     return VSLAM_OK;
 }
 
+extern "C" int vslam_hamming_top2_batch(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
+                                        const uint8_t* const* dev_t, const int32_t* nt, int32_t* const* idx2,
+                                        int32_t* const* dist2);
+/* one problem = a batch of one (k_hamming_top2_batch splits the train set over as many workgroups as fill the GPU) */
 extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t* dev_t, int nt,
                                   int32_t* idx2, int32_t* dist2) {
     if (!fe || nq < 0 || nt < 0 || nt > 65535 || (nq && (!dev_q || !idx2 || !dist2)) || (nt && !dev_t)) {
@@ -1495,25 +1519,100 @@ extern "C" int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, co
         return VSLAM_ERR_INVALID;
     }
     if (nq == 0) return VSLAM_OK;
+    const int32_t nq1 = nq, nt1 = nt;
+    return vslam_hamming_top2_batch(fe, 1, &dev_q, &nq1, &dev_t, &nt1, &idx2, &dist2);
+}
+
+extern "C" int vslam_hamming_top2_batch(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
+                                        const uint8_t* const* dev_t, const int32_t* nt, int32_t* const* idx2,
+                                        int32_t* const* dist2) {
+    if (!fe || nprob < 0 || nprob > VSLAM_MAX_TOP2_JOBS || (nprob && (!dev_q || !nq || !dev_t || !nt || !idx2 || !dist2))) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    Top2Jobs J;
+    memset(&J, 0, sizeof(J));
+    size_t rows = 0;
+    int max_nq = 0, max_nt = 0;
+    for (int p = 0; p < nprob; p++) {
+        if (nq[p] < 0 || nt[p] < 0 || nt[p] > 65535 || (nq[p] && (!dev_q[p] || !idx2[p] || !dist2[p])) || (nt[p] && !dev_t[p])) {
+            g_err = "invalid arguments";
+            return VSLAM_ERR_INVALID;
+        }
+        J.job[p].q = (const uint32_t*)dev_q[p];
+        J.job[p].t = (const uint32_t*)dev_t[p];
+        J.job[p].nq = nq[p];
+        J.job[p].nt = nt[p];
+        J.job[p].row0 = (uint32_t)rows;
+        rows += (size_t)nq[p];
+        max_nq = std::max(max_nq, nq[p]);
+        max_nt = std::max(max_nt, nt[p]);
+    }
+    if (rows == 0) return VSLAM_OK;
     HIPCHK(hipSetDevice(fe->p.device));
-    const int ntiles = std::max(vk_hamming_top2_tiles(nt), 1);
+    const int nsplit = vk_hamming_top2_batch_split(nprob, max_nq, max_nt);
     int rc;
-    if ((rc = vslam_ensure((void**)&fe->d_part, &fe->part_bytes, (size_t)nq * ntiles * 8))) return rc;
-    if (fe->top2_cap < (size_t)nq) {
+    if ((rc = vslam_ensure((void**)&fe->d_part, &fe->part_bytes, rows * nsplit * 8))) return rc;
+    if (fe->top2_cap < rows) {
         hipFree(fe->d_idx2);
         hipFree(fe->d_dist2);
         fe->d_idx2 = fe->d_dist2 = nullptr;
         fe->top2_cap = 0;
-        HIPCHK(hipMalloc((void**)&fe->d_idx2, (size_t)nq * 8));
-        HIPCHK(hipMalloc((void**)&fe->d_dist2, (size_t)nq * 8));
-        fe->top2_cap = nq;
+        HIPCHK(hipMalloc((void**)&fe->d_idx2, rows * 8));
+        HIPCHK(hipMalloc((void**)&fe->d_dist2, rows * 8));
+        fe->top2_cap = rows;
     }
-    if (nt == 0) HIPCHK(hipMemsetAsync(fe->d_part, 0xFF, (size_t)nq * ntiles * 8, fe->stream));
-    vk_hamming_top2(fe->stream, dev_q, nq, dev_t, nt, fe->d_part, fe->d_idx2, fe->d_dist2);
+    if ((rc = vslam_ensure_pinned(&fe->h_top2, &fe->h_top2_bytes, rows * 16))) return rc;
+    /* a split that lies past a problem's last tile, or a problem without train descriptors, writes nothing: "missing" */
+    HIPCHK(hipMemsetAsync(fe->d_part, 0xFF, rows * nsplit * 8, fe->stream));
+    vk_hamming_top2_batch(fe->stream, J, nprob, max_nq, (int)rows, nsplit, fe->d_part, fe->d_idx2, fe->d_dist2);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(idx2, fe->d_idx2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
-    HIPCHK(hipMemcpyAsync(dist2, fe->d_dist2, (size_t)nq * 8, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipMemcpyAsync(fe->h_top2, fe->d_idx2, rows * 8, hipMemcpyDeviceToHost, fe->stream));
+    HIPCHK(hipMemcpyAsync(fe->h_top2 + rows * 8, fe->d_dist2, rows * 8, hipMemcpyDeviceToHost, fe->stream));
     HIPCHK(vslam_stream_wait(fe->stream));
+    for (int p = 0; p < nprob; p++) {
+        if (!nq[p]) continue;
+        memcpy(idx2[p], fe->h_top2 + (size_t)J.job[p].row0 * 8, (size_t)nq[p] * 8);
+        memcpy(dist2[p], fe->h_top2 + rows * 8 + (size_t)J.job[p].row0 * 8, (size_t)nq[p] * 8);
+    }
+    return VSLAM_OK;
+}
+
+/* enqueue-only form for profilers and pipelines: results stay in the context's device arrays (rows back to back) */
+extern "C" int vslam_hamming_top2_batch_dev_async(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
+                                                  const uint8_t* const* dev_t, const int32_t* nt) {
+    if (!fe || nprob <= 0 || nprob > VSLAM_MAX_TOP2_JOBS || !dev_q || !nq || !dev_t || !nt) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    Top2Jobs J;
+    memset(&J, 0, sizeof(J));
+    size_t rows = 0;
+    int max_nq = 0, max_nt = 0;
+    for (int p = 0; p < nprob; p++) {
+        if (nq[p] < 0 || nt[p] < 0 || nt[p] > 65535 || (nq[p] && !dev_q[p]) || (nt[p] && !dev_t[p])) {
+            g_err = "invalid arguments";
+            return VSLAM_ERR_INVALID;
+        }
+        J.job[p].q = (const uint32_t*)dev_q[p];
+        J.job[p].t = (const uint32_t*)dev_t[p];
+        J.job[p].nq = nq[p];
+        J.job[p].nt = nt[p];
+        J.job[p].row0 = (uint32_t)rows;
+        rows += (size_t)nq[p];
+        max_nq = std::max(max_nq, nq[p]);
+        max_nt = std::max(max_nt, nt[p]);
+    }
+    if (rows == 0) return VSLAM_OK;
+    HIPCHK(hipSetDevice(fe->p.device));
+    const int nsplit = vk_hamming_top2_batch_split(nprob, max_nq, max_nt);
+    if (fe->part_bytes < rows * nsplit * 8 || fe->top2_cap < rows) { /* sized by a previous vslam_hamming_top2_batch */
+        g_err = "vslam_hamming_top2_batch_dev_async: call vslam_hamming_top2_batch with these sizes first (it allocates)";
+        return VSLAM_ERR_INVALID;
+    }
+    HIPCHK(hipMemsetAsync(fe->d_part, 0xFF, rows * nsplit * 8, fe->stream));
+    vk_hamming_top2_batch(fe->stream, J, nprob, max_nq, (int)rows, nsplit, fe->d_part, fe->d_idx2, fe->d_dist2);
+    HIPCHK(hipGetLastError());
     return VSLAM_OK;
 }
 

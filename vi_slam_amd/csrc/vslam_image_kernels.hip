@@ -1034,15 +1034,61 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
 #ifndef FB_XCD_CHUNK
 #define FB_XCD_CHUNK 4
 #endif
+#ifdef VSLAM_FAST_COUNT /* diagnostic build: how often a wave executes each block of k_fast_bands (tools/fast_band_counts.py
+ * multiplies by the blocks' static instruction counts: the per-phase instruction budget) */
+__device__ unsigned long long g_fb_cnt[32];
+#define FCNT(k)                                                                                       \
+    do {                                                                                              \
+        const unsigned long long m_ = __ballot(1);                                                    \
+        if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)m_) - 1) atomicAdd(&g_fb_cnt[k], 1ull); \
+    } while (0)
+#define FCNTN(k, n)                                                                                   \
+    do {                                                                                              \
+        const unsigned long long m_ = __ballot(1);                                                    \
+        if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)m_) - 1) atomicAdd(&g_fb_cnt[k], (unsigned long long)(n)); \
+    } while (0)
+extern "C" int vslam_dbg_fast_band_counts(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fb_cnt), sizeof(g_fb_cnt)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fb_cnt), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#else
+#define FCNT(k) do { } while (0)
+#define FCNTN(k, n) do { } while (0)
+#endif
+/* ds_write_b16 of `code` by the lanes of mA to atA, then by the lanes of mB to atB (masks are subsets of exec) */
+__device__ __forceinline__ void lds_store_b16_two(uint64_t mA, uint64_t mB, uint32_t atA, uint32_t atB, uint32_t code) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\tds_write_b16 %3, %5\n\t"
+                 "s_mov_b64 exec, %2\n\tds_write_b16 %4, %5\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mA), "s"(mB), "v"(atA), "v"(atB), "v"(code) : "memory");
+}
+__device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_i24(uint32_t a, int b, uint32_t c) { /* a * b + c, 24-bit signed factors */
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
-             const BandDesc* __restrict__ bands, int nbands, const CellDesc* __restrict__ cells, uint8_t* cand_region,
-             size_t cand_stride, int ncells, int iniTh, int minTh, int nslots, int lds_total, int by_image) {
+             const BandDesc* __restrict__ bands, int nbands, const uint4* __restrict__ classes,
+             const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells, int iniTh, int minTh,
+             int nslots, int lds_total, int by_image) {
     extern __shared__ __align__(16) uint8_t smemb[];
     constexpr int P = FB_P;
     constexpr int NW = NT / 64;
-    __shared__ uint32_t s_cnt[2]; /* nD (+ both) | nB << 16 of the chunk being swept; the other one is zeroed meanwhile */
+    __shared__ uint32_t s_cnt[2]; /* nD | nB << 16 of the chunk being swept; the other one is zeroed meanwhile */
     __shared__ uint32_t s_any;    /* bit c: cell c of the band kept a corner */
     __shared__ uint32_t s_nq;     /* stage 2: quad columns to sweep */
 
@@ -1064,10 +1110,11 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
         }
         if (slot >= nslots || band >= nbands) return;
     }
+    FCNT(0);
     const uint4 bd = ((const uint4*)bands)[band]; /* scalar cache */
     const int cell0 = (int)bd.x;
     const int level = (int)(bd.y & 15u), ncell = (int)((bd.y >> 4) & 15u), wcell = (int)((bd.y >> 8) & 255u);
-    const uint32_t rcpw = bd.y >> 16;
+    const int bclass = (int)(bd.y >> 16);
     const int bx0 = (int)(bd.z & 0xFFFFu), by0 = (int)(bd.z >> 16);
     const int ww = (int)(bd.w & 0xFFFFu), wh = (int)(bd.w >> 16);
     const int iw = ww - 6, ih = wh - 6;
@@ -1087,7 +1134,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     const int lcap = ((lds_total - (int)((uint8_t*)list - smemb)) >> 1) & ~1; /* entries; even */
 
     /* stage the window: columns bx0 - 1 .. of wh rows, 17 eight-byte lanes per row; every load is issued before the first
-     * LDS store, and the tiles are zeroed / the tables built while they are in flight */
+     * LDS store, and the tiles are zeroed / the tables fetched while they are in flight */
     constexpr int LPR = P / 8, RPS = NT / LPR;
     constexpr int NSW = (52 + RPS - 1) / RPS > 4 ? 4 : (52 + RPS - 1) / RPS; /* sweeps kept in registers: windows of up to 52 rows */
     const int srow = tid / LPR, scol = (tid - srow * LPR) * 8;
@@ -1101,17 +1148,13 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
         if (stager && y < wh) wreg[u] = *(const uint2*)(gsrc + (uint32_t)(__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)scol));
     }
     {
+        /* the band's column tables (host: one 272-byte record per (cell pitch, interior width) class) */
+        uint4 tabv = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 17) tabv = classes[bclass * 17 + tid];
         const int nz = (int)(((uint8_t*)(keep + ih * FB_KW) - sc) >> 4); /* score tile + keep words, 16-byte stores */
         for (int i = tid; i < nz; i += NT) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid < 136) {
-            const int x = tid;
-            const int c = (int)(((uint32_t)x * rcpw) >> 16); /* x / wcell, exact for x < 256 (rcpw = ceil(65536 / wcell)) */
-            const bool inside = x < iw;
-            const int cend = min((c + 1) * wcell, iw) - 1;
-            cellbit[x] = inside ? (uint8_t)(1u << c) : (uint8_t)0;
-            cellfl[x] = inside ? (uint8_t)((x == c * wcell ? 1 : 0) | (x == cend ? 2 : 0)) : (uint8_t)0;
-        }
-        if (tid < 8) ((uint32_t*)qtab)[tid] = 0u;
+        if (tid < 17) ((uint4*)cellbit)[tid] = tabv;
+        if (tid >= 64 && tid < 72) ((uint32_t*)qtab)[tid - 64] = 0u;
         if (tid == 0) {
             s_cnt[0] = 0u;
             s_cnt[1] = 0u;
@@ -1129,9 +1172,13 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     __syncthreads();
 
     const uint32_t* W32 = (const uint32_t*)win;
-    const int QW = (iw + 3) >> 2;            /* quad columns of the band */
-    const int CR = min(ih, lcap / (4 * QW)); /* rows swept at once: every pixel of them has a list entry (>= 2, host) */
-    const int sc_off = whe * P - 2 * P - 3;  /* score byte of a pixel relative to its window byte */
+    const int QW = (iw + 3) >> 2; /* quad columns of the band */
+    /* rows swept at once.  A pixel that passes both compass tests is listed twice (dark and bright), every other survivor
+     * once: the list holds every pixel of lcap / 128 rows once -- the optimistic chunk, all of a usual band -- and of half
+     * as many rows twice -- the chunk after an overflow, which the two counters show before anything reads the list */
+    int CR = min(ih, lcap >> 7);
+    const int sc_off = whe * P - 2 * P - 3; /* score byte of a pixel relative to its window byte */
+    const uint32_t list_lo = lds_addr(list), list_hi = lds_addr(list) + 2u * (uint32_t)(lcap - 1);
     int T = iniTh;
     uint32_t act = 0xFFu; /* cells swept in this stage */
     int nq = QW;
@@ -1145,19 +1192,22 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
          * v + 0x7FFF is above every pixel): no validity masks inside the sweep.  Halves of TTv[par]: pixels par, par + 2 */
         uint32_t TTv[2];
         {
-            const uint32_t cb = *(const uint32_t*)(cellbit + 4 * qx);
-            const bool lv = qs < nq;
-            uint32_t t4[4];
+            uint32_t m = *(const uint32_t*)(cellbit + 4 * qx) & (act * 0x01010101u);
+            if (qs >= nq) m = 0u;
+            const uint32_t dT = (uint32_t)(0x7FFF - T) * 0x00010001u;
 #pragma unroll
-            for (int p = 0; p < 4; p++) t4[p] = (lv && (((cb >> (8 * p)) & act) != 0u)) ? (uint32_t)T : 0x7FFFu;
-            TTv[0] = t4[0] | (t4[2] << 16);
-            TTv[1] = t4[1] | (t4[3] << 16);
+            for (int pp = 0; pp < 2; pp++) {
+                const uint32_t h = pk_min(__builtin_amdgcn_perm(0u, m, pp ? 0x0c030c01u : 0x0c020c00u), 0x00010001u);
+                TTv[pp] = pk_sub_sat(0x7FFF7FFFu, pk_mul_lo(h, dT));
+            }
         }
-        const int RPI = NT >> sh;             /* rows per iteration of the workgroup */
-        const int wrow = (wv * 64) >> sh;     /* first row of this wave inside an iteration */
+        const int RPI = NT >> sh;         /* rows per iteration of the workgroup */
+        const int wrow = (wv * 64) >> sh; /* first row of this wave inside an iteration */
+        const uint32_t codeq = (uint32_t)((qly << 8) + 4 * qx);
         for (int r0 = 0;;) {
             const int r1 = min(r0 + CR, ih);
             for (int ly0 = r0; ly0 + wrow < r1; ly0 += RPI) { /* wave-uniform: iterations below the chunk are skipped */
+                FCNT(1);
                 const int ly = ly0 + qly;
                 const bool rowok = ly < r1;
                 const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
@@ -1180,35 +1230,32 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 }
 #undef EVN
 #undef ODD
-                uint64_t mD[4], mB[4], mX[4];
+                /* survivors go straight to the lists: per pixel column j one compare per polarity whose lane mask lands in an
+                 * SGPR pair, ranks from v_mbcnt, totals from s_bcnt1, ONE LDS atomic per wave and iteration for the list space,
+                 * two stores under the lane masks.  The dark list grows from the front, the bright one from the back. */
+                uint64_t mD[4], mB[4];
                 uint32_t totD = 0, totB = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint64_t dk = (j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1]);
-                    const uint64_t br = (j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1]);
-                    mD[j] = dk;
-                    mX[j] = dk & br;
-                    mB[j] = br & ~dk;
+                    mD[j] = (j >> 1) ? half_hi_nonzero(passD[j & 1]) : half_lo_nonzero(passD[j & 1]);
+                    mB[j] = (j >> 1) ? half_hi_nonzero(passB[j & 1]) : half_lo_nonzero(passB[j & 1]);
                     totD += (uint32_t)__popcll(mD[j]);
                     totB += (uint32_t)__popcll(mB[j]);
                 }
                 if (totD | totB) { /* wave-uniform */
+                    FCNT(2);
                     uint32_t base = 0;
                     if (lane == 0) base = lds_add_rtn(lds_addr(&s_cnt[par]), totD | (totB << 16));
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    /* dark entries grow from the front of the list, bright-only ones from its back */
-                    const uint32_t aD = lds_addr(list) + 2u * (base & 0xFFFFu);
-                    const uint32_t aB = lds_addr(list) + 2u * (uint32_t)(lcap - 1) - 2u * (base >> 16);
-                    const uint32_t code0 = (uint32_t)((ly << 8) + 4 * qx);
-                    uint32_t pD = 0, pB = 0;
+                    uint32_t aD = list_lo + 2u * (base & 0xFFFFu), aB = list_hi - 2u * (base >> 16);
+                    const uint32_t code0 = codeq + ((uint32_t)ly0 << 8);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t code = code0 + j;
-                        const uint32_t atD = aD + 2u * pD + 2u * lane_rank(mD[j]);
-                        const uint32_t atB = aB - 2u * pB - 2u * lane_rank(mB[j]);
-                        lds_store_b16_masked2(mD[j] | mB[j], mX[j], lane_select(mD[j], atD, atB), code, code | 0x8000u);
-                        pD += (uint32_t)__popcll(mD[j]);
-                        pB += (uint32_t)__popcll(mB[j]);
+                        const uint32_t atD = aD + 2u * lane_rank(mD[j]);
+                        const uint32_t atB = mad_i24(lane_rank(mB[j]), -2, aB);
+                        lds_store_b16_two(mD[j], mB[j], atD, atB, code0 + j);
+                        aD += 2u * (uint32_t)__popcll(mD[j]);
+                        aB -= 2u * (uint32_t)__popcll(mB[j]);
                     }
                 }
             }
@@ -1220,35 +1267,39 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 nD = (int)(tot & 0xFFFFu);
                 nB = (int)(tot >> 16);
             }
+            if (nD + nB > lcap) { /* block-uniform: the two lists ran into each other -- these rows again, half as many */
+                CR = max(2, lcap >> 8);
+                par ^= 1; /* the other counter is zero; this one is zeroed one chunk later, like every used one */
+                continue;
+            }
             if (tid == 0) s_cnt[par ^ 1] = 0u; /* the next chunk's / stage's counter: its last readers passed a barrier ago */
-            /* networks: TWO list entries per thread in the halves of packed registers; dark pairs go to the threads 0 ..,
-             * bright pairs to the threads right behind them, so only the wave that holds the seam runs both polarities */
+            FCNT(11);
+            if (wv == 0) { FCNTN(13, nD); FCNTN(14, nB); }
+            /* networks: TWO list entries per thread in the halves of packed registers.  First every dark pair, then -- behind a
+             * barrier -- every bright pair, which keeps the larger of its score and the one already in the tile: a pixel on
+             * both lists ends with max(dark, bright), and no wave runs a second network for the few lanes that hold one */
             const int nDp = (nD + 1) >> 1, nBp = (nB + 1) >> 1;
-            for (int u = tid; u < nDp + nBp; u += NT) {
-                if (u < nDp) {
-                    const uint32_t e2 = *(const uint32_t*)(list + 2 * u);
-                    const uint32_t eA = e2 & 0xFFFFu, eB = 2 * u + 1 < nD ? e2 >> 16 : eA;
-                    const uint8_t* cA = win + (((eA >> 8) & 0x7Fu) + 3) * P + (eA & 255u) + 4;
-                    const uint8_t* cB = win + (((eB >> 8) & 0x7Fu) + 3) * P + (eB & 255u) + 4;
-                    uint32_t a = fast_pair_score<1, P>(cA, cB);
-                    if ((eA | eB) & 0x8000u) {
-                        const uint32_t b = fast_pair_score<-1, P>(cA, cB);
-                        const uint32_t m = ((eA & 0x8000u) ? 0xFFFFu : 0u) | ((eB & 0x8000u) ? 0xFFFF0000u : 0u);
-                        a = pk_max(a, b & m);
-                    }
-                    a = pk_sub_sat(a, 0x00010001u); /* OpenCV's score: max(dark, bright) - 1, not below 0 */
-                    ((uint8_t*)cA)[sc_off] = (uint8_t)a;
-                    ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
-                } else {
-                    const int j = u - nDp; /* bright entries 2j (high half) and 2j + 1 (low half), counted from the back */
-                    const uint32_t e2 = *(const uint32_t*)(list + lcap - 2 - 2 * j);
-                    const uint32_t eA = e2 >> 16, eB = 2 * j + 1 < nB ? e2 & 0xFFFFu : eA;
-                    const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
-                    const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
-                    const uint32_t a = pk_sub_sat(fast_pair_score<-1, P>(cA, cB), 0x00010001u);
-                    ((uint8_t*)cA)[sc_off] = (uint8_t)a;
-                    ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
-                }
+            for (int u = tid; u < nDp; u += NT) {
+                FCNT(3);
+                const uint32_t e2 = *(const uint32_t*)(list + 2 * u);
+                const uint32_t eA = e2 & 0xFFFFu, eB = 2 * u + 1 < nD ? e2 >> 16 : eA;
+                const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
+                const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
+                const uint32_t a = pk_sub_sat(fast_pair_score<1, P>(cA, cB), 0x00010001u); /* OpenCV's score: max(..) - 1, not below 0 */
+                ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
+            }
+            __syncthreads();
+            for (int u = tid; u < nBp; u += NT) { /* bright entries 2u (high half) and 2u + 1 (low half), counted from the back */
+                FCNT(5);
+                const uint32_t e2 = *(const uint32_t*)(list + lcap - 2 - 2 * u);
+                const uint32_t eA = e2 >> 16, eB = 2 * u + 1 < nB ? e2 & 0xFFFFu : eA;
+                const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
+                const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
+                const uint32_t old = (uint32_t)cA[sc_off] | ((uint32_t)cB[sc_off] << 16);
+                const uint32_t a = pk_max(pk_sub_sat(fast_pair_score<-1, P>(cA, cB), 0x00010001u), old);
+                ((uint8_t*)cA)[sc_off] = (uint8_t)a;
+                ((uint8_t*)cB)[sc_off] = (uint8_t)(a >> 16);
             }
             __syncthreads();
             /* NMS at T where a score exists (listed pixels below T cannot suppress anything), for the rows whose 3x3
@@ -1257,11 +1308,13 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
             const int nhi = last ? ih - 1 : r1 - 2;
             const int ntot = nD + nB;
             for (int i = tid; i < ntot; i += NT) {
-                const int code = (i < nD ? list[i] : list[lcap - 1 - (i - nD)]) & 0x7FFF;
+                FCNT(6);
+                const int code = i < nD ? list[i] : list[lcap - 1 - (i - nD)];
                 const int ly = code >> 8, x = code & 255;
                 const uint8_t* q = sc + (ly + 1) * P + x + 1;
                 const int s = q[0];
                 if (s >= T && ly <= nhi) {
+                    FCNT(7);
                     const int fl = cellfl[x];
                     /* every cell is its own cv::FAST call: scores across a cell border count as 0 */
                     int ml = max(max((int)q[-P - 1], (int)q[-1]), (int)q[P - 1]);
@@ -1282,9 +1335,10 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
         }
         __syncthreads();
         /* cells empty at iniThFAST: again, whole, at minThFAST (fextractor.cpp:800-807).  Scores already in the tile
-         * belong to pixels that are listed again (the pre-test is monotone in T) and get rewritten. */
+         * belong to pixels that are listed again (the pre-test is monotone in T) and are recomputed to the same value. */
         const uint32_t empty = ((1u << ncell) - 1u) & ~s_any;
         if (stage == 1 || minTh == iniTh || empty == 0u) break; /* block-uniform */
+        FCNT(10);
         T = minTh;
         act = empty;
         if (wv == 0) { /* the quad columns that touch an empty cell, in order */
@@ -1311,6 +1365,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
         const int ox = bx0 + 3 - VSLAM_BORDER + b0, oy = by0 + 3 - VSLAM_BORDER;
         uint32_t running = 0;
         for (int rb = 0; rb < ih; rb += 32) {
+            FCNT(8);
             const int row = rb + (lane >> 1);
             uint32_t bits = 0u;
             if (row < ih && nb > 0) {
@@ -1327,6 +1382,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 uint32_t o = cbase + running + in1 - c1;
                 const uint8_t* srow_ = sc + (row + 1) * P + b0 + 1;
                 while (bits) {
+                    FCNT(9);
                     const int k = __ffs(bits) - 1;
                     bits &= bits - 1;
                     cand[o++] = ((uint32_t)srow_[k] << 24) | ((uint32_t)(oy + row) << 12) | (uint32_t)(ox + k);
@@ -1354,7 +1410,7 @@ int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band) {
 }
 
 void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
-                   const BandDesc* bands, int nbands, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                   const BandDesc* bands, int nbands, const uint8_t* classes, const CellDesc* cells, int ncells, uint8_t* cand_region,
                    size_t cand_stride, int iniTh, int minTh, int max_wh, int std_wh, int nslots, const vslam_tuning& T) {
     constexpr int NT = 256;
     /* LDS per workgroup: eight workgroups (32 waves) per CU fit when a band takes at most 20 KB.  The list gets what the
@@ -1363,7 +1419,7 @@ void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const
      * less than the tallest band needs for chunks of 8 rows, nor than what a sweep's idle lanes may READ (rows up to an
      * iteration's height below the window: results dropped, but the addresses stay inside the allocation). */
     const size_t budget = 20480 - 64; /* 64: the kernel's static variables */
-    size_t lds = std::max(budget, fast_band_fixed_lds(max_wh) + 2 * (size_t)(8 * 128));
+    size_t lds = std::max(budget, fast_band_fixed_lds(max_wh) + 2 * (size_t)(8 * 256)); /* chunks of >= 8 rows, every pixel twice */
     lds = std::max(lds, (size_t)(max_wh + NT / 8 + 1) * FB_P + 256);
     lds = (lds + 15) & ~(size_t)15;
     (void)std_wh;
@@ -1373,6 +1429,6 @@ void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const
     dim3 grid;
     if (by_image) grid = dim3((unsigned)(8 * nbands * ((nslots + 7) / 8)), 1);
     else grid = dim3((unsigned)((nbands + 8 * FB_XCD_CHUNK - 1) / (8 * FB_XCD_CHUNK) * (8 * FB_XCD_CHUNK)), (unsigned)nslots);
-    hipLaunchKernelGGL((k_fast_bands<NT>), grid, dim3(NT), lds + lds_pad, st, pyr, slot_stride, src, g, bands, nbands, cells,
-                       cand_region, cand_stride, ncells, it, mt, nslots, (int)lds, by_image);
+    hipLaunchKernelGGL((k_fast_bands<NT>), grid, dim3(NT), lds + lds_pad, st, pyr, slot_stride, src, g, bands, nbands,
+                       (const uint4*)classes, cells, cand_region, cand_stride, ncells, it, mt, nslots, (int)lds, by_image);
 }

@@ -17,9 +17,11 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
                         const int8_t* pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma);
 
 void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint8_t* out);
-int vk_hamming_top2_tiles(int nt);
-void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
-                     int32_t* idx2, int32_t* dist2);
+/* nprob problems in one launch: part holds nrows * nsplit * 2 words (nrows = queries of all problems back to back,
+ * Top2Job::row0), idx2 / dist2 nrows * 2; nsplit from vk_hamming_top2_batch_split */
+int vk_hamming_top2_batch_split(int nprob, int max_nq, int max_nt);
+void vk_hamming_top2_batch(hipStream_t st, const Top2Jobs& jobs, int nprob, int max_nq, int nrows, int nsplit, uint32_t* part,
+                           int32_t* idx2, int32_t* dist2);
 
 void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                  uint8_t* blur, const uint32_t* tasks, int ntasks, const int32_t taps[7], int rows_per_task,
@@ -36,7 +38,7 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
  * kernel's limits (0 = a band list it can run) */
 int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band);
 void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
-                   const BandDesc* bands, int nbands, const CellDesc* cells, int ncells, uint8_t* cand_region,
+                   const BandDesc* bands, int nbands, const uint8_t* classes, const CellDesc* cells, int ncells, uint8_t* cand_region,
                    size_t cand_stride, int iniTh, int minTh, int max_wh, int std_wh, int nslots, const vslam_tuning& T);
 void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
                         const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,

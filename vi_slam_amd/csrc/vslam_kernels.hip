@@ -381,72 +381,6 @@ k_hamming_matrix(const uint32_t* __restrict__ q, int nq, const uint32_t* __restr
     }
 }
 
-/* partial top-2 per (query, train tile): key = dist << 16 | train index (smaller key = better; ties
- * resolve to the lower train index, i.e. first-wins in ascending order like the reference loops). */
-__global__ void __launch_bounds__(256)
-k_hamming_top2_partial(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, int nt,
-                       uint32_t* __restrict__ part /* [nq][ntiles][2] */, int ntiles) {
-    __shared__ uint4 s_t[HAM_TT * 2];
-    __shared__ uint32_t s_k[4][HAM_TQ][2];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int qi = blockIdx.x * HAM_TQ + lane;
-    const int t0 = blockIdx.y * HAM_TT;
-    for (int i = tid; i < HAM_TT * 2; i += 256) {
-        const int ti = t0 + (i >> 1);
-        s_t[i] = ti < nt ? ((const uint4*)t)[(size_t)ti * 2 + (i & 1)] : make_uint4(0, 0, 0, 0);
-    }
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    if (qi < nq) {
-        qa = ((const uint4*)q)[(size_t)qi * 2];
-        qb = ((const uint4*)q)[(size_t)qi * 2 + 1];
-    }
-    __syncthreads();
-    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    for (int j = wv * 64; j < wv * 64 + 64; j++) {
-        const int ti = t0 + j;
-        if (ti >= nt) break;
-        const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
-        const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) +
-                           __popc(qa.w ^ ta.w) + __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) +
-                           __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-        const uint32_t key = (d << 16) | (uint32_t)ti;
-        if (key < k1) { k2 = k1; k1 = key; }
-        else if (key < k2) k2 = key;
-    }
-    s_k[wv][lane][0] = k1;
-    s_k[wv][lane][1] = k2;
-    __syncthreads();
-    if (wv == 0 && qi < nq) {
-        uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
-#pragma unroll
-        for (int w2 = 0; w2 < 4; w2++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const uint32_t key = s_k[w2][lane][e];
-                if (key < b1) { b2 = b1; b1 = key; }
-                else if (key < b2) b2 = key;
-            }
-        part[((size_t)qi * ntiles + blockIdx.y) * 2] = b1;
-        part[((size_t)qi * ntiles + blockIdx.y) * 2 + 1] = b2;
-    }
-}
-
-__global__ void k_hamming_top2_merge(const uint32_t* __restrict__ part, int nq, int ntiles,
-                                     int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
-    for (int i = 0; i < ntiles * 2; i++) {
-        const uint32_t key = part[(size_t)qi * ntiles * 2 + i];
-        if (key < b1) { b2 = b1; b1 = key; }
-        else if (key < b2) b2 = key;
-    }
-    idx2[2 * qi] = b1 == 0xFFFFFFFFu ? -1 : (int)(b1 & 0xFFFF);
-    dist2[2 * qi] = b1 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(b1 >> 16);
-    idx2[2 * qi + 1] = b2 == 0xFFFFFFFFu ? -1 : (int)(b2 & 0xFFFF);
-    dist2[2 * qi + 1] = b2 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(b2 >> 16);
-}
-
 /* diagnostics: evaluate the device float helpers on arrays (tests pin them against glibc / the oracle) */
 __global__ void k_dbg_sincos(const float* __restrict__ x, int n, float* s, float* c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,17 +448,138 @@ void vk_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* 
                        out);
 }
 
-int vk_hamming_top2_tiles(int nt) { return (nt + HAM_TT - 1) / HAM_TT; }
-
-void vk_hamming_top2(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint32_t* part,
-                     int32_t* idx2, int32_t* dist2) {
-    if (nq <= 0) return;
-    const int ntiles = vk_hamming_top2_tiles(nt);
-    if (ntiles > 0) {
-        dim3 grid((nq + HAM_TQ - 1) / HAM_TQ, ntiles);
-        hipLaunchKernelGGL(k_hamming_top2_partial, grid, dim3(256), 0, st, (const uint32_t*)q, nq,
-                           (const uint32_t*)t, nt, part, ntiles);
-    }
-    hipLaunchKernelGGL(k_hamming_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part, nq, ntiles, idx2,
-                       dist2);
+/* ------------------------------------------------------------------------------------------------
+ * The brute-force matcher for P independent problems in ONE launch (the cv::BFMatcher::knnMatch(.., 2) sites,
+ * frame.cpp:1167-1174: e.g. the stereo pairs of a step), shaped to be bound by the integer ALU rather than by launches:
+ *   - a workgroup owns 64 queries (one per lane, 8 dwords in VGPRs, the same in all four waves) and a RANGE of the
+ *     train descriptors (grid.y splits the train set only as far as the GPU needs workgroups);
+ *   - the range is walked in tiles of 256 descriptors, double-buffered in LDS: the next tile's global loads are issued
+ *     before the current tile is computed and stored after it, one barrier per tile;
+ *   - wave w sweeps descriptors [64w, 64w + 64) of a tile: two broadcast ds_read_b128, 8 v_xor + 8 v_bcnt (the count
+ *     accumulates in the instruction), key = dist << 16 | index, and the running two smallest keys by
+ *     k2 = med3(k1, k2, key), k1 = min(k1, key): 19 VALU instructions per 64 pairs, 16 of them the arithmetic itself;
+ *   - the four waves' pairs are merged through LDS, the ranges' by k_hamming_top2_merge_batch.
+ * Ties resolve to the lower train index, as in the reference's ascending loops.
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
+__global__ void __launch_bounds__(256)
+k_hamming_top2_batch(Top2Jobs jobs, int nsplit, uint32_t* __restrict__ part /* [row][nsplit][2] */) {
+    __shared__ uint4 s_t[2][HAM_TT * 2];
+    __shared__ uint32_t s_k[4][HAM_TQ][2];
+    const Top2Job jb = jobs.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x * HAM_TQ >= jb.nq) return; /* block-uniform: problems of different sizes share the grid */
+    const int qi = blockIdx.x * HAM_TQ + lane;
+    /* this workgroup's train range: whole tiles, the ranges of the nsplit workgroups cover [0, nt) */
+    const int ntile = (jb.nt + HAM_TT - 1) / HAM_TT, tps = (ntile + nsplit - 1) / nsplit;
+    const int tile0 = (int)blockIdx.y * tps, tile1 = min(tile0 + tps, ntile);
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (qi < jb.nq) {
+        qa = ((const uint4*)jb.q)[(size_t)qi * 2];
+        qb = ((const uint4*)jb.q)[(size_t)qi * 2 + 1];
+    }
+    const uint4* T4 = (const uint4*)jb.t;
+    const int n4 = jb.nt * 2; /* uint4 elements of the train array */
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    auto fetch = [&](int tile) { /* two uint4 per thread: elements tid and tid + 256 of the tile's 512 */
+        const int e0 = tile * (HAM_TT * 2) + tid, e1 = e0 + 256;
+        r0 = e0 < n4 ? T4[e0] : make_uint4(0, 0, 0, 0);
+        r1 = e1 < n4 ? T4[e1] : make_uint4(0, 0, 0, 0);
+    };
+    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    if (tile0 < tile1) {
+        fetch(tile0);
+        s_t[0][tid] = r0;
+        s_t[0][tid + 256] = r1;
+    }
+    __syncthreads();
+    for (int tile = tile0; tile < tile1; tile++) {
+        const int b = (tile - tile0) & 1;
+        if (tile + 1 < tile1) fetch(tile + 1); /* in flight while this tile is computed */
+        const int tb0 = tile * HAM_TT + wv * 64;          /* first train index of this wave's 64 */
+        const int cnt = min(64, jb.nt - tb0);             /* wave-uniform */
+        const uint4* st = &s_t[b][(wv * 64) * 2];
+        if (cnt == 64) {
+#pragma unroll 8
+            for (int j = 0; j < 64; j++) {
+                const uint4 ta = st[2 * j], tb = st[2 * j + 1];
+                uint32_t d = __popc(qa.x ^ ta.x);
+                d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+                d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+                const uint32_t key = (d << 16) | (uint32_t)(tb0 + j);
+                k2 = umed3(k1, k2, key);
+                k1 = min(k1, key);
+            }
+        } else {
+            for (int j = 0; j < cnt; j++) {
+                const uint4 ta = st[2 * j], tb = st[2 * j + 1];
+                uint32_t d = __popc(qa.x ^ ta.x);
+                d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+                d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+                const uint32_t key = (d << 16) | (uint32_t)(tb0 + j);
+                k2 = umed3(k1, k2, key);
+                k1 = min(k1, key);
+            }
+        }
+        if (tile + 1 < tile1) { /* the other buffer was last read one iteration ago, behind the barrier below */
+            s_t[b ^ 1][tid] = r0;
+            s_t[b ^ 1][tid + 256] = r1;
+        }
+        __syncthreads();
+    }
+    s_k[wv][lane][0] = k1;
+    s_k[wv][lane][1] = k2;
+    __syncthreads();
+    if (wv == 0 && qi < jb.nq) {
+        uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const uint32_t key = s_k[w2][lane][e];
+                b2 = umed3(b1, b2, key);
+                b1 = min(b1, key);
+            }
+        const size_t o = ((size_t)(jb.row0 + (uint32_t)qi) * nsplit + blockIdx.y) * 2;
+        part[o] = b1;
+        part[o + 1] = b2;
+    }
+}
+
+__global__ void k_hamming_top2_merge_batch(const uint32_t* __restrict__ part, int nrows, int nsplit,
+                                           int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+    for (int i = 0; i < nsplit * 2; i++) {
+        const uint32_t key = part[(size_t)r * nsplit * 2 + i];
+        b2 = umed3(b1, b2, key);
+        b1 = min(b1, key);
+    }
+    idx2[2 * r] = b1 == 0xFFFFFFFFu ? -1 : (int)(b1 & 0xFFFF);
+    dist2[2 * r] = b1 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(b1 >> 16);
+    idx2[2 * r + 1] = b2 == 0xFFFFFFFFu ? -1 : (int)(b2 & 0xFFFF);
+    dist2[2 * r + 1] = b2 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(b2 >> 16);
+}
+
+/* how many workgroups share a problem's train set: as few as fill the GPU (~4 workgroups per CU), never more than it
+ * has tiles */
+int vk_hamming_top2_batch_split(int nprob, int max_nq, int max_nt) {
+    const int qt = std::max(1, (max_nq + HAM_TQ - 1) / HAM_TQ), ntile = std::max(1, (max_nt + HAM_TT - 1) / HAM_TT);
+    const int want = (1024 + nprob * qt - 1) / (nprob * qt);
+    return std::max(1, std::min(want, ntile));
+}
+
+void vk_hamming_top2_batch(hipStream_t st, const Top2Jobs& jobs, int nprob, int max_nq, int nrows, int nsplit, uint32_t* part,
+                           int32_t* idx2, int32_t* dist2) {
+    if (nprob <= 0 || nrows <= 0) return;
+    if (max_nq > 0)
+        hipLaunchKernelGGL(k_hamming_top2_batch, dim3((max_nq + HAM_TQ - 1) / HAM_TQ, nsplit, nprob), dim3(256), 0, st, jobs, nsplit,
+                           part);
+    hipLaunchKernelGGL(k_hamming_top2_merge_batch, dim3((nrows + 255) / 256), dim3(256), 0, st, part, nrows, nsplit, idx2, dist2);
+}
+
