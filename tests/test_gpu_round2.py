@@ -2,6 +2,7 @@
 matcher overflow reporting, the in-library RCCL exchange at world size 1, and the BASELINE configs that round 1
 left without a parity test (stereo / init matcher at 1920x1080 N=4000, mono N=2000 = the YAML value)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -122,6 +123,29 @@ def test_search_init_more_octave0_keypoints_than_the_context_quota():
     finally:
         src.close()
         dst.close()
+
+
+def test_bench_verify_exchange_world1_collective_path():
+    """bench.py --force-collective (RCCL, world size 1: the ring shift is a self-send through the same ncclSend/ncclRecv
+    group) with the GPU-side proof of the exchange, for both exchange forms: the arrived slot equals the slot this GPU makes
+    itself from the left neighbour's frame, and the matcher output agrees"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--workload",
+                        "kitti00_mono_1241x376_n1000", "--inputs", "device", "--no-cpu-baseline", "--steps", "4", "--warmup", "1",
+                        "--min-seconds", "0.05"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["exchange_verified"] is True, d["exchange"]
+    ver = d["exchange"]["verify"]
+    assert set(ver) == {"ring", "allgather"}
+    for mode, v in ver.items():
+        assert v["verified"] and v["keypoints_compared_rank0"] > 500 and v["matches_rank0"] > 100, (mode, v)
+    assert d["exchange"]["transport"] == "rccl"
 
 
 def test_rccl_ring_and_allgather_world1_on_context_stream():

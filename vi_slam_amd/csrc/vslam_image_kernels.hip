@@ -1073,10 +1073,13 @@ __device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) {
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ uint32_t mad_i24(uint32_t a, int b, uint32_t c) { /* a * b + c, 24-bit signed factors */
+__device__ __forceinline__ uint32_t sub_twice(uint32_t a, uint32_t s_base) { /* s_base - 2 * a; s_base wave-uniform (an SGPR operand) */
     uint32_t r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(r) : "v"(a), "s"(s_base));
     return r;
+}
+__device__ __forceinline__ uint32_t lane_rank_from(uint64_t m, uint32_t start) { /* start + set bits of m below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, start));
 }
 
 template <int NT>
@@ -1209,7 +1212,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
             for (int ly0 = r0; ly0 + wrow < r1; ly0 += RPI) { /* wave-uniform: iterations below the chunk are skipped */
                 FCNT(1);
                 const int ly = ly0 + qly;
-                const bool rowok = ly < r1;
+                if (ly >= r1) continue; /* rows below the chunk: those lanes sit the iteration out (lane 0 never does) */
                 const uint32_t* rowc = W32 + (ly + 3) * (P / 4) + qx;
                 const uint32_t A0 = rowc[0], C = rowc[1], E = rowc[2];
                 const uint32_t U = W32[ly * (P / 4) + qx + 1], Dn = W32[(ly + 6) * (P / 4) + qx + 1];
@@ -1221,7 +1224,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
 #pragma unroll
                 for (int pp = 0; pp < 2; pp++) {
                     const uint32_t v = pp ? ODD(C) : EVN(C);
-                    const uint32_t TT = rowok ? TTv[pp] : 0x7FFF7FFFu;
+                    const uint32_t TT = TTv[pp];
                     const uint32_t vm = pk_sub_sat(v, TT), vp = pk_add(v, TT);
                     const uint32_t u = pp ? ODD(U) : EVN(U), d = pp ? ODD(Dn) : EVN(Dn);
                     const uint32_t l = pp ? ODD(Lf) : EVN(Lf), r = pp ? ODD(Rt) : EVN(Rt);
@@ -1244,16 +1247,25 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 }
                 if (totD | totB) { /* wave-uniform */
                     FCNT(2);
+                    /* the list space of this wave's survivors: one returning LDS add by lane 0.  Its round trip is covered
+                     * by the ranks, which do not need the base: the add is issued here and waited for behind them */
                     uint32_t base = 0;
-                    if (lane == 0) base = lds_add_rtn(lds_addr(&s_cnt[par]), totD | (totB << 16));
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    uint32_t aD = list_lo + 2u * (base & 0xFFFFu), aB = list_hi - 2u * (base >> 16);
+                    if (lane == 0)
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(base) : "v"(lds_addr(&s_cnt[par])), "v"(totD | (totB << 16)) : "memory");
                     const uint32_t code0 = codeq + ((uint32_t)ly0 << 8);
+                    uint32_t rD[4], rB[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t atD = aD + 2u * lane_rank(mD[j]);
-                        const uint32_t atB = mad_i24(lane_rank(mB[j]), -2, aB);
-                        lds_store_b16_two(mD[j], mB[j], atD, atB, code0 + j);
+                        rD[j] = lane_rank(mD[j]);
+                        rB[j] = lane_rank(mB[j]);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base) : : "memory");
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    /* the entries of the pixel columns before j go into the (scalar) base of column j */
+                    uint32_t aD = list_lo + 2u * (base & 0xFFFFu), aB = list_hi - 2u * (base >> 16);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        lds_store_b16_two(mD[j], mB[j], aD + 2u * rD[j], sub_twice(rB[j], aB), code0 + j);
                         aD += 2u * (uint32_t)__popcll(mD[j]);
                         aB -= 2u * (uint32_t)__popcll(mB[j]);
                     }
