@@ -608,6 +608,12 @@ class Pipeline:
         if not self.args.gc:
             gc.collect()
             gc.disable()
+            # the collection above left the GPU idle for tens of milliseconds; the first blocks of the region then ran 10-13 %
+            # below the rest (profiles/r04_slow_blocks.txt): refill the pipeline, untimed, before the bracket
+            self.stamps = None
+            self.run(steps)
+            env["barrier"]()
+            self.stamps = []
         t0 = time.perf_counter()
         self.run(steps * reps)  # the timed region: the product path as a caller runs it (no per-stage events)
         env["barrier"]()
@@ -638,12 +644,17 @@ class Pipeline:
                 self.state[k] = v
         frames_per_step = (self.B // 2 if self.stereo else self.B) * env["world"]
         n = steps * reps
-        # spread over the repeats: the rate of every block of `steps` consecutive steps (delivery time stamps of this rank;
-        # the first block also carries the pipeline's fill)
-        blocks = [frames_per_step * steps / (stamps[(r + 1) * steps - 1] - stamps[r * steps - 1]) for r in range(1, reps)
-                  if stamps[(r + 1) * steps - 1] > stamps[r * steps - 1]]
+        # spread over the region: the rate of every block of `bs` consecutive steps (delivery time stamps of this rank; the
+        # first block also carries the pipeline's fill).  The contexts in flight finish their steps in BURSTS -- three short
+        # delivery gaps, then a long one, up to 8 x the mean at 1080p (profiles/r04_slow_blocks.txt) -- so the rate of a block
+        # is quantised by (one between-burst gap / block length): +-10-16 % for blocks of 20 steps whatever the GPU does.
+        # Blocks of 25 bursts bound that at +-2 %; what is left is the pipeline's own variation.
+        bs = max(steps, 25 * self.NCTX)
+        nblk = len(stamps) // bs
+        blocks = [frames_per_step * bs / (stamps[(r + 1) * bs - 1] - stamps[r * bs - 1]) for r in range(1, nblk)
+                  if stamps[(r + 1) * bs - 1] > stamps[r * bs - 1]]
         blocks.sort()
-        spread = ({"min": blocks[0], "median": blocks[len(blocks) // 2], "max": blocks[-1], "blocks": len(blocks)}
+        spread = ({"min": blocks[0], "median": blocks[len(blocks) // 2], "max": blocks[-1], "blocks": len(blocks), "block_steps": bs}
                   if blocks else None)
         return {"value": frames_per_step * n / dt, "ms_per_step": dt / n * 1e3, "reps": reps, "seconds": dt, "prof": prof,
                 "spread": spread,

@@ -95,8 +95,9 @@ typedef struct vslam_tuning {
                                      index (vslam_fe_event_wait) recorded between them; see vslam_fe_stage_images_async */
     int32_t oct_threads;          /* VSLAM_OCT_THREADS: 256 | 512 | 1024 threads per quadtree problem (default: 1024 for contexts of
                                      one or two images, 512 for frames above a megapixel, else 256) */
-    int32_t fast_kernel;          /* VSLAM_FAST_KERNEL: 3 = one workgroup per FAST cell (k_fast_cells_v3), 4 = one workgroup per
-                                     band of cells of a cell row sharing one staged window (k_fast_bands, default) */
+    int32_t fast_kernel;          /* VSLAM_FAST_KERNEL: 3 = one workgroup per FAST cell (k_fast_cells_v3; default for contexts of one
+                                     or two images), 4 = one workgroup per band of cells of a cell row sharing one staged
+                                     window (k_fast_bands; default for batches) */
     int32_t fast_band_cells;      /* VSLAM_FAST_BAND_CELLS: cells per band of k_fast_bands (1..4, default 4; fewer where 4 cell
                                      interiors are wider than 128 px) */
     int32_t wave_prio;            /* VSLAM_WAVE_PRIO: bit mask of kernel classes that raise their wave priority (s_setprio 3)

@@ -144,7 +144,7 @@ def test_bench_verify_exchange_world1_collective_path():
     ver = d["exchange"]["verify"]
     assert set(ver) == {"ring", "allgather"}
     for mode, v in ver.items():
-        assert v["verified"] and v["keypoints_compared_rank0"] > 500 and v["matches_rank0"] > 100, (mode, v)
+        assert v["verified"] and v["keypoints_compared_rank0"] > 500 and v["matches_rank0"] > 20, (mode, v)
     assert d["exchange"]["transport"] == "rccl"
 
 

@@ -73,7 +73,7 @@ struct vslam_fe {
     /* FAST bands (k_fast_bands): up to four cells of a cell row per workgroup; nbands == 0: not available for this geometry */
     BandDesc* d_bands = nullptr;
     uint8_t* d_band_classes = nullptr; /* 272-byte column tables, BandDesc::lnw >> 16 indexes them */
-    int nbands = 0, band_max_wh = 0;
+    int nbands = 0, band_max_wh = 0, band_max_iw = 0;
     /* candidates: per slot [total, overflow, CellOut[ncells], cand[cand_cap]] */
     uint8_t* d_cand = nullptr;
     uint8_t* h_cand = nullptr; /* pinned */

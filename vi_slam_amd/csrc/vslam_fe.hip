@@ -312,6 +312,7 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             if ((rc = upload(&fe->d_bands, db.data(), db.size() * sizeof(BandDesc)))) return rc;
             fe->nbands = (int)db.size();
             fe->band_max_wh = mwh;
+            fe->band_max_iw = miw;
         }
     }
     const int ncells = (int)fe->cells.size();
@@ -898,10 +899,12 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    /* vslam_tuning.fast_kernel: 4 (default) = one workgroup per band of cells, 3 = one per cell */
-    if (fe->nbands > 0 && tune_or(fe->tune.fast_kernel, 4) != 3)
+    /* vslam_tuning.fast_kernel: 4 = one workgroup per band of cells (default for batches: 17 % fewer instructions, every
+     * image byte fetched once), 3 = one per cell (default for contexts of one or two images, where the launch is a frame's
+     * latency: 15 instead of 21 us, four times as many and shorter workgroups) */
+    if (fe->nbands > 0 && tune_or(fe->tune.fast_kernel, fe->B <= 2 ? 3 : 4) != 3)
         vk_fast_bands(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_bands, fe->nbands, fe->d_band_classes, fe->d_cells,
-                      (int)fe->cells.size(), fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->band_max_wh, 0, nimg,
+                      (int)fe->cells.size(), fe->d_cand, fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->band_max_wh, fe->band_max_iw, nimg,
                       fe->tune);
     else
         vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,

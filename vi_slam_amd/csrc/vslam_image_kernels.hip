@@ -1028,8 +1028,6 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
  *   - output: wave w writes cell w's candidates in raster order into the cell's fixed segment (same layout as v3).
  * Scores do not depend on the cell a pixel belongs to, so the result is identical to one cv::FAST per cell.
  * ---------------------------------------------------------------------------------------------- */
-#define FB_P 136      /* LDS pitch: 128 interior columns + the 6-px ring + the one-column shift, a multiple of 8 */
-#define FB_KW 4       /* keep words per interior row (128 columns) */
 #define FB_MAXC 4     /* cells per band */
 #ifndef FB_XCD_CHUNK
 #define FB_XCD_CHUNK 4
@@ -1082,14 +1080,15 @@ __device__ __forceinline__ uint32_t lane_rank_from(uint64_t m, uint32_t start) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, start));
 }
 
-template <int NT>
+template <int NT, int P> /* P: LDS pitch = interior columns + 8: 136 (bands of up to 128 columns) or 72 (up to 64) */
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g,
              const BandDesc* __restrict__ bands, int nbands, const uint4* __restrict__ classes,
              const CellDesc* __restrict__ cells, uint8_t* cand_region, size_t cand_stride, int ncells, int iniTh, int minTh,
              int nslots, int lds_total, int by_image) {
     extern __shared__ __align__(16) uint8_t smemb[];
-    constexpr int P = FB_P;
+    constexpr int KW = (P - 8) / 32; /* keep words per interior row */
+    constexpr int LOGW = P == 136 ? 7 : 6; /* log2 of the interior columns a row can have */
     constexpr int NW = NT / 64;
     __shared__ uint32_t s_cnt[2]; /* nD | nB << 16 of the chunk being swept; the other one is zeroed meanwhile */
     __shared__ uint32_t s_any;    /* bit c: cell c of the band kept a corner */
@@ -1130,7 +1129,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     uint8_t* win = smemb;          /* window column c at LDS column c + 1 */
     uint8_t* sc = win + whe * P;
     uint32_t* keep = (uint32_t*)(sc + (((ih + 2) * P + 15) & ~15));
-    uint8_t* cellbit = (uint8_t*)(keep + ih * FB_KW); /* 1 << (cell of interior column x), 0 outside the interior */
+    uint8_t* cellbit = (uint8_t*)(keep + ih * KW); /* 1 << (cell of interior column x), 0 outside the interior */
     uint8_t* cellfl = cellbit + 136;                  /* bit 0: first column of its cell, bit 1: last column */
     uint8_t* qtab = cellfl + 136;                     /* stage 2: the quad columns of the empty cells */
     uint16_t* list = (uint16_t*)(qtab + 32);
@@ -1154,7 +1153,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
         /* the band's column tables (host: one 272-byte record per (cell pitch, interior width) class) */
         uint4 tabv = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 17) tabv = classes[bclass * 17 + tid];
-        const int nz = (int)(((uint8_t*)(keep + ih * FB_KW) - sc) >> 4); /* score tile + keep words, 16-byte stores */
+        const int nz = (int)(((uint8_t*)(keep + ih * KW) - sc) >> 4); /* score tile + keep words, 16-byte stores */
         for (int i = tid; i < nz; i += NT) ((uint4*)sc)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 17) ((uint4*)cellbit)[tid] = tabv;
         if (tid >= 64 && tid < 72) ((uint32_t*)qtab)[tid - 64] = 0u;
@@ -1177,9 +1176,9 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     const uint32_t* W32 = (const uint32_t*)win;
     const int QW = (iw + 3) >> 2; /* quad columns of the band */
     /* rows swept at once.  A pixel that passes both compass tests is listed twice (dark and bright), every other survivor
-     * once: the list holds every pixel of lcap / 128 rows once -- the optimistic chunk, all of a usual band -- and of half
+     * once: the list holds every pixel of lcap / (P - 8) rows once -- the optimistic chunk, all of a usual band -- and of half
      * as many rows twice -- the chunk after an overflow, which the two counters show before anything reads the list */
-    int CR = min(ih, lcap >> 7);
+    int CR = min(ih, lcap >> LOGW);
     const int sc_off = whe * P - 2 * P - 3; /* score byte of a pixel relative to its window byte */
     const uint32_t list_lo = lds_addr(list), list_hi = lds_addr(list) + 2u * (uint32_t)(lcap - 1);
     int T = iniTh;
@@ -1280,7 +1279,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 nB = (int)(tot >> 16);
             }
             if (nD + nB > lcap) { /* block-uniform: the two lists ran into each other -- these rows again, half as many */
-                CR = max(2, lcap >> 8);
+                CR = max(2, lcap >> (LOGW + 1));
                 par ^= 1; /* the other counter is zero; this one is zeroed one chunk later, like every used one */
                 continue;
             }
@@ -1335,7 +1334,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                     if (fl & 2) mr = 0;
                     const int mx = max(max((int)q[-P], (int)q[P]), max(ml, mr));
                     if (s > mx) {
-                        atomicOr(&keep[ly * FB_KW + (x >> 5)], 1u << (x & 31));
+                        atomicOr(&keep[ly * KW + (x >> 5)], 1u << (x & 31));
                         atomicOr(&s_any, (uint32_t)cellbit[x]);
                     }
                 }
@@ -1381,9 +1380,9 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
             const int row = rb + (lane >> 1);
             uint32_t bits = 0u;
             if (row < ih && nb > 0) {
-                const uint32_t* kr = keep + row * FB_KW;
+                const uint32_t* kr = keep + row * KW;
                 const int w = b0 >> 5;
-                const uint32_t lo = kr[w], hi = w + 1 < FB_KW ? kr[w + 1] : 0u;
+                const uint32_t lo = kr[w], hi = w + 1 < KW ? kr[w + 1] : 0u;
                 bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b0 & 31));
                 if (nb < 32) bits &= (1u << nb) - 1u;
             }
@@ -1409,10 +1408,10 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     }
 }
 
-/* LDS a band of wh window rows needs before its survivor list (k_fast_bands' layout) */
-static size_t fast_band_fixed_lds(int wh) {
-    const int ih = wh - 6, whe = (wh + 1) & ~1;
-    return (size_t)whe * FB_P + (size_t)((((ih + 2) * FB_P) + 15) & ~15) + (size_t)ih * FB_KW * 4 + 136 + 136 + 32;
+/* LDS a band of wh window rows needs before its survivor list (k_fast_bands' layout); P = LDS pitch */
+static size_t fast_band_fixed_lds(int wh, int P) {
+    const int ih = wh - 6, whe = (wh + 1) & ~1, KW = (P - 8) / 32;
+    return (size_t)whe * P + (size_t)((((ih + 2) * P) + 15) & ~15) + (size_t)ih * KW * 4 + 136 + 136 + 32;
 }
 
 int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band) {
@@ -1423,24 +1422,33 @@ int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band) {
 
 void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                    const BandDesc* bands, int nbands, const uint8_t* classes, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                   size_t cand_stride, int iniTh, int minTh, int max_wh, int std_wh, int nslots, const vslam_tuning& T) {
-    constexpr int NT = 256;
-    /* LDS per workgroup: eight workgroups (32 waves) per CU fit when a band takes at most 20 KB.  The list gets what the
-     * window, the score tile and the tables leave: enough for every pixel of the usual band (cells of up to ~34 rows: one
-     * chunk); taller bands are swept in chunks (the kernel derives the chunk height from the space it finds).  Never
-     * less than the tallest band needs for chunks of 8 rows, nor than what a sweep's idle lanes may READ (rows up to an
-     * iteration's height below the window: results dropped, but the addresses stay inside the allocation). */
-    const size_t budget = 20480 - 64; /* 64: the kernel's static variables */
-    size_t lds = std::max(budget, fast_band_fixed_lds(max_wh) + 2 * (size_t)(8 * 256)); /* chunks of >= 8 rows, every pixel twice */
-    lds = std::max(lds, (size_t)(max_wh + NT / 8 + 1) * FB_P + 256);
+                   size_t cand_stride, int iniTh, int minTh, int max_wh, int max_iw, int nslots, const vslam_tuning& T) {
+    /* one shape: bands of up to 128 interior columns (four 31-px cells) by four waves, LDS pitch 136.  (A second shape --
+     * bands of up to 64 columns by two waves, pitch 72: the same work per cell behind barriers of two waves instead of four --
+     * was built in round 4 and measured no faster: 90.6 vs 89.7 us per 32 KITTI images, 41.5 M instead of 39.2 M
+     * instructions for the shorter rows' idle lanes; removed.) */
+    (void)max_iw;
+    constexpr int P = 136, NT = 256;
+    const bool narrow = false;
+    /* LDS per workgroup: 32 waves per CU fit when a four-wave band takes at most 20 KB (a two-wave band 10 KB).  The list
+     * gets what the window, the score tile and the tables leave: enough for every pixel of the usual band (cells of up to
+     * ~34 rows: one chunk); taller bands are swept in chunks (the kernel derives the chunk height from the space it
+     * finds).  Never less than the tallest band needs for chunks of 8 rows with every pixel listed twice, nor than what a
+     * sweep's idle lanes may READ (rows up to an iteration's height below the window: results dropped, but the
+     * addresses stay inside the allocation). */
+    const size_t budget = (narrow ? 10240 : 20480) - 64; /* 64: the kernel's static variables */
+    size_t lds = std::max(budget, fast_band_fixed_lds(max_wh, P) + 2 * (size_t)(8 * 2 * (P - 8)));
+    lds = std::max(lds, (size_t)(max_wh + NT / 8 + 1) * P + 256);
     lds = (lds + 15) & ~(size_t)15;
-    (void)std_wh;
     const int lds_pad = std::max(0, tune_or(T.fast_lds_pad, 0)); /* extra LDS per workgroup (occupancy experiments) */
     const int it = std::min(iniTh, 256), mt = std::min(minTh, 256);
     const int by_image = nslots >= 8 ? 1 : 0;
     dim3 grid;
     if (by_image) grid = dim3((unsigned)(8 * nbands * ((nslots + 7) / 8)), 1);
     else grid = dim3((unsigned)((nbands + 8 * FB_XCD_CHUNK - 1) / (8 * FB_XCD_CHUNK) * (8 * FB_XCD_CHUNK)), (unsigned)nslots);
-    hipLaunchKernelGGL((k_fast_bands<NT>), grid, dim3(NT), lds + lds_pad, st, pyr, slot_stride, src, g, bands, nbands,
-                       (const uint4*)classes, cells, cand_region, cand_stride, ncells, it, mt, nslots, (int)lds, by_image);
+#define FB_LAUNCH(NT_, P_)                                                                                                   \
+    hipLaunchKernelGGL((k_fast_bands<NT_, P_>), grid, dim3(NT_), lds + lds_pad, st, pyr, slot_stride, src, g, bands, nbands, \
+                       (const uint4*)classes, cells, cand_region, cand_stride, ncells, it, mt, nslots, (int)lds, by_image)
+    FB_LAUNCH(256, 136);
+#undef FB_LAUNCH
 }

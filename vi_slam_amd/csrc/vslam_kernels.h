@@ -39,7 +39,7 @@ void vk_fast_cells_v3(hipStream_t st, const uint8_t* pyr, size_t slot_stride, co
 int vk_fast_bands_check(int max_wh, int max_iw, int max_cells_per_band);
 void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const PyramidGeom& g,
                    const BandDesc* bands, int nbands, const uint8_t* classes, const CellDesc* cells, int ncells, uint8_t* cand_region,
-                   size_t cand_stride, int iniTh, int minTh, int max_wh, int std_wh, int nslots, const vslam_tuning& T);
+                   size_t cand_stride, int iniTh, int minTh, int max_wh, int max_iw, int nslots, const vslam_tuning& T);
 void vk_resize_level_v2(hipStream_t st, uint8_t* pyr, size_t slot_stride, const BatchSrc& src, const LevelGeom& sg,
                         const LevelGeom& dg, int src_level, const uint16_t* qbase, const ResizeQuad* quads,
                         const uint16_t* ytab, const int16_t* yb, int nslots);
