@@ -42,7 +42,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # issue time of a wave64 VALU instruction of the classes the FAST kernel is made of (packed 16-bit, v_perm, v_alignbyte, v_cmp,
-# v_mbcnt, DPP/SDWA forms: 4 cycles per SIMD at ~2.26 GHz; profiles/r03_issue_rate_probe.txt); 256 CUs x 4 SIMDs
+# v_mbcnt, DPP/SDWA forms: 4 cycles per SIMD at ~2.26 GHz; profiles/r03_issue_rate_probe.txt, unchanged in round 4); 256 CUs x 4 SIMDs
 VALU_NS_PER_WAVE_INST, NUM_SIMDS = 1.77, 1024
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -129,7 +129,7 @@ def pmc_traffic(kernel, cfg, batch):
     FETCH_SIZE / WRITE_SIZE passes).  gfx950's FETCH_SIZE counts 64 B per 128-B request, i.e. half of a coalesced
     stream (MI355X_MICROARCH.md 'HBM'); the factor 2 is applied here.  Only valid for the geometry / batch /
     feature count the profile was taken with; otherwise None."""
-    for rnd in ("r03", "r02"):  # the newest committed summary for this geometry
+    for rnd in ("r04", "r03", "r02"):  # the newest committed summary for this geometry
         name = "%s_pmc_traffic_%dx%d_n%d_b%d.json" % (rnd, cfg["w"], cfg["h"], cfg["nf"], batch)
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -295,6 +295,16 @@ class Pipeline:
         self.ctxs = [V.FExtractor(nf, 1.2, 8, 20, 7, w, h, device=env["local_rank"], max_batch=B, tuning=tuning)
                      for _ in range(self.NCTX)]
         self.fe = self.ctxs[0]
+        # FAST(t) starts when FAST(t-1) has finished: never two FAST launches resident at once.  FAST takes every CU's whole LDS;
+        # with two of them in flight the pipeline flips between a smooth state (mono 187 k frames/s) and one that runs like three
+        # contexts (172 k, a 400-us delivery gap every ~10 steps) for hundreds of steps at a time; chained it stays at 186 k
+        # (+6 %, HBM-resident and host inputs alike).  The stereo workloads' contexts are independent of each other -- no
+        # cross-frame matcher -- and a chain is the only coupling they would have: it buys them nothing (-0.5 %) and lets one late
+        # context hold up the other three (blocks at 60-75 % of the rate in two of four runs): auto = mono only
+        self.fast_chain = args.fast_chain == "on" or (args.fast_chain == "auto" and not self.stereo)
+        if self.fast_chain:
+            for k, c in enumerate(self.ctxs):
+                c.set_fast_gate(self.ctxs[(k - 1) % self.NCTX])
         self.matchers = [V.FMatcher(c, 0.9, True) for c in self.ctxs]
         self.lap = (0, 0) if self.stereo else (0, 1000)  # frame.cpp:107-108 vs :289
         # ---- synthetic frames (host copies kept for the pinned-input mode)
@@ -700,7 +710,10 @@ def roofline_of(pl, stage_alone, stage_pipe, res_dev):
     nlaunch = pl.fe.pyramid_launches() if hasattr(pl.fe, "pyramid_launches") else 7
     per_launch = {k: (v / nlaunch if k == "pyramid" else v) for k, v in stage_alone.items() if k != "octree"}
     dom = max(per_launch, key=per_launch.get)
-    kernel = KERNEL_OF[dom] if dom != "pyramid" else ("k_resize_level_v2(x%d)" % nlaunch if nlaunch > 2 else "k_pyramid")
+    kof = dict(KERNEL_OF)
+    if pl.args.fast_kernel != 3 and pl.B > 2:  # the library's default for batches (vslam_tuning.fast_kernel)
+        kof["fast"] = "k_fast_bands"
+    kernel = kof[dom] if dom != "pyramid" else ("k_resize_level_v2(x%d)" % nlaunch if nlaunch > 2 else "k_pyramid")
     bytes_per_launch = ab[dom] * pl.B / (nlaunch if dom == "pyramid" else 1.0)
     ms = per_launch[dom]
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -879,6 +892,9 @@ def main():
                     help="host inputs: 1 = a step's upload goes as two transfers and the chain event sits between them")
     ap.add_argument("--upload-chain", type=int, default=1,
                     help="host inputs: upload of step t waits (GPU-side event) for the upload of step t-L; 0 = no pacing")
+    ap.add_argument("--fast-chain", default="auto", choices=["auto", "on", "off"],
+                    help="chain the contexts' FAST launches (vslam_fe_set_fast_gate); auto = the workloads whose contexts are coupled "
+                         "by a cross-frame matcher anyway (A/B: profiles/r04_fast_chain_ab.txt)")
     ap.add_argument("--gc", action="store_true", help="leave Python's cyclic garbage collector on inside the timed region (A/B)")
     ap.add_argument("--stamp-dump", default="", help="write the host clock of every step's enqueue and wait to PREFIX.<workload>.<inputs>.json")
     ap.add_argument("--stream-priority", type=int, default=2, choices=[0, 1, 2],

@@ -221,6 +221,11 @@ int vslam_fe_wait_for(vslam_fe* waiter, vslam_fe* signal);
 int vslam_fe_event_record(vslam_fe* fe, int idx);
 int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx);
 
+/* Pacing between contexts kept in flight: with a gate set, the FAST launch of every later pass of `fe` starts only when the
+ * FAST launch of `signal`'s latest pass has finished (GPU-side event; no host synchronisation).  FAST takes a CU's whole
+ * LDS while it runs; chaining the contexts' FAST launches keeps two of them from being resident at once.  NULL removes it. */
+int vslam_fe_set_fast_gate(vslam_fe* fe, vslam_fe* signal);
+
 /* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */
 void* vslam_fe_stream(vslam_fe* fe);
 

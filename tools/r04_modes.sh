@@ -7,16 +7,8 @@ mkdir -p $O
 WL=kitti00_mono_1241x376_n1000
 run() { name=$1; shift; timeout -k 10 240 env "$@" python bench.py --workload $WL --inputs device --no-cpu-baseline --min-seconds 1.5 --stamp-dump $O/st_$name ${EXTRA[@]} > $O/b_$name.json 2> $O/b_$name.err; echo "$name rc=$? $(python3 -c "import json; d=json.load(open('$O/b_$name.json')); print(d['value'], d.get('spread'))" 2>/dev/null)"; }
 EXTRA=(); run default A=1
-EXTRA=(); run default2 A=1
-EXTRA=(--stream-priority 0); run prio0 A=1
-EXTRA=(--stream-priority 1); run prio1 A=1
-EXTRA=(--inflight 3); run ctx3 A=1
-EXTRA=(--inflight 5); run ctx5 A=1
-EXTRA=(); run hwq4 GPU_MAX_HW_QUEUES=4
-EXTRA=(); run hwq16 GPU_MAX_HW_QUEUES=16
-EXTRA=(--delivery separate); run delivsep A=1
-EXTRA=(--fast-kernel 3); run k3 A=1
-EXTRA=(--batch 24); run b24 A=1
+EXTRA=(--fast-chain); run chain A=1
+EXTRA=(--fast-chain); run chain2 A=1
 python3 - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/modes/st_*.json')):

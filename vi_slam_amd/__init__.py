@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vslam_search_by_projection_sim3",
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
-    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates", "vslam_hamming_top2_batch", "vslam_hamming_top2_batch_dev_async",
+    "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates", "vslam_hamming_top2_batch", "vslam_hamming_top2_batch_dev_async", "vslam_fe_set_fast_gate",
 ]
 
 
@@ -528,6 +528,12 @@ class FExtractor:
 
     def event_record(self, idx):
         _check(lib().vslam_fe_event_record(self._h, idx))
+
+    def set_fast_gate(self, other):
+        """this context's FAST launches wait (GPU side) for `other`'s latest FAST launch; None removes the gate"""
+        L = lib()
+        L.vslam_fe_set_fast_gate.argtypes = [C.c_void_p, C.c_void_p]
+        _check(L.vslam_fe_set_fast_gate(self._h, other._h if other is not None else None))
 
     def event_wait(self, other, idx):
         """GPU-side: this context's later work waits for `other`'s last recorded event idx."""

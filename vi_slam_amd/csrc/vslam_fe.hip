@@ -86,6 +86,7 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->ev_x) hipEventDestroy(fe->ev_x);
     for (int i = 0; i < 4; i++)
         if (fe->ev_user[i]) hipEventDestroy(fe->ev_user[i]);
+    if (fe->ev_fast) hipEventDestroy(fe->ev_fast);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
@@ -616,6 +617,23 @@ extern "C" int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx) 
     return VSLAM_OK;
 }
 
+/* Pacing of the one kernel that takes a CU's whole LDS: with a gate set, the FAST launch of every pass of `fe` waits (GPU side)
+ * for the FAST launch of `signal`'s latest pass to have finished, so that a pipelined caller who keeps several contexts in
+ * flight never has two FAST launches resident at once (bench.py --fast-chain).  signal == NULL removes the gate.  Passes
+ * with a gate are not captured into graphs (an event of another stream cannot be waited for inside a capture). */
+extern "C" int vslam_fe_set_fast_gate(vslam_fe* fe, vslam_fe* signal) {
+    if (!fe || (signal && (signal == fe || signal->p.device != fe->p.device))) return VSLAM_ERR_INVALID;
+    fe->fast_gate = signal;
+    if (signal) {
+        HIPCHK(hipSetDevice(signal->p.device));
+        if (!signal->ev_fast) HIPCHK(hipEventCreateWithFlags(&signal->ev_fast, hipEventDisableTiming));
+        signal->fast_gated_by_someone = true;
+        fe->use_graph = false;
+        signal->use_graph = false;
+    }
+    return VSLAM_OK;
+}
+
 extern "C" int vslam_fe_set_profiling(vslam_fe* fe, int on) {
     if (!fe) return VSLAM_ERR_INVALID;
     HIPCHK(hipSetDevice(fe->p.device));
@@ -899,6 +917,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
+    if (fe->fast_gate && fe->fast_gate->ev_fast) HIPCHK(hipStreamWaitEvent(st, fe->fast_gate->ev_fast, 0));
     /* vslam_tuning.fast_kernel: 4 = one workgroup per band of cells (default for batches: 17 % fewer instructions, every
      * image byte fetched once), 3 = one per cell (default for contexts of one or two images, where the launch is a frame's
      * latency: 15 instead of 21 us, four times as many and shorter workgroups) */
@@ -909,6 +928,7 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     else
         vk_fast_cells_v3(st, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_cells, (int)fe->cells.size(), fe->d_cand,
                          fe->cand_stride, p.ini_th_fast, p.min_th_fast, fe->tile_rows, fe->tile_pitch, fe->max_px, nimg, fe->tune);
+    if (fe->fast_gated_by_someone && fe->ev_fast) HIPCHK(hipEventRecord(fe->ev_fast, st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[2], st));
     return VSLAM_OK;
 }
