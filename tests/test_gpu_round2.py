@@ -125,6 +125,45 @@ def test_search_init_more_octave0_keypoints_than_the_context_quota():
         dst.close()
 
 
+def test_fast_gate_chains_contexts_without_changing_results():
+    """vslam_fe_set_fast_gate: three contexts in a ring, each one's FAST launch waiting for the previous context's latest one;
+    passes enqueued round-robin without host waits complete (no cycle in time) and equal the oracle"""
+    import torch
+    W, H, NF, B = 640, 360, 500, 4
+    ctxs = [V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=B) for _ in range(3)]
+    try:
+        for k, c in enumerate(ctxs):
+            c.set_fast_gate(ctxs[(k - 1) % 3])
+        frames = [synth.make_frame(W, H, seed=11, step=s) for s in range(B)]
+        pitch = (W + 127) & ~127
+        dev = torch.zeros((B, H, pitch), dtype=torch.uint8, device="cuda")
+        for s in range(B):
+            dev[s, :, :W] = torch.from_numpy(frames[s]).cuda()
+        ptrs = [dev[s].data_ptr() for s in range(B)]
+        torch.cuda.synchronize()
+        e = orbo.Extractor(NF)
+        want = [e.compute(f) for f in frames]
+        nchecked = 0
+        for t in range(9 + 2):  # three rounds over the ring; a pass is collected two enqueues later
+            if t < 9:
+                ctxs[t % 3].compute_batch_async(ptrs, pitch, (0, 0), to_host=True)
+            if t >= 2:
+                out = ctxs[(t - 2) % 3].wait()
+                for s in range(B):
+                    kk, dd, _ = out[s]
+                    ok, od, _ = want[s]
+                    assert len(kk) == len(ok) and all(np.array_equal(kk[f], ok[f]) for f in kk.dtype.names)
+                    assert np.array_equal(dd, od)
+                nchecked += 1
+        assert nchecked == 9
+        ctxs[0].set_fast_gate(None)
+        out = ctxs[0].compute_batch(frames)
+        assert len(out[0][0]) == len(want[0][0])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_bench_verify_exchange_world1_collective_path():
     """bench.py --force-collective (RCCL, world size 1: the ring shift is a self-send through the same ncclSend/ncclRecv
     group) with the GPU-side proof of the exchange, for both exchange forms: the arrived slot equals the slot this GPU makes

@@ -1290,10 +1290,14 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
              * barrier -- every bright pair, which keeps the larger of its score and the one already in the tile: a pixel on
              * both lists ends with max(dark, bright), and no wave runs a second network for the few lanes that hold one */
             const int nDp = (nD + 1) >> 1, nBp = (nB + 1) >> 1;
+            /* a thread keeps the codes of the first pair it scores on either list and runs the NMS of those four pixels itself,
+             * behind the barrier: no second walk of the list for them (0xFFFF: no entry; its row 255 lies below every band) */
+            uint32_t keptD = 0xFFFFFFFFu, keptB = 0xFFFFFFFFu;
             for (int u = tid; u < nDp; u += NT) {
                 FCNT(3);
                 const uint32_t e2 = *(const uint32_t*)(list + 2 * u);
                 const uint32_t eA = e2 & 0xFFFFu, eB = 2 * u + 1 < nD ? e2 >> 16 : eA;
+                if (u == tid) keptD = eA | (eB << 16);
                 const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
                 const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
                 const uint32_t a = pk_sub_sat(fast_pair_score<1, P>(cA, cB), 0x00010001u); /* OpenCV's score: max(..) - 1, not below 0 */
@@ -1305,6 +1309,7 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                 FCNT(5);
                 const uint32_t e2 = *(const uint32_t*)(list + lcap - 2 - 2 * u);
                 const uint32_t eA = e2 >> 16, eB = 2 * u + 1 < nB ? e2 & 0xFFFFu : eA;
+                if (u == tid) keptB = eA | (eB << 16);
                 const uint8_t* cA = win + ((eA >> 8) + 3) * P + (eA & 255u) + 4;
                 const uint8_t* cB = win + ((eB >> 8) + 3) * P + (eB & 255u) + 4;
                 const uint32_t old = (uint32_t)cA[sc_off] | ((uint32_t)cB[sc_off] << 16);
@@ -1317,14 +1322,13 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
              * neighbourhood is complete: all of a chunk but its last row, which the next chunk lists again */
             const bool last = r1 >= ih;
             const int nhi = last ? ih - 1 : r1 - 2;
-            const int ntot = nD + nB;
-            for (int i = tid; i < ntot; i += NT) {
+            auto nms_one = [&](uint32_t code) {
                 FCNT(6);
-                const int code = i < nD ? list[i] : list[lcap - 1 - (i - nD)];
-                const int ly = code >> 8, x = code & 255;
+                const int ly = (int)(code >> 8), x = (int)(code & 255u);
+                if (ly > nhi) return;
                 const uint8_t* q = sc + (ly + 1) * P + x + 1;
                 const int s = q[0];
-                if (s >= T && ly <= nhi) {
+                if (s >= T) {
                     FCNT(7);
                     const int fl = cellfl[x];
                     /* every cell is its own cv::FAST call: scores across a cell border count as 0 */
@@ -1338,7 +1342,14 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
                         atomicOr(&s_any, (uint32_t)cellbit[x]);
                     }
                 }
-            }
+            };
+            nms_one(keptD & 0xFFFFu);
+            nms_one(keptD >> 16);
+            nms_one(keptB & 0xFFFFu);
+            nms_one(keptB >> 16);
+            /* entries beyond the first pair of every thread (more than 2 * NT on a list: dense texture, 1080p) */
+            for (int i = 2 * NT + tid; i < nD; i += NT) nms_one(list[i]);
+            for (int i = 2 * NT + tid; i < nB; i += NT) nms_one(list[lcap - 1 - i]);
             par ^= 1;
             if (last) break;
             __syncthreads(); /* the next chunk's sweep overwrites the list */
