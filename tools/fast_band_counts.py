@@ -12,7 +12,7 @@ import vi_slam_amd as V  # noqa: E402
 from vi_slam_amd import synth  # noqa: E402
 
 W, H, NF, B = (int(a) for a in (sys.argv[1:5] + ["1241", "376", "1000", "32"][len(sys.argv) - 1:]))
-NAMES = ["waves", "sweep_iter", "sweep_store", "net_dark", "net_both", "net_bright", "nms_iter", "nms_inner", "out_pass",
+NAMES = ["waves", "sweep_iter", "sweep_store", "net_dark", "unused", "net_bright", "nms_call", "nms_inner", "out_pass",
          "out_bit_iter", "stage2", "chunks", "net_loop_iter", "nD_sum", "nB_sum"]
 fe = V.FExtractor(NF, 1.2, 8, 20, 7, W, H, max_batch=B, tuning=dict(fast_kernel=4))
 pitch = (W + 127) & ~127
