@@ -50,7 +50,15 @@ struct BlurTapsV2 {
 #ifndef BLUR_WPB
 #define BLUR_WPB 4 /* wave tasks per workgroup of k_blur7_v2 (independent of each other; 1 and 2 measured) */
 #endif
-template <bool SYM> /* SYM: k[j] == k[6-j] (every Gaussian): the column pass folds mirrored rows first */
+/* Column pass on PAIRS of consecutive rows (round 4): the row-pass results are at most 255 * 256 and fit 16 bits, so two
+ * rows of one pixel share a register and v_dot2_u32_u16 applies two taps at once: a window of seven rows is three pairs
+ * and the newest row -- 3 dot2 + 1 mad per pixel and one v_lshl_or to make the new pair, instead of 4 multiplies and 6 adds.
+ * Every consecutive pair (r, r+1) is made once, when row r+1 arrives, and serves as the first, second and third pair of
+ * three successive windows; six pairs are alive at a time, so the row loop is unrolled by six. */
+typedef unsigned short ushort2b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2b, a), __builtin_bit_cast(ushort2b, b), c, false);
+}
 __global__ void __launch_bounds__(64 * BLUR_WPB)
 k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, uint8_t* blur,
            const uint32_t* __restrict__ tasks, int ntasks, int nslots, int rows_per_task, BlurTapsV2 T) {
@@ -87,7 +95,6 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
     const uint32_t sel = (uint32_t)(bx[0] - bc) | ((uint32_t)(bx[1] - bc) << 8) | ((uint32_t)(bx[2] - bc) << 16) |
                          ((uint32_t)(bx[3] - bc) << 24);
 
-    uint32_t hq[7][4]; /* ring of row-pass results, hq[r % 7] */
     auto load_row = [&](int yy) -> uint2 { /* raw window; the v_perm happens where the row is consumed */
         const uint32_t* row = (const uint32_t*)(img + (size_t)refl101_v2(yy, h) * pitch + bc);
         return make_uint2(row[0], row[1]);
@@ -102,44 +109,57 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
         o[2] = udot4(Lw, T.l2, udot4(Cw, T.c2, udot4(Rw, T.r2, 0)));
         o[3] = udot4(Cw, T.c3, udot4(Rw, T.r3, 0));
     };
-    /* prologue: rows y0-3 .. y0+2 */
+    /* taps of the pairs: low half = the earlier row */
+    const uint32_t W01 = T.k[0] | (T.k[1] << 16), W23 = T.k[2] | (T.k[3] << 16), W45 = T.k[4] | (T.k[5] << 16);
+    uint32_t pr[6][4]; /* pair k % 6 = rows (k, k + 1), counted from y0 - 3 */
+    uint32_t prev[4];  /* the newest row's results (the low half of the next pair) */
+    /* prologue: rows y0-3 .. y0+2 = rows 0 .. 5, pairs 0 .. 4 */
+    {
+        uint32_t o[4];
+        hpass(load_row(y0 - 3), prev);
 #pragma unroll
-    for (int r = 0; r < 6; r++) hpass(load_row(y0 - 3 + r), hq[r]);
+        for (int r = 1; r < 6; r++) {
+            hpass(load_row(y0 - 3 + r), o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pr[r - 1][c] = prev[c] | (o[c] << 16);
+                prev[c] = o[c];
+            }
+        }
+    }
     const bool writer = lane >= 1 && lane <= 62 && x < w; /* halo lanes and lanes past the image do not store */
-    /* input rows are fetched seven iterations ahead (a ring of 7 dwords): with only a few waves per SIMD one
+    /* input rows are fetched six iterations ahead (a ring of 6 dwords pairs): with only a few waves per SIMD one
      * row of look-ahead left the wave waiting on HBM every iteration */
-    uint2 nw[7];
+    uint2 nw[6];
 #pragma unroll
-    for (int u = 0; u < 7; u++) nw[u] = load_row(y0 + 3 + u);
-    for (int rb = 0; rb < nrows; rb += 7) {
+    for (int u = 0; u < 6; u++) nw[u] = load_row(y0 + 3 + u);
+    for (int rb = 0; rb < nrows; rb += 6) {
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
+        for (int u = 0; u < 6; u++) {
             const int r = rb + u;
             if (r < nrows) { /* wave-uniform */
-                hpass(nw[u], hq[(u + 6) % 7]);
-                if (r + 7 < nrows) nw[u] = load_row(y0 + r + 10);
+                uint32_t o[4];
+                hpass(nw[u], o); /* row r + 6 of the count from y0 - 3: the newest row of output row r's window */
+                if (r + 6 < nrows) nw[u] = load_row(y0 + r + 9);
                 uint32_t px[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    uint32_t acc = 32768u;
-                    if (SYM) { /* sums of two row-pass values stay below 2^24: the 24-bit multiplies are exact */
-                        acc += __umul24(T.k[3], hq[(u + 3) % 7][c]);
-                        acc += __umul24(T.k[0], hq[u % 7][c] + hq[(u + 6) % 7][c]);
-                        acc += __umul24(T.k[1], hq[(u + 1) % 7][c] + hq[(u + 5) % 7][c]);
-                        acc += __umul24(T.k[2], hq[(u + 2) % 7][c] + hq[(u + 4) % 7][c]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 7; k++) acc += __umul24(T.k[k], hq[(u + k) % 7][c]);
-                    }
+                    /* window rows r .. r+6: pairs r, r+2, r+4 and the newest row */
+                    uint32_t acc = __umul24(T.k[6], o[c]) + 32768u;
+                    acc = udot2_u16(pr[(u + 4) % 6][c], W45, acc);
+                    acc = udot2_u16(pr[(u + 2) % 6][c], W23, acc);
+                    acc = udot2_u16(pr[u][c], W01, acc);
                     px[c] = min(acc >> 16, 255u);
+                    pr[(u + 5) % 6][c] = prev[c] | (o[c] << 16); /* pair r+5 = rows (r+5, r+6): used from the next row on */
+                    prev[c] = o[c];
                 }
                 if (writer) {
-                    uint8_t* o = out + (size_t)(y0 + r) * lg.pitch + x;
-                    if (x + 3 < w) *(uint32_t*)o = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                    uint8_t* op = out + (size_t)(y0 + r) * lg.pitch + x;
+                    if (x + 3 < w) *(uint32_t*)op = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
                     else {
-                        o[0] = (uint8_t)px[0];
-                        if (x + 1 < w) o[1] = (uint8_t)px[1];
-                        if (x + 2 < w) o[2] = (uint8_t)px[2];
+                        op[0] = (uint8_t)px[0];
+                        if (x + 1 < w) op[1] = (uint8_t)px[1];
+                        if (x + 2 < w) op[2] = (uint8_t)px[2];
                     }
                 }
             }
@@ -160,13 +180,8 @@ void vk_blur7_v2(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const B
     T.c3 = pk(k0, k1, k2, k3); T.r3 = pk(k4, k5, k6, 0);
     for (int i = 0; i < 7; i++) T.k[i] = taps[i];
     const int nwork = ((ntasks + BLUR_WPB - 1) / BLUR_WPB) * nslots;
-    const bool sym = taps[0] == taps[6] && taps[1] == taps[5] && taps[2] == taps[4];
-    if (sym)
-        hipLaunchKernelGGL(k_blur7_v2<true>, dim3(((nwork + 7) / 8) * 8), dim3(64 * BLUR_WPB), 0, st, pyr, slot_stride, src, g, blur, tasks,
-                       ntasks, nslots, rows_per_task, T);
-    else
-        hipLaunchKernelGGL(k_blur7_v2<false>, dim3(((nwork + 7) / 8) * 8), dim3(64 * BLUR_WPB), 0, st, pyr, slot_stride, src, g, blur, tasks,
-                       ntasks, nslots, rows_per_task, T);
+    hipLaunchKernelGGL(k_blur7_v2, dim3(((nwork + 7) / 8) * 8), dim3(64 * BLUR_WPB), 0, st, pyr, slot_stride, src, g, blur, tasks, ntasks,
+                       nslots, rows_per_task, T);
 }
 
 /* ------------------------------------------------------------------------------------------------
