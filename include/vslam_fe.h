@@ -103,7 +103,9 @@ typedef struct vslam_tuning {
     int32_t wave_prio;            /* VSLAM_WAVE_PRIO: bit mask of kernel classes that raise their wave priority (s_setprio 3)
                                      at entry: 1 = quadtree + output order, 2 = orientation/descriptors, 4 = matchers
                                      (k_si_*, k_stereo_*), 8 = result packing; default 0 */
-    int32_t reserved[3];
+    int32_t oct_precount;         /* VSLAM_OCT_PRECOUNT: 1 = the quadtree's counting walk as a launch of its own with a level's keys dealt
+                                     to up to eight workgroups (k_oct_count); 0 (default) = inside the quadtree workgroup */
+    int32_t reserved[2];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 
@@ -289,6 +291,11 @@ int vslam_hamming_top2(vslam_fe* fe, const uint8_t* dev_q, int nq, const uint8_t
  * (nt[p] <= 65535).  idx2[p] / dist2[p]: host arrays of nq[p] * 2 entries, semantics as above. */
 int vslam_hamming_top2_batch(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
                              const uint8_t* const* dev_t, const int32_t* nt, int32_t* const* idx2, int32_t* const* dist2);
+/* Enqueue-only form for pipelines and profilers: the same launch on fe's stream, nothing waited for or copied; the results
+ * stay in the context's device arrays (rows of all problems back to back).  Sizes as in a previous vslam_hamming_top2_batch
+ * on this context (which allocates); VSLAM_ERR_INVALID otherwise. */
+int vslam_hamming_top2_batch_dev_async(vslam_fe* fe, int nprob, const uint8_t* const* dev_q, const int32_t* nq,
+                                       const uint8_t* const* dev_t, const int32_t* nt);
 
 /* Frame::ComputeStereoFishEyeMatches (frame.cpp:1149-1174), descriptor half: cv::BFMatcher(NORM_HAMMING).knnMatch of the
  * lapping-area descriptors -- left rows [mono_left, n_left) against right rows [mono_right, n_right), k = 2 -- and the

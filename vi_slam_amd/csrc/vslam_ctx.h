@@ -74,6 +74,9 @@ struct vslam_fe {
     CellDesc* d_cells = nullptr;
     int tile_pitch = 0, tile_rows = 0, max_px = 0;
     /* FAST bands (k_fast_bands): up to four cells of a cell row per workgroup; nbands == 0: not available for this geometry */
+    OctPart* d_oct_parts = nullptr; /* k_oct_count: parts of every level; nullptr: walk 1 inside k_octree_v4 */
+    uint32_t* d_oct_cnt = nullptr;  /* leaf counters [B][sum of the levels' leaves] */
+    int oct_maxcells = 0;
     BandDesc* d_bands = nullptr;
     uint8_t* d_band_classes = nullptr; /* 272-byte column tables, BandDesc::lnw >> 16 indexes them */
     int nbands = 0, band_max_wh = 0, band_max_iw = 0;

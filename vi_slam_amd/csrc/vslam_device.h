@@ -64,6 +64,14 @@ struct SelKp {
     uint32_t out;      /* index into the slot's output arrays (lapping-area order, fextractor.cpp:1118-1127) */
 };
 
+/* One part of a level's key-counting walk (k_oct_count): the keys with ylo <= y < yhi -- whole rows of leaves of the implicit
+ * quadtree, so every leaf is counted by exactly one part -- which lie in the FAST cells [ca, cb) (cell rows that overlap the
+ * y range; a cell row on a boundary is read by both parts, each taking its own keys). */
+struct OctPart {
+    int32_t ylo, yhi, ca, cb;
+};
+#define VSLAM_OCT_MAX_PARTS 8
+
 /* Per-level parameters of the GPU quadtree distribution (k_octree). */
 struct OctParams {
     int32_t N[VSLAM_MAX_LEVELS];      /* mnFeaturesPerLevel */
@@ -88,6 +96,14 @@ struct OctParams {
     int32_t fineLdsOff;                /* the fine arrays live in LDS at this byte offset of the dynamic allocation ... */
     int32_t fineLdsBytes;              /* ... and take this many bytes (the largest level's two arrays) */
     const uint32_t* lut;               /* device; nullptr: no fine grid (walk-per-pass kernel only) */
+    /* k_oct_count (vslam_tuning.oct_precount): walk 1 of k_octree_v4 as a launch of its own, a level's keys dealt to up to
+     * eight workgroups by leaf row; the leaf counters travel through fineCnt[slot][fineCntOff[level] + leaf] */
+    const OctPart* parts;              /* [level][VSLAM_OCT_MAX_PARTS]; nullptr: walk 1 inside k_octree_v4 */
+    uint32_t* fineCnt;
+    int32_t fineCntStride;             /* words per slot */
+    int32_t maxPartCells;              /* most FAST cells a part spans (LDS of k_oct_count) */
+    int32_t partBits[VSLAM_MAX_LEVELS];   /* log2(parts of the level) = leading y decisions of the leaf index that select the part */
+    int32_t fineCntOff[VSLAM_MAX_LEVELS]; /* word offset of the level's counters inside a slot */
 };
 
 /* One stereo pair for the matcher kernels (Frame::ComputeStereoMatches). */

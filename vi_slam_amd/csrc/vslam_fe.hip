@@ -41,6 +41,8 @@ static void free_ctx(vslam_fe* fe) {
     for (auto& g : fe->pyr_groups) hipFree(g.d_tiles);
     hipFree(fe->d_cells);
     hipFree(fe->d_bands);
+    hipFree(fe->d_oct_parts);
+    hipFree(fe->d_oct_cnt);
     hipFree(fe->d_band_classes);
     hipFree(fe->d_cand);
     if (fe->h_cand) hipHostFree(fe->h_cand);
@@ -403,6 +405,8 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
         O.selStride = selOff;
         O.maxNodes = (maxNodes + 15) & ~15;
         std::vector<uint32_t> lut;
+        std::vector<OctPart> parts((size_t)VSLAM_MAX_LEVELS * VSLAM_OCT_MAX_PARTS);
+        int maxPartCells = 1, cntWords = 0, maxcells_all = 0;
         {
             /* k_octree_v4's fine grid: one level deeper than the depth at which a full quadtree has N nodes (nIni * 4^d
              * at depth d), so that the split passes, which stop at N nodes, mostly stay above it; keys that cluster
@@ -438,6 +442,44 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 O.lutW[l] = (int32_t)xs.size();
                 lut.insert(lut.end(), xs.begin(), xs.end());
                 lut.insert(lut.end(), ys.begin(), ys.end());
+                /* k_oct_count's parts of the level: rows of leaves = the first kb y decisions of the leaf index; as many
+                 * as leave a part at least ~48 FAST cells (up to eight) */
+                const int cf = fe->level_cell_first[l], cl = fe->level_cell_first[l + 1], ncl = cl - cf;
+                int kb = 0;
+                while (kb < 3 && kb < D && (ncl >> (kb + 1)) >= 48) kb++;
+                O.partBits[l] = kb;
+                O.fineCntOff[l] = cntWords;
+                cntWords += ((O.nIni[l] << (2 * D)) + 3) & ~3;
+                auto part_of = [&](uint32_t code) {
+                    int pb = 0;
+                    for (int t = 0; t < kb; t++) pb = (pb << 1) | (int)((code >> (2 * D - 1 - 2 * t)) & 1u);
+                    return pb;
+                };
+                for (int pi = 0; pi < (1 << kb); pi++) {
+                    OctPart& op = parts[(size_t)l * VSLAM_OCT_MAX_PARTS + pi];
+                    op.ylo = op.yhi = 0;
+                    bool any = false;
+                    for (int y = 0; y <= H; y++)
+                        if (part_of(ys[y]) == pi) {
+                            if (!any) op.ylo = y;
+                            op.yhi = y + 1;
+                            any = true;
+                        }
+                    /* the FAST cells whose interior rows (border-relative: y0 + 3 - 16 .. y1 - 3 - 16) meet [ylo, yhi);
+                     * cells are listed cell row by cell row, so they are one contiguous range */
+                    op.ca = op.cb = cf;
+                    bool first = true;
+                    for (int c = cf; c < cl && any; c++) {
+                        const int cy0 = (int)fe->cells[c].y0 + 3 - VSLAM_FAST_BORDER, cy1 = (int)fe->cells[c].y1 - 3 - VSLAM_FAST_BORDER;
+                        if (cy1 > op.ylo && cy0 < op.yhi) {
+                            if (first) op.ca = c;
+                            op.cb = c + 1;
+                            first = false;
+                        }
+                    }
+                    maxPartCells = std::max(maxPartCells, op.cb - op.ca);
+                }
+                maxcells_all = std::max(maxcells_all, O.nIni[l] << (2 * D));
             }
             O.fineLdsOff = (int32_t)nb;
             O.fineLdsBytes = (int32_t)(2 * ((size_t)maxcells + 1) * 4 + 16);
@@ -469,6 +511,28 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
                 int rc;
                 if ((rc = upload(&fe->d_oct_lut, lut.data(), lut.size() * 4))) return rc;
                 O.lut = fe->d_oct_lut;
+                /* vslam_tuning.oct_precount = 1: walk 1 as k_oct_count, a level's keys over up to eight workgroups.  Built and
+                 * measured in round 4 (profiles/r04_oct_precount_ab.txt), bit-exact, and NOT the default: the stage is 4 % shorter
+                 * for 32 KITTI frames (78 vs 81 us) but 9 % longer at 1080p (253 vs 232 us) and 11 % longer for one or two
+                 * frames (52 vs 47 us; 0.129 vs 0.126 ms per frame end to end): a part's walk is a chain of dependent round
+                 * trips per batch of keys, not a matter of keys per CU -- eight parts of 256 threads still make 21 of them where
+                 * the 512-thread workgroup made 48 -- and what they save is spent on a launch boundary, on every part summing
+                 * the level's cell counts again, and on walk 2 reading keys another CU wrote.  Its three prefix sums travel in
+                 * 21-bit fields: candidate buffers of 2^21 entries and more keep the walk inside in any case */
+                fe->oct_maxcells = maxcells_all;
+                if (tune_or(fe->tune.oct_precount, 0) == 1 && fe->cand_cap < (1 << 21)) {
+                    if ((rc = upload(&fe->d_oct_parts, parts.data(), parts.size() * sizeof(OctPart)))) return rc;
+                    HIPCHK(hipMalloc((void**)&fe->d_oct_cnt, (size_t)fe->B * cntWords * 4));
+                    HIPCHK(hipMemset(fe->d_oct_cnt, 0, (size_t)fe->B * cntWords * 4));
+                    if (vk_oct_count_set_max_lds(vk_oct_count_lds(maxcells_all, maxPartCells)) != 0) {
+                        g_err = "hipFuncSetAttribute(k_oct_count, max dynamic LDS) failed";
+                        return VSLAM_ERR_HIP;
+                    }
+                    O.parts = fe->d_oct_parts;
+                    O.fineCnt = fe->d_oct_cnt;
+                    O.fineCntStride = cntWords;
+                    O.maxPartCells = maxPartCells;
+                }
             } else {
                 HIPCHK(hipMalloc((void**)&fe->d_nid, np * 2));
             }
@@ -1055,6 +1119,9 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     enqueue_blur(fe, nimg);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[4], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[7], st));
+    if (fe->oct.parts)
+        vk_oct_count(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1], (size_t)fe->cand_cap,
+                     p.nlevels, nimg, fe->oct_maxcells);
     vk_octree(st, fe->d_cand, fe->cand_stride, (int)fe->cells.size(), fe->oct, fe->d_pts[0], fe->d_pts[1],
               fe->d_nid, fe->d_oct_sorted, (size_t)fe->cand_cap, fe->d_sel_xyr, fe->d_sel_cnt, d_err, p.nlevels, nimg,
               fe->d_oct_redo, fe->tune.oct_regkeys, fe->oct_threads, wave_prio_on(fe->tune, 1));

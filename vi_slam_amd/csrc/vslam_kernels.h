@@ -49,6 +49,12 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
                uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
                int regkeys, int threads = 1024, int prio = 0);
+/* k_oct_count: walk 1 of the quadtree as a launch of its own (OctParams::parts); LDS = counters of the largest level + the
+ * cell offsets of the largest part */
+size_t vk_oct_count_lds(int maxcells, int maxPartCells);
+int vk_oct_count_set_max_lds(size_t bytes);
+void vk_oct_count(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P, uint32_t* keys_a,
+                  uint32_t* aux_a, size_t pts_stride, int nlevels, int nslots, int maxcells);
 void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uint32_t* sel_xyr, int32_t* sel_cnt, int lap0,
                    int lap1, SelKp* sel, int32_t* slot_counts, int cap, int32_t* err_flag, int nslots,
                    const int32_t* deep_flags, int prio = 0);

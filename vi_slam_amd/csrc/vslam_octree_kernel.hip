@@ -561,7 +561,9 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 /* REGKEYS: keys (and their cell | rank words) of problems up to OKPT * 1024 keys stay in registers between the two walks
  * (1-2 images: latency); otherwise both are written to the slot's scratch by walk 1 and re-read, coalesced, by walk 2
  * (batches: fewer VGPRs, so that foreign waves fit next to a 1024-thread workgroup). */
-template <bool REGKEYS, int OTV> /* OTV: threads of the workgroup (256 / 512 / 1024, vk_octree) */
+/* PRE (round 4, vslam_tuning.oct_precount): walk 1 has run as k_oct_count -- the keys of the level are in pa[] in key order, their
+ * leaf | rank << 16 in aux[], the leaf counters in P.fineCnt -- and this kernel starts from the counts. */
+template <bool REGKEYS, int OTV, bool PRE = false> /* OTV: threads of the workgroup (256 / 512 / 1024, vk_octree) */
 __global__ void __launch_bounds__(OTV)
 k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* keys_a,
             uint32_t* aux_a, uint2* sorted_a, size_t pts_stride, uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag,
@@ -639,16 +641,18 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
      * sizes MAXN >= ncl / 4, i.e. 14 * MAXN words of node arrays): the walk needs ONE global round trip (the keys) */
     uint32_t* coff = (uint32_t*)nxt;
     uint32_t* cbas = coff + ncl + 1;
-    for (int k = 0; k < K; k++) {
-        const int c = c0 + tid * K + k;
-        if (c < c1) {
-            const CellOut co = cout[c];
-            coff[c - c0] = woff;
-            cbas[c - c0] = co.base;
-            woff += co.count;
+    if (!PRE) {
+        for (int k = 0; k < K; k++) {
+            const int c = c0 + tid * K + k;
+            if (c < c1) {
+                const CellOut co = cout[c];
+                coff[c - c0] = woff;
+                cbas[c - c0] = co.base;
+                woff += co.count;
+            }
         }
+        if (tid == 0) coff[ncl] = ntot;
     }
-    if (tid == 0) coff[ncl] = ntot;
     if (n == 0) {
         if (tid == 0) *ocnt = 0;
         return;
@@ -662,17 +666,22 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     uint32_t* PS = Hc + cells + 1;                  /* their exclusive prefix sums */
     const uint32_t* __restrict__ xs = P.lut + P.lutOff[level];
     const uint32_t* __restrict__ ys = xs + P.lutW[level];
-    for (int i = tid; i <= cells; i += OTV) Hc[i] = 0u;
+    if (PRE) { /* the counters k_oct_count left for this (slot, level) */
+        const uint32_t* __restrict__ Hg = P.fineCnt + (size_t)slot * P.fineCntStride + P.fineCntOff[level];
+        for (int i = tid; i <= cells; i += OTV) Hc[i] = i < cells ? Hg[i] : 0u;
+    } else {
+        for (int i = tid; i <= cells; i += OTV) Hc[i] = 0u;
+    }
     /* the path tables are cold (another XCD's L2 or HBM) the first time a workgroup touches them: start pulling their
      * lines now, the key loads below hide the round trip */
     uint32_t warm = 0u;
-    if (tid * 16 < P.lutW[level] + Hh + 1) warm = xs[tid * 16]; /* consumed (by nothing) behind walk 1 */
+    if (!PRE && tid * 16 < P.lutW[level] + Hh + 1) warm = xs[tid * 16]; /* consumed (by nothing) behind walk 1 */
     __syncthreads();
 
     /* positions are dealt to WAVES in contiguous chunks of EW (a multiple of 64) and to the lanes of a wave interleaved:
      * lane l holds positions wbeg + 64 k + l, so that a wave's loads (mostly one FAST cell segment after the other) and
      * its stores are coalesced */
-    const bool inReg = REGKEYS && n <= OKPT * OTV;
+    const bool inReg = !PRE && REGKEYS && n <= OKPT * OTV;
     const int KW = (n + OTV - 1) / OTV, EW = KW * 64; /* keys per lane, positions per wave */
     const int wbeg = wv * EW;
     uint32_t keyR[OKPT];
@@ -681,7 +690,7 @@ k_octree_v4(const uint8_t* __restrict__ cand_region, size_t cand_stride, int nce
     for (int k = 0; k < OKPT; k++) keyR[k] = auxR[k] = 0u;
 
     /* ---- 1. walk 1: read every key, count it into its fine cell; the counter's old value is its rank in the cell */
-    {
+    if (!PRE) {
         const int p0 = wbeg + lane;
         int c = 0;
         if (p0 < n) {
@@ -1134,6 +1143,156 @@ k_assign_out(OctParams P, PyramidGeom g, uint32_t* sel_xyr, int32_t* sel_cnt,
 
 size_t vk_octree_lds_bytes(int maxNodes) { return (size_t)maxNodes * (16 + 16 + 8 + 8 + 2 + 2 + 2 + 2) + 64; }
 
+/* ------------------------------------------------------------------------------------------------
+ * k_oct_count (round 4): walk 1 of k_octree_v4 -- every key read once and counted into its leaf, the
+ * counter's old value being its rank in the leaf -- as a launch of its own in which a level's keys are dealt to up to eight
+ * workgroups.  The parts are ROWS OF LEAVES: a key's part is the leading y decisions of its leaf index (P.partBits), i.e. a
+ * y range (OctPart), so every leaf is counted by exactly one workgroup -- its rank needs no merging -- and a part reads the
+ * FAST cell rows that overlap its y range (a row on a boundary is read by both parts; each takes its own keys).  The
+ * level-0 problem of a 1080p frame (65 k keys, 55 us of look-ups and LDS atomics on ONE CU inside k_octree_v4) becomes
+ * eight workgroups of 8 k keys.  Outputs: pa[] (keys in key order), aux[] (leaf | rank << 16) and the leaf counters.
+ * ---------------------------------------------------------------------------------------------- */
+#define OCNT_T 256
+__global__ void __launch_bounds__(OCNT_T)
+k_oct_count(const uint8_t* __restrict__ cand_region, size_t cand_stride, int ncells, OctParams P, uint32_t* keys_a,
+            uint32_t* aux_a, size_t pts_stride) {
+    extern __shared__ __align__(16) uint8_t csm[];
+    __shared__ u64 s_w64[OCNT_T / 64];
+    __shared__ uint32_t s_w32[OCNT_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int part = blockIdx.x, level = blockIdx.y, slot = blockIdx.z;
+    const int kb = P.partBits[level];
+    if (part >= (1 << kb)) return;
+    const OctPart pt = P.parts[level * VSLAM_OCT_MAX_PARTS + part];
+    const uint32_t* hdr = (const uint32_t*)(cand_region + (size_t)slot * cand_stride);
+    const CellOut* cout = (const CellOut*)(hdr + 2);
+    const uint32_t* cand = (const uint32_t*)(cout + ncells);
+    const int c0 = P.cellFirst[level], c1 = P.cellFirst[level + 1];
+    /* keys of the levels in front of this one | of this level in front of the part's cells | of this level: three 21-bit
+     * sums in one scan (a level of 2^20 keys or more is refused by k_octree_v4 anyway) */
+    u64 sums = 0ull;
+    for (int c = tid; c < c1; c += OCNT_T) {
+        const u64 cnt = cout[c].count;
+        sums += c < c0 ? cnt : (cnt << 42) | (c < pt.ca ? cnt << 21 : 0ull);
+    }
+    u64 tot3;
+    block_excl_scan<u64, OCNT_T>(sums, s_w64, &tot3);
+    const uint32_t off0 = (uint32_t)(tot3 & 0x1FFFFFull), Sa = (uint32_t)((tot3 >> 21) & 0x1FFFFFull);
+    const uint32_t n = (uint32_t)(tot3 >> 42);
+    if (off0 + n > (uint32_t)P.ptsCap || n >= (1u << 20) || hdr[1] != 0 || n == 0) return; /* k_octree_v4 reports it */
+    uint32_t* pa = keys_a + (size_t)slot * pts_stride + off0;
+    uint32_t* aux = aux_a + (size_t)slot * pts_stride + off0;
+    const int D = P.fineD[level];
+    const int cells = P.nIni[level] << (2 * D);
+    uint32_t* Hl = (uint32_t*)csm;          /* this part's leaf counters (all leaves; only its own are ever touched) */
+    uint32_t* coff = Hl + cells + 1;        /* first local position of every cell of the part (+ sentinel) */
+    uint32_t* cbas = coff + P.maxPartCells + 1;
+    const int ncl = pt.cb - pt.ca, K = (ncl + OCNT_T - 1) / OCNT_T;
+    uint32_t mine = 0;
+    for (int k = 0; k < K; k++) {
+        const int c = pt.ca + tid * K + k;
+        if (c < pt.cb) mine += cout[c].count;
+    }
+    uint32_t npart;
+    uint32_t woff = block_excl_scan<uint32_t, OCNT_T>(mine, s_w32, &npart);
+    for (int k = 0; k < K; k++) {
+        const int c = pt.ca + tid * K + k;
+        if (c < pt.cb) {
+            const CellOut co = cout[c];
+            coff[c - pt.ca] = woff;
+            cbas[c - pt.ca] = co.base;
+            woff += co.count;
+        }
+    }
+    if (tid == 0) coff[ncl] = npart;
+    for (int i = tid; i <= cells; i += OCNT_T) Hl[i] = 0u;
+    const uint32_t* __restrict__ xs = P.lut + P.lutOff[level];
+    const uint32_t* __restrict__ ys = xs + P.lutW[level];
+    __syncthreads();
+    /* local positions are dealt to waves in contiguous chunks and to the lanes of a wave interleaved, as in k_octree_v4 */
+    const int np = (int)npart;
+    const int KW = (np + OCNT_T - 1) / OCNT_T, EW = KW * 64;
+    const int p0 = wv * EW + lane;
+    if (np > 0) {
+        int c = 0;
+        if (p0 < np) {
+            int lo = 0, hi = ncl - 1; /* last cell with coff <= p0 */
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (coff[mid] <= (uint32_t)p0) lo = mid;
+                else hi = mid - 1;
+            }
+            c = lo;
+        }
+        uint32_t cbase = p0 < np ? cbas[c] : 0u, cfirst = p0 < np ? coff[c] : 0u, cnext = p0 < np ? coff[c + 1] : 0u;
+        for (int kb0 = 0; kb0 < KW; kb0 += O4BATCH) {
+            uint32_t kk[O4BATCH], ff[O4BATCH];
+            bool own[O4BATCH];
+#pragma unroll
+            for (int j = 0; j < O4BATCH; j++) {
+                const int i = p0 + 64 * (kb0 + j);
+                kk[j] = 0u;
+                own[j] = false;
+                if (kb0 + j < KW && i < np) {
+                    while ((uint32_t)i >= cnext) {
+                        c++;
+                        cfirst = cnext;
+                        cnext = coff[c + 1];
+                        cbase = cbas[c];
+                    }
+                    kk[j] = cand[cbase + ((uint32_t)i - cfirst)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < O4BATCH; j++) {
+                const int i = p0 + 64 * (kb0 + j);
+                const int y = (int)((kk[j] >> 12) & 0xFFF);
+                own[j] = kb0 + j < KW && i < np && y >= pt.ylo && y < pt.yhi;
+                ff[j] = own[j] ? xs[kk[j] & 0xFFF] | ys[y] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < O4BATCH; j++)
+                if (own[j]) ff[j] |= atomicAdd(&Hl[ff[j]], 1u) << 16;
+#pragma unroll
+            for (int j = 0; j < O4BATCH; j++)
+                if (own[j]) {
+                    const uint32_t pos = Sa + (uint32_t)(p0 + 64 * (kb0 + j)); /* position in the level's key order */
+                    pa[pos] = kk[j];
+                    aux[pos] = ff[j];
+                }
+        }
+    }
+    __syncthreads();
+    /* the counters of this part's leaves: leaf index = root << 2D | (y_d << 1 | x_d) per depth, the part = its first kb y bits */
+    uint32_t* Hg = P.fineCnt + (size_t)slot * P.fineCntStride + P.fineCntOff[level];
+    for (int leaf = tid; leaf < cells; leaf += OCNT_T) {
+        int pb = 0;
+        for (int t = 0; t < kb; t++) pb = (pb << 1) | (int)(((uint32_t)leaf >> (2 * D - 1 - 2 * t)) & 1u);
+        if (pb == part) Hg[leaf] = Hl[leaf];
+    }
+}
+
+size_t vk_oct_count_lds(int maxcells, int maxPartCells) { return ((size_t)maxcells + 1 + 2 * ((size_t)maxPartCells + 1)) * 4 + 16; }
+
+int vk_oct_count_set_max_lds(size_t bytes) {
+    static std::mutex mu;
+    static size_t have_dev[64] = {0};
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (bytes <= have_dev[dev]) return 0;
+    const int rc = (int)hipFuncSetAttribute((const void*)k_oct_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc) return rc;
+    have_dev[dev] = bytes;
+    return 0;
+}
+
+void vk_oct_count(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P, uint32_t* keys_a,
+                  uint32_t* aux_a, size_t pts_stride, int nlevels, int nslots, int maxcells) {
+    hipLaunchKernelGGL(k_oct_count, dim3(VSLAM_OCT_MAX_PARTS, nlevels, nslots), dim3(OCNT_T), vk_oct_count_lds(maxcells, P.maxPartCells), st,
+                       cand_region, cand_stride, ncells, P, keys_a, aux_a, pts_stride);
+}
+
 void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, int ncells, const OctParams& P,
                uint32_t* keys_a, uint32_t* aux_a, uint16_t* nid_a, void* sorted_a, size_t pts_stride,
                uint32_t* sel_xyr, int32_t* sel_cnt, int32_t* err_flag, int nlevels, int nslots, int32_t* deep_flags,
@@ -1154,13 +1313,18 @@ void vk_octree(hipStream_t st, const uint8_t* cand_region, size_t cand_stride, i
          * slots and issue cycles to the other contexts' kernels: 256 instead of 1024 threads is +4 % mono, +7 % stereo,
          * +13 % mono at 2000 features in the pipeline; 1080p, with 65 k keys on level 0, wants 512 (+2 %; 256: -2 %) */
         const int th = rk ? 1024 : (threads == 256 || threads == 512) ? threads : 1024;
-#define OCT4_LAUNCH(RK, TH)                                                                                               \
-    hipLaunchKernelGGL((k_octree_v4<RK, TH>), grid, dim3(TH), lds, st, cand_region, cand_stride, ncells, Pq, keys_a, aux_a, \
+#define OCT4_LAUNCH(RK, TH, PRE)                                                                                          \
+    hipLaunchKernelGGL((k_octree_v4<RK, TH, PRE>), grid, dim3(TH), lds, st, cand_region, cand_stride, ncells, Pq, keys_a, aux_a, \
                        (uint2*)sorted_a, pts_stride, sel_xyr, sel_cnt, err_flag, deep_flags)
-        if (rk) OCT4_LAUNCH(true, 1024);
-        else if (th == 256) OCT4_LAUNCH(false, 256);
-        else if (th == 512) OCT4_LAUNCH(false, 512);
-        else OCT4_LAUNCH(false, 1024);
+        if (Pq.parts) { /* walk 1 ran as k_oct_count: the keys are not in registers, whatever the batch size */
+            const int tp = rk ? 1024 : th;
+            if (tp == 256) OCT4_LAUNCH(false, 256, true);
+            else if (tp == 512) OCT4_LAUNCH(false, 512, true);
+            else OCT4_LAUNCH(false, 1024, true);
+        } else if (rk) OCT4_LAUNCH(true, 1024, false);
+        else if (th == 256) OCT4_LAUNCH(false, 256, false);
+        else if (th == 512) OCT4_LAUNCH(false, 512, false);
+        else OCT4_LAUNCH(false, 1024, false);
 #undef OCT4_LAUNCH
     }
     else
@@ -1189,9 +1353,11 @@ int vk_octree_set_max_lds(size_t bytes) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
     size_t& have = have_dev[dev];
     if (bytes <= have) return 0;
-    const void* fns[5] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true, 1024>, (const void*)k_octree_v4<false, 1024>,
-                          (const void*)k_octree_v4<false, 512>, (const void*)k_octree_v4<false, 256>};
-    for (int i = 0; i < 5; i++) {
+    const void* fns[8] = {(const void*)k_octree_v2, (const void*)k_octree_v4<true, 1024>, (const void*)k_octree_v4<false, 1024>,
+                          (const void*)k_octree_v4<false, 512>, (const void*)k_octree_v4<false, 256>,
+                          (const void*)k_octree_v4<false, 1024, true>, (const void*)k_octree_v4<false, 512, true>,
+                          (const void*)k_octree_v4<false, 256, true>};
+    for (int i = 0; i < 8; i++) {
         const int rc = (int)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (rc) return rc;
     }

@@ -48,6 +48,7 @@ const EnvField kEnv[] = {
     TF("VSLAM_FAST_KERNEL", fast_kernel, nullptr, nullptr),
     TF("VSLAM_FAST_BAND_CELLS", fast_band_cells, nullptr, nullptr),
     TF("VSLAM_WAVE_PRIO", wave_prio, nullptr, nullptr),
+    TF("VSLAM_OCT_PRECOUNT", oct_precount, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;
