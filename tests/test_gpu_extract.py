@@ -109,6 +109,26 @@ def test_other_geometries(cfg):
         fe.close()
 
 
+@pytest.mark.parametrize("cfg", [(1241, 376, 2000, 4, -1), (1920, 1080, 4000, 3, -1), (640, 360, 600, 2, 1), (752, 480, 5000, 2, 3)])
+def test_quadtree_with_the_counting_walk_as_its_own_launch(cfg):
+    """vslam_tuning.oct_precount = 1 (k_oct_count: a level's keys dealt to up to eight workgroups by rows of leaves, the
+    quadtree kernel starts from the counters) and fast_kernel = 4 for small batches too: same keypoints and descriptors as the
+    oracle, also with a forced shallow / deep fine grid (every node splits below it)"""
+    w, h, nf, b, fd = cfg
+    tn = dict(oct_precount=1, fast_kernel=4)
+    if fd >= 0:
+        tn["oct_fine_depth"] = fd
+    fe = V.FExtractor(nf, 1.2, 8, 20, 7, w, h, max_batch=b, tuning=tn)
+    try:
+        imgs = [synth.make_frame(w, h, seed=5, step=s) for s in range(b)]
+        out = fe.compute_batch(imgs)
+        e = orbo.Extractor(nf)
+        for s in (0, b - 1):
+            _assert_same(out[s], e.compute(imgs[s]), (cfg, s))
+    finally:
+        fe.close()
+
+
 def test_low_texture_cells_fall_back_to_min_threshold():
     # faint texture only: no FAST corner at 20 anywhere, cells must rerun at 7 (fextractor.cpp:803-807)
     rng = np.random.default_rng(8)
