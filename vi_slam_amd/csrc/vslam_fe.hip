@@ -207,7 +207,11 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
              * issue slots; short ones (16) for contexts of one or two images, where a frame's latency counts and more
              * workgroups per image finish sooner (batch-1 latency through the C ABI: 0.135 ms with 12-16 rows, 0.137 with
              * 20-28, 0.142 with 36, 0.146 with 48) */
-            const int pyr_rows = fe->tune.pyr_rows >= 0 ? fe->tune.pyr_rows : (fe->B <= 2 ? 16 : 48);
+            /* tile height: 16 rows for one or two images (latency), 48 for batches -- least halo, which is what counts in a
+             * VALU-bound pipeline -- and 40 above a megapixel, where the step is the sum of the wide kernels' single-context
+             * times and the pyramid alone is 7 % shorter with smaller tiles (profiles/r04_pyramid_tile_sweep.txt: 1080p +1.8 %) */
+            const int pyr_rows = fe->tune.pyr_rows >= 0 ? fe->tune.pyr_rows
+                                 : fe->B <= 2 ? 16 : (size_t)p.width * p.height > 1000000 ? 40 : 48;
 #ifndef VSLAM_PYR_LDS_KB
 #define VSLAM_PYR_LDS_KB 64 /* LDS a pyramid tile's cascade may take (32 / 48 / 96 measured) */
 #endif

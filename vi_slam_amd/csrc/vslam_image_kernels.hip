@@ -1455,14 +1455,13 @@ void vk_fast_bands(hipStream_t st, const uint8_t* pyr, size_t slot_stride, const
      * instructions for the shorter rows' idle lanes; removed.) */
     (void)max_iw;
     constexpr int P = 136, NT = 256;
-    const bool narrow = false;
-    /* LDS per workgroup: 32 waves per CU fit when a four-wave band takes at most 20 KB (a two-wave band 10 KB).  The list
+    /* LDS per workgroup: 32 waves per CU fit when a four-wave band takes at most 20 KB.  The list
      * gets what the window, the score tile and the tables leave: enough for every pixel of the usual band (cells of up to
      * ~34 rows: one chunk); taller bands are swept in chunks (the kernel derives the chunk height from the space it
      * finds).  Never less than the tallest band needs for chunks of 8 rows with every pixel listed twice, nor than what a
      * sweep's idle lanes may READ (rows up to an iteration's height below the window: results dropped, but the
      * addresses stay inside the allocation). */
-    const size_t budget = (narrow ? 10240 : 20480) - 64; /* 64: the kernel's static variables */
+    const size_t budget = 20480 - 64; /* 64: the kernel's static variables */
     size_t lds = std::max(budget, fast_band_fixed_lds(max_wh, P) + 2 * (size_t)(8 * 2 * (P - 8)));
     lds = std::max(lds, (size_t)(max_wh + NT / 8 + 1) * P + 256);
     lds = (lds + 15) & ~(size_t)15;
