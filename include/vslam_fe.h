@@ -105,7 +105,9 @@ typedef struct vslam_tuning {
                                      (k_si_*, k_stereo_*), 8 = result packing; default 0 */
     int32_t oct_precount;         /* VSLAM_OCT_PRECOUNT: 1 = the quadtree's counting walk as a launch of its own with a level's keys dealt
                                      to up to eight workgroups (k_oct_count); 0 (default) = inside the quadtree workgroup */
-    int32_t reserved[2];
+    int32_t desc_kpw;             /* VSLAM_DESC_KPW: 1 | 4 keypoints per wave of the descriptor kernel (default: 1 for contexts of one or
+                                     two images, else 4) */
+    int32_t reserved[1];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

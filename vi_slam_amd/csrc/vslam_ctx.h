@@ -48,6 +48,7 @@ struct vslam_fe {
     hipEvent_t ev_cand = nullptr;
     hipEvent_t ev_x = nullptr; /* cross-context ordering (vslam_fe_wait_for) */
     hipEvent_t ev_user[4] = {};  /* vslam_fe_event_record / _wait */
+    int desc_kpw_hint = -1;           /* keypoints per wave of the descriptor kernel for the pass being enqueued (-1: by batch size) */
     hipEvent_t ev_fast = nullptr;     /* recorded behind the FAST launch of every pass once a gate refers to this context */
     vslam_fe* fast_gate = nullptr;    /* vslam_fe_set_fast_gate: this context's FAST waits for that context's last FAST */
     bool fast_gated_by_someone = false;

@@ -1135,7 +1135,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
-                           nimg, wave_prio_on(fe->tune, 2));
+                           nimg, wave_prio_on(fe->tune, 2), fe->tune.desc_kpw >= 0 ? fe->tune.desc_kpw : fe->desc_kpw_hint);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
     HIPCHK(hipGetLastError());
     return VSLAM_OK; /* counts travel to the host with the results (vslam_enqueue_extract) */

@@ -429,12 +429,17 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
-                            int cap, int atan_fma, int nslots, int prio) {
-    const int kpw = nslots <= 2 ? 1 : DESC_KPW;
+                            int cap, int atan_fma, int nslots, int prio, int kpw_override) {
+    /* keypoints per wave: 4, one after the other with the next one's loads in flight (110 VGPRs, 4 waves per SIMD), for batches;
+     * 1 (48 VGPRs, 8 waves per SIMD, four times the waves) for one or two images; vslam_tuning.desc_kpw forces either */
+    const int kpw = kpw_override == 1 ? 1 : kpw_override == 2 ? 2 : kpw_override == DESC_KPW ? DESC_KPW : nslots <= 2 ? 1 : DESC_KPW;
     const int per_wg = DESC_WPB * kpw;
     const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
     if (kpw == 1)
         hipLaunchKernelGGL(k_orient_describe_dev<1>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
+                           src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork, prio);
+    else if (kpw == 2)
+        hipLaunchKernelGGL(k_orient_describe_dev<2>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,
                            src, g, sel, slot_counts, pattern, kps, desc, cap, atan_fma, bps, nwork, prio);
     else
         hipLaunchKernelGGL(k_orient_describe_dev<DESC_KPW>, dim3(((nwork + 7) / 8) * 8), dim3(64 * DESC_WPB), 0, st, pyr, blur, slot_stride,

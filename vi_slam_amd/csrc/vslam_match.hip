@@ -153,7 +153,13 @@ extern "C" int vslam_frame_stereo_batch_async(vslam_fe* fe, int npairs, const ui
     const bool blk = want_host && fe->dev_octree && 2 * npairs == fe->B && fe->res_init_bytes >= (size_t)npairs * fe->cap * 8 &&
                      fe->block_region_owner != VSLAM_REGION_INIT && fe->d_res;
     if (blk) fe->block_region_owner = VSLAM_REGION_STEREO;
+    /* stereo frames: the contexts of a pipelined caller are independent of each other and the step is the sum of the wide
+     * kernels' single-context times; the descriptor kernel alone is 8-10 % shorter with one keypoint per wave (48 VGPRs, 8 waves
+     * per SIMD) than with four (110 VGPRs, 4 waves, the trigonometry of four keypoints in one pass: fewer instructions, which
+     * is what the VALU-bound mono pipeline wants): KITTI stereo +3.3 %, profiles/r04_describe_kpw_ab.txt */
+    fe->desc_kpw_hint = 1;
     int rc = vslam_enqueue_extract(fe, 2 * npairs, imgs, pitch, imgs_on_device, 0, 0, blk ? 2 : (want_host != 0));
+    fe->desc_kpw_hint = -1;
     if (rc == VSLAM_OK) {
         int sl[VSLAM_MAX_STEREO_JOBS], sr[VSLAM_MAX_STEREO_JOBS];
         for (int j = 0; j < npairs; j++) {

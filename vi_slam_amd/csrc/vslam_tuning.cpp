@@ -49,6 +49,7 @@ const EnvField kEnv[] = {
     TF("VSLAM_FAST_BAND_CELLS", fast_band_cells, nullptr, nullptr),
     TF("VSLAM_WAVE_PRIO", wave_prio, nullptr, nullptr),
     TF("VSLAM_OCT_PRECOUNT", oct_precount, nullptr, nullptr),
+    TF("VSLAM_DESC_KPW", desc_kpw, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;
