@@ -513,6 +513,30 @@ int vslam_voc_create(int device, int depth_levels, int weighting, int norm, int 
                      const int32_t* child_count, const int32_t* child_ids, int n_child_ids, const uint8_t* node_desc,
                      const double* node_weight, const int32_t* node_word_id, vslam_voc** out);
 void vslam_voc_destroy(vslam_voc* voc);
+/* DBoW3::Vocabulary::load(const std::string&) (thirdparty/DBoW3/DBoW3/src/Vocabulary.cpp:1084-1112), the call
+ * core::System makes at start-up (src/core/system.cpp:76).  vslam_voc_load reads the file and uploads it; the
+ * vslam_voc_file_* functions are its host half (no GPU needed): open parses, info / arrays expose the flat node table
+ * in vslam_voc_create's layout (pointers stay valid until close).  Formats, tried in the reference's order: DBoW3's
+ * binary stream (magic 88877711233; format 1 plain, 2 in QuickLZ level-1 chunks -- what Vocabulary::save writes by
+ * default under any file name), then the text form for names containing ".txt" (format 3; weights keep float
+ * precision as in load_fromtxt, :1372-1446).  cv::FileStorage YAML/XML vocabularies and descriptors other than
+ * 1 x 32 CV_8U return VSLAM_ERR_UNSUPPORTED; a damaged file returns VSLAM_ERR_INVALID (every read is bounds-checked).
+ * scoring is DBoW3's ScoringType (0 L1_NORM .. 5 DOT_PRODUCT); norm is what its scoring object's mustNormalize says,
+ * in vslam_voc_create's encoding.  vslam_voc_file_last_error: message of the last failed vslam_voc_file_* call of
+ * this thread (vslam_voc_load copies it into vslam_last_error). */
+typedef struct vslam_voc_file vslam_voc_file;
+int vslam_voc_file_open(const char* path, vslam_voc_file** out);
+void vslam_voc_file_close(vslam_voc_file* f);
+int vslam_voc_file_info(const vslam_voc_file* f, int* branching, int* depth_levels, int* scoring, int* weighting,
+                        int* norm, int* n_nodes, int* n_words, int* n_child_ids, int* format);
+int vslam_voc_file_arrays(const vslam_voc_file* f, const int32_t** child_start, const int32_t** child_count,
+                          const int32_t** child_ids, const uint8_t** node_desc, const double** node_weight,
+                          const int32_t** node_word_id);
+const char* vslam_voc_file_last_error(void);
+int vslam_voc_load(int device, const char* path, vslam_voc** out);
+/* test hook of the reader: decode one QuickLZ 1.5 level-1 packet (header + payload) of at most n bytes into dst;
+ * returns the decoded size and the packet's size in *used, -1 for a damaged packet or a short dst. */
+long vslam_dbg_qlz_decode(const uint8_t* packet, size_t n, uint8_t* dst, size_t cap, size_t* used);
 int vslam_voc_info(const vslam_voc* voc, int* depth_levels, int* weighting, int* norm, int* n_nodes);
 int vslam_bow_transform(vslam_fe* fe, const vslam_voc* voc, const uint8_t* dev_desc, int n, int levelsup,
                         int32_t* word_id, double* weight, int32_t* node_id);

@@ -477,6 +477,36 @@ def test_compute_bow_tree_walk_and_vectors(fe):
         Vt.close()
 
 
+def test_vocabulary_loaded_from_dbow3_files(fe, tmp_path, golden_dir):
+    """Vocabulary::load (Vocabulary.cpp:1084-1112) -> ComputeBoW: the plain binary stream, the committed stream whose
+    chunks the reference's QuickLZ compressed, and the text form give the BowVector / FeatureVector of the oracle fed
+    with the arrays the files were written from (text: weights rounded to float, as load_fromtxt does)."""
+    import vocfile
+    res = fe.compute_batch([synth.make_frame(1241, 376, step=5)])
+    _, pd, n = fe.slot_buffers(0)
+    desc = res[0][1].copy()
+    voc = synth.make_vocabulary(8, 3, seed=5)
+    cases = [(os.path.join(golden_dir, "voc_k8_L3_quicklz.dbow3"), voc)]
+    vocfile.write_binary(str(tmp_path / "plain.dbow3"), voc)
+    cases.append((str(tmp_path / "plain.dbow3"), voc))
+    vocfile.write_text(str(tmp_path / "ORBvoc.txt"), voc)
+    as_text = dict(voc, weight=voc["weight"].astype(np.float32).astype(np.float64))
+    cases.append((str(tmp_path / "ORBvoc.txt"), as_text))
+    for path, v in cases:
+        vv = V.Vocabulary.load(path)
+        try:
+            assert (vv.L, vv.weighting, vv.norm, vv.n_nodes) == (3, 0, 1, 585)
+            got = vv.transform(fe, pd, n, 2)
+            want = orbo.bow_transform(v, desc, 2)
+            for k in ("word", "weight", "nid", "bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+                assert np.array_equal(got[k], want[k]), (path, k)
+        finally:
+            vv.close()
+    with pytest.raises(V.VslamError) as e:
+        V.Vocabulary.load(str(tmp_path / "nothing.dbow3"))
+    assert e.value.code == V.ERR_INVALID and "cannot open" in str(e.value)
+
+
 @pytest.mark.parametrize("k,L,levelsup,ratio,ori", [(10, 4, 2, 0.7, True), (10, 5, 4, 0.9, False), (4, 3, 3, 0.75, True)])
 def test_search_by_bow_equals_oracle(fe, k, L, levelsup, ratio, ori):
     """FMatcher::SearchByBoW (fmatcher.cpp:546-748): ComputeBoW of both frames on the device, then one wave per

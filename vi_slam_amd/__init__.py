@@ -49,6 +49,8 @@ ABI_SYMBOLS = [
     "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_comm_rank", "vslam_comm_world",
     "vslam_exchange_ring", "vslam_exchange_allgather", "vslam_host_alloc", "vslam_host_free",
     "vslam_fe_stage_images_async", "vslam_fe_octree_stats", "vslam_fe_delivery_stats", "vslam_dbg_search_init_replay_stats", "vslam_tuning_init", "vslam_fe_set_tuning", "vslam_stereo_fisheye_candidates", "vslam_hamming_top2_batch", "vslam_hamming_top2_batch_dev_async", "vslam_fe_set_fast_gate",
+    "vslam_voc_load", "vslam_voc_file_open", "vslam_voc_file_close", "vslam_voc_file_info", "vslam_voc_file_arrays",
+    "vslam_voc_file_last_error", "vslam_dbg_qlz_decode",
 ]
 
 
@@ -130,6 +132,35 @@ class _InitJob(C.Structure):  # vslam_init_job
                 ("dev_prev_matched", C.c_void_p)]
 
 
+def bind_voc_file(L):
+    """ctypes signatures of the vocabulary-file reader (in libvslam_fe.so and in the GPU-free libvslam_host.so)"""
+    vp = C.c_void_p
+    L.vslam_voc_file_open.argtypes = [C.c_char_p, vp]
+    L.vslam_voc_file_close.argtypes = [vp]
+    L.vslam_voc_file_close.restype = None
+    L.vslam_voc_file_info.argtypes = [vp] + [vp] * 9
+    L.vslam_voc_file_arrays.argtypes = [vp] + [vp] * 6
+    L.vslam_voc_file_last_error.restype = C.c_char_p
+    L.vslam_dbg_qlz_decode.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, vp]
+    L.vslam_dbg_qlz_decode.restype = C.c_long
+    return L
+
+
+def qlz_decode(packet, library=None, cap=None):
+    """vslam_dbg_qlz_decode: one QuickLZ level-1 packet -> (bytes, packet size); raises ValueError on a damaged packet."""
+    L = library if library is not None else lib()
+    packet = bytes(packet)
+    n = len(packet)
+    if cap is None:
+        cap = 16 + 128 * n
+    dst = C.create_string_buffer(max(cap, 1))
+    used = C.c_size_t(0)
+    got = L.vslam_dbg_qlz_decode(packet, n, dst, cap, C.byref(used))
+    if got < 0:
+        raise ValueError("damaged QuickLZ packet")
+    return dst.raw[:got], used.value
+
+
 _lib = None
 
 
@@ -167,6 +198,8 @@ def lib():
         L.vslam_distinctive_descriptors.argtypes = [vp, vp, vp, i, vp]
         L.vslam_voc_create.argtypes = [i, i, i, i, i, vp, vp, vp, i, vp, vp, vp, vp]
         L.vslam_voc_destroy.argtypes = [vp]
+        L.vslam_voc_load.argtypes = [i, C.c_char_p, vp]
+        bind_voc_file(L)
         L.vslam_voc_destroy.restype = None
         L.vslam_voc_info.argtypes = [vp, vp, vp, vp, vp]
         L.vslam_bow_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
@@ -1030,6 +1063,41 @@ def bow_assemble(weighting, norm, word, weight, nid):
                 fv_feat=ff[:fo[nf.value]])
 
 
+VOC_FORMATS = {1: "dbow3-binary", 2: "dbow3-binary-quicklz", 3: "dbow3-text"}
+
+
+def read_vocabulary_file(path, library=None):
+    """DBoW3::Vocabulary::load's parsing half (vslam_voc_file_*; no GPU needed): the flat node table of a vocabulary
+    file as a dict in vi_slam_amd.synth.make_vocabulary's layout, plus scoring / n_words / format."""
+    L = library if library is not None else lib()
+    h = C.c_void_p()
+    rc = L.vslam_voc_file_open(os.fsencode(path), C.byref(h))
+    if rc != VSLAM_OK:
+        raise VslamError(rc, (L.vslam_voc_file_last_error() or b"").decode())
+    try:
+        iv = [C.c_int() for _ in range(9)]
+        L.vslam_voc_file_info(h, *[C.byref(x) for x in iv])
+        k, depth, scoring, weighting, norm, n_nodes, n_words, n_child, fmt = (x.value for x in iv)
+        ptrs = [C.c_void_p() for _ in range(6)]
+        L.vslam_voc_file_arrays(h, *[C.byref(x) for x in ptrs])
+
+        def arr(ptr, n, ctype, dtype):
+            if n == 0:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (n,)).astype(dtype, copy=True)
+
+        return dict(k=k, L=depth, scoring=scoring, weighting=weighting, norm=norm, n_words=n_words,
+                    format=VOC_FORMATS.get(fmt, str(fmt)),
+                    child_start=arr(ptrs[0], n_nodes, C.c_int32, np.int32),
+                    child_count=arr(ptrs[1], n_nodes, C.c_int32, np.int32),
+                    child_ids=arr(ptrs[2], n_child, C.c_int32, np.int32),
+                    desc=arr(ptrs[3], n_nodes * 32, C.c_uint8, np.uint8).reshape(n_nodes, 32),
+                    weight=arr(ptrs[4], n_nodes, C.c_double, np.float64),
+                    word_id=arr(ptrs[5], n_nodes, C.c_int32, np.int32))
+    finally:
+        L.vslam_voc_file_close(h)
+
+
 class Vocabulary:
     """DBoW3::Vocabulary on the device (flat node arrays, see vi_slam_amd.synth.make_vocabulary for the layout)."""
 
@@ -1045,6 +1113,18 @@ class Vocabulary:
         _check(lib().vslam_voc_create(device, self.L, self.weighting, self.norm, len(cs), _p(cs), _p(cc), _p(ci), len(ci),
                                       _p(nd), _p(nw), _p(wi), C.byref(h)))
         self._h = h
+
+    @classmethod
+    def load(cls, path, device=0):
+        """DBoW3::Vocabulary::load(filename) (Vocabulary.cpp:1084-1112): binary (plain or QuickLZ) or .txt vocabulary."""
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        _check(lib().vslam_voc_load(device, os.fsencode(path), C.byref(h)))
+        self._h = h
+        iv = [C.c_int() for _ in range(4)]
+        lib().vslam_voc_info(h, *[C.byref(x) for x in iv])
+        self.L, self.weighting, self.norm, self.n_nodes = (x.value for x in iv)
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

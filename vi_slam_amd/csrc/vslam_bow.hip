@@ -68,6 +68,31 @@ static int up(T** dst, const void* src, size_t bytes) {
     return VSLAM_OK;
 }
 
+/* DBoW3::Vocabulary::load(filename) (Vocabulary.cpp:1084-1112; called by core::System, system.cpp:76): parse the file on
+ * the host (vslam_voc_file.cpp) and upload the node table. */
+extern "C" int vslam_voc_load(int device, const char* path, vslam_voc** out) {
+    if (!out) {
+        g_err = "invalid arguments";
+        return VSLAM_ERR_INVALID;
+    }
+    *out = nullptr;
+    vslam_voc_file* f = nullptr;
+    int rc = vslam_voc_file_open(path, &f);
+    if (rc != VSLAM_OK) {
+        g_err = vslam_voc_file_last_error();
+        return rc;
+    }
+    int L = 0, weighting = 0, norm = 0, n_nodes = 0, n_child = 0;
+    const int32_t *cs, *cc, *ci, *wi;
+    const uint8_t* nd;
+    const double* nw;
+    vslam_voc_file_info(f, nullptr, &L, nullptr, &weighting, &norm, &n_nodes, nullptr, &n_child, nullptr);
+    vslam_voc_file_arrays(f, &cs, &cc, &ci, &nd, &nw, &wi);
+    rc = vslam_voc_create(device, L, weighting, norm, n_nodes, cs, cc, ci, n_child, nd, nw, wi, out);
+    vslam_voc_file_close(f);
+    return rc;
+}
+
 extern "C" void vslam_voc_destroy(vslam_voc* v) {
     if (!v) return;
     hipSetDevice(v->device);
