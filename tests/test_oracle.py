@@ -114,6 +114,32 @@ def test_gaussian_taps_and_blur_invariants():
     assert np.array_equal(orbo.blur7(im), ((v + 32768) >> 16).astype(np.uint8))
 
 
+def test_gaussian_taps_follow_from_sigma_2_by_the_published_fixed_point_rule():
+    """Where {18,34,48,56,48,34,18} comes from (NOT a pin -- OpenCV is not here; a derivation from the published rule):
+    FExtractor::compute calls GaussianBlur(7x7, sigma 2, 2, BORDER_REFLECT_101) (fextractor.cpp:1086); for 8-bit images
+    OpenCV 4.2 filters with Q8 fixed-point taps made from exp(-x^2 / (2 sigma^2)) / sum by rounding from the outermost tap
+    inwards, carrying each tap's rounding error into the next one, and giving the centre what is left of 256.  Rounding
+    every tap on its own (the older rule, kept as a knob: Knobs.gauss_taps / vslam_fe_params.gauss_taps) gives
+    {18,34,49,55,49,34,18}, sum 257."""
+    x = np.arange(-3, 4, dtype=np.float64)
+    g = np.exp(-x * x / (2.0 * 2.0 * 2.0))
+    g /= g.sum()
+    taps, err = [0] * 7, 0.0
+    for i in range(3):
+        adj = g[i] * 256.0 + err
+        v = int(np.rint(adj))
+        err = adj - v
+        taps[i] = taps[6 - i] = v
+        assert abs(adj - np.floor(adj) - 0.5) > 1e-3      # no tap sits on a rounding boundary: exp()'s last bits do not matter
+    taps[3] = 256 - sum(taps)
+    assert taps == [18, 34, 48, 56, 48, 34, 18]
+    alone = [int(np.rint(v * 256.0)) for v in g]
+    assert alone == [18, 34, 49, 55, 49, 34, 18] and sum(alone) == 257
+    im = np.random.default_rng(5).integers(0, 256, (40, 52), dtype=np.uint8)
+    assert np.array_equal(orbo.blur7(im), orbo.blur7(im, taps=taps))          # the oracle's default IS the derived set
+    assert not np.array_equal(orbo.blur7(im), orbo.blur7(im, taps=alone))
+
+
 def test_resize_linear_invariants():
     # a constant image stays constant; output of the 1.2x step stays within the source range
     im = np.full((100, 120), 93, np.uint8)
