@@ -228,8 +228,8 @@ int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx);
 /* Pacing between contexts kept in flight: with a gate set, the FAST launch of every later pass of `fe` starts only when the
  * FAST launch of `signal`'s latest pass has finished (GPU-side event; no host synchronisation).  FAST takes a CU's whole
  * LDS while it runs; chaining the contexts' FAST launches keeps two of them from being resident at once.  NULL removes it.
- * `signal` must outlive every later pass of `fe` (remove the gate, or stop using `fe`, before destroying it); passes of gated
- * contexts are not replayed from captured graphs. */
+ * Destroying `signal` removes the gate (later passes of `fe` run un-gated); do not destroy it from another thread while a
+ * pass of `fe` is being enqueued.  Passes of gated contexts are not replayed from captured graphs. */
 int vslam_fe_set_fast_gate(vslam_fe* fe, vslam_fe* signal);
 
 /* Stream the context launches on (hipStream_t as void*), for event timing by the caller. */

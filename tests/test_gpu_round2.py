@@ -159,6 +159,10 @@ def test_fast_gate_chains_contexts_without_changing_results():
         ctxs[0].set_fast_gate(None)
         out = ctxs[0].compute_batch(frames)
         assert len(out[0][0]) == len(want[0][0])
+        # destroying a context that gates another one removes the gate: context 2 (gated by 1) keeps working
+        ctxs[1].close()
+        out = ctxs[2].compute_batch(frames)
+        assert all(np.array_equal(out[s][1], want[s][1]) for s in range(B))
     finally:
         for c in ctxs:
             c.close()

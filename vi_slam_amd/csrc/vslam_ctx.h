@@ -52,6 +52,7 @@ struct vslam_fe {
     hipEvent_t ev_fast = nullptr;     /* recorded behind the FAST launch of every pass once a gate refers to this context */
     vslam_fe* fast_gate = nullptr;    /* vslam_fe_set_fast_gate: this context's FAST waits for that context's last FAST */
     bool fast_gated_by_someone = false;
+    std::vector<vslam_fe*> gate_waiters; /* contexts whose fast_gate is this one: un-gated when this context is destroyed */
 
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;

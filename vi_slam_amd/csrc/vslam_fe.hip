@@ -12,7 +12,9 @@
 #endif
 #include "vslam_ctx.h"
 
+#include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -23,6 +25,16 @@ std::string& vslam_err() {
     return e;
 }
 extern "C" const char* vslam_last_error(void) { return vslam_err().c_str(); }
+
+static std::mutex g_gate_mu; /* the gate links between contexts (set / destroy may come from different threads) */
+
+static void gate_unlink(vslam_fe* fe) { /* g_gate_mu held */
+    if (fe->fast_gate) {
+        auto& w = fe->fast_gate->gate_waiters;
+        w.erase(std::remove(w.begin(), w.end(), fe), w.end());
+        fe->fast_gate = nullptr;
+    }
+}
 
 static void free_ctx(vslam_fe* fe) {
     if (!fe) return;
@@ -88,6 +100,12 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->ev_x) hipEventDestroy(fe->ev_x);
     for (int i = 0; i < 4; i++)
         if (fe->ev_user[i]) hipEventDestroy(fe->ev_user[i]);
+    {   /* a destroyed context gates nobody: its waiters run un-gated from now on */
+        std::lock_guard<std::mutex> lk(g_gate_mu);
+        gate_unlink(fe);
+        for (vslam_fe* w : fe->gate_waiters) w->fast_gate = nullptr;
+        fe->gate_waiters.clear();
+    }
     if (fe->ev_fast) hipEventDestroy(fe->ev_fast);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
@@ -691,8 +709,11 @@ extern "C" int vslam_fe_event_wait(vslam_fe* waiter, vslam_fe* signal, int idx) 
  * with a gate are not captured into graphs (an event of another stream cannot be waited for inside a capture). */
 extern "C" int vslam_fe_set_fast_gate(vslam_fe* fe, vslam_fe* signal) {
     if (!fe || (signal && (signal == fe || signal->p.device != fe->p.device))) return VSLAM_ERR_INVALID;
-    fe->fast_gate = signal;
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    gate_unlink(fe);
     if (signal) {
+        fe->fast_gate = signal;
+        signal->gate_waiters.push_back(fe);
         HIPCHK(hipSetDevice(signal->p.device));
         if (!signal->ev_fast) HIPCHK(hipEventCreateWithFlags(&signal->ev_fast, hipEventDisableTiming));
         signal->fast_gated_by_someone = true;
