@@ -107,10 +107,7 @@ typedef struct vslam_tuning {
                                      to up to eight workgroups (k_oct_count); 0 (default) = inside the quadtree workgroup */
     int32_t desc_kpw;             /* VSLAM_DESC_KPW: 1 | 4 keypoints per wave of the descriptor kernel (default: 1 for contexts of one or
                                      two images, else 4) */
-    int32_t desc_split;           /* VSLAM_DESC_SPLIT: 1 = orientation (16 keypoints per wave, the trigonometry once per wave) and
-                                     descriptors as two launches (default for batches), 0 = one fused launch (default for
-                                     contexts of one or two images) */
-    int32_t reserved[3];
+    int32_t reserved[1];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

@@ -94,7 +94,6 @@ struct vslam_fe {
     int blur_rows = 32; /* output rows per wave task of k_blur7_v2 (VSLAM_BLUR_ROWS) */
     /* selection + outputs */
     SelKp* d_sel = nullptr;
-    float4* d_rot = nullptr; /* {angle, cos, sin, -} per selected keypoint: k_orient_dev -> k_describe_dev (vslam_tuning.desc_split) */
     SelKp* h_sel = nullptr; /* pinned, B*cap */
     uint8_t* d_res = nullptr;  /* the context's result block: counts (res_counts_bytes) | kps B*cap | desc B*cap*32 */
     uint8_t* h_res = nullptr;  /* pinned mirror, same layout */

@@ -60,7 +60,6 @@ static void free_ctx(vslam_fe* fe) {
     if (fe->h_cand) hipHostFree(fe->h_cand);
     hipFree(fe->d_blur_tasks);
     hipFree(fe->d_sel);
-    hipFree(fe->d_rot);
     if (fe->h_sel) hipHostFree(fe->h_sel);
     hipFree(fe->d_res); /* d_counts, d_kps and d_desc are views into it; h_res likewise */
     if (fe->h_res) hipHostFree(fe->h_res);
@@ -378,7 +377,6 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
 
     const size_t nk = (size_t)fe->B * fe->cap;
     HIPCHK(hipMalloc((void**)&fe->d_sel, nk * sizeof(SelKp)));
-    HIPCHK(hipMalloc((void**)&fe->d_rot, nk * sizeof(float4)));
     HIPCHK((hipError_t)vslam_pinned_alloc((void**)&fe->h_sel, nk * sizeof(SelKp)));
     /* ONE result block per context -- counts | keypoints | descriptors, back to back -- and one pinned mirror of it: a
      * full batch leaves the device in a single transfer (vslam_fe.hip: enqueue_extract_plain) */
@@ -1158,8 +1156,7 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
-                           nimg, wave_prio_on(fe->tune, 2), fe->tune.desc_kpw >= 0 ? fe->tune.desc_kpw : fe->desc_kpw_hint,
-                           tune_or(fe->tune.desc_split, nimg > 2 ? 1 : 0) == 1 ? fe->d_rot : nullptr);
+                           nimg, wave_prio_on(fe->tune, 2), fe->tune.desc_kpw >= 0 ? fe->tune.desc_kpw : fe->desc_kpw_hint);
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[6], st));
     HIPCHK(hipGetLastError());
     return VSLAM_OK; /* counts travel to the host with the results (vslam_enqueue_extract) */

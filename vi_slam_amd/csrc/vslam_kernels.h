@@ -61,7 +61,7 @@ void vk_assign_out(hipStream_t st, const OctParams& P, const PyramidGeom& g, uin
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
-                            int cap, int atan_fma, int nslots, int prio = 0, int kpw_override = -1, float4* rot = nullptr);
+                            int cap, int atan_fma, int nslots, int prio = 0, int kpw_override = -1);
 
 void vk_dbg_sincos(hipStream_t st, const float* x, int n, float* s, float* c);
 void vk_dbg_logf(hipStream_t st, const float* x, int n, float* y);

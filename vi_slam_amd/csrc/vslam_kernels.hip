@@ -345,158 +345,6 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
 }
 
 /* ------------------------------------------------------------------------------------------------
- * K4 in two launches (round 4): orientation, then descriptors.
- * Why: the angle's fastAtan2 and the glibc-exact cosf / sinf are ~120 double-precision instructions, which issue at half
- * the rate of everything else here.  In the fused kernel they run once per WAVE, for the 1 .. 4 keypoints a wave owns, on
- * lanes that all but those few idle: with one keypoint per wave (the shape the stereo entry uses, for its latency) they
- * are 40 % of the kernel's issue time.  k_orient_dev gives a wave ORI_KPW keypoints -- the moments wave by wave as before,
- * but reduced on DPP adds instead of LDS permutes -- parks keypoint k's moments in lane k and runs the trigonometry ONCE
- * for all of them; {angle, cos, sin} go through HBM (16 bytes per keypoint) to k_describe_dev, which is the fused kernel's
- * phase C alone.  Same arithmetic in the same order per keypoint: bit-identical results.
- * ---------------------------------------------------------------------------------------------- */
-#define ORI_KPW 16
-#define ORI_WPB 4
-
-/* sum over the wave on DPP: quad swaps, row rotations, row broadcasts (masked-out rows add 0); total in lane 63 */
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_take0(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-    v += dpp_take0<0xb1, 0xf>(v);  /* quad_perm [1,0,3,2] */
-    v += dpp_take0<0x4e, 0xf>(v);  /* quad_perm [2,3,0,1] */
-    v += dpp_take0<0x124, 0xf>(v); /* row_ror:4 */
-    v += dpp_take0<0x128, 0xf>(v); /* row_ror:8 */
-    v += dpp_take0<0x142, 0xa>(v); /* row_bcast:15 into rows 1, 3 */
-    v += dpp_take0<0x143, 0xc>(v); /* row_bcast:31 into rows 2, 3 */
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-/* old with lane `sel` replaced by the uniform sval; sel is a constant after unrolling (the lane select must be an inline
- * constant: a second SGPR operand would break the constant-bus limit) */
-__device__ __forceinline__ int write_lane(int sval, int sel, int old) {
-#define WL_CASE(L) case L: asm("v_writelane_b32 %0, %1, " #L : "+v"(old) : "s"(sval)); break;
-    switch (sel) {
-        WL_CASE(0) WL_CASE(1) WL_CASE(2) WL_CASE(3) WL_CASE(4) WL_CASE(5) WL_CASE(6) WL_CASE(7)
-        WL_CASE(8) WL_CASE(9) WL_CASE(10) WL_CASE(11) WL_CASE(12) WL_CASE(13) WL_CASE(14) WL_CASE(15)
-    }
-#undef WL_CASE
-    return old;
-}
-
-__global__ void __launch_bounds__(64 * ORI_WPB)
-k_orient_dev(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel,
-             const int32_t* __restrict__ slot_counts, float4* __restrict__ rot, int cap, int atan_fma, int bps, int nwork, int prio) {
-    wave_prio_raise(prio);
-    const int per_xcd = (nwork + 7) >> 3; /* XCD-aware order as in k_orient_describe_dev */
-    const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (w >= nwork) return;
-    const int slot = w / bps;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = ((w - slot * bps) * ORI_WPB + wave) * ORI_KPW;
-    const int n = slot_counts[slot * 4];
-    if (k0 >= n) return; /* wave-uniform */
-    const int nk = min(ORI_KPW, n - k0);
-    const SelKp* ss = sel + (size_t)slot * cap + k0;
-    uint32_t wu[4], wm[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        wu[k] = g_mom_wu[lane + 64 * k];
-        wm[k] = g_mom_wm[lane + 64 * k];
-    }
-    /* keypoints in groups of four: the raw patches of group j + 1 are requested before group j is reduced */
-    uint32_t raw[2][4][4];
-    auto issue = [&](int grp, uint32_t (*r)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const SelKp s = ss[min(4 * grp + j, nk - 1)]; /* slots past the last keypoint repeat it: loaded, never used */
-            const LevelGeom lg = g.lv[s.level];
-            int pitch;
-            const uint8_t* img = level_base(pyr, slot_stride, src, lg, s.level, s.slot, &pitch);
-            const uint8_t* rp = img + (size_t)((int)s.y - 15) * pitch + ((int)s.x - 15);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i = lane + 64 * k;
-                r[j][k] = 0;
-                if (i < 248) r[j][k] = *(const uint32_t*)(rp + (size_t)(i >> 3) * pitch + 4 * (i & 7));
-            }
-        }
-    };
-    int my01 = 0, my10 = 0;
-    issue(0, raw[0]);
-#pragma unroll
-    for (int grp = 0; grp < ORI_KPW / 4; grp++) {
-        if (4 * grp < nk) { /* wave-uniform */
-            if (4 * (grp + 1) < nk && grp + 1 < ORI_KPW / 4) issue(grp + 1, raw[(grp + 1) & 1]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int m10 = 0, m01 = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int row = (lane + 64 * k) >> 3;
-                    const int rs = (int)__builtin_amdgcn_udot4(raw[grp & 1][j][k], wm[k], 0u, false);
-                    m10 += (int)__builtin_amdgcn_udot4(raw[grp & 1][j][k], wu[k], 0u, false) - 15 * rs;
-                    m01 += (row - 15) * rs;
-                }
-                const int t10 = wave_sum_i32(m10), t01 = wave_sum_i32(m01);
-                my10 = write_lane(t10, 4 * grp + j, my10);
-                my01 = write_lane(t01, 4 * grp + j, my01);
-            }
-        }
-    }
-    const float angle = fast_atan2_deg((float)my01, (float)my10, atan_fma);
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    const float ca = vslam_trig::glibc_cosf(rad), sb = vslam_trig::glibc_sinf(rad);
-    if (lane < nk) rot[(size_t)slot * cap + k0 + lane] = make_float4(angle, ca, sb, 0.f);
-}
-
-/* phase C of describe_run for keypoints whose {angle, cos, sin} k_orient_dev left in rot[] */
-template <int KPW>
-__global__ void __launch_bounds__(64 * DESC_WPB)
-k_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slot_stride, BatchSrc src, PyramidGeom g,
-               const SelKp* __restrict__ sel, const int32_t* __restrict__ slot_counts, const float4* __restrict__ rot,
-               const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap, int bps, int nwork, int prio) {
-    __shared__ __align__(16) uint8_t s_tile[DESC_WPB][DESC_TILE_BYTES];
-    wave_prio_raise(prio);
-    const int per_xcd = (nwork + 7) >> 3;
-    const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (w >= nwork) return;
-    const int slot = w / bps;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = ((w - slot * bps) * DESC_WPB + wave) * KPW;
-    const int n = slot_counts[slot * 4];
-    if (k0 >= n) return; /* wave-uniform */
-    const int nk = min(KPW, n - k0);
-    const SelKp* ss = sel + (size_t)slot * cap + k0;
-    const float4* rr = rot + (size_t)slot * cap + k0;
-    char4 pat[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = ((const char4*)pattern)[k * 64 + lane];
-    SelKp s[KPW];
-    DescAddr A[KPW];
-    float4 r[KPW];
-#pragma unroll
-    for (int k = 0; k < KPW; k++) {
-        s[k] = ss[min(k, nk - 1)];
-        r[k] = rr[min(k, nk - 1)];
-        A[k] = desc_addr(pyr, blur, slot_stride, src, g, s[k]);
-    }
-    uint32_t blr[6], blrn[6];
-    desc_issue_blur(A[0], lane, blr);
-#pragma unroll
-    for (int k = 0; k < KPW; k++)
-        if (k < nk) {
-            if (k + 1 < nk) desc_issue_blur(A[min(k + 1, KPW - 1)], lane, blrn);
-            desc_sample(A[k], s[k], blr, s_tile[wave], pat, r[k].x, r[k].y, r[k].z, kps, desc, cap, lane);
-            if (k + 1 < nk) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) blr[j] = blrn[j];
-            }
-        }
-}
-
-/* ------------------------------------------------------------------------------------------------
  * K5  all-pairs 256-bit Hamming (FMatcher::DescriptorDistance, fmatcher.cpp:2859-2875)
  *     64 queries per workgroup (one per lane, 8 dwords in VGPRs); the 4 waves each sweep a quarter of a
  *     256-descriptor train tile staged in LDS (all lanes read the same address: LDS broadcast), xor +
@@ -581,27 +429,10 @@ void vk_orient_describe(hipStream_t st, const uint8_t* pyr, const uint8_t* blur,
 void vk_orient_describe_dev(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, size_t slot_stride,
                             const BatchSrc& src, const PyramidGeom& g, const SelKp* sel,
                             const int32_t* slot_counts, const int8_t* pattern, vslam_kp* kps, uint8_t* desc,
-                            int cap, int atan_fma, int nslots, int prio, int kpw_override, float4* rot) {
+                            int cap, int atan_fma, int nslots, int prio, int kpw_override) {
     /* keypoints per wave: 4, one after the other with the next one's loads in flight (110 VGPRs, 4 waves per SIMD), for batches;
      * 1 (48 VGPRs, 8 waves per SIMD, four times the waves) for one or two images; vslam_tuning.desc_kpw forces either */
     const int kpw = kpw_override == 1 ? 1 : kpw_override == 2 ? 2 : kpw_override == DESC_KPW ? DESC_KPW : nslots <= 2 ? 1 : DESC_KPW;
-    if (rot) { /* two launches: orientation for ORI_KPW keypoints per wave, then the descriptors */
-        const int obps = (cap + ORI_WPB * ORI_KPW - 1) / (ORI_WPB * ORI_KPW), onwork = obps * nslots;
-        hipLaunchKernelGGL(k_orient_dev, dim3(((onwork + 7) / 8) * 8), dim3(64 * ORI_WPB), 0, st, pyr, slot_stride, src, g, sel,
-                           slot_counts, rot, cap, atan_fma, obps, onwork, prio);
-        const int per = DESC_WPB * kpw, dbps = (cap + per - 1) / per, dnwork = dbps * nslots;
-        const dim3 dgrid(((dnwork + 7) / 8) * 8), dblock(64 * DESC_WPB);
-        if (kpw == 1)
-            hipLaunchKernelGGL(k_describe_dev<1>, dgrid, dblock, 0, st, pyr, blur, slot_stride, src, g, sel, slot_counts, rot, pattern,
-                               kps, desc, cap, dbps, dnwork, prio);
-        else if (kpw == 2)
-            hipLaunchKernelGGL(k_describe_dev<2>, dgrid, dblock, 0, st, pyr, blur, slot_stride, src, g, sel, slot_counts, rot, pattern,
-                               kps, desc, cap, dbps, dnwork, prio);
-        else
-            hipLaunchKernelGGL(k_describe_dev<DESC_KPW>, dgrid, dblock, 0, st, pyr, blur, slot_stride, src, g, sel, slot_counts, rot,
-                               pattern, kps, desc, cap, dbps, dnwork, prio);
-        return;
-    }
     const int per_wg = DESC_WPB * kpw;
     const int bps = (cap + per_wg - 1) / per_wg, nwork = bps * nslots;
     if (kpw == 1)
