@@ -289,7 +289,11 @@ __device__ __forceinline__ uint32_t fast_pair_score(const uint8_t* ca, const uin
  * ---------------------------------------------------------------------------------------------- */
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int hdot2(uint32_t taps, uint32_t coef) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, taps), __builtin_bit_cast(short2v, coef), 0, false);
+    /* the three-address form with the constant 0 as accumulator: from the builtin hipcc makes the two-address v_dot2c_i32_i16
+     * and a v_mov_b32 0 in front of every one of them */
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(taps), "v"(coef));
+    return r;
 }
 
 __global__ void __launch_bounds__(256)
