@@ -13,6 +13,7 @@
  * generations are in the git history only.)
  */
 #include "vslam_kernels.h"
+#include "vslam_wave.h"
 
 __device__ __forceinline__ const uint8_t* level_base_v2(const uint8_t* pyr, size_t slot_stride,
                                                         const BatchSrc& src, const LevelGeom& lg, int level,
@@ -96,7 +97,8 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
                          ((uint32_t)(bx[3] - bc) << 24);
 
     auto load_row = [&](int yy) -> uint2 { /* raw window; the v_perm happens where the row is consumed */
-        const uint32_t* row = (const uint32_t*)(img + (size_t)refl101_v2(yy, h) * pitch + bc);
+        /* 32-bit offsets: the row term is scalar arithmetic, the lane term one add (64-bit v_mad_i64_i32 is quarter rate) */
+        const uint32_t* row = (const uint32_t*)(img + ((uint32_t)refl101_v2(yy, h) * (uint32_t)pitch + (uint32_t)bc));
         return make_uint2(row[0], row[1]);
     };
     auto hpass = [&](uint2 raw, uint32_t* o) {
@@ -154,7 +156,7 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
                     prev[c] = o[c];
                 }
                 if (writer) {
-                    uint8_t* op = out + (size_t)(y0 + r) * lg.pitch + x;
+                    uint8_t* op = out + ((uint32_t)(y0 + r) * (uint32_t)lg.pitch + (uint32_t)x); /* writer lanes: x >= 0 */
                     if (x + 3 < w) *(uint32_t*)op = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
                     else {
                         op[0] = (uint8_t)px[0];
@@ -289,11 +291,23 @@ __device__ __forceinline__ uint32_t fast_pair_score(const uint8_t* ca, const uin
  * ---------------------------------------------------------------------------------------------- */
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int hdot2(uint32_t taps, uint32_t coef) {
-    /* the three-address form with the constant 0 as accumulator: from the builtin hipcc makes the two-address v_dot2c_i32_i16
-     * and a v_mov_b32 0 in front of every one of them */
-    int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(taps), "v"(coef));
-    return r;
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, taps), __builtin_bit_cast(short2v, coef), 0, false);
+}
+/* Four horizontal passes at once in the three-address form with the constant 0 as accumulator: from the builtin hipcc makes the
+ * two-address v_dot2c_i32_i16 and a v_mov_b32 0 in front of every one of them.  A dot instruction's result may not be read by
+ * another kind of VALU instruction for three wait states, which the compiler only knows of its own dots: the s_nop 2 closes
+ * the block (the compiler's own sequences carry the same nops). */
+__device__ __forceinline__ void hdot2x4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint4 cf, int* h0, int* h1, int* h2,
+                                        int* h3) {
+    int r0, r1, r2, r3;
+    asm("v_dot2_i32_i16 %0, %4, %8, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %9, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %10, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %11, 0\n\t"
+        "s_nop 2"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(cf.x), "v"(cf.y), "v"(cf.z), "v"(cf.w));
+    *h0 = r0; *h1 = r1; *h2 = r2; *h3 = r3;
 }
 
 __global__ void __launch_bounds__(256)
@@ -370,6 +384,21 @@ __device__ __forceinline__ uint4 pyr_load16_tail(const uint8_t* p, int nvalid) {
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
 
+struct PyrTileU { /* PyrTileDev in scalar registers */
+    int c0, nc, r0, nr, sq0, sq1, sr0, sr1;
+    uint32_t lds_off, pitch, rt_off;
+};
+__device__ __forceinline__ PyrTileU pyr_tile_uniform(const PyrTileDev& t) {
+    PyrTileU u;
+#define PTU(f) u.f = __builtin_amdgcn_readfirstlane((int)t.f)
+    PTU(c0); PTU(nc); PTU(r0); PTU(nr); PTU(sq0); PTU(sq1); PTU(sr0); PTU(sr1);
+#undef PTU
+    u.lds_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.lds_off);
+    u.pitch = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pitch);
+    u.rt_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.rt_off);
+    return u;
+}
+
 template <int NT> /* threads per workgroup: NT / 64 waves share the rows of a tile */
 __global__ void __launch_bounds__(NT)
 k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, int nslots, uint8_t* reset_cand,
@@ -424,7 +453,8 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
          * only the LAST row ends with the buffer (reading a few bytes into the next row is harmless) */
         const int readable = G.l0 == 0 ? G.readable_w0 : spitch;
         const int last_row = G.lg[0].h - 1;
-        const int nch = (int)S0.pitch >> 4, rpi = 64 / nch;
+        const uint32_t s0pitch = (uint32_t)__builtin_amdgcn_readfirstlane((int)S0.pitch);
+        const int nch = (int)s0pitch >> 4, rpi = 64 / nch;
         const int rsub = lane / nch, ch = lane - rsub * nch;
         const bool lact = rsub < rpi;
         const int col = S0.c0 + 16 * ch;
@@ -435,7 +465,7 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
                 const int row = ((kb + u) * NW + wave) * rpi + rsub;
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (lact && row < S0.nr) {
-                    const uint8_t* gp = img + (size_t)(S0.r0 + row) * spitch + col;
+                    const uint8_t* gp = img + mad24u_s((uint32_t)(S0.r0 + row), (uint32_t)spitch, (uint32_t)col); /* 32-bit, full rate */
                     if (col + 16 <= readable || (G.l0 == 0 && S0.r0 + row < last_row)) v[u] = *(const uint4*)gp;
                     else if (col < readable) v[u] = pyr_load16_tail(gp, readable - col);
                 }
@@ -443,7 +473,7 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int row = ((kb + u) * NW + wave) * rpi + rsub;
-                if (lact && row < S0.nr) *(uint4*)(psm + S0.lds_off + (size_t)row * S0.pitch + 16 * ch) = v[u];
+                if (lact && row < S0.nr) *(uint4*)(psm + mad24u_s((uint32_t)row, s0pitch, S0.lds_off + 16u * (uint32_t)ch)) = v[u];
             }
         }
     }
@@ -451,7 +481,9 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
 #pragma unroll
     for (int j = 1; j <= VSLAM_PYR_GROUP_LEVELS; j++) {
         if (j > G.nl) break; /* uniform */
-        const PyrTileDev S = T[j - 1], D = T[j];
+        /* the tile records are the same for every lane -- said so field by field (16-bit fields come through vector loads):
+         * row addresses are then scalar multiplies instead of quarter-rate v_mul_lo_u32 in the row loop */
+        const PyrTileU S = pyr_tile_uniform(T[j - 1]), D = pyr_tile_uniform(T[j]);
         if (lane < (D.nc >> 2) && D.nr > 0) {
             const int q = (D.c0 >> 2) + lane;
             const int loc = qloc[j - 1];
@@ -477,10 +509,9 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
         const uint32_t* pr_ = (const uint32_t*)(psm + sbase + __mul24((int)(SY), sp));                        \
         const uint32_t x0_ = pr_[0], x1_ = pr_[1], x2_ = pr_[2];                                             \
         const uint32_t lo_ = __builtin_amdgcn_alignbyte(x1_, x0_, sh), hi_ = __builtin_amdgcn_alignbyte(x2_, x1_, sh); \
-        H0 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.x), cf.x) >> 4;                                        \
-        H1 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.y), cf.y) >> 4;                                        \
-        H2 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.z), cf.z) >> 4;                                        \
-        H3 = hdot2(__builtin_amdgcn_perm(hi_, lo_, sel.w), cf.w) >> 4;                                        \
+        hdot2x4(__builtin_amdgcn_perm(hi_, lo_, sel.x), __builtin_amdgcn_perm(hi_, lo_, sel.y),                \
+                __builtin_amdgcn_perm(hi_, lo_, sel.z), __builtin_amdgcn_perm(hi_, lo_, sel.w), cf, &H0, &H1, &H2, &H3); \
+        H0 >>= 4; H1 >>= 4; H2 >>= 4; H3 >>= 4;                                                               \
     }
             for (int r = rb; r < re; r++) {
                 const uint2 e = rt[r];

@@ -66,12 +66,13 @@ k_resize_level(uint8_t* pyr, size_t slot_stride, BatchSrc src, LevelGeom sg, Lev
  *   m10 = sum u I = sum (u + 15) I - 15 sum I,   m01 = sum v I = sum_rows v * (sum_row I)      (exact int32). */
 __device__ uint32_t g_mom_wu[256];
 __device__ uint32_t g_mom_wm[256];
+__device__ uint32_t g_mom_wr[256]; /* row (0 .. 30) in every byte inside the disc: sum of row * I by the same dot4 */
 
 void vk_upload_disc(const int umax[16]) {
-    uint32_t wu[256], wm[256];
+    uint32_t wu[256], wm[256], wr[256];
     for (int i = 0; i < 256; i++) {
         const int row = i >> 3, dw = i & 7, v = row - 15;
-        wu[i] = wm[i] = 0;
+        wu[i] = wm[i] = wr[i] = 0;
         if (row > 30) continue;
         for (int j = 0; j < 4; j++) {
             const int u = 4 * dw + j - 15;
@@ -79,11 +80,13 @@ void vk_upload_disc(const int umax[16]) {
             if (inside) {
                 wu[i] |= (uint32_t)(u + 15) << (8 * j);
                 wm[i] |= 1u << (8 * j);
+                wr[i] |= (uint32_t)row << (8 * j);
             }
         }
     }
     hipMemcpyToSymbol(HIP_SYMBOL(g_mom_wu), wu, sizeof(wu));
     hipMemcpyToSymbol(HIP_SYMBOL(g_mom_wm), wm, sizeof(wm));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mom_wr), wr, sizeof(wr));
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x, int fma) {
@@ -156,7 +159,7 @@ __device__ __forceinline__ void desc_issue_raw(const DescAddr& A, int lane, uint
     for (int k = 0; k < 4; k++) { /* item i = lane + 64 k -> row i >> 3, dword i & 7 (rows 0..30 of 31) */
         const int i = lane + 64 * k;
         raw[k] = 0;
-        if (i < 248) raw[k] = *(const uint32_t*)(A.raw + (size_t)(i >> 3) * A.pitch + 4 * (i & 7)); /* unaligned dword */
+        if (i < 248) raw[k] = *(const uint32_t*)(A.raw + mad24u_s((uint32_t)(i >> 3), (uint32_t)A.pitch, 4u * (uint32_t)(i & 7))); /* unaligned dword */
     }
 }
 __device__ __forceinline__ void desc_issue_blur(const DescAddr& A, int lane, uint32_t blr[6]) {
@@ -165,21 +168,25 @@ __device__ __forceinline__ void desc_issue_blur(const DescAddr& A, int lane, uin
         const int i = lane + 64 * k;
         const int row = (i * 205) >> 11; /* i / 10 for i < 1024 */
         blr[k] = 0;
-        if (i < 370) blr[k] = *(const uint32_t*)(A.blr + (size_t)row * A.bpitch + 4 * (i - row * 10));
+        if (i < 370) blr[k] = *(const uint32_t*)(A.blr + mad24u_s((uint32_t)row, (uint32_t)A.bpitch, (uint32_t)mad24i(row, -10, i) << 2));
     }
 }
 
-/* IC_Angle moments of one keypoint: every lane ends up with the wave's sums */
-__device__ __forceinline__ void desc_moments(const uint32_t raw[4], const uint32_t wu[4], const uint32_t wm[4], int lane,
-                                             int* m01_out, int* m10_out) {
-    int m10 = 0, m01 = 0;
+/* IC_Angle moments of one keypoint: every lane ends up with the wave's sums.  Three dot4 chains per lane -- sum of (u + 15) I,
+ * of row I and of I over the lane's four dwords (the row of a dword is a per-lane constant, so it sits in the byte weights
+ * wr = row * wm) -- then m10 = A - 15 S, m01 = R - 15 S: no multiplies (a 32-bit v_mul_lo is a quarter-rate instruction, and
+ * a hand-placed 24-bit one right behind a dot4 would sit inside the dot -> VALU wait states only the compiler keeps track of) */
+__device__ __forceinline__ void desc_moments(const uint32_t raw[4], const uint32_t wu[4], const uint32_t wm[4],
+                                             const uint32_t wr[4], int* m01_out, int* m10_out) {
+    uint32_t A = 0, R = 0, S = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int row = (lane + 64 * k) >> 3;
-        const int rs = (int)__builtin_amdgcn_udot4(raw[k], wm[k], 0u, false);
-        m10 += (int)__builtin_amdgcn_udot4(raw[k], wu[k], 0u, false) - 15 * rs;
-        m01 += (row - 15) * rs;
+        A = __builtin_amdgcn_udot4(raw[k], wu[k], A, false);
+        R = __builtin_amdgcn_udot4(raw[k], wr[k], R, false);
+        S = __builtin_amdgcn_udot4(raw[k], wm[k], S, false);
     }
+    const int s15 = (int)((S << 4) - S);
+    int m10 = (int)A - s15, m01 = (int)R - s15;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         m10 += __shfl_xor(m10, o, 64);
@@ -210,7 +217,8 @@ __device__ __forceinline__ void desc_sample(const DescAddr& A, const SelKp s, co
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = tile[xo + r0 * DESC_TP + c0], t1 = tile[xo + r1 * DESC_TP + c1];
+        /* |r| <= 18: 24-bit multiplies (a 32-bit v_mul_lo is a quarter-rate instruction) */
+        const int t0 = tile[xo + mad24i(r0, DESC_TP, c0)], t1 = tile[xo + mad24i(r1, DESC_TP, c1)];
         w[q] = __ballot(t0 < t1);
     }
     vslam_kp* okp = kps + (size_t)s.slot * cap + s.out;
@@ -233,11 +241,12 @@ __device__ __forceinline__ void desc_sample(const DescAddr& A, const SelKp s, co
 
 /* the per-lane constants of a wave: disc weights of its four raw-patch items, its four pattern point pairs */
 __device__ __forceinline__ void desc_lane_tables(const int8_t* __restrict__ pattern, int lane, uint32_t wu[4],
-                                                 uint32_t wm[4], char4 pat[4]) {
+                                                 uint32_t wm[4], uint32_t wr[4], char4 pat[4]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         wu[k] = g_mom_wu[lane + 64 * k];
         wm[k] = g_mom_wm[lane + 64 * k];
+        wr[k] = g_mom_wr[lane + 64 * k];
         pat[k] = ((const char4*)pattern)[k * 64 + lane]; /* descriptor bit k*64 + lane */
     }
 }
@@ -258,9 +267,9 @@ __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, co
     const int lane = threadIdx.x & 63;
     if (k0 >= kend) return; /* wave-uniform */
     const int nk = kend - k0; /* 1 .. KPW, wave-uniform */
-    uint32_t wu[4], wm[4];
+    uint32_t wu[4], wm[4], wr[4];
     char4 pat[4];
-    desc_lane_tables(pattern, lane, wu, wm, pat);
+    desc_lane_tables(pattern, lane, wu, wm, wr, pat);
     SelKp s[KPW];
     DescAddr A[KPW];
     uint32_t raw[KPW][4];
@@ -279,7 +288,7 @@ __device__ __forceinline__ void describe_run(const uint8_t* __restrict__ pyr, co
     for (int k = 0; k < KPW; k++)
         if (k < nk) {
             int m01, m10;
-            desc_moments(raw[k], wu, wm, lane, &m01, &m10);
+            desc_moments(raw[k], wu, wm, wr, &m01, &m10);
             if (lane == k) {
                 my01 = m01;
                 my10 = m10;
@@ -310,7 +319,7 @@ k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ b
                   BatchSrc src, PyramidGeom g, const SelKp* __restrict__ sel, int nsel,
                   const int8_t* __restrict__ pattern, vslam_kp* kps, uint8_t* desc, int cap, int atan_fma) {
     __shared__ __align__(16) uint8_t s_tile[4][DESC_TILE_BYTES];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* scalar keypoint records, as in the _dev form */
     const int k0 = (blockIdx.x * 4 + wave) * DESC_KPW;
     describe_run<DESC_KPW>(pyr, blur, slot_stride, src, g, sel, k0, min(k0 + DESC_KPW, nsel), pattern, kps, desc, cap, atan_fma,
                            s_tile[wave]);
@@ -337,7 +346,9 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
     const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (w >= nwork) return;
     const int slot = w / bps;
-    const int wave = threadIdx.x >> 6;
+    /* wave-uniform, and said so: the keypoint records then come through scalar loads and every address derived from them is
+     * scalar arithmetic instead of 64-bit vector multiplies (quarter-rate instructions) */
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k0 = ((w - slot * bps) * DESC_WPB + wave) * KPW;
     const int n = slot_counts[slot * 4];
     describe_run<KPW>(pyr, blur, slot_stride, src, g, sel + (size_t)slot * cap, k0, min(k0 + KPW, n), pattern, kps, desc,

@@ -1,4 +1,4 @@
-/* vslam_wave.h -- wave64 helpers shared by the matcher kernels (device code only). */
+/* vslam_wave.h -- wave64 / instruction-selection helpers shared by the kernels (device code only). */
 #ifndef VSLAM_WAVE_H
 #define VSLAM_WAVE_H
 #include <hip/hip_runtime.h>
@@ -27,6 +27,19 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
  * `on` is a kernel argument: a scalar branch around one s_setprio. */
 __device__ __forceinline__ void wave_prio_raise(int on) {
     if (on) __builtin_amdgcn_s_setprio(3);
+}
+
+/* a * b + c on the 24-bit multiplier (full rate; a 32-bit v_mul_lo / v_mad_u64 is a quarter-rate instruction and hipcc turns
+ * __umul24 back into one where it can prove the operands small).  _s: b is wave-uniform (an SGPR operand) */
+__device__ __forceinline__ uint32_t mad24u_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int mad24i(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 #endif /* VSLAM_WAVE_H */
