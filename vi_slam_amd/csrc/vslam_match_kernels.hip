@@ -111,8 +111,8 @@ k_stereo_best(StereoJobs jobs, float maxD, int nrows, int max_band, const uint32
     wave_prio_raise(prio);
     const StereoJob jb = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= JNL(jb)) return; /* wave-uniform */
+    const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* wave-uniform, and said so */
+    if (iL >= JNL(jb)) return;
     const uint32_t* rs = row_start + (size_t)blockIdx.y * (nrows + 1);
     const uint16_t* it = items + (size_t)blockIdx.y * capR * max_band;
     const float2* ra = rattr + (size_t)blockIdx.y * capR;
@@ -200,10 +200,10 @@ k_stereo_refine(StereoJobs jobs, PyramidGeom g, const uint8_t* pyrL, size_t stri
             for (int i = sub; i < 99; i += 16) { /* 33 left dwords, then 66 right dwords */
                 if (i < 33) {
                     const int row = i / 3, dw = i - row * 3;
-                    *(uint32_t*)&s_pl[grp][row * 12 + dw * 4] = *(const uint32_t*)(imL + (size_t)(cy - 5 + row) * pL + cxL - 5 + dw * 4);
+                    *(uint32_t*)&s_pl[grp][row * 12 + dw * 4] = *(const uint32_t*)(imL + mad24u((uint32_t)(cy - 5 + row), (uint32_t)pL, (uint32_t)(cxL - 5 + dw * 4)));
                 } else {
                     const int j = i - 33, row = j / 6, dw = j - row * 6;
-                    *(uint32_t*)&s_pr[grp][row * 24 + dw * 4] = *(const uint32_t*)(imR + (size_t)(cy - 5 + row) * pR + cxR0 - 10 + dw * 4);
+                    *(uint32_t*)&s_pr[grp][row * 24 + dw * 4] = *(const uint32_t*)(imR + mad24u((uint32_t)(cy - 5 + row), (uint32_t)pR, (uint32_t)(cxR0 - 10 + dw * 4)));
                 }
             }
         } else {

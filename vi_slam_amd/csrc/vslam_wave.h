@@ -36,6 +36,11 @@ __device__ __forceinline__ uint32_t mad24u_s(uint32_t a, uint32_t b_uniform, uin
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
     return r;
 }
+__device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int mad24i(int a, int b, int c) {
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
