@@ -405,7 +405,8 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
                 size_t cand_stride, int32_t* reset_err) {
     extern __shared__ __align__(16) uint8_t psm[];
     constexpr int NW = NT / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* wave-uniform, and said so: the row loops go scalar */
     /* the pass's first launch also zeroes the (total, overflow) header of every slot's candidate buffer and the
      * quadtree's error word (FAST and the quadtree come later on the stream): no launch of its own for 33 stores */
     if (reset_cand && blockIdx.x == 0) {
@@ -1144,7 +1145,8 @@ k_fast_bands(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, 
     __shared__ uint32_t s_any;    /* bit c: cell c of the band kept a corner */
     __shared__ uint32_t s_nq;     /* stage 2: quad columns to sweep */
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform, and said so: loop bounds and per-cell records go scalar */
     /* XCD-aware order (workgroups b and b + 8 share an XCD and its L2).  Full batches: XCD k takes the images k, k + 8, ...
      * whole -- neighbouring bands share six window columns, the next cell row shares six window rows, and the eight XCDs
      * get the same mix of levels -- so every image byte is fetched into one L2 once.  Fewer than eight images: chunks of
