@@ -19,6 +19,7 @@
  */
 #include "../../include/vslam_fastgrid.h"
 #include "vslam_ctx.h"
+#include "vslam_wave.h"
 
 #define FG_MAX_LEVELS 8
 #define FG_MAX_BATCH 64
@@ -189,9 +190,11 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
             const int WD = WP >> 2, maxd = (lg.pitch >> 2) - 1, d0 = (x0 - 4) >> 2; /* arithmetic shift: -1 for x0 = 0 */
             const uint32_t mD = ((1u << 20) + WD - 1) / WD;
             for (int i = tid; i < WD * WH; i += NT) {
-                const int wy = (int)(((uint32_t)i * mD) >> 20), wd = i - wy * WD;
+                /* 24-bit multiplies throughout (i < 2^20, the magic numbers < 2^21, rows and pitches < 2^24): a 32-bit
+                 * v_mul_lo_u32 or a 64-bit address multiply is a quarter-rate instruction */
+                const int wy = (int)(mad24u((uint32_t)i, mD, 0u) >> 20), wd = i - (int)mad24u((uint32_t)wy, (uint32_t)WD, 0u);
                 const int gy = min(max(y0 - 4 + wy, 0), lg.h - 1), gd = min(max(d0 + wd, 0), maxd);
-                ((uint32_t*)win)[i] = ((const uint32_t*)(img + (size_t)gy * lg.pitch))[gd];
+                ((uint32_t*)win)[i] = *(const uint32_t*)(img + mad24u((uint32_t)gy, (uint32_t)lg.pitch, 4u * (uint32_t)gd));
             }
         } else { /* 1- and 2-pixel cells of very coarse levels */
             for (int i = tid; i < WP * WH; i += NT) {
@@ -209,11 +212,11 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
          * (a quarter of the pixels on textured images) compacted into a list so that the expensive part -- ring
          * gather, masks, arc test, score -- runs on dense lanes */
         for (int i = tid; i < RP * RH; i += NT) {
-            const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
+            const int ry = (int)(mad24u((uint32_t)i, mRP, 0u) >> 20), rx = i - (int)mad24u((uint32_t)ry, (uint32_t)RP, 0u);
             const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
             respS[i] = 0.0f;
             const bool cand = gx >= G.dhb && gy >= G.dvb && gx < lg.w - G.dhb && gy < lg.h - G.dvb &&
-                              !fg_precheck_fails(win + (ry + 3) * WP + rx + 3, WP, G.thr);
+                              !fg_precheck_fails(win + mad24u((uint32_t)(ry + 3), (uint32_t)WP, (uint32_t)(rx + 3)), WP, G.thr);
             const unsigned long long m = __ballot(cand);
             if (m) { /* wave-uniform */
                 const int lane = tid & 63;
@@ -227,8 +230,8 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
         const int nlist = s_nlist;
         for (int k = tid; k < nlist; k += NT) {
             const int i = list[k];
-            const int ry = (int)(((uint32_t)i * mRP) >> 20), rx = i - ry * RP;
-            respS[i] = fg_response_px(win + (ry + 3) * WP + rx + 3, WP, G.thr, G.arc, G.score);
+            const int ry = (int)(mad24u((uint32_t)i, mRP, 0u) >> 20), rx = i - (int)mad24u((uint32_t)ry, (uint32_t)RP, 0u);
+            respS[i] = fg_response_px(win + mad24u((uint32_t)(ry + 3), (uint32_t)WP, (uint32_t)(rx + 3)), WP, G.thr, G.arc, G.score);
         }
         __syncthreads();
         if (resp_out && l == resp_level && slot == resp_slot)
@@ -245,7 +248,7 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
             const int py = i >> cshift, px = i & (cwl - 1);
             const int gx = x0 + px, gy = y0 + py;
             if (py < yoff || gx < G.hb || gx >= lg.w - G.hb || gy >= lg.h - G.vb) continue;
-            const float* rp = respS + (py + 1) * RP + px + 1;
+            const float* rp = respS + mad24u((uint32_t)(py + 1), (uint32_t)RP, (uint32_t)(px + 1));
             float c = rp[0];
             if (!(c > 0.0f)) continue;
 #pragma unroll
