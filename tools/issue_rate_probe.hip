@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -131,6 +132,50 @@ __global__ void __launch_bounds__(256) k_pk_fma_f32(uint32_t* out, WaveRec* rec,
     EPILOGUE((uint32_t)(a.x + b.x + c.x + d.x + e.x + f.x + g.x + h.x));
 }
 
+/* 64-bit integer multiply-adds (what size_t address arithmetic compiles to) and FP64: 64-bit register pairs */
+__global__ void __launch_bounds__(256) k_mad_u64_u32(uint32_t* out, WaveRec* rec, int iters) {
+    unsigned long long a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7;
+    uint32_t s = 0x00030005u, s2 = 0x07060504u;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\t"
+                        "v_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\t"
+                        "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7\n\t")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s), "v"(s2) : "vcc");
+    EPILOGUE((uint32_t)(a + b + c + d + e + f + g + h));
+}
+__global__ void __launch_bounds__(256) k_mad_i64_i32(uint32_t* out, WaveRec* rec, int iters) {
+    unsigned long long a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7;
+    uint32_t s = 0x00030005u, s2 = 0x07060504u;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4("v_mad_i64_i32 %0, vcc, %8, %9, %0\n\tv_mad_i64_i32 %1, vcc, %8, %9, %1\n\tv_mad_i64_i32 %2, vcc, %8, %9, %2\n\t"
+                        "v_mad_i64_i32 %3, vcc, %8, %9, %3\n\tv_mad_i64_i32 %4, vcc, %8, %9, %4\n\tv_mad_i64_i32 %5, vcc, %8, %9, %5\n\t"
+                        "v_mad_i64_i32 %6, vcc, %8, %9, %6\n\tv_mad_i64_i32 %7, vcc, %8, %9, %7\n\t")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s), "v"(s2) : "vcc");
+    EPILOGUE((uint32_t)(a + b + c + d + e + f + g + h));
+}
+__global__ void __launch_bounds__(256) k_fma_f64(uint32_t* out, WaveRec* rec, int iters) {
+    double a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7, s = 1.0000001, s2 = 0.5;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4(BLK8_3("v_fma_f64", "")) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s), "v"(s2));
+    EPILOGUE((uint32_t)(a + b + c + d + e + f + g + h));
+}
+__global__ void __launch_bounds__(256) k_lshl_add_u64(uint32_t* out, WaveRec* rec, int iters) {
+    unsigned long long a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7, s = 12345;
+    PROLOGUE();
+    for (int i = 0; i < iters; i++)
+        asm volatile(R4("v_lshl_add_u64 %0, %0, 1, %8\n\tv_lshl_add_u64 %1, %1, 1, %8\n\tv_lshl_add_u64 %2, %2, 1, %8\n\tv_lshl_add_u64 %3, %3, 1, %8\n\t"
+                        "v_lshl_add_u64 %4, %4, 1, %8\n\tv_lshl_add_u64 %5, %5, 1, %8\n\tv_lshl_add_u64 %6, %6, 1, %8\n\tv_lshl_add_u64 %7, %7, 1, %8\n\t")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(s));
+    EPILOGUE((uint32_t)(a + b + c + d + e + f + g + h));
+}
+VKERNEL(k_mul_hi_u32, BLK8("v_mul_hi_u32", ""))
+VKERNEL(k_mul_hi_u24, BLK8("v_mul_hi_u32_u24", ""))
+VKERNEL(k_dot2_i16, BLK8_3("v_dot2_i32_i16", ""))
+VKERNEL(k_dot2_u16, BLK8_3("v_dot2_u32_u16", ""))
+
 /* SALU: 8 independent SGPR chains */
 __global__ void __launch_bounds__(256) k_salu(uint32_t* out, WaveRec* rec, int iters) {
     uint32_t a = blockIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7, s = 3;
@@ -190,6 +235,14 @@ int main(int argc, char** argv) {
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device %s, %d CUs, reported clock %d kHz; iters %d x 32 instructions per wave\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, iters);
     printf("cyc/instr chip-wide = (last wave end - first wave start, 100 MHz s_memrealtime) x shader MHz / 100 / (instructions per wave x waves per SIMD); median wave = the same from one wave's own s_memtime span\n");
+    /* argv[2] = "mul": only the multiply / 64-bit / FP64 rows added in round 4 (what address arithmetic compiles to) */
+    const bool only_mul = argc > 2 && std::string(argv[2]) == "mul";
+    const Row rows_mul[] = {
+        {"v_add_u32", k_add_u32, 32}, {"v_mul_u32_u24", k_mul_u24, 32}, {"v_mad_u32_u24", k_mad_u32_u24, 32}, {"v_mul_hi_u32_u24", k_mul_hi_u24, 32},
+        {"v_mul_lo_u32", k_mul_lo, 32}, {"v_mul_hi_u32", k_mul_hi_u32, 32}, {"v_mad_u64_u32", k_mad_u64_u32, 32}, {"v_mad_i64_i32", k_mad_i64_i32, 32},
+        {"v_lshl_add_u64", k_lshl_add_u64, 32}, {"v_fma_f32", k_fma_f32, 32}, {"v_fma_f64", k_fma_f64, 32}, {"v_dot2_i32_i16", k_dot2_i16, 32},
+        {"v_dot2_u32_u16", k_dot2_u16, 32}, {"v_dot4_u32_u8", k_dot4_u8, 32},
+    };
     const Row rows[] = {
         {"v_add_u32", k_add_u32, 32}, {"v_and_b32", k_and_b32, 32}, {"v_xor_b32", k_xor_b32, 32}, {"v_min_u32", k_min_u32, 32},
         {"v_min3_i32", k_min3_i32, 32}, {"v_max3_u32", k_max3_u32, 32}, {"v_pk_min_u16", k_pk_min_u16, 32}, {"v_pk_max_u16", k_pk_max_u16, 32},
@@ -237,6 +290,12 @@ int main(int argc, char** argv) {
         printf("%-30s wps %d: %6.2f cyc/%s chip-wide  (median wave %.2f)  clock %4.0f MHz  event %.3f ms  waves %zu\n", name, wps, per,
                per_block == 64 ? "pair " : "instr", cyc[cyc.size() / 2] / ((double)iters * 32 * wps), clk, ms, cyc.size());
     };
+    if (only_mul) {
+        for (const Row& r : rows_mul)
+            for (int wps : {1, 2, 4, 8})
+                run(r.name, wps, r.per_block, iters, [&](int nwg) { hipLaunchKernelGGL(r.fn, dim3(nwg), dim3(256), 0, 0, out, rec, iters); });
+        return 0;
+    }
     for (const Row& r : rows)
         for (int wps : {1, 2, 4, 8})
             run(r.name, wps, r.per_block, iters, [&](int nwg) { hipLaunchKernelGGL(r.fn, dim3(nwg), dim3(256), 0, 0, out, rec, iters); });

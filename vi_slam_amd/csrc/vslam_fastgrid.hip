@@ -190,8 +190,8 @@ k_fg_detect(const uint8_t* __restrict__ pyr, FgGeom G, uint8_t* grid, float* res
             const int WD = WP >> 2, maxd = (lg.pitch >> 2) - 1, d0 = (x0 - 4) >> 2; /* arithmetic shift: -1 for x0 = 0 */
             const uint32_t mD = ((1u << 20) + WD - 1) / WD;
             for (int i = tid; i < WD * WH; i += NT) {
-                /* 24-bit multiplies throughout (i < 2^20, the magic numbers < 2^21, rows and pitches < 2^24): a 32-bit
-                 * v_mul_lo_u32 or a 64-bit address multiply is a quarter-rate instruction */
+                /* 24-bit multiply-adds throughout (i < 2^20, the magic numbers < 2^21, rows and pitches < 2^24): one
+                 * instruction where the 32-bit / size_t forms take a multiply plus adds or a 64-bit chain */
                 const int wy = (int)(mad24u((uint32_t)i, mD, 0u) >> 20), wd = i - (int)mad24u((uint32_t)wy, (uint32_t)WD, 0u);
                 const int gy = min(max(y0 - 4 + wy, 0), lg.h - 1), gd = min(max(d0 + wd, 0), maxd);
                 ((uint32_t*)win)[i] = *(const uint32_t*)(img + mad24u((uint32_t)gy, (uint32_t)lg.pitch, 4u * (uint32_t)gd));

@@ -97,7 +97,7 @@ k_blur7_v2(const uint8_t* __restrict__ pyr, size_t slot_stride, BatchSrc src, Py
                          ((uint32_t)(bx[3] - bc) << 24);
 
     auto load_row = [&](int yy) -> uint2 { /* raw window; the v_perm happens where the row is consumed */
-        /* 32-bit offsets: the row term is scalar arithmetic, the lane term one add (64-bit v_mad_i64_i32 is quarter rate) */
+        /* 32-bit offsets: the row term is scalar arithmetic, the lane term one add, the load takes the scalar base */
         const uint32_t* row = (const uint32_t*)(img + ((uint32_t)refl101_v2(yy, h) * (uint32_t)pitch + (uint32_t)bc));
         return make_uint2(row[0], row[1]);
     };
@@ -483,7 +483,7 @@ k_pyramid_group(uint8_t* pyr, size_t slot_stride, BatchSrc src, PyrGroupDev G, i
     for (int j = 1; j <= VSLAM_PYR_GROUP_LEVELS; j++) {
         if (j > G.nl) break; /* uniform */
         /* the tile records are the same for every lane -- said so field by field (16-bit fields come through vector loads):
-         * row addresses are then scalar multiplies instead of quarter-rate v_mul_lo_u32 in the row loop */
+         * row addresses are then scalar multiplies instead of vector ones in the row loop */
         const PyrTileU S = pyr_tile_uniform(T[j - 1]), D = pyr_tile_uniform(T[j]);
         if (lane < (D.nc >> 2) && D.nr > 0) {
             const int q = (D.c0 >> 2) + lane;

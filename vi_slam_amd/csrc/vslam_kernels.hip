@@ -174,8 +174,9 @@ __device__ __forceinline__ void desc_issue_blur(const DescAddr& A, int lane, uin
 
 /* IC_Angle moments of one keypoint: every lane ends up with the wave's sums.  Three dot4 chains per lane -- sum of (u + 15) I,
  * of row I and of I over the lane's four dwords (the row of a dword is a per-lane constant, so it sits in the byte weights
- * wr = row * wm) -- then m10 = A - 15 S, m01 = R - 15 S: no multiplies (a 32-bit v_mul_lo is a quarter-rate instruction, and
- * a hand-placed 24-bit one right behind a dot4 would sit inside the dot -> VALU wait states only the compiler keeps track of) */
+ * wr = row * wm) -- then m10 = A - 15 S, m01 = R - 15 S: twelve dot4 and three adds instead of eight dot4, eight multiplies
+ * and their adds (and no hand-placed instruction right behind a dot4: it would sit inside the dot -> VALU wait states only
+ * the compiler keeps track of) */
 __device__ __forceinline__ void desc_moments(const uint32_t raw[4], const uint32_t wu[4], const uint32_t wm[4],
                                              const uint32_t wr[4], int* m01_out, int* m10_out) {
     uint32_t A = 0, R = 0, S = 0;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void desc_sample(const DescAddr& A, const SelKp s, co
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        /* |r| <= 18: 24-bit multiplies (a 32-bit v_mul_lo is a quarter-rate instruction) */
+        /* |r| <= 18: row * 40 + column as ONE v_mad_i32_i24 */
         const int t0 = tile[xo + mad24i(r0, DESC_TP, c0)], t1 = tile[xo + mad24i(r1, DESC_TP, c1)];
         w[q] = __ballot(t0 < t1);
     }
@@ -347,7 +348,7 @@ k_orient_describe_dev(const uint8_t* __restrict__ pyr, const uint8_t* __restrict
     if (w >= nwork) return;
     const int slot = w / bps;
     /* wave-uniform, and said so: the keypoint records then come through scalar loads and every address derived from them is
-     * scalar arithmetic instead of 64-bit vector multiplies (quarter-rate instructions) */
+     * scalar arithmetic instead of 64-bit vector multiply-add chains in 4 x 30 more VGPRs */
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k0 = ((w - slot * bps) * DESC_WPB + wave) * KPW;
     const int n = slot_counts[slot * 4];

@@ -29,8 +29,10 @@ __device__ __forceinline__ void wave_prio_raise(int on) {
     if (on) __builtin_amdgcn_s_setprio(3);
 }
 
-/* a * b + c on the 24-bit multiplier (full rate; a 32-bit v_mul_lo / v_mad_u64 is a quarter-rate instruction and hipcc turns
- * __umul24 back into one where it can prove the operands small).  _s: b is wave-uniform (an SGPR operand) */
+/* a * b + c as ONE instruction on the 24-bit multiplier (hipcc turns __umul24 back into a 32-bit multiply plus adds, or a
+ * 64-bit v_mad_u64_u32 chain for size_t address arithmetic, where it can prove the operands small; all of them issue at the
+ * same rate on gfx950 -- profiles/r04_issue_rate_multiplies.txt -- so this is about instruction COUNT).  _s: b is wave-uniform
+ * (an SGPR operand) */
 __device__ __forceinline__ uint32_t mad24u_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
