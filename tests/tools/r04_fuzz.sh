@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: the oracle-checked fuzzers (tests/tools/) over the kernels rewritten this round: random extractor configurations
 # with the band FAST kernel and four keypoints per wave forced (single-image contexts would take the per-cell kernel and one
-# keypoint per wave), the library defaults, the grid detector, the init matcher.   usage (through gpurun): bash tools/r04_fuzz.sh
+# keypoint per wave), the library defaults, the grid detector, the init matcher.   usage (through gpurun): bash tests/tools/r04_fuzz.sh
 set -o pipefail
 O=gpurun_out/fuzz
 mkdir -p $O
