@@ -107,11 +107,7 @@ typedef struct vslam_tuning {
                                      to up to eight workgroups (k_oct_count); 0 (default) = inside the quadtree workgroup */
     int32_t desc_kpw;             /* VSLAM_DESC_KPW: 1 | 4 keypoints per wave of the descriptor kernel (default: 1 for contexts of one or
                                      two images, else 4) */
-    int32_t blur_stream;          /* VSLAM_BLUR_STREAM (read at creation): 1 = the 7x7 blur of a pass runs on a second stream of the context,
-                                     forked behind the pyramid and joined in front of the descriptors, i.e. beside FAST and the
-                                     quadtree of the same pass instead of between them (default for batches; never inside a
-                                     captured graph or a profiled pass), 0 = everything on the context's one stream */
-    int32_t reserved[2];
+    int32_t reserved[1];
 } vslam_tuning;
 void vslam_tuning_init(vslam_tuning* t); /* every field = -1 (library default) */
 

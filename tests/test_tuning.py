@@ -49,4 +49,4 @@ def test_python_mirror_matches_the_header():
     body = hdr[hdr.index("typedef struct vslam_tuning {"):hdr.index("} vslam_tuning;")]
     fields = re.findall(r"int32_t (\w+);", body)
     assert fields == V.TUNING_FIELDS
-    assert "int32_t reserved[2];" in body
+    assert "int32_t reserved[1];" in body

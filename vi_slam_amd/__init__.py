@@ -101,11 +101,11 @@ TUNING_FIELDS = ["pyramid_per_level", "pyr_rows", "pyr_threads", "blur_rows", "f
                  "oct_debug", "graphs", "h2d_route", "d2h_route", "copy_wgs", "pull_depth",
                  "init_topm", "init_match_host", "sbp_topm", "sbp_sequential", "si_queries_per_block", "fg_threads",
                  "wait_spin", "numa", "host_prof", "stream_priority", "stage_split_event",
-                 "oct_threads", "fast_kernel", "fast_band_cells", "wave_prio", "oct_precount", "desc_kpw", "blur_stream"]
+                 "oct_threads", "fast_kernel", "fast_band_cells", "wave_prio", "oct_precount", "desc_kpw"]
 
 
 class _Tuning(C.Structure):  # vslam_tuning
-    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 2)]
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 1)]
 
 
 def make_tuning(**kw):

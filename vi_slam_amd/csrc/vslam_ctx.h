@@ -49,10 +49,6 @@ struct vslam_fe {
     hipEvent_t ev_x = nullptr; /* cross-context ordering (vslam_fe_wait_for) */
     hipEvent_t ev_user[4] = {};  /* vslam_fe_event_record / _wait */
     int desc_kpw_hint = -1;           /* keypoints per wave of the descriptor kernel for the pass being enqueued (-1: by batch size) */
-    hipStream_t stream_b = nullptr;   /* vslam_tuning.blur_stream: the blur of a pass, forked behind the pyramid, joined before the descriptors */
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_ok = false;             /* this pass may use stream_b (not while a graph is being captured) */
-    bool blur_pending = false;        /* the blur of the pass being enqueued is on stream_b and not joined yet */
     hipEvent_t ev_fast = nullptr;     /* recorded behind the FAST launch of every pass once a gate refers to this context */
     vslam_fe* fast_gate = nullptr;    /* vslam_fe_set_fast_gate: this context's FAST waits for that context's last FAST */
     bool fast_gated_by_someone = false;

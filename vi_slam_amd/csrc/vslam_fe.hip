@@ -107,9 +107,6 @@ static void free_ctx(vslam_fe* fe) {
         fe->gate_waiters.clear();
     }
     if (fe->ev_fast) hipEventDestroy(fe->ev_fast);
-    if (fe->ev_fork) hipEventDestroy(fe->ev_fork);
-    if (fe->ev_join) hipEventDestroy(fe->ev_join);
-    if (fe->stream_b) hipStreamDestroy(fe->stream_b);
     for (int i = 0; i < 10; i++)
         if (fe->ev_prof[i]) hipEventDestroy(fe->ev_prof[i]);
     if (fe->stream) hipStreamDestroy(fe->stream);
@@ -579,16 +576,6 @@ static int create_impl(const vslam_fe_params* pp, vslam_fe* fe) {
             HIPCHK(hipStreamCreateWithPriority(&fe->stream, hipStreamNonBlocking, pr == 1 ? lo : hi));
         else
             HIPCHK(hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking));
-        /* the second stream (vslam_tuning.blur_stream) comes from the OTHER priority pool than the context's own, so that
-         * the two never share a hardware queue with each other or with the other contexts' streams of either kind */
-        if (tune_or(fe->tune.blur_stream, fe->B > 2 ? 1 : 0) == 1) {
-            if (pr != 2 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-                HIPCHK(hipStreamCreateWithPriority(&fe->stream_b, hipStreamNonBlocking, hi));
-            else
-                HIPCHK(hipStreamCreateWithFlags(&fe->stream_b, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&fe->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&fe->ev_join, hipEventDisableTiming));
-        }
     }
     HIPCHK(hipEventCreateWithFlags(&fe->ev_cand, hipEventDisableTiming));
     fe->use_graph = fe->tune.graphs != 0; /* 0: never replay captured graphs */
@@ -998,10 +985,6 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
     }
     fe->last_nimg = nimg;
     fe->cand_on_host = false;
-    if (fe->blur_pending) { /* a pass that failed between its fork and its join: the pyramid below must not overtake that blur */
-        HIPCHK(hipStreamWaitEvent(st, fe->ev_join, 0));
-        fe->blur_pending = false;
-    }
     /* per-slot candidate header (total, overflow) and the device-quadtree error word: one tiny kernel instead
      * of two runtime memsets */
     int32_t* d_errw = fe->dev_octree ? fe->d_counts + (size_t)fe->B * 4 : nullptr;
@@ -1023,16 +1006,6 @@ static int enqueue_front(vslam_fe* fe, int nimg, const uint8_t* const* imgs, siz
                             fe->d_xtab[l], fe->d_xa[l], fe->d_ytab[l], fe->d_yb[l], nimg);
     }
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[1], st));
-    if (fe->stream_b && fe->side_ok && !prof) {
-        /* fork: the blur needs the pyramid only; on the second stream it runs beside FAST and the quadtree of this pass (a wide
-         * VALU-bound kernel beside a latency-bound one) instead of between them, and the pass's chain is one wide kernel shorter */
-        HIPCHK(hipEventRecord(fe->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(fe->stream_b, fe->ev_fork, 0));
-        vk_blur7_v2(fe->stream_b, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks, fe->n_blur_tasks, fe->taps,
-                    fe->blur_rows, nimg);
-        HIPCHK(hipEventRecord(fe->ev_join, fe->stream_b));
-        fe->blur_pending = true;
-    }
     if (fe->fast_gate && fe->fast_gate->ev_fast) HIPCHK(hipStreamWaitEvent(st, fe->fast_gate->ev_fast, 0));
     /* vslam_tuning.fast_kernel: 4 = one workgroup per band of cells (default for batches: 17 % fewer instructions, every
      * image byte fetched once), 3 = one per cell (default for contexts of one or two images, where the launch is a frame's
@@ -1077,7 +1050,6 @@ static int wait_candidates(vslam_fe* fe, int nimg) {
 }
 
 static void enqueue_blur(vslam_fe* fe, int nimg) {
-    if (fe->blur_pending) return; /* already running on the second stream (enqueue_front); joined in front of the descriptors */
     vk_blur7_v2(fe->stream, fe->d_pyr, fe->slot_stride, fe->src, fe->geom, fe->d_blur, fe->d_blur_tasks,
                 fe->n_blur_tasks, fe->taps, fe->blur_rows, nimg);
 }
@@ -1144,10 +1116,6 @@ static int enqueue_back_host(vslam_fe* fe, int nimg, int lap0, int lap1) {
     }
     /* device-side consumers (stereo matcher) read the counts from HBM */
     HIPCHK(hipMemcpyAsync(fe->d_counts, fe->h_counts, (size_t)nimg * 16, hipMemcpyHostToDevice, st));
-    if (fe->blur_pending) { /* join (also when nothing was selected: the stream's end must cover the blurred levels) */
-        HIPCHK(hipStreamWaitEvent(st, fe->ev_join, 0));
-        fe->blur_pending = false;
-    }
     if (nsel) {
         HIPCHK(hipMemcpyAsync(fe->d_sel, fe->h_sel, (size_t)nsel * sizeof(SelKp), hipMemcpyHostToDevice, st));
         if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
@@ -1186,10 +1154,6 @@ static int enqueue_back_dev(vslam_fe* fe, int nimg, int lap0, int lap1) {
                   d_err, nimg, fe->d_oct_redo, wave_prio_on(fe->tune, 1));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[8], st));
     if (prof) HIPCHK(hipEventRecord(fe->ev_prof[5], st));
-    if (fe->blur_pending) { /* join */
-        HIPCHK(hipStreamWaitEvent(st, fe->ev_join, 0));
-        fe->blur_pending = false;
-    }
     vk_orient_describe_dev(st, fe->d_pyr, fe->d_blur, fe->slot_stride, fe->src, fe->geom, fe->d_sel, fe->d_counts,
                            fe->d_pattern, fe->d_kps, fe->d_desc, fe->cap, (p.flags & VSLAM_FLAG_ATAN_FMA) ? 1 : 0,
                            nimg, wave_prio_on(fe->tune, 2), fe->tune.desc_kpw >= 0 ? fe->tune.desc_kpw : fe->desc_kpw_hint);
@@ -1245,7 +1209,6 @@ static int enqueue_extract_impl(vslam_fe* fe, int nimg, const uint8_t* const* im
     /* Host-image passes of one shape replay a captured HIP graph: every kernel argument of such a pass is fixed
      * (staging, pyramid and result buffers belong to the context), so the ~20 launches become one hipGraphLaunch. */
     const bool graphable = fe->use_graph && on_device != VSLAM_IMGS_DEVICE && fe->dev_octree && !fe->profiling;
-    fe->side_ok = !graphable; /* no second stream inside a captured graph */
     if (!graphable) return enqueue_extract_plain(fe, nimg, imgs, pitch, on_device, lap0, lap1, want_host);
     long long key = ((long long)nimg << 48) ^ ((long long)(uint16_t)lap0 << 32) ^ ((long long)(uint16_t)lap1 << 16) ^
                     (long long)(want_host & 3) ^ ((long long)(lap0 >> 16) << 40) ^ ((long long)(lap1 >> 16) << 24) ^

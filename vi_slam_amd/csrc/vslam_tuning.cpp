@@ -50,7 +50,6 @@ const EnvField kEnv[] = {
     TF("VSLAM_WAVE_PRIO", wave_prio, nullptr, nullptr),
     TF("VSLAM_OCT_PRECOUNT", oct_precount, nullptr, nullptr),
     TF("VSLAM_DESC_KPW", desc_kpw, nullptr, nullptr),
-    TF("VSLAM_BLUR_STREAM", blur_stream, nullptr, nullptr),
 };
 #undef TF
 vslam_tuning g_process;
