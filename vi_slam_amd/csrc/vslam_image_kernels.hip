@@ -295,8 +295,8 @@ __device__ __forceinline__ int hdot2(uint32_t taps, uint32_t coef) {
 }
 /* Four horizontal passes at once in the three-address form with the constant 0 as accumulator: from the builtin hipcc makes the
  * two-address v_dot2c_i32_i16 and a v_mov_b32 0 in front of every one of them.  A dot instruction's result may not be read by
- * another kind of VALU instruction for three wait states, which the compiler only knows of its own dots: the s_nop 2 closes
- * the block (the compiler's own sequences carry the same nops). */
+ * another kind of VALU instruction for three wait states (nor overwritten by one for four), which the compiler only knows of
+ * its own dots: the s_nop 3 closes the block (the compiler's own sequences carry such nops too). */
 __device__ __forceinline__ void hdot2x4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint4 cf, int* h0, int* h1, int* h2,
                                         int* h3) {
     int r0, r1, r2, r3;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void hdot2x4(uint32_t t0, uint32_t t1, uint32_t t2, u
         "v_dot2_i32_i16 %1, %5, %9, 0\n\t"
         "v_dot2_i32_i16 %2, %6, %10, 0\n\t"
         "v_dot2_i32_i16 %3, %7, %11, 0\n\t"
-        "s_nop 2"
+        "s_nop 3"
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
         : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(cf.x), "v"(cf.y), "v"(cf.z), "v"(cf.w));
     *h0 = r0; *h1 = r1; *h2 = r2; *h3 = r3;
